@@ -1,0 +1,256 @@
+/*
+ * oracle/ref_driver.cpp -- TEST INFRASTRUCTURE, not product code.
+ *
+ * A thin driver that is compiled TOGETHER WITH the unmodified Edge Impulse SDK
+ * sources where they lie under /root/reference (never copied into this repo) to
+ * produce oracle/_ref/libei_ref_<model>.so.  It exposes, through a plain C ABI,
+ *   - the reference's public entry point run_classifier() on an int16 clip,
+ *   - taps on the public leaves it is made of (extract_mfcc_features,
+ *     speechpy::feature::mfe / mfcc, numpy::log / dct2, processing::cmvnw,
+ *     feature::filterbanks, trained_model_* and the per-op int8 tensors),
+ *   - a timing loop used as bench.py's cpu_baseline (kind "reference").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * the resulting library.  Build recipe: oracle/Makefile (target `ref`).
+ *
+ * Reference interfaces used (L476 copy):
+ *   SDK/classifier/ei_run_classifier.h:650  run_classifier
+ *   SDK/classifier/ei_run_classifier.h:293  run_inference
+ *   SDK/classifier/ei_run_dsp.h:256         extract_mfcc_features
+ *   SDK/dsp/speechpy/feature.hpp:54,193,370 filterbanks / mfe / mfcc
+ *   SDK/dsp/speechpy/processing.hpp:326     cmvnw
+ *   MODEL/tflite-model/trained_model_compiled.cpp:380-475 trained_model_*
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <time.h>
+
+/* The generated model is included (not linked) so that the per-op tensors in
+ * its anonymous namespace (tflTensors[]) can be tapped. */
+#include "tflite-model/trained_model_compiled.cpp"
+#include "edge-impulse-sdk/classifier/ei_run_classifier.h"
+
+using namespace ei;
+
+/* ---- porting hooks (SDK/porting/ei_classifier_porting.h:45-76) ---------- */
+static int g_print = 0;
+EI_IMPULSE_ERROR ei_run_impulse_check_canceled() { return EI_IMPULSE_OK; }
+EI_IMPULSE_ERROR ei_sleep(int32_t) { return EI_IMPULSE_OK; }
+uint64_t ei_read_timer_us() {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000ull + ts.tv_nsec / 1000;
+}
+uint64_t ei_read_timer_ms() { return ei_read_timer_us() / 1000; }
+void ei_printf(const char *format, ...) {
+    if (!g_print) return;
+    va_list a; va_start(a, format); vprintf(format, a); va_end(a);
+}
+void ei_printf_float(float f) { ei_printf("%f", f); }
+void DebugLog(const char *s) { ei_printf("%s", s); }
+
+/* ---- signal_t over an int16 clip (L476/Core/Src/main.cpp:526-531) ------- */
+static const int16_t *g_pcm = NULL;
+static size_t g_pcm_len = 0;
+static size_t g_get_data_calls = 0;
+static int pcm_get_data(size_t offset, size_t length, float *out_ptr) {
+    g_get_data_calls++;
+    if (offset + length > g_pcm_len) return -1;
+    return numpy::int16_to_float(g_pcm + offset, out_ptr, length);
+}
+
+extern "C" {
+
+int eiref_label_count(void) { return EI_CLASSIFIER_LABEL_COUNT; }
+const char *eiref_label(int i) { return ei_classifier_inferencing_categories[i]; }
+int eiref_feature_count(void) { return EI_CLASSIFIER_NN_INPUT_FRAME_SIZE; }
+void eiref_set_print(int on) { g_print = on; }
+
+/* copy of the DSP config the model was exported with (model_metadata.h:120) */
+void eiref_get_mfcc_config(int *ints /*[8]*/, float *floats /*[3]*/) {
+    ei_dsp_config_mfcc_t *c = (ei_dsp_config_mfcc_t *)ei_dsp_blocks[0].config;
+    ints[0] = c->axes; ints[1] = c->num_cepstral; ints[2] = c->num_filters;
+    ints[3] = c->fft_length; ints[4] = c->win_size; ints[5] = c->low_frequency;
+    ints[6] = c->high_frequency; ints[7] = c->pre_shift;
+    floats[0] = c->frame_length; floats[1] = c->frame_stride; floats[2] = c->pre_cof;
+}
+
+/* Full reference path. scores[LABEL_COUNT]; returns EI_IMPULSE_ERROR.
+ * total_length_after / get_data call count are reported for the boundary tests. */
+int eiref_run_classifier(const int16_t *pcm, size_t n, float *scores,
+                         size_t *total_length_after, size_t *get_data_calls) {
+    g_pcm = pcm; g_pcm_len = n; g_get_data_calls = 0;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    ei_impulse_result_t result;
+    memset(&result, 0, sizeof(result));
+    EI_IMPULSE_ERROR r = run_classifier(&signal, &result, g_print != 0);
+    for (int i = 0; i < EI_CLASSIFIER_LABEL_COUNT; i++) scores[i] = result.classification[i].value;
+    if (total_length_after) *total_length_after = signal.total_length;
+    if (get_data_calls) *get_data_calls = g_get_data_calls;
+    return (int)r;
+}
+
+/* extract_mfcc_features with an arbitrary ei_dsp_config_mfcc_t.
+ * features must hold rows*num_cepstral floats; returns EIDSP code. */
+int eiref_extract_mfcc(const int16_t *pcm, size_t n, int num_cepstral, float frame_length,
+                       float frame_stride, int num_filters, int fft_length, int win_size,
+                       int low_frequency, int high_frequency, float pre_cof, int pre_shift,
+                       float *features, size_t features_cap) {
+    g_pcm = pcm; g_pcm_len = n;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    ei_dsp_config_mfcc_t cfg = { 1, num_cepstral, frame_length, frame_stride, num_filters,
+                                 fft_length, win_size, low_frequency, high_frequency,
+                                 pre_cof, pre_shift };
+    matrix_t fm(1, features_cap, features);
+    return extract_mfcc_features(&signal, &fm, &cfg);
+}
+
+/* speechpy::feature::mfcc without CMVN (pre-emphasis as extract_mfcc_features does it) */
+int eiref_mfcc_nocmvn(const int16_t *pcm, size_t n, int num_cepstral, float frame_length,
+                      float frame_stride, int num_filters, int fft_length,
+                      int low_frequency, int high_frequency, float pre_cof, int pre_shift,
+                      float *out /*[rows*num_cepstral]*/) {
+    g_pcm = pcm; g_pcm_len = n;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    class speechpy::processing::preemphasis pre(&signal, pre_shift, pre_cof);
+    preemphasis = &pre;
+    signal_t ps;
+    ps.total_length = n;
+    ps.get_data = &preemphasized_audio_signal_get_data;
+    matrix_size_t sz = speechpy::feature::calculate_mfcc_buffer_size(
+        n, EI_CLASSIFIER_FREQUENCY, frame_length, frame_stride, num_cepstral);
+    matrix_t fm(sz.rows, sz.cols, out);
+    return speechpy::feature::mfcc(&fm, &ps, EI_CLASSIFIER_FREQUENCY, frame_length, frame_stride,
+                                   num_cepstral, num_filters, fft_length, low_frequency, high_frequency);
+}
+
+/* speechpy::feature::mfe: mel energies (after zero_handling, before log) + frame energies */
+int eiref_mfe(const int16_t *pcm, size_t n, float frame_length, float frame_stride,
+              int num_filters, int fft_length, int low_frequency, int high_frequency,
+              float pre_cof, int pre_shift, float *out_features, float *out_energies) {
+    g_pcm = pcm; g_pcm_len = n;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    class speechpy::processing::preemphasis pre(&signal, pre_shift, pre_cof);
+    preemphasis = &pre;
+    signal_t ps;
+    ps.total_length = n;
+    ps.get_data = &preemphasized_audio_signal_get_data;
+    matrix_size_t sz = speechpy::feature::calculate_mfe_buffer_size(
+        n, EI_CLASSIFIER_FREQUENCY, frame_length, frame_stride, num_filters);
+    matrix_t fm(sz.rows, sz.cols, out_features);
+    matrix_t em(sz.rows, 1, out_energies);
+    return speechpy::feature::mfe(&fm, &em, &ps, EI_CLASSIFIER_FREQUENCY, frame_length, frame_stride,
+                                  num_filters, fft_length, low_frequency, high_frequency);
+}
+
+/* pre-emphasised samples as the frame loop sees them (processing.hpp:52-138) */
+int eiref_preemphasis(const int16_t *pcm, size_t n, float pre_cof, int pre_shift,
+                      size_t offset, size_t length, float *out) {
+    g_pcm = pcm; g_pcm_len = n;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    class speechpy::processing::preemphasis pre(&signal, pre_shift, pre_cof);
+    return pre.get_data(offset, length, out);
+}
+
+int eiref_power_spectrum(float *frame, size_t frame_size, float *out, int fft_length) {
+    return speechpy::processing::power_spectrum(frame, frame_size, out, fft_length / 2 + 1, fft_length);
+}
+
+/* filterbank in the transposed [coefficients][num_filters] layout mfe() uses */
+int eiref_filterbanks(int num_filters, int fft_length, int low_frequency, int high_frequency, float *out) {
+    int coefficients = fft_length / 2 + 1;
+    matrix_t fb(num_filters, coefficients, out);
+    memset(out, 0, sizeof(float) * num_filters * coefficients);
+    return speechpy::feature::filterbanks(&fb, num_filters, coefficients, EI_CLASSIFIER_FREQUENCY,
+                                          low_frequency, high_frequency, true);
+}
+
+float eiref_log(float x) { return numpy::log(x); }
+float eiref_frequency_to_mel(float f) { return speechpy::functions::frequency_to_mel(f); }
+float eiref_mel_to_frequency(float m) { return speechpy::functions::mel_to_frequency(m); }
+int eiref_dct2_ortho(float *inout, size_t n) { return numpy::dct2(inout, n, DCT_NORMALIZATION_ORTHO); }
+int eiref_cmvnw(float *inout, int rows, int cols, int win_size, int variance_normalization) {
+    matrix_t m(rows, cols, inout);
+    return speechpy::processing::cmvnw(&m, win_size, variance_normalization != 0);
+}
+int eiref_num_frames(size_t n, float frame_length, float frame_stride) {
+    return speechpy::processing::calculate_no_of_stack_frames(n, EI_CLASSIFIER_FREQUENCY, frame_length,
+                                                              frame_stride, false);
+}
+/* kiss_fftr tap: complex spectrum of a real frame (n_fft even) */
+int eiref_rfft_complex(const float *in, size_t n_fft, float *out_ri /*[(n_fft/2+1)*2]*/) {
+    return numpy::rfft(in, n_fft, (fft_complex_t *)out_ri, n_fft / 2 + 1, n_fft);
+}
+
+/* run_inference on a float feature vector (quantise + NN + dequantise) */
+int eiref_run_inference(const float *features, float *scores) {
+    matrix_t fm(1, EI_CLASSIFIER_NN_INPUT_FRAME_SIZE, (float *)features);
+    ei_impulse_result_t result;
+    memset(&result, 0, sizeof(result));
+    EI_IMPULSE_ERROR r = run_inference(&fm, &result, false);
+    for (int i = 0; i < EI_CLASSIFIER_LABEL_COUNT; i++) scores[i] = result.classification[i].value;
+    return (int)r;
+}
+
+/* NN only, from a given int8 input tensor, with every op output tapped.
+ * tensor_ids[k] selects tflTensors[] entries to copy out after invoke; because the
+ * arena is shared between tensors, the taps are taken by re-running the graph node by
+ * node.  out is a flat byte buffer, sizes[k] receives tensor bytes. */
+int eiref_nn_taps(const int8_t *input, int n_taps, const int *tensor_ids, int8_t *out, int *sizes) {
+    if (trained_model_init(ei_aligned_malloc) != kTfLiteOk) return -6;
+    TfLiteTensor *in = trained_model_input(0);
+    memcpy(in->data.int8, input, in->bytes);
+    size_t off = 0;
+    int rc = 0;
+    const size_t n_nodes = sizeof(nodeData) / sizeof(nodeData[0]);
+    /* sizes[] = -1 until produced */
+    for (int k = 0; k < n_taps; k++) sizes[k] = -1;
+    size_t *offs = (size_t *)malloc(sizeof(size_t) * n_taps);
+    for (int k = 0; k < n_taps; k++) { offs[k] = off; off += tflTensors[tensor_ids[k]].bytes; }
+    for (size_t i = 0; i < n_nodes; ++i) {
+        if (registrations[nodeData[i].used_op_index].invoke(&ctx, &tflNodes[i]) != kTfLiteOk) { rc = -3; break; }
+        int produced = tflNodes[i].outputs->data[0];
+        for (int k = 0; k < n_taps; k++) {
+            if (tensor_ids[k] == produced) {
+                memcpy(out + offs[k], tflTensors[produced].data.raw, tflTensors[produced].bytes);
+                sizes[k] = (int)tflTensors[produced].bytes;
+            }
+        }
+    }
+    free(offs);
+    trained_model_reset(ei_aligned_free);
+    return rc;
+}
+
+int eiref_tensor_count(void) { return (int)(sizeof(tensorData) / sizeof(tensorData[0])); }
+int eiref_tensor_bytes(int id) { return (int)tensorData[id].bytes; }
+
+/* CPU baseline: loop run_classifier over n_clips clips ([n_clips][len] int16), `iters` passes.
+ * Returns seconds of wall time; checksum defeats dead-code elimination. */
+double eiref_time_run_classifier(const int16_t *pcm, size_t n_clips, size_t len, int iters, float *checksum) {
+    float acc = 0.f;
+    uint64_t t0 = ei_read_timer_us();
+    float scores[EI_CLASSIFIER_LABEL_COUNT];
+    for (int it = 0; it < iters; it++) {
+        for (size_t c = 0; c < n_clips; c++) {
+            eiref_run_classifier(pcm + c * len, len, scores, NULL, NULL);
+            acc += scores[0];
+        }
+    }
+    uint64_t t1 = ei_read_timer_us();
+    if (checksum) *checksum = acc;
+    return (double)(t1 - t0) * 1e-6;
+}
+
+} /* extern "C" */
