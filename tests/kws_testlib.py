@@ -1,0 +1,408 @@
+"""ctypes bindings used by the tests: the C oracle (oracle/libkws_oracle.so), the compiled
+reference (oracle/_ref/libei_ref_l476.so, only where it has been built) and small helpers.
+
+Test infrastructure only -- nothing here is imported by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libkws_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libei_ref_l476.so")
+MODELS = os.path.join(ROOT, "models")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CLIP_LEN = 16000
+
+
+class MfccConfig(C.Structure):
+    _fields_ = [("num_cepstral", C.c_int), ("frame_length", C.c_float), ("frame_stride", C.c_float),
+                ("num_filters", C.c_int), ("fft_length", C.c_int), ("win_size", C.c_int),
+                ("low_frequency", C.c_int), ("high_frequency", C.c_int), ("pre_cof", C.c_float),
+                ("pre_shift", C.c_int), ("sampling_frequency", C.c_int)]
+
+    def copy(self, **kw):
+        c = MfccConfig()
+        for f, _ in self._fields_:
+            setattr(c, f, kw.get(f, getattr(self, f)))
+        return c
+
+
+def L476_CONFIG():
+    return MfccConfig(13, 0.02, 0.02, 32, 256, 101, 300, 4000, 0.98, 1, 16000)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(ROOT, "oracle", "kws_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+class Oracle:
+    """The plain-C restatement (oracle/kws_oracle.c)."""
+
+    def __init__(self):
+        build_oracle()
+        L = self.L = C.CDLL(ORACLE_SO)
+        L.kwso_log.restype = C.c_float
+        L.kwso_log.argtypes = [C.c_float]
+        L.kwso_frequency_to_mel.restype = C.c_float
+        L.kwso_frequency_to_mel.argtypes = [C.c_float]
+        L.kwso_mel_to_frequency.restype = C.c_float
+        L.kwso_mel_to_frequency.argtypes = [C.c_float]
+        L.kwso_num_frames.argtypes = [C.c_size_t, C.POINTER(MfccConfig)]
+        L.kwso_filterbanks.argtypes = [C.POINTER(MfccConfig), C.c_void_p]
+        L.kwso_preemphasis.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.kwso_rfft_complex.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.kwso_power_spectrum.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.kwso_mfe.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(MfccConfig), C.c_void_p, C.c_void_p]
+        L.kwso_dct2_ortho.argtypes = [C.c_void_p, C.c_int]
+        L.kwso_mfcc_nocmvn.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(MfccConfig), C.c_void_p]
+        L.kwso_cmvnw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.kwso_extract_mfcc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(MfccConfig), C.c_void_p]
+        L.kwso_srdhm.restype = C.c_int32
+        L.kwso_srdhm.argtypes = [C.c_int32, C.c_int32]
+        L.kwso_rdivpot.restype = C.c_int32
+        L.kwso_rdivpot.argtypes = [C.c_int32, C.c_int]
+        L.kwso_mbqm.restype = C.c_int32
+        L.kwso_mbqm.argtypes = [C.c_int32, C.c_int32, C.c_int]
+        L.kwso_quantize_multiplier.argtypes = [C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+        L.kwso_exp_on_negative_values_q5_26.restype = C.c_int32
+        L.kwso_exp_on_negative_values_q5_26.argtypes = [C.c_int32]
+        L.kwso_one_over_one_plus_x.restype = C.c_int32
+        L.kwso_one_over_one_plus_x.argtypes = [C.c_int32]
+        L.kwso_model_load.restype = C.c_void_p
+        L.kwso_model_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.kwso_model_free.argtypes = [C.c_void_p]
+        for f in ("label_count", "feature_count", "raw_sample_count", "tensor_count"):
+            getattr(L, "kwso_model_" + f).argtypes = [C.c_void_p]
+        L.kwso_model_label.restype = C.c_char_p
+        L.kwso_model_label.argtypes = [C.c_void_p, C.c_int]
+        L.kwso_model_tensor_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.kwso_model_mfcc_config.argtypes = [C.c_void_p, C.POINTER(MfccConfig)]
+        L.kwso_quantize_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kwso_nn_invoke.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kwso_dequantize_output.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kwso_run_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kwso_run_classifier.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.kwso_run_classifier_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]
+        L.kwso_time_run_classifier.restype = C.c_double
+        L.kwso_time_run_classifier.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.kwso_synth_fill.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+
+    # ---- clips
+    def synth(self, seed, first, n, clip_len=CLIP_LEN):
+        out = np.empty((n, clip_len), np.int16)
+        self.L.kwso_synth_fill(seed, first, n, clip_len, _ptr(out))
+        return out
+
+    # ---- DSP
+    def num_frames(self, n, cfg):
+        return self.L.kwso_num_frames(n, C.byref(cfg))
+
+    def filterbanks(self, cfg):
+        out = np.zeros((cfg.fft_length // 2 + 1, cfg.num_filters), np.float32)
+        rc = self.L.kwso_filterbanks(C.byref(cfg), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def preemphasis(self, pcm, cof, shift, offset, length):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        out = np.zeros(length, np.float32)
+        rc = self.L.kwso_preemphasis(_ptr(pcm), pcm.size, cof, shift, offset, length, _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def rfft_complex(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros((x.size // 2 + 1, 2), np.float32)
+        rc = self.L.kwso_rfft_complex(_ptr(x), x.size, _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def power_spectrum(self, frame, fft_length):
+        frame = np.ascontiguousarray(frame, np.float32)
+        out = np.zeros(fft_length // 2 + 1, np.float32)
+        rc = self.L.kwso_power_spectrum(_ptr(frame), frame.size, _ptr(out), fft_length)
+        assert rc == 0, rc
+        return out
+
+    def mfe(self, pcm, cfg):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nf = self.num_frames(pcm.size, cfg)
+        feat = np.zeros((nf, cfg.num_filters), np.float32)
+        en = np.zeros(nf, np.float32)
+        rc = self.L.kwso_mfe(_ptr(pcm), pcm.size, C.byref(cfg), _ptr(feat), _ptr(en))
+        assert rc == 0, rc
+        return feat, en
+
+    def dct2_ortho(self, v):
+        v = np.array(v, np.float32)
+        rc = self.L.kwso_dct2_ortho(_ptr(v), v.size)
+        assert rc == 0, rc
+        return v
+
+    def mfcc_nocmvn(self, pcm, cfg):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nf = self.num_frames(pcm.size, cfg)
+        out = np.zeros((nf, cfg.num_cepstral), np.float32)
+        rc = self.L.kwso_mfcc_nocmvn(_ptr(pcm), pcm.size, C.byref(cfg), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def cmvnw(self, m, win_size, var_norm=True):
+        m = np.array(m, np.float32)
+        rc = self.L.kwso_cmvnw(_ptr(m), m.shape[0], m.shape[1], win_size, int(var_norm))
+        assert rc == 0, rc
+        return m
+
+    def extract_mfcc(self, pcm, cfg):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nf = self.num_frames(pcm.size, cfg)
+        out = np.zeros(nf * cfg.num_cepstral, np.float32)
+        rc = self.L.kwso_extract_mfcc(_ptr(pcm), pcm.size, C.byref(cfg), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def quantize_multiplier(self, m):
+        q, s = C.c_int32(), C.c_int()
+        self.L.kwso_quantize_multiplier(m, C.byref(q), C.byref(s))
+        return q.value, s.value
+
+
+class OracleModel:
+    def __init__(self, oracle, path):
+        self.o = oracle
+        self.blob = open(path, "rb").read()
+        self.h = oracle.L.kwso_model_load(self.blob, len(self.blob))
+        assert self.h, "kwso_model_load failed for %s" % path
+        L = oracle.L
+        self.n_labels = L.kwso_model_label_count(self.h)
+        self.labels = [L.kwso_model_label(self.h, i).decode() for i in range(self.n_labels)]
+        self.n_features = L.kwso_model_feature_count(self.h)
+        self.raw_sample_count = L.kwso_model_raw_sample_count(self.h)
+        self.cfg = MfccConfig()
+        L.kwso_model_mfcc_config(self.h, C.byref(self.cfg))
+        self.tensor_bytes = [L.kwso_model_tensor_bytes(self.h, i) for i in range(L.kwso_model_tensor_count(self.h))]
+
+    def quantize_input(self, feat):
+        feat = np.ascontiguousarray(feat, np.float32)
+        q = np.zeros(self.n_features, np.int8)
+        self.o.L.kwso_quantize_input(self.h, _ptr(feat), _ptr(q))
+        return q
+
+    def nn_invoke(self, q, taps=False):
+        q = np.ascontiguousarray(q, np.int8)
+        out = np.zeros(self.n_labels, np.int8)
+        tp = np.zeros(sum(self.tensor_bytes), np.int8) if taps else None
+        rc = self.o.L.kwso_nn_invoke(self.h, _ptr(q), _ptr(out), _ptr(tp) if taps else None)
+        assert rc == 0, rc
+        if not taps:
+            return out
+        offs = np.cumsum([0] + self.tensor_bytes)
+        return out, [tp[offs[i]:offs[i + 1]] for i in range(len(self.tensor_bytes))]
+
+    def dequantize(self, out_q):
+        out_q = np.ascontiguousarray(out_q, np.int8)
+        s = np.zeros(self.n_labels, np.float32)
+        self.o.L.kwso_dequantize_output(self.h, _ptr(out_q), _ptr(s))
+        return s
+
+    def run_inference(self, feat):
+        feat = np.ascontiguousarray(feat, np.float32)
+        s = np.zeros(self.n_labels, np.float32)
+        rc = self.o.L.kwso_run_inference(self.h, _ptr(feat), _ptr(s))
+        assert rc == 0, rc
+        return s
+
+    def run_batch(self, pcm, want_features=False):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        B, n = pcm.shape
+        s = np.zeros((B, self.n_labels), np.float32)
+        f = np.zeros((B, self.n_features), np.float32)
+        q = np.zeros((B, self.n_features), np.int8)
+        rc = self.o.L.kwso_run_classifier_batch(self.h, _ptr(pcm), n, B, _ptr(s), _ptr(f), _ptr(q))
+        if rc != 0:
+            return rc
+        return (s, f, q) if want_features else s
+
+    def time_run(self, pcm, iters=1):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        chk = C.c_float()
+        return self.o.L.kwso_time_run_classifier(self.h, _ptr(pcm), pcm.shape[0], pcm.shape[1], iters, C.byref(chk))
+
+
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+class Reference:
+    """The unmodified reference SDK compiled by oracle/Makefile (target ref)."""
+
+    def __init__(self):
+        L = self.L = C.CDLL(REF_SO)
+        L.eiref_label.restype = C.c_char_p
+        L.eiref_run_classifier.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eiref_extract_mfcc.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t]
+        L.eiref_mfcc_nocmvn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.eiref_mfe.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.eiref_preemphasis.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.eiref_power_spectrum.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.eiref_filterbanks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.eiref_log.restype = C.c_float
+        L.eiref_log.argtypes = [C.c_float]
+        L.eiref_frequency_to_mel.restype = C.c_float
+        L.eiref_frequency_to_mel.argtypes = [C.c_float]
+        L.eiref_mel_to_frequency.restype = C.c_float
+        L.eiref_mel_to_frequency.argtypes = [C.c_float]
+        L.eiref_dct2_ortho.argtypes = [C.c_void_p, C.c_size_t]
+        L.eiref_cmvnw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.eiref_num_frames.argtypes = [C.c_size_t, C.c_float, C.c_float]
+        L.eiref_rfft_complex.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.eiref_run_inference.argtypes = [C.c_void_p, C.c_void_p]
+        L.eiref_nn_taps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eiref_time_run_classifier.restype = C.c_double
+        L.eiref_time_run_classifier.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        self.n_labels = L.eiref_label_count()
+        self.labels = [L.eiref_label(i).decode() for i in range(self.n_labels)]
+        self.n_features = L.eiref_feature_count()
+        self.tensor_bytes = [L.eiref_tensor_bytes(i) for i in range(L.eiref_tensor_count())]
+
+    def run_classifier(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        s = np.zeros(self.n_labels, np.float32)
+        tl, gc = C.c_size_t(), C.c_size_t()
+        rc = self.L.eiref_run_classifier(_ptr(pcm), pcm.size, _ptr(s), C.byref(tl), C.byref(gc))
+        return rc, s, tl.value, gc.value
+
+    def _cfg_args(self, cfg, with_win):
+        a = [cfg.num_cepstral, cfg.frame_length, cfg.frame_stride, cfg.num_filters, cfg.fft_length]
+        if with_win:
+            a.append(cfg.win_size)
+        return a + [cfg.low_frequency, cfg.high_frequency, cfg.pre_cof, cfg.pre_shift]
+
+    def num_frames(self, n, cfg):
+        return self.L.eiref_num_frames(n, cfg.frame_length, cfg.frame_stride)
+
+    def extract_mfcc(self, pcm, cfg):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nf = self.num_frames(pcm.size, cfg)
+        out = np.zeros(nf * cfg.num_cepstral, np.float32)
+        rc = self.L.eiref_extract_mfcc(_ptr(pcm), pcm.size, *self._cfg_args(cfg, True), _ptr(out), out.size)
+        assert rc == 0, rc
+        return out
+
+    def mfcc_nocmvn(self, pcm, cfg):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nf = self.num_frames(pcm.size, cfg)
+        out = np.zeros((nf, cfg.num_cepstral), np.float32)
+        rc = self.L.eiref_mfcc_nocmvn(_ptr(pcm), pcm.size, *self._cfg_args(cfg, False), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def mfe(self, pcm, cfg):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nf = self.num_frames(pcm.size, cfg)
+        feat = np.zeros((nf, cfg.num_filters), np.float32)
+        en = np.zeros(nf, np.float32)
+        rc = self.L.eiref_mfe(_ptr(pcm), pcm.size, cfg.frame_length, cfg.frame_stride, cfg.num_filters,
+                              cfg.fft_length, cfg.low_frequency, cfg.high_frequency, cfg.pre_cof, cfg.pre_shift,
+                              _ptr(feat), _ptr(en))
+        assert rc == 0, rc
+        return feat, en
+
+    def preemphasis(self, pcm, cof, shift, offset, length):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        out = np.zeros(length, np.float32)
+        rc = self.L.eiref_preemphasis(_ptr(pcm), pcm.size, cof, shift, offset, length, _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def power_spectrum(self, frame, fft_length):
+        frame = np.array(frame, np.float32)
+        out = np.zeros(fft_length // 2 + 1, np.float32)
+        rc = self.L.eiref_power_spectrum(_ptr(frame), frame.size, _ptr(out), fft_length)
+        assert rc == 0, rc
+        return out
+
+    def filterbanks(self, cfg):
+        out = np.zeros((cfg.fft_length // 2 + 1, cfg.num_filters), np.float32)
+        hf = cfg.high_frequency if cfg.high_frequency else cfg.sampling_frequency // 2
+        rc = self.L.eiref_filterbanks(cfg.num_filters, cfg.fft_length, cfg.low_frequency, hf, _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def rfft_complex(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros((x.size // 2 + 1, 2), np.float32)
+        rc = self.L.eiref_rfft_complex(_ptr(x), x.size, _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def dct2_ortho(self, v):
+        v = np.array(v, np.float32)
+        rc = self.L.eiref_dct2_ortho(_ptr(v), v.size)
+        assert rc == 0, rc
+        return v
+
+    def cmvnw(self, m, win_size, var_norm=True):
+        m = np.array(m, np.float32)
+        rc = self.L.eiref_cmvnw(_ptr(m), m.shape[0], m.shape[1], win_size, int(var_norm))
+        assert rc == 0, rc
+        return m
+
+    def run_inference(self, feat):
+        feat = np.ascontiguousarray(feat, np.float32)
+        s = np.zeros(self.n_labels, np.float32)
+        rc = self.L.eiref_run_inference(_ptr(feat), _ptr(s))
+        assert rc == 0, rc
+        return s
+
+    def nn_taps(self, q):
+        """all op outputs (tensor id -> bytes) of the int8 graph for input tensor q"""
+        q = np.ascontiguousarray(q, np.int8)
+        ids = np.arange(len(self.tensor_bytes), dtype=np.int32)
+        out = np.zeros(sum(self.tensor_bytes), np.int8)
+        sizes = np.zeros(ids.size, np.int32)
+        rc = self.L.eiref_nn_taps(_ptr(q), ids.size, _ptr(ids), _ptr(out), _ptr(sizes))
+        assert rc == 0, rc
+        offs = np.cumsum([0] + self.tensor_bytes)
+        return {int(i): out[offs[i]:offs[i + 1]].copy() for i in ids if sizes[i] >= 0}
+
+    def time_run(self, pcm, iters=1):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        chk = C.c_float()
+        return self.L.eiref_time_run_classifier(_ptr(pcm), pcm.shape[0], pcm.shape[1], iters, C.byref(chk))
+
+
+def bits(a):
+    """view float32 array as uint32 for exact comparison"""
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def special_clips():
+    """known-answer / edge-case clips"""
+    z = np.zeros(CLIP_LEN, np.int16)
+    alt = np.empty(CLIP_LEN, np.int16)
+    alt[0::2] = 32767
+    alt[1::2] = -32767
+    step = np.zeros(CLIP_LEN, np.int16)
+    step[8000:] = 20000
+    imp = np.zeros(CLIP_LEN, np.int16)
+    imp[5000] = 32767
+    imp[15999] = -32768
+    mn = np.full(CLIP_LEN, -32768, np.int16)
+    ramp = (np.arange(CLIP_LEN) * 4 - 32000).astype(np.int16)
+    return {"zeros": z, "alternating_fullscale": alt, "step": step, "impulses": imp, "min": mn, "ramp": ramp}

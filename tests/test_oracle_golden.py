@@ -1,0 +1,136 @@
+"""The C restatement (oracle/kws_oracle.c) against golden vectors generated from the unmodified
+reference (tools/make_golden.py).  Runs everywhere (CPU only, no /root/reference needed).
+Bar: bit-exact, float32 compared as uint32."""
+import os
+
+import numpy as np
+import pytest
+
+from kws_testlib import GOLDEN, L476_CONFIG, bits, special_clips
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_leaves(oracle):
+    g = _load("leaves_l476.npz")
+    cfg = L476_CONFIG()
+    y = np.float32([oracle.L.kwso_log(float(x)) for x in g["log_x"]])
+    assert (bits(y) == bits(g["log_y"])).all()
+    # known answers quoted in SURVEY 8(a) rows 8 and 10
+    assert oracle.L.kwso_log(1.0) == 0.0
+    assert abs(oracle.L.kwso_log(1.1920929e-07) - (-15.9423847)) < 1e-6
+    y = np.float32([oracle.L.kwso_frequency_to_mel(float(f)) for f in g["mel_f"]])
+    assert (bits(y) == bits(g["mel_y"])).all()
+    fb = oracle.filterbanks(cfg)
+    assert (bits(fb) == bits(g["filterbank_l476"])).all()
+    assert int((fb != 0).sum()) == 39              # 39 non-zeros, bins 2..63 only
+    nz = np.nonzero(fb)[0]
+    assert nz.min() == 2 and nz.max() <= 63
+    assert (bits(oracle.filterbanks(cfg.copy(high_frequency=0))) == bits(g["filterbank_l432"])).all()
+    assert (bits(oracle.filterbanks(cfg.copy(num_filters=40, high_frequency=0))) == bits(g["filterbank_40"])).all()
+    assert (bits(oracle.dct2_ortho(np.arange(32))) == bits(g["dct_ramp32"])).all()
+    assert (bits(oracle.dct2_ortho(np.arange(40))) == bits(g["dct_ramp40"])).all()   # radix-5 path
+    # half-output DCT quirk: outputs 17..31 are input*2*sqrt(1/64)
+    assert np.allclose(g["dct_ramp32"][17:], np.arange(17, 32) * 0.25)
+    assert (bits(oracle.rfft_complex(g["rfft256_x"])) == bits(g["rfft256_y"])).all()
+    assert (bits(oracle.rfft_complex(g["rfft32_x"])) == bits(g["rfft32_y"])).all()
+    assert (bits(oracle.cmvnw(g["cmvn_x"], 101, True)) == bits(g["cmvn_y"])).all()
+    assert (bits(oracle.cmvnw(g["cmvn_x"], 101, False)) == bits(g["cmvn_y_novar"])).all()
+
+
+def test_end_to_end(oracle, l476):
+    g = _load("e2e_l476.npz")
+    n = int(g["clips_per_seed"])
+    k = 0
+    for seed in g["seeds"]:
+        clips = oracle.synth(int(seed), 0, n)
+        s, f, _ = l476.run_batch(clips, want_features=True)
+        assert (bits(f) == bits(g["features"][k:k + n])).all()
+        assert (bits(s) == bits(g["scores"][k:k + n])).all()
+        k += n
+    sp = special_clips()
+    for i, name in enumerate(g["special_names"]):
+        s, f, _ = l476.run_batch(sp[str(name)], want_features=True)
+        assert (bits(f[0]) == bits(g["special_features"][i])).all(), name
+        assert (bits(s[0]) == bits(g["special_scores"][i])).all(), name
+
+
+def test_silence_canary(oracle, l476):
+    """all-zero clip -> c0 column is -0.888889 in every frame (a pure summation-order
+    artefact), other columns 0, scores {0.25, 0.22266, 0.25, 0.27734}."""
+    s, f, _ = l476.run_batch(np.zeros(16000, np.int16), want_features=True)
+    f = f.reshape(49, 13)
+    assert np.allclose(f[:, 0], -0.888889, atol=1e-6)
+    assert (f[:, 1:] == 0).all()
+    assert np.allclose(s[0], [0.25, 0.22265625, 0.25, 0.27734375])
+
+
+def test_every_stage(oracle, l476):
+    g = _load("deep_l476.npz")
+    cfg = L476_CONFIG()
+    sp = special_clips()
+    for k in range(int(g["n"])):
+        seed, idx = g["ids"][k]
+        clip = oracle.synth(int(seed), int(idx), 1)[0] if seed >= 0 else sp[["step", "impulses"][idx]]
+        p = f"c{k}_"
+        assert (bits(oracle.preemphasis(clip, cfg.pre_cof, 1, 0, 320)) == bits(g[p + "pre_f0"])).all()
+        assert (bits(oracle.preemphasis(clip, cfg.pre_cof, 1, 7 * 320, 320)) == bits(g[p + "pre_f7"])).all()
+        assert (bits(oracle.power_spectrum(g[p + "pre_f7"], 256)) == bits(g[p + "ps_f7"])).all()
+        mel, en = oracle.mfe(clip, cfg)
+        assert (bits(mel) == bits(g[p + "mel"])).all()
+        assert (bits(en) == bits(g[p + "energy"])).all()
+        assert (bits(oracle.mfcc_nocmvn(clip, cfg)) == bits(g[p + "mfcc"])).all()
+        f = oracle.extract_mfcc(clip, cfg)
+        assert (bits(f) == bits(g[p + "features"])).all()
+        q = l476.quantize_input(f)
+        assert (q == g[p + "q_in"]).all()
+        out, taps = l476.nn_invoke(q, taps=True)
+        n_checked = 0
+        for tid in range(len(taps)):
+            key = p + f"t{tid}"
+            if key in g.files:
+                assert (taps[tid] == g[key]).all(), (k, tid)
+                n_checked += 1
+        assert n_checked == 15                      # one output per graph node
+        assert (bits(l476.dequantize(out)) == bits(g[p + "scores"])).all()
+
+
+def test_framing(oracle):
+    cfg = L476_CONFIG()
+    assert oracle.num_frames(16000, cfg) == 49      # floor((16000-320)/320)
+    import ctypes
+    assert oracle.L.kwso_frame_length_samples(ctypes.byref(cfg)) == 320
+    assert oracle.num_frames(4000, cfg) == 11
+    assert oracle.num_frames(640, cfg) == 1
+
+
+def test_fixed_point_known_answers(oracle):
+    L = oracle.L
+    assert L.kwso_srdhm(-2**31, -2**31) == 2**31 - 1
+    assert L.kwso_srdhm(1 << 30, 1 << 30) == 1 << 29
+    assert L.kwso_srdhm(-3, 1 << 30) == -1          # truncating division: (-3*2^30 + 1-2^30)/2^31 -> -1
+    assert L.kwso_rdivpot(5, 1) == 3 and L.kwso_rdivpot(-5, 1) == -3 and L.kwso_rdivpot(-6, 2) == -2
+    assert oracle.quantize_multiplier(0.5) == (1 << 30, 0)
+    assert oracle.quantize_multiplier(1.0) == (1 << 30, 1)
+    assert oracle.quantize_multiplier(0.0) == (0, 0)
+    assert L.kwso_exp_on_negative_values_q5_26(0) == 2**31 - 1
+    # exp(-1) in Q0.31 within gemmlowp's accuracy
+    assert abs(L.kwso_exp_on_negative_values_q5_26(-(1 << 26)) / 2**31 - np.exp(-1)) < 1e-6
+    assert abs(L.kwso_one_over_one_plus_x(0) / 2**31 - 1.0) < 1e-6
+    assert abs(L.kwso_one_over_one_plus_x(1 << 30) / 2**31 - 1 / 1.5) < 1e-6
+
+
+def test_model_blob(l476, l432):
+    assert l476.labels == ["no", "noise", "unknown", "yes"]
+    assert l432.labels == ["_noise", "_unknown", "trick_or_treat"]
+    assert l476.n_features == 637 and l432.n_features == 637
+    assert l476.cfg.high_frequency == 4000 and l432.cfg.high_frequency == 0
+    assert len(l476.tensor_bytes) == 31
+
+
+def test_bad_blob_rejected(oracle):
+    assert not oracle.L.kwso_model_load(b"XXXX" + b"\0" * 64, 68)
+    blob = open(os.path.join(os.path.dirname(GOLDEN), "..", "models", "l476_no_yes.kwsm"), "rb").read()
+    assert not oracle.L.kwso_model_load(blob[:200], 200)   # truncated

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference compiled by `make -C oracle ref`.
+
+Runs only where /root/reference exists (the build container).  The vectors are data: inputs are the
+deterministic synthetic clips of include/kws/kws_synth.h (regenerated in the tests from seed/index, plus
+the hand-made edge-case clips of tests/kws_testlib.special_clips) and the values are what the reference
+returned for them at each stage of run_classifier():
+  pre-emphasised frames, power spectrum, mel energies, frame energies, MFCC before CMVN,
+  features (after CMVN), int8 input tensor, every int8 op output, final scores.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from kws_testlib import GOLDEN, L476_CONFIG, Oracle, Reference, special_clips  # noqa: E402
+
+SEEDS = (1, 2, 3)
+CLIPS_PER_SEED = 32      # end-to-end vectors
+DEEP_PER_SEED = 2        # clips with every intermediate stage stored
+
+
+def main():
+    ref = Reference()
+    synth = Oracle()          # only used for kwso_synth_fill (shared integer generator)
+    cfg = L476_CONFIG()
+    os.makedirs(GOLDEN, exist_ok=True)
+
+    # ---- leaves / tables --------------------------------------------------------------------
+    xs = np.concatenate([np.float32([1.1920929e-07, 1e-30, 1e-10, 0.5, 2 / 3, 1.0, 4 / 3, 2.5, 1e4, 3e38]),
+                         np.exp(np.linspace(-40, 40, 200)).astype(np.float32)])
+    leaves = {
+        "log_x": xs, "log_y": np.float32([ref.L.eiref_log(float(x)) for x in xs]),
+        "mel_f": np.float32([0, 300, 1000, 4000, 8000]),
+        "mel_y": np.float32([ref.L.eiref_frequency_to_mel(f) for f in (0, 300, 1000, 4000, 8000)]),
+        "filterbank_l476": ref.filterbanks(cfg),
+        "filterbank_l432": ref.filterbanks(cfg.copy(high_frequency=0)),
+        "filterbank_40": ref.filterbanks(cfg.copy(num_filters=40, high_frequency=0)),
+        "dct_ramp32": ref.dct2_ortho(np.arange(32, dtype=np.float32)),
+        "dct_ramp40": ref.dct2_ortho(np.arange(40, dtype=np.float32)),
+    }
+    rng = np.random.default_rng(7)
+    x256 = rng.standard_normal(256).astype(np.float32)
+    leaves["rfft256_x"] = x256
+    leaves["rfft256_y"] = ref.rfft_complex(x256)
+    x32 = rng.standard_normal(32).astype(np.float32)
+    leaves["rfft32_x"] = x32
+    leaves["rfft32_y"] = ref.rfft_complex(x32)
+    m = (rng.standard_normal((49, 13)) * np.float32([5] + [1] * 12)).astype(np.float32)
+    leaves["cmvn_x"] = m
+    leaves["cmvn_y"] = ref.cmvnw(m, 101, True)
+    leaves["cmvn_y_novar"] = ref.cmvnw(m, 101, False)
+    np.savez_compressed(os.path.join(GOLDEN, "leaves_l476.npz"), **leaves)
+
+    # ---- end-to-end -------------------------------------------------------------------------
+    e2e = {"seeds": np.int32(SEEDS), "clips_per_seed": np.int32(CLIPS_PER_SEED)}
+    feats, scores, qin, outq = [], [], [], []
+    t_in, t_out = 0, len(ref.tensor_bytes) - 1
+    for seed in SEEDS:
+        clips = synth.synth(seed, 0, CLIPS_PER_SEED)
+        for c in clips:
+            rc, s, total_len_after, n_calls = ref.run_classifier(c)
+            assert rc == 0 and total_len_after == 16000 and n_calls == 98
+            f = ref.extract_mfcc(c, cfg)
+            feats.append(f)
+            scores.append(s)
+    e2e["features"] = np.stack(feats)
+    e2e["scores"] = np.stack(scores)
+    sp = special_clips()
+    e2e["special_names"] = np.array(sorted(sp))
+    e2e["special_features"] = np.stack([ref.extract_mfcc(sp[k], cfg) for k in sorted(sp)])
+    e2e["special_scores"] = np.stack([ref.run_classifier(sp[k])[1] for k in sorted(sp)])
+    np.savez_compressed(os.path.join(GOLDEN, "e2e_l476.npz"), **e2e)
+
+    # ---- deep (every stage) -----------------------------------------------------------------
+    deep = {}
+    from kws_testlib import OracleModel, MODELS
+    om = OracleModel(synth, os.path.join(MODELS, "l476_no_yes.kwsm"))   # only for the quantise step below
+    k = 0
+    deep_clips = [synth.synth(seed, i, 1)[0] for seed in SEEDS for i in range(DEEP_PER_SEED)]
+    deep_ids = [(seed, i) for seed in SEEDS for i in range(DEEP_PER_SEED)]
+    deep_clips += [sp["step"], sp["impulses"]]
+    deep_ids += [(-1, 0), (-1, 1)]
+    deep["ids"] = np.int32(deep_ids)
+    for c in deep_clips:
+        p = f"c{k}_"
+        deep[p + "pre_f0"] = ref.preemphasis(c, cfg.pre_cof, cfg.pre_shift, 0, 320)
+        deep[p + "pre_f7"] = ref.preemphasis(c, cfg.pre_cof, cfg.pre_shift, 7 * 320, 320)
+        deep[p + "ps_f7"] = ref.power_spectrum(deep[p + "pre_f7"], cfg.fft_length)
+        mel, en = ref.mfe(c, cfg)
+        deep[p + "mel"], deep[p + "energy"] = mel, en
+        deep[p + "mfcc"] = ref.mfcc_nocmvn(c, cfg)
+        f = ref.extract_mfcc(c, cfg)
+        deep[p + "features"] = f
+        # int8 input tensor: quantised with the restatement (pinned against the reference's
+        # run_inference in tests/test_oracle_vs_reference.py), then every op output from the reference
+        q = om.quantize_input(f)
+        taps = ref.nn_taps(q)
+        deep[p + "q_in"] = q
+        for tid, v in taps.items():
+            deep[p + f"t{tid}"] = v
+        deep[p + "scores"] = ref.run_inference(f)
+        k += 1
+    deep["n"] = np.int32(k)
+    np.savez_compressed(os.path.join(GOLDEN, "deep_l476.npz"), **deep)
+    for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz"):
+        print(fn, os.path.getsize(os.path.join(GOLDEN, fn)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
