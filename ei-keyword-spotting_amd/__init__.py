@@ -1,0 +1,194 @@
+"""ei-keyword-spotting_amd -- MI355X-native drop-in for the Edge Impulse `run_classifier()` hot path.
+
+The product is the C-ABI shared library `libkws_mi355x.so` built from `csrc/` (hand-written HIP kernels for
+gfx950 + the C host side; headers in `include/kws/`).  This module is only a thin ctypes binding over that C ABI
+for Python callers, the tests and `bench.py`; it contains no arithmetic of its own and has NO CPU fallback: if the
+library (or a GPU) is missing, loading / creating a model raises.
+
+Because the directory name carries a hyphen, import it through `__graft_entry__.load_package()` or
+`importlib` (see `__graft_entry__.py`).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libkws_mi355x.so")
+MODELS_DIR = os.path.join(ROOT, "models")
+DEFAULT_MODEL = os.path.join(MODELS_DIR, "l476_no_yes.kwsm")
+
+EI_IMPULSE_OK = 0
+ERROR_NAMES = {0: "EI_IMPULSE_OK", -1: "EI_IMPULSE_ERROR_SHAPES_DONT_MATCH", -2: "EI_IMPULSE_CANCELED",
+               -3: "EI_IMPULSE_TFLITE_ERROR", -5: "EI_IMPULSE_DSP_ERROR", -6: "EI_IMPULSE_TFLITE_ARENA_ALLOC_FAILED",
+               -7: "EI_IMPULSE_CUBEAI_ERROR", -8: "EI_IMPULSE_ALLOC_FAILED", -17: "KWS_ERROR_NO_MODEL",
+               -18: "KWS_ERROR_UNSUPPORTED_MODEL", -19: "KWS_ERROR_HIP", -20: "KWS_ERROR_BAD_ARGUMENT"}
+
+# every symbol include/kws/kws.h and include/kws/ei_compat.h declare
+EXPORTED_SYMBOLS = [
+    "run_classifier", "run_inference", "run_classifier_init", "run_classifier_continuous",
+    "run_moving_average_filter", "ei_run_impulse_check_canceled", "ei_sleep", "ei_read_timer_ms",
+    "ei_read_timer_us", "ei_printf", "ei_printf_float",
+    "kws_create", "kws_create_from_file", "kws_destroy", "kws_last_error", "kws_label_count", "kws_label",
+    "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes", "kws_set_default_model",
+    "kws_default_model", "kws_run_classifier_batch_device", "kws_run_classifier_batch",
+    "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
+    "kws_synth_clips_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
+    "kws_device_synchronize",
+]
+
+
+class KwsError(RuntimeError):
+    def __init__(self, code, detail):
+        super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "?"), code, detail))
+        self.code = code
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libkws_mi355x.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("%s is missing: run __graft_entry__.build() (hipcc, gfx950) first" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+        L.kws_last_error.restype = C.c_char_p
+        L.kws_create.argtypes = [vp, sz, i32, C.POINTER(vp)]
+        L.kws_create_from_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+        L.kws_destroy.argtypes = [vp]
+        for f in ("kws_label_count", "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes"):
+            getattr(L, f).argtypes = [vp]
+        L.kws_label.restype = C.c_char_p
+        L.kws_label.argtypes = [vp, i32]
+        L.kws_set_default_model.argtypes = [vp]
+        L.kws_default_model.restype = vp
+        L.kws_run_classifier_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+        L.kws_run_classifier_batch.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.kws_extract_mfcc_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.kws_run_inference_batch_device.argtypes = [vp, vp, sz, vp, vp]
+        L.kws_nn_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
+        L.kws_nn_batch.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+        L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
+        L.kws_device_malloc.argtypes = [C.POINTER(vp), sz]
+        L.kws_device_free.argtypes = [vp]
+        L.kws_memcpy_h2d.argtypes = [vp, vp, sz]
+        L.kws_memcpy_d2h.argtypes = [vp, vp, sz]
+        L.run_classifier.argtypes = [vp, vp, C.c_bool]
+        L.run_inference.argtypes = [vp, vp, C.c_bool]
+        L.run_moving_average_filter.restype = C.c_float
+        L.run_moving_average_filter.argtypes = [vp, C.c_float]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != EI_IMPULSE_OK:
+        raise KwsError(rc, lib().kws_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- SDK structs (include/kws/ei_compat.h) for callers that want the reference's own call shape --------------
+GET_DATA_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_float))
+
+
+class Signal(C.Structure):                       # signal_t, EIDSP_SIGNAL_C_FN_POINTER=1 layout
+    _fields_ = [("get_data", GET_DATA_FN), ("total_length", C.c_size_t)]
+
+
+class Matrix(C.Structure):                       # ei::matrix_t data members
+    _fields_ = [("buffer", C.POINTER(C.c_float)), ("rows", C.c_uint32), ("cols", C.c_uint32),
+                ("buffer_managed_by_me", C.c_bool)]
+
+
+def result_struct(n_labels):
+    class Classification(C.Structure):
+        _fields_ = [("label", C.c_char_p), ("value", C.c_float)]
+
+    class Timing(C.Structure):
+        _fields_ = [("sampling", C.c_int), ("dsp", C.c_int), ("classification", C.c_int), ("anomaly", C.c_int)]
+
+    class Result(C.Structure):                   # ei_impulse_result_t for EI_CLASSIFIER_LABEL_COUNT = n_labels
+        _fields_ = [("classification", Classification * n_labels), ("anomaly", C.c_float), ("timing", Timing)]
+
+    return Result
+
+
+class Model:
+    """A loaded .kwsm model on one MI355X (kws_handle)."""
+
+    def __init__(self, path=DEFAULT_MODEL, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _check(self.L.kws_create_from_file(path.encode(), device, C.byref(h)))
+        self.h = h
+        self.device = device
+        self.n_labels = self.L.kws_label_count(h)
+        self.labels = [self.L.kws_label(h, i).decode() for i in range(self.n_labels)]
+        self.n_features = self.L.kws_feature_count(h)
+        self.clip_samples = self.L.kws_clip_samples(h)
+        self.n_frames = self.L.kws_frame_count(h)
+        self.pooled_tap_bytes = self.L.kws_pooled_tap_bytes(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kws_destroy(self.h)
+            self.h = None
+
+    def set_default(self):
+        _check(self.L.kws_set_default_model(self.h))
+
+    # ---- host (numpy) convenience paths: copy in, run on the GPU, copy out --------------------------------
+    def run_classifier_batch(self, pcm, want_features=False):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        B = pcm.shape[0]
+        assert pcm.shape[1] == self.clip_samples
+        s = np.zeros((B, self.n_labels), np.float32)
+        f = np.zeros((B, self.n_features), np.float32)
+        q = np.zeros((B, self.n_features), np.int8)
+        _check(self.L.kws_run_classifier_batch(self.h, _p(pcm), B, _p(s), _p(f), _p(q)))
+        return (s, f, q) if want_features else s
+
+    def nn_batch(self, q):
+        q = np.ascontiguousarray(q, np.int8).reshape(-1, self.n_features)
+        B = q.shape[0]
+        s = np.zeros((B, self.n_labels), np.float32)
+        tp = np.zeros((B, self.pooled_tap_bytes), np.int8)
+        tf = np.zeros((B, self.n_labels), np.int8)
+        to = np.zeros((B, self.n_labels), np.int8)
+        _check(self.L.kws_nn_batch(self.h, _p(q), B, _p(s), _p(tp), _p(tf), _p(to)))
+        return s, tp, tf, to
+
+    # ---- device-pointer paths (torch tensors or raw pointers); asynchronous on `stream` -------------------
+    def run_classifier_batch_device(self, pcm_ptr, B, scores_ptr, features_ptr=None, q_ptr=None, stream=None):
+        _check(self.L.kws_run_classifier_batch_device(self.h, pcm_ptr, B, scores_ptr, features_ptr, q_ptr, stream))
+
+    def extract_mfcc_batch_device(self, pcm_ptr, B, features_ptr, q_ptr=None, stream=None):
+        _check(self.L.kws_extract_mfcc_batch_device(self.h, pcm_ptr, B, features_ptr, q_ptr, stream))
+
+    def run_inference_batch_device(self, features_ptr, B, scores_ptr, stream=None):
+        _check(self.L.kws_run_inference_batch_device(self.h, features_ptr, B, scores_ptr, stream))
+
+    def nn_batch_device(self, q_ptr, B, scores_ptr, stream=None):
+        _check(self.L.kws_nn_batch_device(self.h, q_ptr, B, scores_ptr, None, None, None, stream))
+
+
+def synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream=None):
+    _check(lib().kws_synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream))

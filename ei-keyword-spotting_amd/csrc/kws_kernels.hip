@@ -1,0 +1,648 @@
+// kws_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4), wave64.
+//
+// One wavefront owns one 1 s / 16 kHz clip.  Kernel 1 (kws_mfcc_kernel) replaces the reference's
+// extract_mfcc_features() (SDK/classifier/ei_run_dsp.h:256-308): coalesced 16-byte int16 loads, pre-emphasis in
+// registers, the 256-point real FFT staged in LDS, power spectrum, sparse mel gather, fast log, DCT, windowed
+// CMVN and the int8 quantisation of ei_run_classifier.h:436-444.  Kernel 2 (kws_nn_kernel) replaces the
+// EON-compiled TFLite-Micro graph (MODEL/tflite-model/trained_model_compiled.cpp:312-328).
+//
+// BIT-EXACTNESS CONTRACT.  Every floating-point operation below is performed in the same order, at the same
+// precision and with the same (separate) roundings as the reference's x86-64 build: the FFT replays KissFFT's
+// radix-4,4,4,2 decimation (kissfft/kiss_fft.cpp:15-84, kiss_fftr.cpp:66-120) butterfly by butterfly, no
+// multiply-add is ever contracted (this file is compiled with -ffp-contract=off, the only fused operations are
+// the ones the reference itself writes as fmaf()), the magnitude and the CMVN variance go through fp64 exactly
+// as the reference's pow()/sqrt() calls do, and sequential fp32 sums keep their order.  Integer work is exact.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "kws_plan.h"
+#include "../../include/kws/kws_synth.h"
+
+#pragma clang fp contract(off)
+
+#define KWS_WAVE 64
+
+// Wave-local LDS hand-off: lanes of ONE wave exchange data through LDS.  LDS operations of a wave execute in
+// issue order, so only the compiler has to be kept from reordering (same idiom as rocPRIM's wave barrier).
+#define WAVE_SYNC()                                                   \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+        __builtin_amdgcn_wave_barrier();                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+    } while (0)
+
+struct cf { float r, i; };
+
+__device__ __forceinline__ cf cmul(cf a, cf b)   // C_MUL, _kiss_fft_guts.h: four products, one sub, one add
+{
+    cf m;
+    float rr = a.r * b.r, ii = a.i * b.i, ri = a.r * b.i, ir = a.i * b.r;
+    m.r = rr - ii;
+    m.i = ri + ir;
+    return m;
+}
+__device__ __forceinline__ cf cadd(cf a, cf b) { cf c; c.r = a.r + b.r; c.i = a.i + b.i; return c; }
+__device__ __forceinline__ cf csub(cf a, cf b) { cf c; c.r = a.r - b.r; c.i = a.i - b.i; return c; }
+
+// kf_bfly4, forward transform (kiss_fft.cpp:38-84)
+__device__ __forceinline__ void bfly4(cf &f0, cf &f1, cf &f2, cf &f3, cf t1, cf t2, cf t3)
+{
+    cf s0 = cmul(f1, t1), s1 = cmul(f2, t2), s2 = cmul(f3, t3);
+    cf s5 = csub(f0, s1);
+    f0 = cadd(f0, s1);
+    cf s3 = cadd(s0, s2), s4 = csub(s0, s2);
+    f2 = csub(f0, s3);
+    f0 = cadd(f0, s3);
+    f1.r = s5.r + s4.i;
+    f1.i = s5.i - s4.r;
+    f3.r = s5.r - s4.i;
+    f3.i = s5.i + s4.r;
+}
+
+__device__ __forceinline__ cf ld_cf(const float *b, int n) { float2 v = *(const float2 *)(b + 2 * n); cf c; c.r = v.x; c.i = v.y; return c; }
+__device__ __forceinline__ void st_cf(float *b, int n, cf c) { *(float2 *)(b + 2 * n) = make_float2(c.r, c.i); }
+__device__ __forceinline__ cf to_cf(float2 v) { cf c; c.r = v.x; c.i = v.y; return c; }
+
+// numpy::log (SDK/dsp/numpy.hpp:1350-1371): the fmaf() calls are the reference's own
+__device__ __forceinline__ float fast_log(float a)
+{
+    int g = __float_as_int(a);
+    int e = (int)(((unsigned)g - 0x3f2aaaabu) & 0xff800000u);
+    g = (int)((unsigned)g - (unsigned)e);
+    float m = __int_as_float(g);
+    float i = (float)e * 1.19209290e-7f;
+    float f = m - 1.0f;
+    float s = f * f;
+    float r = __fmaf_rn(0.230836749f, f, -0.279208571f);
+    float t = __fmaf_rn(0.331826031f, f, -0.498910338f);
+    r = __fmaf_rn(r, s, t);
+    r = __fmaf_rn(r, s, f);
+    r = __fmaf_rn(i, 0.693147182f, r);
+    return r;
+}
+
+// software_rfft's magnitude + power_spectrum's scaling (numpy.hpp:1410, processing.hpp:306-309):
+//   mag = (float)sqrt(pow(re,2) + pow(im,2))  [double];  P = (1.0/fft) * (mag*mag)
+__device__ __forceinline__ float bin_power(cf f, float inv_fft)
+{
+    double re = (double)f.r, im = (double)f.i;
+    double s = __fma_rn(re, re, im * im);     // both squares are exact in fp64: one rounding, as re*re + im*im
+    float mag = (float)__dsqrt_rn(s);
+    float sq = mag * mag;
+    return sq * inv_fft;                       // power-of-two fft length: exact scaling
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 1: MFCC + CMVN + input quantisation.  FFT 256, 32 mel filters (shipped configs); 64 threads = 1 clip.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KWS_FFT = 256;
+constexpr int KWS_NC = 128;        // complex FFT size
+constexpr int KWS_NBINS = 129;
+constexpr int KWS_NF = 32;         // mel filters
+constexpr int KWS_MAXF = 52;       // frames per clip supported by the lane=frame stages
+constexpr int KWS_MAXCEP = 17;     // DCT only produces outputs 0..N/2 (fast-dct-fft.cpp:71)
+constexpr int KWS_MELS = KWS_NF + 1;   // padded row stride of the log-mel buffer
+
+template <int CHP>   // frame PAIRS per chunk
+struct MfccSmem {
+    static constexpr int CHF = 2 * CHP;
+    float z[2][KWS_FFT];                 // per half-wave: pre-emphasised frame, then the in-place complex FFT
+    float p[KWS_NBINS * CHF];            // power spectrum [bin][frame in chunk]; later the padded CMVN matrix
+    float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
+    float mfcc[KWS_MAXF * KWS_MAXCEP];   // cepstra before CMVN [frame][coef] (row stride = n_cepstral)
+    float energy[KWS_MAXF];
+};
+
+template <int CHP, bool F32IN>   // F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM
+__global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
+                                                            float *__restrict__ features, int8_t *__restrict__ q_out,
+                                                            float in_scale, int in_zp)
+{
+    constexpr int CHF = 2 * CHP;
+    __shared__ MfccSmem<CHP> sm;
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, t = lane & 31;
+
+    // ---- per-lane twiddles, fixed for the whole launch -------------------------------------------------
+    const cf tw0 = to_cf(P.tw[0]);
+    const int k01 = t & 1, g01 = t >> 1;
+    const int n0 = (g01 >> 2) + 4 * (g01 & 3);            // digit-reversed input base of this lane's radix-4 group
+    const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
+    const int K2 = t & 7, G2 = t >> 3;
+    const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
+    const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
+    const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
+    const int nfr = P.n_frames, ncep = P.n_cepstral;
+    const int n_pairs = (nfr + 1) >> 1;
+    float *zb = sm.z[half];
+
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+        const int16_t *x = (const int16_t *)pcm_v + (size_t)clip * P.n_samples;
+        const float *xf = (const float *)pcm_v + (size_t)clip * P.n_samples;
+
+        for (int pair0 = 0; pair0 < n_pairs; pair0 += CHP) {
+            const int pair1 = min(pair0 + CHP, n_pairs);
+            for (int pr = pair0; pr < pair1; ++pr) {
+                // ---- load 8 samples/lane (16 B, coalesced: 32 lanes = the 256 used samples of a frame) -----
+                const int f = 2 * pr + half;
+                const int fc = min(f, nfr - 1);            // tail pair: second half recomputes the last frame
+                const int s0 = fc * P.frame_stride + 8 * t;
+                // x[n-1] for the first of the 8 samples; wraps to x[N-1] at n = 0 (processing.hpp:68, 104-106)
+                const int ip = (s0 == 0) ? (P.n_samples - 1) : (s0 - 1);
+                float y[8];
+                if (F32IN) {
+                    const float4 r0 = *(const float4 *)(xf + s0), r1 = *(const float4 *)(xf + s0 + 4);
+                    const float v[8] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
+                    float prev = xf[ip];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float pl = P.pre_cof * prev;                                   // cof * prev, then subtract
+                        y[j] = v[j] - pl;
+                        prev = v[j];
+                    }
+                } else {
+                    const int4 raw = *(const int4 *)(x + s0);
+                    float prev = (float)x[ip] * (1.0f / 32768.0f);
+                    const int w[4] = { raw.x, raw.y, raw.z, raw.w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);   // numpy::int16_to_float
+                        float hi = (float)(short)(w[j] >> 16) * (1.0f / 32768.0f);
+                        float pl = P.pre_cof * prev;
+                        y[2 * j] = lo - pl;
+                        float ph = P.pre_cof * lo;
+                        y[2 * j + 1] = hi - ph;
+                        prev = hi;
+                    }
+                }
+                *(float4 *)(zb + 8 * t) = make_float4(y[0], y[1], y[2], y[3]);
+                *(float4 *)(zb + 8 * t + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                WAVE_SYNC();
+
+                // ---- kf_bfly2 (m=1) fused with kf_bfly4 (m=2): kiss_fft.cpp:232-296 levels 4 and 3 ---------
+                cf u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cf a = ld_cf(zb, n0 + 16 * i), b = ld_cf(zb, n0 + 16 * i + 64);
+                    cf tt = cmul(b, tw0);
+                    u[i] = k01 ? csub(a, tt) : cadd(a, tt);
+                }
+                bfly4(u[0], u[1], u[2], u[3], a1, a2, a3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, 8 * g01 + k01 + 2 * i, u[i]);
+                WAVE_SYNC();
+                // ---- kf_bfly4 m=8, fstride=4 ----------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
+                bfly4(u[0], u[1], u[2], u[3], b1, b2, b3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, u[i]);
+                WAVE_SYNC();
+                // ---- kf_bfly4 m=32, fstride=1 ---------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, t + 32 * i);
+                bfly4(u[0], u[1], u[2], u[3], c1, c2, c3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
+                WAVE_SYNC();
+
+                // ---- kiss_fftr split (kiss_fftr.cpp:84-119) + power spectrum -------------------------------
+                const int fr = f - 2 * pair0;                 // frame slot in the chunk
+                float *pcol = sm.p + fr;
+                const bool live = f < nfr;
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;            // 1..64
+                    const cf stw = rep ? st2 : st1;
+                    cf fpk = ld_cf(zb, k), fq = ld_cf(zb, KWS_NC - k);
+                    cf fpnk; fpnk.r = fq.r; fpnk.i = -fq.i;
+                    cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    cf twv = cmul(f2k, stw);
+                    cf lo, hi;
+                    lo.r = (f1k.r + twv.r) * 0.5f;             // HALF_OF
+                    lo.i = (f1k.i + twv.i) * 0.5f;
+                    hi.r = (f1k.r - twv.r) * 0.5f;
+                    hi.i = (twv.i - f1k.i) * 0.5f;
+                    if (live) {
+                        if (k != KWS_NC / 2) pcol[k * CHF] = bin_power(lo, P.inv_fft);   // k == 64: overwritten by the
+                        pcol[(KWS_NC - k) * CHF] = bin_power(hi, P.inv_fft);            // "ncfft-k" store
+                    }
+                }
+                if (t == 0 && live) {
+                    cf d = ld_cf(zb, 0);
+                    cf dc, ny;
+                    dc.r = d.r + d.i; dc.i = 0.0f;
+                    ny.r = d.r - d.i; ny.i = 0.0f;
+                    pcol[0] = bin_power(dc, P.inv_fft);
+                    pcol[KWS_NC * CHF] = bin_power(ny, P.inv_fft);
+                }
+                WAVE_SYNC();
+            }
+
+            // ---- per chunk: frame energy (sequential fp32 sum, numpy.hpp:88-94) -------------------------------
+            const int f_base = 2 * pair0;
+            const int nfc = min(2 * pair1, nfr) - f_base;
+            if (lane < nfc) {
+                float e = 0.0f;
+                for (int k = 0; k < KWS_NBINS; ++k) e += sm.p[k * CHF + lane];
+                if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
+                sm.energy[f_base + lane] = e;
+            }
+            // ---- mel: sparse ascending-bin gather == dot_by_row (numpy.hpp:183-211), zero_handling, log ------
+            for (int idx = lane; idx < nfc * KWS_NF; idx += KWS_WAVE) {
+                const int fr = idx >> 5, j = idx & 31;
+                const int b0 = P.filt_start[j], b1e = P.filt_start[j + 1];
+                float acc = 0.0f;
+                for (int n = b0; n < b1e; ++n) {
+                    float prod = sm.p[P.filt_bin[n] * CHF + fr] * P.filt_w[n];
+                    acc += prod;
+                }
+                if (acc == 0.0f) acc = FLT_EPSILON;                                    // functions.hpp:63-69
+                sm.mel[(f_base + fr) * KWS_MELS + j] = fast_log(acc);
+            }
+            WAVE_SYNC();
+        }
+
+        // ---- DCT-II via 32-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
+        if (lane < nfr) {
+            float v[KWS_NF];
+            const float *mrow = sm.mel + lane * KWS_MELS;
+#pragma unroll
+            for (int i = 0; i < KWS_NF; ++i) v[i] = mrow[i];
+            // even/odd reorder, then packed as 16 complex points: in[i] = v[2i], in[31-i] = v[2i+1]
+            cf F[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = q + 4 * j;                       // complex input index
+                    const int i0 = 2 * n, i1 = 2 * n + 1;          // real input indices
+                    F[4 * q + j].r = (i0 < 16) ? v[2 * i0] : v[2 * (31 - i0) + 1];
+                    F[4 * q + j].i = (i1 < 16) ? v[2 * i1] : v[2 * (31 - i1) + 1];
+                }
+            }
+            const cf d0 = to_cf(P.dct_tw[0]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bfly4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3], d0, d0, d0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+            cf R[KWS_MAXCEP];
+            R[0].r = F[0].r + F[0].i; R[0].i = 0.0f;
+            R[16].r = F[0].r - F[0].i; R[16].i = 0.0f;
+#pragma unroll
+            for (int k = 1; k <= 8; ++k) {
+                cf fpk = F[k], fpnk;
+                fpnk.r = F[16 - k].r; fpnk.i = -F[16 - k].i;
+                cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
+                if (k != 8) {
+                    R[k].r = (f1k.r + twv.r) * 0.5f;
+                    R[k].i = (f1k.i + twv.i) * 0.5f;
+                }
+                R[16 - k].r = (f1k.r - twv.r) * 0.5f;
+                R[16 - k].i = (twv.i - f1k.i) * 0.5f;
+            }
+            float *orow = sm.mfcc + lane * ncep;
+#pragma unroll
+            for (int i = 0; i < KWS_MAXCEP; ++i) {
+                if (i < ncep) {
+                    float a = R[i].r * P.dct_cos[i];
+                    float b = R[i].i * P.dct_sin[i];
+                    float d = (a + b) * 2.0f;
+                    d = d * (i == 0 ? P.dct_s0 : P.dct_s1);
+                    orow[i] = d;
+                }
+            }
+            // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
+            for (int i = KWS_MAXCEP; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * P.dct_s1;
+            orow[0] = fast_log(sm.energy[lane]);                                       // feature.hpp:425-429
+        }
+        WAVE_SYNC();
+
+        // ---- cmvnw (processing.hpp:326-389): padded matrix in LDS, then per (row, col) the reference's sums -----
+        const int prow = nfr + 2 * P.pad;
+        float *padm = sm.p;
+        for (int idx = lane; idx < prow * ncep; idx += KWS_WAVE) {
+            const int pr = idx / ncep, c = idx - pr * ncep;
+            padm[idx] = sm.mfcc[P.pad_map[pr] * ncep + c];
+        }
+        WAVE_SYNC();
+        const int win = P.win_size;
+        const float fwin = (float)win;
+        float *fout = features + (size_t)clip * (nfr * ncep);
+        for (int idx = lane; idx < nfr * ncep; idx += KWS_WAVE) {
+            const float *col = padm + idx;                       // (r + j) * ncep + c == idx + j * ncep
+            float sum = 0.0f;
+            for (int j = 0; j < win; ++j) sum += col[j * ncep];
+            const float mean = sum / fwin;
+            float sd = 0.0f;
+            for (int j = 0; j < win; ++j) {
+                float d = col[j * ncep] - mean;
+                double dd = (double)d;
+                sd = (float)__fma_rn(dd, dd, (double)sd);        // std += pow(d, 2): fp64 square-accumulate, fp32 store
+            }
+            const float dev = __fsqrt_rn(sd / fwin);
+            const float xv = sm.mfcc[idx];
+            const float o = (xv - mean) / (dev + FLT_EPSILON);
+            fout[idx] = o;
+            if (q_out) {
+                // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
+                float qv = roundf(o / in_scale) + (float)in_zp;
+                int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
+                q_out[(size_t)clip * (nfr * ncep) + idx] = (int8_t)(iv & 0xff);
+            }
+        }
+        WAVE_SYNC();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  gemmlowp / TFLite fixed-point helpers (fixedpoint.h:329-368, TFL/kernels/internal/common.h:138-162)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int srdhm(int a, int b)
+{
+    const bool overflow = (a == b) && (a == (int)0x80000000);
+    const long long ab = (long long)a * (long long)b;
+    const int nudge = ab >= 0 ? (1 << 30) : (1 - (1 << 30));
+    const int hi = (int)((ab + nudge) / (1ll << 31));          // truncating division
+    return overflow ? 0x7fffffff : hi;
+}
+__device__ __forceinline__ int rdivpot(int x, int e)
+{
+    const int mask = (int)((1ll << e) - 1);
+    const int rem = x & mask;
+    const int thr = (mask >> 1) + (x < 0 ? 1 : 0);
+    return (x >> e) + (rem > thr ? 1 : 0);
+}
+__device__ __forceinline__ int mbqm(int x, int mult, int shift)
+{
+    const int ls = shift > 0 ? shift : 0, rs = shift > 0 ? 0 : -shift;
+    return rdivpot(srdhm((int)((unsigned)x << ls), mult), rs);
+}
+__device__ __forceinline__ int sat_shl(int x, int e)
+{
+    const int thr = (int)((1u << (31 - e)) - 1);
+    if (x > thr) return 0x7fffffff;
+    if (x < -thr) return (int)0x80000000;
+    return x << e;
+}
+__device__ __forceinline__ int one_over_one_plus_x(int a)     // fixedpoint.h:842-862
+{
+    const long long sum = (long long)a + 0x7fffffffll;
+    const int half_den = (int)((sum + (sum >= 0 ? 1 : -1)) / 2);
+    int x = (int)(1515870810u + (unsigned)srdhm(half_den, -1010580540));
+    for (int i = 0; i < 3; ++i) {
+        const int hdx = srdhm(half_den, x);
+        const int one_minus = (int)((1u << 29) - (unsigned)hdx);
+        x = (int)((unsigned)x + (unsigned)sat_shl(srdhm(x, one_minus), 2));
+    }
+    return sat_shl(x, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 2: the int8 CNN.  4 waves per workgroup share the weights and the ADD look-up tables in LDS; each wave
+//  owns one clip.  conv accumulators are exact int32 (v_dot4_i32_i8); because requantisation, the folded
+//  ADD+ReLU table and the clamps are all monotonically non-decreasing, max-pooling is applied to the raw
+//  accumulators first (max commutes with a non-decreasing map), then ONE requantisation per pooled output.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KWS_NN_WAVES = 4;
+constexpr int KWS_POOL_MAX = 8;
+
+struct NnTaps {            // optional debug outputs for the parity tests (all int8, per clip)
+    int8_t *pooled;        // concatenation of every block's pooled output [pool_w][out_c]
+    int pooled_stride;
+    int8_t *fc;            // [fc_out]
+    int8_t *out_q;         // [n_labels]
+};
+
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+                                                                         float *__restrict__ scores, NnTaps taps)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- shared: weights + ADD tables of every block ---------------------------------------------------------
+    unsigned char *sp = smem_raw;
+    const int8_t *s_w[KWS_MAX_BLOCKS];
+    const int8_t *s_lut[KWS_MAX_BLOCKS];
+    int act_bytes = 0;
+    for (int b = 0; b < N.n_blocks; ++b) {
+        const KwsConvBlock &k = N.blk[b];
+        const int wbytes = k.out_c * k.taps * k.in_cpad;
+        for (int i = threadIdx.x * 4; i < wbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.w + i);
+        s_w[b] = (const int8_t *)sp;
+        sp += (wbytes + 15) & ~15;
+        const int lbytes = k.out_c * 256;
+        for (int i = threadIdx.x * 4; i < lbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.add_lut + i);
+        s_lut[b] = (const int8_t *)sp;
+        sp += lbytes;
+        const int ab = (k.in_w + k.taps) * k.in_cpad;
+        act_bytes = max(act_bytes, ab);
+    }
+    act_bytes = (act_bytes + 15) & ~15;
+    // per wave: two activation buffers (ping-pong) + a small vector for FC/softmax
+    int8_t *actA = (int8_t *)(sp + wave * (2 * act_bytes + 64 * 4));
+    int8_t *actB = actA + act_bytes;
+    int *vec = (int *)(actB + act_bytes);
+    __syncthreads();
+
+    const int F = N.n_features;
+    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+        // ---- stage the int8 input as [pad_left + t][in_cpad], padding = zero point ((x + offset) == 0) -------
+        {
+            const KwsConvBlock &k = N.blk[0];
+            const int rows = k.in_w + k.taps;
+            const int zp4 = (int)((unsigned)(k.in_zp & 0xff) * 0x01010101u);
+            for (int i = lane * 4; i < rows * k.in_cpad; i += 64 * 4) *(int *)(actA + i) = zp4;
+            WAVE_SYNC();
+            const int8_t *src = q_in + (size_t)clip * F;
+            for (int i = lane; i < k.in_w * k.in_c; i += 64) {
+                const int tt = i / k.in_c, c = i - tt * k.in_c;
+                actA[(tt + k.pad_left) * k.in_cpad + c] = src[i];
+            }
+            WAVE_SYNC();
+        }
+        int8_t *cur = actA, *nxt = actB;
+        int pooled_off = 0;
+        for (int b = 0; b < N.n_blocks; ++b) {
+            const KwsConvBlock &k = N.blk[b];
+            const bool last = (b + 1 == N.n_blocks);
+            const int nrows = last ? 0 : (N.blk[b + 1].in_w + N.blk[b + 1].taps);
+            const int ncp = last ? k.out_c : N.blk[b + 1].in_cpad;
+            const int npl = last ? 0 : N.blk[b + 1].pad_left;
+            if (!last) {
+                const int zp4 = (int)((unsigned)(N.blk[b + 1].in_zp & 0xff) * 0x01010101u);
+                for (int i = lane * 4; i < nrows * ncp; i += 64 * 4) *(int *)(nxt + i) = zp4;
+                WAVE_SYNC();
+            }
+            const int n_out = k.pool_w * k.out_c;
+            const int c4n = k.in_cpad >> 2;
+            for (int idx = lane; idx < n_out; idx += 64) {
+                const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                const int t0 = pw * k.pool_stride;
+                int acc[KWS_POOL_MAX];
+#pragma unroll
+                for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i] = 0;
+                const int *wrow = (const int *)(s_w[b] + (size_t)oc * k.taps * k.in_cpad);
+                for (int tap = 0; tap < k.taps; ++tap) {
+                    for (int c4 = 0; c4 < c4n; ++c4) {
+                        const int wv = wrow[tap * c4n + c4];
+#pragma unroll
+                        for (int i = 0; i < KWS_POOL_MAX; ++i) {
+                            if (i < k.pool) {
+                                const int xv = *(const int *)(cur + (t0 + i + tap) * k.in_cpad + 4 * c4);
+                                acc[i] = __builtin_amdgcn_sdot4(wv, xv, acc[i], false);
+                            }
+                        }
+                    }
+                }
+                int m = (int)0x80000000;
+#pragma unroll
+                for (int i = 0; i < KWS_POOL_MAX; ++i)
+                    if (i < k.pool && t0 + i < k.out_w) m = max(m, acc[i]);
+                m += k.bias_eff[oc];
+                int r = mbqm(m, k.mult[oc], k.shift[oc]) + k.out_zp;          // integer_ops/conv.h:111-116
+                r = min(max(r, k.act_min), k.act_max);
+                const int8_t o = s_lut[b][oc * 256 + (r + 128)];               // ADD(bias)+ReLU, integer_ops/add.h
+                if (last) ((int8_t *)vec)[idx] = o;
+                else nxt[(npl + pw) * ncp + oc] = o;
+                if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
+            }
+            pooled_off += n_out;
+            WAVE_SYNC();
+            int8_t *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        // ---- FULLY_CONNECTED (integer_ops/fully_connected.h:23-63): input = last pooled vector ------------------
+        const int8_t *xin = (const int8_t *)vec;
+        int logit = 0;
+        if (lane < N.fc_out) {
+            int acc = 0;
+            for (int d = 0; d < N.fc_in; ++d)
+                acc += ((int)N.fc_w[lane * N.fc_in + d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
+            acc += N.fc_bias[lane];
+            acc = mbqm(acc, N.fc_mult, N.fc_shift) + N.fc_out_zp;
+            logit = min(max(acc, N.fc_act_min), N.fc_act_max);
+        }
+        WAVE_SYNC();
+        int *lg = vec + 16;     // logits as int32, after the (<=64 byte) pooled vector
+        if (lane < N.fc_out) {
+            lg[lane] = logit;
+            if (taps.fc) taps.fc[(size_t)clip * N.fc_out + lane] = (int8_t)logit;
+        }
+        WAVE_SYNC();
+        // ---- SOFTMAX int8 -> int8 (reference/softmax.h:66-144), every lane < n_labels redundantly ---------------
+        if (lane < N.fc_out) {
+            int mx = -128;
+            for (int c = 0; c < N.fc_out; ++c) mx = max(mx, lg[c]);
+            int sum = 0;
+            for (int c = 0; c < N.fc_out; ++c) {
+                const int d = mx - lg[c];
+                if (N.sm_valid[d]) sum = (int)((unsigned)sum + (unsigned)rdivpot(N.sm_exp[d], 12));
+            }
+            const int hp1 = sum ? __clz(sum) : 32;                                  // GetReciprocal, common.h:530-546
+            const int nbits = 12 - hp1;
+            const int ssm1 = (int)(((unsigned)sum << hp1) - (1u << 31));
+            const int scale = one_over_one_plus_x(ssm1);
+            const int d = mx - logit;
+            int o = -128;
+            if (N.sm_valid[d]) {
+                const int unsat = rdivpot(srdhm(scale, N.sm_exp[d]), nbits + 31 - 8);
+                o = min(max(unsat - 128, -128), 127);
+            }
+            if (taps.out_q) taps.out_q[(size_t)clip * N.fc_out + lane] = (int8_t)o;
+            scores[(size_t)clip * N.fc_out + lane] = (float)(o - N.out_zp) * N.out_scale;   // ei_run_classifier.h:470
+        }
+        WAVE_SYNC();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  float features -> int8 input tensor (the quantise loop of run_inference, ei_run_classifier.h:436-444)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void kws_quantize_kernel(const float *__restrict__ f, int8_t *__restrict__ q, size_t n, float scale, int zp)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float qv = roundf(f[i] / scale) + (float)zp;
+        int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
+        q[i] = (int8_t)(iv & 0xff);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  synthetic clips, generated in HBM (include/kws/kws_synth.h; bit-identical to the host generator)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void kws_synth_kernel(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out)
+{
+    for (uint32_t c = blockIdx.y; c < n_clips; c += gridDim.y) {
+        const kws_synth_params p = kws_synth_clip_params(seed, first_clip + c);
+        for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < clip_len; n += gridDim.x * blockDim.x)
+            out[(size_t)c * clip_len + n] = kws_synth_sample(&p, n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  launchers (called from kws_api.cpp)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KWS_CHP = 9;
+
+int kws_mfcc_p_capacity(void) { return KWS_NBINS * 2 * KWS_CHP; }   // floats available for the padded CMVN matrix
+
+int kws_launch_mfcc(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
+                    float in_scale, int in_zp, int grid_cap, hipStream_t stream)
+{
+    if (n_clips <= 0) return 0;
+    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
+    if (pcm_is_float)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, features,
+                           q_out, in_scale, in_zp);
+    else
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, false>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, features,
+                           q_out, in_scale, in_zp);
+    return (int)hipGetLastError();
+}
+
+size_t kws_nn_smem_bytes(const KwsNnPlan &N)
+{
+    size_t s = 0;
+    int act = 0;
+    for (int b = 0; b < N.n_blocks; ++b) {
+        const KwsConvBlock &k = N.blk[b];
+        s += ((size_t)k.out_c * k.taps * k.in_cpad + 15) & ~(size_t)15;
+        s += (size_t)k.out_c * 256;
+        const int ab = (k.in_w + k.taps) * k.in_cpad;
+        act = ab > act ? ab : act;
+    }
+    act = (act + 15) & ~15;
+    return s + (size_t)KWS_NN_WAVES * (2 * act + 64 * 4);
+}
+
+int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
+                  int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream)
+{
+    if (n_clips <= 0) return 0;
+    int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
+    if (grid > grid_cap) grid = grid_cap;
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
+    hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), kws_nn_smem_bytes(N), stream, N, q_in,
+                       n_clips, scores, taps);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(kws_quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f, q, n, scale, zp);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream)
+{
+    if (n_clips == 0) return 0;
+    dim3 grid((clip_len + 255) / 256, n_clips < 65535u ? n_clips : 65535u);
+    hipLaunchKernelGGL(kws_synth_kernel, grid, dim3(256), 0, stream, seed, first_clip, n_clips, clip_len, out);
+    return (int)hipGetLastError();
+}

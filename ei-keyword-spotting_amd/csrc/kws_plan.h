@@ -1,0 +1,71 @@
+// kws_plan.h -- host <-> device execution plans (internal to libkws_mi355x.so).
+//
+// All tables are built ONCE on the host, in the same precision and order the reference builds them per clip
+// ("batch-first, table-once, fused"), uploaded to HBM, and referenced from these structs.
+#pragma once
+#include <stdint.h>
+
+struct KwsDspPlan {
+    int n_samples;      // EI_CLASSIFIER_RAW_SAMPLE_COUNT (16000)
+    int n_frames;       // speechpy numframes (49)                      processing.hpp:260-284
+    int frame_stride;   // samples (320)
+    int frame_len;      // samples fetched per frame (320); only min(frame_len, fft_len) are used
+    int fft_len;        // 256
+    int n_bins;         // fft_len/2+1
+    int n_filters;      // 32
+    int n_cepstral;     // 13
+    int win_size;       // 101
+    int pad;            // (win_size-1)/2
+    int pre_shift;      // 1
+    float pre_cof;      // 0.98
+    float inv_fft;      // 1/fft_len (power of two => exact)
+    float dct_s0, dct_s1;   // sqrtf(1/(4N)), sqrtf(1/(2N))                numpy.hpp:392-397
+    int max_nz;         // longest mel filter (non-zero taps)
+    // device tables
+    const float2 *tw;        // [fft_len/2]  kiss_fft twiddles              kiss_fft.cpp:351-357
+    const float2 *stw;       // [fft_len/4]  kiss_fftr super twiddles       kiss_fftr.cpp:52-58
+    const int *filt_start;   // [n_filters+1] CSR over the transposed filterbank, ascending bin
+    const int *filt_bin;
+    const float *filt_w;
+    const float2 *dct_tw;    // [n_filters/2]
+    const float2 *dct_stw;   // [n_filters/4]
+    const float *dct_cos;    // [n_filters/2+1] cosf((float)(i*pi/(2N)))    fast-dct-fft.cpp:71-74
+    const float *dct_sin;
+    const int *pad_map;      // [n_frames+2*pad] numpy::pad_1d_symmetric row map   numpy.hpp:479-541
+};
+
+// One "conv block" of the Edge Impulse 1-D CNN family:
+//   RESHAPE -> CONV_2D(1xK) -> RESHAPE -> ADD(bias, ReLU) -> RESHAPE -> MAX_POOL_2D(P) -> RESHAPE
+#define KWS_MAX_BLOCKS 4
+struct KwsConvBlock {
+    int in_w, in_c, in_cpad;   // time steps, channels, channels padded to a multiple of 16
+    int out_c;
+    int taps, pad_left;        // filter width, SAME padding on the left
+    int out_w;                 // conv output width (stride 1)
+    int pool, pool_stride, pool_w;   // pool window, stride, pooled width
+    int in_zp;                 // input zero point (= padding value so that (x + offset) == 0)
+    int out_zp, act_min, act_max;    // conv output zero point and clamp
+    const int8_t *w;           // [out_c][taps][in_cpad], zero padded
+    const int32_t *bias_eff;   // [out_c] bias + input_offset * sum(w)
+    const int32_t *mult;       // [out_c] per-channel quantized multiplier
+    const int32_t *shift;      // [out_c]
+    const int8_t *add_lut;     // [out_c][256] ADD(bias tensor)+ReLU folded: out = lut[c][x+128]
+};
+
+struct KwsNnPlan {
+    int n_blocks;
+    KwsConvBlock blk[KWS_MAX_BLOCKS];
+    int n_features;            // 637
+    int fc_in, fc_out;
+    int fc_in_off, fc_w_off, fc_out_zp, fc_mult, fc_shift, fc_act_min, fc_act_max;
+    const int8_t *fc_w;        // [fc_out][fc_in]
+    const int32_t *fc_bias;    // [fc_out]
+    // softmax (int8 -> int8): exp LUT indexed by (max - x) in [0,255]; 0 where diff < diff_min
+    const int32_t *sm_exp;     // [256] exp_on_negative_values(rescaled diff), Q0.31
+    const uint8_t *sm_valid;   // [256] diff >= diff_min
+    float in_scale;            // input tensor quantisation (ei_run_classifier.h:436-444)
+    int in_zp;
+    float out_scale;           // output dequantisation
+    int out_zp;
+    int n_labels;
+};

@@ -1,0 +1,115 @@
+/*
+ * ei_compat.h -- the DROP-IN boundary: the Edge Impulse C SDK classifier API, implemented by
+ * libkws_mi355x.so on an AMD MI355X instead of by the SDK's CPU code.
+ *
+ * Every declaration below replaces, with the same name, argument meaning and error behaviour, the
+ * reference interface cited next to it (paths relative to
+ * embedded-demos/stm32cubeide/nucleo-l476-keyword-spotting/ei-keyword-spotting/edge-impulse-sdk/).
+ * An application written against the SDK (e.g. L476/Core/Src/main.cpp:190-199) keeps its source: it
+ * includes this header instead of "edge-impulse-sdk/classifier/ei_run_classifier.h" and links
+ * -lkws_mi355x.  Plain C, no HIP or torch types in any signature.
+ */
+#ifndef KWS_EI_COMPAT_H
+#define KWS_EI_COMPAT_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The reference sizes ei_impulse_result_t with a compile-time constant of the exported model
+ * (model-parameters/model_metadata.h:46).  Define EI_CLASSIFIER_LABEL_COUNT before including this
+ * header to match the model you load; it defaults to the shipped no/noise/unknown/yes model. */
+#ifndef EI_CLASSIFIER_LABEL_COUNT
+#define EI_CLASSIFIER_LABEL_COUNT 4
+#endif
+#ifndef EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW
+#define EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW 4          /* model_metadata.h:66-68 */
+#endif
+
+/* porting/ei_classifier_porting.h:34-43 (+ codes < -16 added for the GPU runtime) */
+typedef enum {
+    EI_IMPULSE_OK = 0,
+    EI_IMPULSE_ERROR_SHAPES_DONT_MATCH = -1,
+    EI_IMPULSE_CANCELED = -2,
+    EI_IMPULSE_TFLITE_ERROR = -3,
+    EI_IMPULSE_DSP_ERROR = -5,
+    EI_IMPULSE_TFLITE_ARENA_ALLOC_FAILED = -6,
+    EI_IMPULSE_CUBEAI_ERROR = -7,
+    EI_IMPULSE_ALLOC_FAILED = -8,
+    KWS_ERROR_NO_MODEL = -17,          /* no model loaded (reference: model is compiled in) */
+    KWS_ERROR_UNSUPPORTED_MODEL = -18, /* graph / DSP config outside what the HIP kernels implement */
+    KWS_ERROR_HIP = -19,               /* HIP runtime error, missing device or missing code object */
+    KWS_ERROR_BAD_ARGUMENT = -20
+} EI_IMPULSE_ERROR;
+
+/* dsp/numpy_types.h:234-253 with EIDSP_SIGNAL_C_FN_POINTER=1: 16 bytes on x86-64.
+ * get_data(offset, length, out) must write `length` floats starting at sample `offset`,
+ * returns 0 on success; it is never asked for data beyond total_length. */
+typedef struct ei_signal_t {
+    int (*get_data)(size_t, size_t, float *);
+    size_t total_length;
+} signal_t;
+
+/* dsp/numpy_types.h:55-127 (ei::matrix_t data members; the C++ class adds ctor/dtor only) */
+typedef struct ei_matrix {
+    float *buffer;
+    uint32_t rows;
+    uint32_t cols;
+    bool buffer_managed_by_me;
+} ei_matrix_t;
+
+/* classifier/ei_classifier_types.h:30-52 */
+typedef struct {
+    const char *label;
+    float value;
+} ei_impulse_result_classification_t;
+
+typedef struct {
+    int sampling;
+    int dsp;
+    int classification;
+    int anomaly;
+} ei_impulse_result_timing_t;
+
+typedef struct {
+    ei_impulse_result_classification_t classification[EI_CLASSIFIER_LABEL_COUNT];
+    float anomaly;
+    ei_impulse_result_timing_t timing;
+} ei_impulse_result_t;
+
+typedef struct {
+    uint32_t buf_idx;
+    float running_sum;
+    float maf_buffer[EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW >> 1];
+} ei_impulse_maf;
+
+/* classifier/ei_run_classifier.h:650  -- DSP blocks + run_inference on one window of audio.
+ * `debug` prints the features and per-class scores through ei_printf, as the reference does. */
+EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, bool debug);
+
+/* classifier/ei_run_classifier.h:293  -- quantise, run the network, dequantise */
+EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result, bool debug);
+
+/* classifier/ei_run_classifier.h:164, 184, 134 -- continuous (sliced) mode */
+void run_classifier_init(void);
+EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t *result, bool debug);
+float run_moving_average_filter(ei_impulse_maf *maf, float classification);
+
+/* porting/ei_classifier_porting.h:45-76 -- platform hooks.  The reference requires the application
+ * to define them; this library ships weak defaults (stdout printf, CLOCK_MONOTONIC, never cancelled)
+ * that an application overrides simply by defining the symbol. */
+EI_IMPULSE_ERROR ei_run_impulse_check_canceled(void);
+EI_IMPULSE_ERROR ei_sleep(int32_t time_ms);
+uint64_t ei_read_timer_ms(void);
+uint64_t ei_read_timer_us(void);
+void ei_printf(const char *format, ...);
+void ei_printf_float(float f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+/*
+ * kws.h -- batch extension of the drop-in boundary (last row): the same hot
+ * path as run_classifier() (include/kws/ei_compat.h), for B clips resident in HBM, plus model
+ * loading (the reference compiles its model in; here it is a .kwsm blob made by tools/eon_import.py
+ * from the reference's generated MODEL/tflite-model/trained_model_compiled.cpp:70-328 and
+ * MODEL/model-parameters/model_metadata.h:38-132).
+ *
+ * Plain C ABI: pointers and sizes only.  `*_device` entry points take DEVICE pointers and a
+ * hipStream_t passed as void* (NULL = default stream) and are asynchronous; the others take host
+ * pointers and synchronise.  All return EI_IMPULSE_ERROR values (0 = EI_IMPULSE_OK).
+ */
+#ifndef KWS_H
+#define KWS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ei_compat.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kws_handle kws_handle;
+
+/* Build the execution plan for a model blob on HIP device `device` (tables are computed on the host
+ * exactly as the reference computes them per clip -- filterbank feature.hpp:54-171, twiddles
+ * kiss_fft.cpp:351-357, requantisation multipliers kernel_util_lite.cc:47-120 ... -- and uploaded once). */
+EI_IMPULSE_ERROR kws_create(const void *model_blob, size_t nbytes, int device, kws_handle **out);
+EI_IMPULSE_ERROR kws_create_from_file(const char *path, int device, kws_handle **out);
+void kws_destroy(kws_handle *h);
+const char *kws_last_error(void);          /* thread-local detail string for the last failing call */
+
+int kws_label_count(const kws_handle *h);                /* EI_CLASSIFIER_LABEL_COUNT */
+const char *kws_label(const kws_handle *h, int i);       /* ei_classifier_inferencing_categories[i] */
+int kws_feature_count(const kws_handle *h);              /* EI_CLASSIFIER_NN_INPUT_FRAME_SIZE */
+int kws_clip_samples(const kws_handle *h);               /* EI_CLASSIFIER_RAW_SAMPLE_COUNT */
+int kws_frame_count(const kws_handle *h);                /* MFCC rows (49) */
+int kws_pooled_tap_bytes(const kws_handle *h);           /* bytes/clip of the pooled-activation tap */
+
+/* The model used by the SDK-style entry points run_classifier()/run_inference().  If none was set,
+ * the first call loads the file named by the environment variable KWS_MODEL on device KWS_DEVICE (0). */
+EI_IMPULSE_ERROR kws_set_default_model(kws_handle *h);
+kws_handle *kws_default_model(void);
+
+/* ---- the hot path, batch form: replaces run_classifier() for B clips ------------------------------
+ * pcm      [B][clip_samples] int16, device
+ * scores   [B][label_count]  float, device  (classification[].value of each clip)
+ * features [B][feature_count] float, device, optional (NULL to skip): extract_mfcc_features output
+ * q_in     [B][feature_count] int8,  device, optional: the quantised input tensor              */
+EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores,
+                                                 float *features, int8_t *q_in, void *stream);
+/* host pointers; copies in, runs, copies out, synchronises */
+EI_IMPULSE_ERROR kws_run_classifier_batch(kws_handle *h, const int16_t *pcm, size_t B, float *scores,
+                                          float *features, int8_t *q_in);
+
+/* ---- the two halves, for callers that hold features already (run_inference) and for parity tests --- */
+/* extract_mfcc_features for B clips (classifier/ei_run_dsp.h:256-308) */
+EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features,
+                                               int8_t *q_in, void *stream);
+/* run_inference for B feature vectors (ei_run_classifier.h:293-493) */
+EI_IMPULSE_ERROR kws_run_inference_batch_device(kws_handle *h, const float *features, size_t B, float *scores,
+                                                void *stream);
+/* network only, from int8 input tensors; optional int8 taps (device, may be NULL):
+ *   tap_pooled [B][kws_pooled_tap_bytes]  every MAX_POOL_2D output, in graph order
+ *   tap_fc     [B][label_count]           FULLY_CONNECTED output
+ *   tap_out    [B][label_count]           SOFTMAX output                                         */
+EI_IMPULSE_ERROR kws_nn_batch_device(kws_handle *h, const int8_t *q_in, size_t B, float *scores, int8_t *tap_pooled,
+                                     int8_t *tap_fc, int8_t *tap_out, void *stream);
+EI_IMPULSE_ERROR kws_nn_batch(kws_handle *h, const int8_t *q_in, size_t B, float *scores, int8_t *tap_pooled,
+                              int8_t *tap_fc, int8_t *tap_out);
+
+/* deterministic synthetic clips generated directly in HBM (include/kws/kws_synth.h) */
+EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len,
+                                        int16_t *out, void *stream);
+
+/* device memory helpers so that a pure-C caller needs no HIP headers */
+EI_IMPULSE_ERROR kws_device_malloc(void **ptr, size_t nbytes);
+EI_IMPULSE_ERROR kws_device_free(void *ptr);
+EI_IMPULSE_ERROR kws_memcpy_h2d(void *dst, const void *src, size_t nbytes);
+EI_IMPULSE_ERROR kws_memcpy_d2h(void *dst, const void *src, size_t nbytes);
+EI_IMPULSE_ERROR kws_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

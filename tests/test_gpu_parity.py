@@ -1,0 +1,183 @@
+"""-m gpu: the HIP path (through the C ABI of libkws_mi355x.so) against the C oracle and the committed golden
+vectors.  Bar: BIT-EXACT -- MFCC features compared as uint32, int8 tensors and scores compared exactly."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from kws_testlib import GOLDEN, MODELS, ROOT, bits, special_clips
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401  (first: libamdhip64 of the torch wheel is the one the process uses)
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+@pytest.fixture(scope="module")
+def gpu476(pkg):
+    return pkg.Model(os.path.join(MODELS, "l476_no_yes.kwsm"), device=0)
+
+
+@pytest.fixture(scope="module")
+def gpu432(pkg):
+    return pkg.Model(os.path.join(MODELS, "l432_trick_or_treat.kwsm"), device=0)
+
+
+def test_native_library_is_what_runs(pkg, gpu476):
+    maps = open("/proc/self/maps").read()
+    assert "libkws_mi355x.so" in maps
+    assert gpu476.labels == ["no", "noise", "unknown", "yes"] and gpu476.n_features == 637 and gpu476.n_frames == 49
+
+
+def test_synth_generator_matches_host(pkg, oracle):
+    import torch
+    B = 37
+    t = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(5, 1000, B, 16000, t.data_ptr())
+    torch.cuda.synchronize()
+    assert (t.cpu().numpy() == oracle.synth(5, 1000, B)).all()
+
+
+def test_golden_end_to_end(gpu476, oracle):
+    g = np.load(os.path.join(GOLDEN, "e2e_l476.npz"))
+    n = int(g["clips_per_seed"])
+    k = 0
+    for seed in g["seeds"]:
+        clips = oracle.synth(int(seed), 0, n)
+        s, f, q = gpu476.run_classifier_batch(clips, want_features=True)
+        assert (bits(f) == bits(g["features"][k:k + n])).all()
+        assert (bits(s) == bits(g["scores"][k:k + n])).all()
+        k += n
+    sp = special_clips()
+    names = [str(x) for x in g["special_names"]]
+    s, f, q = gpu476.run_classifier_batch(np.stack([sp[nm] for nm in names]), want_features=True)
+    assert (bits(f) == bits(g["special_features"])).all()
+    assert (bits(s) == bits(g["special_scores"])).all()
+
+
+def test_golden_deep_taps(gpu476):
+    g = np.load(os.path.join(GOLDEN, "deep_l476.npz"))
+    for k in range(int(g["n"])):
+        p = f"c{k}_"
+        s, pooled, fc, out = gpu476.nn_batch(g[p + "q_in"])
+        assert (pooled[0][:210] == g[p + "t21"]).all()       # MAX_POOL_2D #1  [1,7,1,30]
+        assert (pooled[0][210:220] == g[p + "t27"]).all()    # MAX_POOL_2D #2  [1,1,1,10]
+        assert (fc[0] == g[p + "t29"]).all()                 # FULLY_CONNECTED
+        assert (out[0] == g[p + "t30"]).all()                # SOFTMAX
+        assert (bits(s[0]) == bits(g[p + "scores"])).all()
+
+
+@pytest.mark.parametrize("which", ["l476", "l432"])
+def test_oracle_parity_random_clips(which, gpu476, gpu432, l476, l432, oracle):
+    gm, om = (gpu476, l476) if which == "l476" else (gpu432, l432)
+    for seed, first, n in ((31, 0, 256), (32, 5000, 193), (33, 70000, 1)):
+        clips = oracle.synth(seed, first, n)
+        s, f, q = gm.run_classifier_batch(clips, want_features=True)
+        so, fo, qo = om.run_batch(clips, want_features=True)
+        assert (bits(f) == bits(fo)).all(), "%d feature words differ" % int((bits(f) != bits(fo)).sum())
+        assert (q == qo).all()
+        assert (bits(s) == bits(so)).all()
+
+
+@pytest.mark.parametrize("which", ["l476", "l432"])
+def test_nn_bit_exact_random_int8(which, gpu476, gpu432, l476, l432):
+    gm, om = (gpu476, l476) if which == "l476" else (gpu432, l432)
+    rng = np.random.default_rng(4)
+    qs = np.concatenate([rng.integers(-128, 128, (400, 637)).astype(np.int8),
+                         np.clip(rng.normal(-11, 25, (400, 637)), -128, 127).astype(np.int8),
+                         np.repeat(np.arange(-128, 128, dtype=np.int8)[:, None], 637, 1)])
+    s, pooled, fc, out = gm.nn_batch(qs)
+    for i in range(qs.shape[0]):
+        o, taps = om.nn_invoke(qs[i], taps=True)
+        assert (out[i] == o).all(), i
+        assert (fc[i] == taps[29]).all(), i
+        assert (pooled[i][:210] == taps[21]).all() and (pooled[i][210:] == taps[27]).all(), i
+        assert (bits(s[i]) == bits(om.dequantize(o))).all()
+
+
+def test_edge_batches(gpu476, l476, oracle):
+    # empty batch, batch of one, non-multiple-of-wave batch
+    s = gpu476.run_classifier_batch(np.zeros((0, 16000), np.int16))
+    assert s.shape == (0, 4)
+    for n in (1, 3, 65):
+        clips = oracle.synth(77, 0, n)
+        assert (bits(gpu476.run_classifier_batch(clips)) == bits(l476.run_batch(clips))).all()
+
+
+def test_full_size_properties(pkg, gpu476, l476, oracle):
+    """BASELINE config-2 size (65 536 clips, 2 GiB of PCM resident in HBM): size-independent properties --
+    (a) clip order does not matter (each clip is independent: permuting the batch permutes the scores),
+    (b) duplicated clips give identical rows, (c) a strided sample of rows equals the oracle bit for bit,
+    (d) scores are a valid quantised softmax (multiples of 1/256 that sum to ~1)."""
+    import torch
+    B = 65536
+    pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
+    pcm[1::2048] = pcm[0::2048]                                   # (b) duplicates
+    scores = torch.empty((B, 4), dtype=torch.float32, device="cuda:0")
+    gpu476.run_classifier_batch_device(pcm.data_ptr(), B, scores.data_ptr())
+    torch.cuda.synchronize()
+    s = scores.cpu().numpy()
+    assert (s[1::2048] == s[0::2048]).all()
+    perm = torch.randperm(B, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+    pcm2 = pcm[perm].contiguous()
+    scores2 = torch.empty_like(scores)
+    gpu476.run_classifier_batch_device(pcm2.data_ptr(), B, scores2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(scores2, scores[perm])                     # (a)
+    idx = np.arange(7, B, 997)
+    host = pcm[torch.from_numpy(idx).cuda()].cpu().numpy()
+    assert (bits(s[idx]) == bits(l476.run_batch(host))).all()     # (c)
+    assert (np.abs(s * 256 - np.round(s * 256)) == 0).all()       # (d)
+    assert (np.abs(s.sum(1) - 1.0) <= 4 / 256).all()
+
+
+def test_run_classifier_drop_in(pkg, gpu476, l476, oracle):
+    """The SDK call shape of L476/Core/Src/main.cpp:190-199: signal_t + get_data callback -> run_classifier()."""
+    gpu476.set_default()
+    clip = oracle.synth(55, 9, 1)[0]
+    calls = []
+
+    def get_data(offset, length, out):                           # main.cpp:526-531 -> numpy::int16_to_float
+        calls.append((offset, length))
+        assert offset + length <= 16000
+        seg = clip[offset:offset + length].astype(np.float32) / np.float32(32768)
+        ctypes.memmove(out, seg.ctypes.data, 4 * length)
+        return 0
+
+    cb = pkg.GET_DATA_FN(get_data)
+    sig = pkg.Signal(cb, 16000)
+    Result = pkg.result_struct(4)
+    res = Result()
+    rc = pkg.lib().run_classifier(ctypes.byref(sig), ctypes.byref(res), False)
+    assert rc == 0
+    assert sig.total_length == 16000                              # caller's struct untouched
+    got = np.float32([res.classification[i].value for i in range(4)])
+    assert [res.classification[i].label.decode() for i in range(4)] == ["no", "noise", "unknown", "yes"]
+    assert (bits(got) == bits(l476.run_batch(clip)[0])).all()
+    # error convention: get_data failure -> EI_IMPULSE_DSP_ERROR (-5); wrong window length -> -5
+    bad = pkg.GET_DATA_FN(lambda o, l, p: -7)
+    assert pkg.lib().run_classifier(ctypes.byref(pkg.Signal(bad, 16000)), ctypes.byref(res), False) == -5
+    assert pkg.lib().run_classifier(ctypes.byref(pkg.Signal(cb, 8000)), ctypes.byref(res), False) == -5
+    # run_inference on a feature matrix
+    s, f, q = gpu476.run_classifier_batch(clip, want_features=True)
+    fm = np.ascontiguousarray(f[0])
+    mat = pkg.Matrix(fm.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 1, 637, False)
+    assert pkg.lib().run_inference(ctypes.byref(mat), ctypes.byref(res), False) == 0
+    assert (np.float32([res.classification[i].value for i in range(4)]) == s[0]).all()
+    mat_bad = pkg.Matrix(fm.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 1, 600, False)
+    assert pkg.lib().run_inference(ctypes.byref(mat_bad), ctypes.byref(res), False) == -1
+
+
+def test_bad_inputs(pkg):
+    with pytest.raises(pkg.KwsError):
+        pkg.Model("/nonexistent.kwsm")
+    h = ctypes.c_void_p()
+    assert pkg.lib().kws_create(b"XXXXXXXXXXXXXXXX", 16, 0, ctypes.byref(h)) == -20

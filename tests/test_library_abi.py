@@ -1,0 +1,64 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/kws/*.h declares; no compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from kws_testlib import ROOT
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import sys
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    p = load_package()
+    if not os.path.exists(p.LIB_PATH):
+        p.build()
+    return p
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", "kws", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", src)) - {"defined", "int"}
+
+
+def test_exports_every_declared_symbol(pkg):
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    declared = _declared("kws.h") | _declared("ei_compat.h")
+    assert {"run_classifier", "run_inference", "kws_create", "kws_run_classifier_batch_device"} <= declared
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(pkg.EXPORTED_SYMBOLS) == declared
+
+
+def test_struct_layouts_match_reference_abi(pkg):
+    # signal_t 16 B {fn @0, total_length @8}; ei_impulse_result_t (4 labels) 88 B,
+    # classification[i] @16i (label @0, value @8), anomaly @64, timing @68
+    assert ctypes.sizeof(pkg.Signal) == 16 and pkg.Signal.total_length.offset == 8
+    R = pkg.result_struct(4)
+    assert ctypes.sizeof(R) == 88 and R.anomaly.offset == 64 and R.timing.offset == 68
+    R3 = pkg.result_struct(3)
+    assert R3.anomaly.offset == 48 and R3.timing.offset == 52
+    assert ctypes.sizeof(pkg.Matrix) == 24
+
+
+def test_fails_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.KwsError) as e:
+        pkg.Model(pkg.DEFAULT_MODEL)
+    assert e.value.code == -19          # KWS_ERROR_HIP: no CPU fallback
+
+
+def test_moving_average_filter(pkg):
+    # ei_run_classifier.h:134-145 with EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW = 4 (2-tap)
+    class Maf(ctypes.Structure):
+        _fields_ = [("buf_idx", ctypes.c_uint32), ("running_sum", ctypes.c_float), ("maf_buffer", ctypes.c_float * 2)]
+    m = Maf()
+    L = pkg.lib()
+    outs = [L.run_moving_average_filter(ctypes.byref(m), v) for v in (1.0, 0.5, 0.0, 0.25)]
+    assert outs == [0.5, 0.75, 0.25, 0.125]
