@@ -343,7 +343,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 double dd = (double)d;
                 sd = (float)__fma_rn(dd, dd, (double)sd);        // std += pow(d, 2): fp64 square-accumulate, fp32 store
             }
-            const float dev = __fsqrt_rn(sd / fwin);
+            const float dev = sqrtf(sd / fwin);            // correctly rounded (clang expands v_sqrt_f32 + fix-up)
             const float xv = sm.mfcc[idx];
             const float o = (xv - mean) / (dev + FLT_EPSILON);
             fout[idx] = o;
