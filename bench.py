@@ -20,35 +20,57 @@ ALGO_BYTES_PER_CLIP = 16000 * 2 + 4 * 4      # int16 PCM in + C=4 f
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_worker(kind, n_clips, iters):
-    """Child process: time the CPU path on n_clips synthetic clips; prints clips/s."""
+def cpu_worker(kind, n_clips, seconds):
+    """Child process: run the CPU path over n_clips synthetic clips again and again for ~`seconds`; prints clips/s."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from kws_testlib import MODELS, Oracle, OracleModel, Reference
     o = Oracle()
     clips = o.synth(0, 0, n_clips)
-    if kind == "reference":
-        r = Reference()
-        r.time_run(clips[:8], 1)
-        dt = r.time_run(clips, iters)
-    else:
-        m = OracleModel(o, os.path.join(MODELS, "l476_no_yes.kwsm"))
-        m.time_run(clips[:8], 1)
-        dt = m.time_run(clips, iters)
-    print(n_clips * iters / dt)
+    runner = Reference() if kind == "reference" else OracleModel(o, os.path.join(MODELS, "l476_no_yes.kwsm"))
+    runner.time_run(clips[:4], 1)
+    done, spent = 0, 0.0
+    while spent < seconds:
+        spent += runner.time_run(clips, 1)
+        done += n_clips
+    print(done / spent)
 
 
-def cpu_baseline(target_seconds=12.0):
-    """The reference SDK (oracle/_ref, compiled from the unmodified sources) on every host core, one PROCESS per
-    core (the reference keeps state in globals: non-reentrant), bounded sample."""
+def usable_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            if parse:
+                quota, period = parse(open(path).read())
+            else:
+                quota = open(path).read().strip()
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / float(period))))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def cpu_baseline(seconds=8.0):
+    """The reference SDK (oracle/_ref, compiled from the unmodified sources) on the host cores, one PROCESS per core
+    (the reference keeps state in globals: non-reentrant), for a bounded time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from kws_testlib import have_reference
     kind = "reference" if have_reference() else "port"
-    cores = len(os.sched_getaffinity(0))
-    n_clips = 512
-    iters = max(1, int(target_seconds * 850 / n_clips))     # ~850-900 clips/s/core measured in the survey
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, str(n_clips), str(iters)]
+    cores = usable_cores()
+    n_clips = 64
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, str(n_clips)]
+    single = subprocess.run(cmd + ["2.0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        single = float(single.stdout.strip().splitlines()[-1])
+    except Exception:
+        single = float("nan")
     t0 = time.time()
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+    procs = [subprocess.Popen(cmd + [str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(cores)]
     rates = []
     for p in procs:
         out, _ = p.communicate()
@@ -58,9 +80,9 @@ def cpu_baseline(target_seconds=12.0):
             pass
     wall = time.time() - t0
     return {"value": round(sum(rates), 1), "unit": "clips/s", "cores": len(rates), "kind": kind,
-            "per_core": round(sum(rates) / max(1, len(rates)), 1),
-            "sample": "%d processes x %d clips x %d passes of run_classifier() on seed-0 synthetic clips (%.1f s wall)"
-                      % (len(rates), n_clips, iters, wall)}
+            "per_core": round(sum(rates) / max(1, len(rates)), 1), "single_process": round(single, 1),
+            "sample": "%d concurrent processes, each looping run_classifier() over %d seed-0 synthetic clips for %.0f s "
+                      "(%.1f s wall incl. start-up)" % (len(rates), n_clips, seconds, wall)}
 
 
 def main():
@@ -71,10 +93,10 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="clips per GPU per step")
     ap.add_argument("--model", default=os.path.join(ROOT, "models", "l476_no_yes.kwsm"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-worker", nargs=3, metavar=("KIND", "N_CLIPS", "ITERS"))
+    ap.add_argument("--cpu-worker", nargs=3, metavar=("KIND", "N_CLIPS", "SECONDS"))
     a = ap.parse_args()
     if a.cpu_worker:
-        cpu_worker(a.cpu_worker[0], int(a.cpu_worker[1]), int(a.cpu_worker[2]))
+        cpu_worker(a.cpu_worker[0], int(a.cpu_worker[1]), float(a.cpu_worker[2]))
         return
 
     rank = int(os.environ.get("RANK", 0))
