@@ -192,3 +192,22 @@ class Model:
 
 def synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream=None):
     _check(lib().kws_synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream))
+
+
+# ---- multi-GPU: embarrassingly parallel sharding + the one collective of the path ---------------------------
+def shard_first_clip(rank, clips_per_rank):
+    """Rank r owns the contiguous block of clips [r*B, (r+1)*B)."""
+    return rank * clips_per_rank
+
+
+def all_gather_scores(local_scores, world_size):
+    """All-gather the per-clip scores [B][C] of every rank into [world*B][C] (rank-major = global clip order).
+    Works with any torch.distributed backend: "nccl" (= RCCL over xGMI) on the GPUs, "gloo" in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return local_scores
+    out = torch.empty((world_size * local_scores.shape[0], local_scores.shape[1]), dtype=local_scores.dtype,
+                      device=local_scores.device)
+    dist.all_gather_into_tensor(out, local_scores.contiguous())
+    return out
