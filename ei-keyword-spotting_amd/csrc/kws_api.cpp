@@ -30,7 +30,11 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
 size_t kws_nn_smem_bytes(const KwsNnPlan &N);
-int kws_mfcc_p_capacity(void);
+int kws_launch_mfcc_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
+                         int in_zp, int grid_cap, long long *prof_out, hipStream_t stream);
+int kws_mfcc_max_prow(void);
+int kws_mfcc_max_nz(void);
+int kws_mfcc_cmvn_rows(void);
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -435,7 +439,8 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
                     c.fft_length, c.num_filters);
     if (frame_len < c.fft_length || c.pre_shift != 1 || (c.win_size & 1) == 0 || nfr < 1 || nfr > 52 ||
         c.num_cepstral < 1 || c.num_cepstral > c.num_filters || (stride * 2) % 16 != 0 || (P.n_samples * 2) % 16 != 0 ||
-        (nfr - 1) * stride + c.fft_length > P.n_samples || (nfr + 2 * P.pad) * c.num_cepstral > kws_mfcc_p_capacity() ||
+        (nfr - 1) * stride + c.fft_length > P.n_samples || nfr + 2 * P.pad > kws_mfcc_max_prow() || c.win_size < kws_mfcc_cmvn_rows() ||
+        nfr > 4 * kws_mfcc_cmvn_rows() ||
         (size_t)nfr * c.num_cepstral != m.nn_input_frame_size)
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC framing outside the kernel's limits (frames %d, frame_len %d, stride %d, "
                     "cepstra %d, win %d, shift %d)", nfr, frame_len, stride, c.num_cepstral, c.win_size, c.pre_shift);
@@ -466,6 +471,8 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     }
     fstart[N] = (int)fbin.size();
     P.max_nz = max_nz;
+    if (max_nz > kws_mfcc_max_nz())
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "mel filter with %d taps (kernel keeps at most %d in registers)", max_nz, kws_mfcc_max_nz());
     std::vector<int> pmap;
     h_pad_map(nfr, P.pad, pmap);
 
@@ -771,6 +778,15 @@ EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm
     if (!h || !pcm || !features) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     return mfcc_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
+}
+
+// development aid (not in the public headers): per-phase shader-clock totals of workgroup 0
+EI_IMPULSE_ERROR kws_dev_mfcc_phase_profile(kws_handle *h, const int16_t *pcm, size_t B, float *features, int8_t *q_in, long long *prof_dev)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = kws_launch_mfcc_prof(h->dsp, pcm, (int)B, features, q_in, h->nn.in_scale, h->nn.in_zp, grid_cap_mfcc(h), prof_dev, nullptr);
+    if (rc) return fail(KWS_ERROR_HIP, "launch failed");
+    return EI_IMPULSE_OK;
 }
 
 EI_IMPULSE_ERROR kws_nn_batch_device(kws_handle *h, const int8_t *q_in, size_t B, float *scores, int8_t *tap_pooled, int8_t *tap_fc,

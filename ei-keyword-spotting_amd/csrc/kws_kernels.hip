@@ -104,27 +104,59 @@ constexpr int KWS_MAXF = 52;       // frames per clip supported by the lane=fram
 constexpr int KWS_MAXCEP = 17;     // DCT only produces outputs 0..N/2 (fast-dct-fft.cpp:71)
 constexpr int KWS_MELS = KWS_NF + 1;   // padded row stride of the log-mel buffer
 
+constexpr int KWS_MAXNZ = 12;      // longest mel filter kept in registers
+constexpr int KWS_MAXPROW = 256;   // rows of the symmetric-padded CMVN matrix (n_frames + win_size - 1)
+constexpr int KWS_CR = 13;         // CMVN: consecutive rows owned by one lane
+
 template <int CHP>   // frame PAIRS per chunk
 struct MfccSmem {
     static constexpr int CHF = 2 * CHP;
     float z[2][KWS_FFT];                 // per half-wave: pre-emphasised frame, then the in-place complex FFT
-    float p[KWS_NBINS * CHF];            // power spectrum [bin][frame in chunk]; later the padded CMVN matrix
+    float p[KWS_NBINS * CHF];            // power spectrum [bin][frame in chunk]
     float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
     float mfcc[KWS_MAXF * KWS_MAXCEP];   // cepstra before CMVN [frame][coef] (row stride = n_cepstral)
     float energy[KWS_MAXF];
+    int map[KWS_MAXPROW];                // numpy::pad_1d_symmetric row map (numpy.hpp:479-541)
 };
 
-template <int CHP, bool F32IN>   // F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM
+// one frame pair's worth of samples for this lane: 8 samples + the sample before them
+template <bool F32IN> struct RawSamples;
+template <> struct RawSamples<false> { int4 v; short prev; };
+template <> struct RawSamples<true> { float4 v0, v1; float prev; };
+
+template <bool F32IN>
+__device__ __forceinline__ RawSamples<F32IN> fetch_samples(const void *clip_base, int s0, int n_samples)
+{
+    // x[n-1] for the first of the 8 samples; wraps to x[N-1] at n = 0 (processing.hpp:68, 104-106)
+    const int ip = (s0 == 0) ? (n_samples - 1) : (s0 - 1);
+    RawSamples<F32IN> r;
+    if constexpr (F32IN) {
+        const float *xf = (const float *)clip_base;
+        r.v0 = *(const float4 *)(xf + s0);
+        r.v1 = *(const float4 *)(xf + s0 + 4);
+        r.prev = xf[ip];
+    } else {
+        const int16_t *x = (const int16_t *)clip_base;
+        r.v = *(const int4 *)(x + s0);
+        r.prev = x[ip];
+    }
+    return r;
+}
+
+// PROF: development aid -- per-phase shader-clock totals of block 0 are written to prof_out (tools/gpu_phase_profile.py)
+#define KWS_NPHASE 10
+#define PH(i) do { if (PROF) { long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
+template <int CHP, bool F32IN, bool PROF = false>   // F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM
 __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
                                                             float *__restrict__ features, int8_t *__restrict__ q_out,
-                                                            float in_scale, int in_zp)
+                                                            float in_scale, int in_zp, long long *prof_out = nullptr)
 {
     constexpr int CHF = 2 * CHP;
     __shared__ MfccSmem<CHP> sm;
     const int lane = threadIdx.x;
     const int half = lane >> 5, t = lane & 31;
 
-    // ---- per-lane twiddles, fixed for the whole launch -------------------------------------------------
+    // ---- per-lane constants, fixed for the whole launch --------------------------------------------------
     const cf tw0 = to_cf(P.tw[0]);
     const int k01 = t & 1, g01 = t >> 1;
     const int n0 = (g01 >> 2) + 4 * (g01 & 3);            // digit-reversed input base of this lane's radix-4 group
@@ -135,26 +167,42 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
     const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
     const int nfr = P.n_frames, ncep = P.n_cepstral;
     const int n_pairs = (nfr + 1) >> 1;
+    const int prow = nfr + 2 * P.pad;
     float *zb = sm.z[half];
+    // this lane's mel filter (filter index = lane & 31 in every pass of the mel stage): ascending-bin taps in registers
+    int fbin[KWS_MAXNZ];
+    float fwt[KWS_MAXNZ];
+    {
+        const int b0 = P.filt_start[t], b1e = P.filt_start[t + 1];
+#pragma unroll
+        for (int n = 0; n < KWS_MAXNZ; ++n) {
+            const bool on = b0 + n < b1e;
+            fbin[n] = on ? P.filt_bin[b0 + n] * CHF : -1;
+            fwt[n] = on ? P.filt_w[b0 + n] : 0.0f;
+        }
+    }
+    for (int i = lane; i < prow; i += KWS_WAVE) sm.map[i] = P.pad_map[i];
+    WAVE_SYNC();
+    long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
-        const int16_t *x = (const int16_t *)pcm_v + (size_t)clip * P.n_samples;
-        const float *xf = (const float *)pcm_v + (size_t)clip * P.n_samples;
+        const void *xbase = F32IN ? (const void *)((const float *)pcm_v + (size_t)clip * P.n_samples)
+                                  : (const void *)((const int16_t *)pcm_v + (size_t)clip * P.n_samples);
+        // software prefetch: the samples of pair p+1 are requested before pair p is transformed
+        RawSamples<F32IN> nxt = fetch_samples<F32IN>(xbase, min(half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
 
         for (int pair0 = 0; pair0 < n_pairs; pair0 += CHP) {
             const int pair1 = min(pair0 + CHP, n_pairs);
             for (int pr = pair0; pr < pair1; ++pr) {
-                // ---- load 8 samples/lane (16 B, coalesced: 32 lanes = the 256 used samples of a frame) -----
+                // ---- 8 samples/lane (16 B, coalesced: 32 lanes = the 256 samples of a frame that rfft keeps) -----
                 const int f = 2 * pr + half;
-                const int fc = min(f, nfr - 1);            // tail pair: second half recomputes the last frame
-                const int s0 = fc * P.frame_stride + 8 * t;
-                // x[n-1] for the first of the 8 samples; wraps to x[N-1] at n = 0 (processing.hpp:68, 104-106)
-                const int ip = (s0 == 0) ? (P.n_samples - 1) : (s0 - 1);
+                const RawSamples<F32IN> cur = nxt;
+                if (pr + 1 < n_pairs)
+                    nxt = fetch_samples<F32IN>(xbase, min(f + 2, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
                 float y[8];
-                if (F32IN) {
-                    const float4 r0 = *(const float4 *)(xf + s0), r1 = *(const float4 *)(xf + s0 + 4);
-                    const float v[8] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
-                    float prev = xf[ip];
+                if constexpr (F32IN) {
+                    const float v[8] = { cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w };
+                    float prev = cur.prev;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         float pl = P.pre_cof * prev;                                   // cof * prev, then subtract
@@ -162,23 +210,23 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                         prev = v[j];
                     }
                 } else {
-                    const int4 raw = *(const int4 *)(x + s0);
-                    float prev = (float)x[ip] * (1.0f / 32768.0f);
-                    const int w[4] = { raw.x, raw.y, raw.z, raw.w };
+                    float prev = (float)cur.prev * (1.0f / 32768.0f);
+                    const int w[4] = { cur.v.x, cur.v.y, cur.v.z, cur.v.w };
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float lo = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);   // numpy::int16_to_float
                         float hi = (float)(short)(w[j] >> 16) * (1.0f / 32768.0f);
                         float pl = P.pre_cof * prev;
                         y[2 * j] = lo - pl;
-                        float ph = P.pre_cof * lo;
-                        y[2 * j + 1] = hi - ph;
+                        float ph_ = P.pre_cof * lo;
+                        y[2 * j + 1] = hi - ph_;
                         prev = hi;
                     }
                 }
                 *(float4 *)(zb + 8 * t) = make_float4(y[0], y[1], y[2], y[3]);
                 *(float4 *)(zb + 8 * t + 4) = make_float4(y[4], y[5], y[6], y[7]);
                 WAVE_SYNC();
+                PH(0);
 
                 // ---- kf_bfly2 (m=1) fused with kf_bfly4 (m=2): kiss_fft.cpp:232-296 levels 4 and 3 ---------
                 cf u[4];
@@ -207,6 +255,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
                 WAVE_SYNC();
 
+                PH(1);
                 // ---- kiss_fftr split (kiss_fftr.cpp:84-119) + power spectrum -------------------------------
                 const int fr = f - 2 * pair0;                 // frame slot in the chunk
                 float *pcol = sm.p + fr;
@@ -238,6 +287,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                     pcol[KWS_NC * CHF] = bin_power(ny, P.inv_fft);
                 }
                 WAVE_SYNC();
+                PH(2);
             }
 
             // ---- per chunk: frame energy (sequential fp32 sum, numpy.hpp:88-94) -------------------------------
@@ -245,23 +295,30 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
             const int nfc = min(2 * pair1, nfr) - f_base;
             if (lane < nfc) {
                 float e = 0.0f;
-                for (int k = 0; k < KWS_NBINS; ++k) e += sm.p[k * CHF + lane];
+                const float *pl = sm.p + lane;
+#pragma unroll 16
+                for (int k = 0; k < KWS_NBINS - 1; ++k) e += pl[k * CHF];
+                e += pl[(KWS_NBINS - 1) * CHF];
                 if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
                 sm.energy[f_base + lane] = e;
             }
+            PH(3);
             // ---- mel: sparse ascending-bin gather == dot_by_row (numpy.hpp:183-211), zero_handling, log ------
             for (int idx = lane; idx < nfc * KWS_NF; idx += KWS_WAVE) {
-                const int fr = idx >> 5, j = idx & 31;
-                const int b0 = P.filt_start[j], b1e = P.filt_start[j + 1];
+                const int fr = idx >> 5;                                              // filter j == lane & 31 == t
                 float acc = 0.0f;
-                for (int n = b0; n < b1e; ++n) {
-                    float prod = sm.p[P.filt_bin[n] * CHF + fr] * P.filt_w[n];
-                    acc += prod;
+#pragma unroll
+                for (int n = 0; n < KWS_MAXNZ; ++n) {
+                    if (fbin[n] >= 0) {
+                        float prod = sm.p[fbin[n] + fr] * fwt[n];
+                        acc += prod;
+                    }
                 }
                 if (acc == 0.0f) acc = FLT_EPSILON;                                    // functions.hpp:63-69
-                sm.mel[(f_base + fr) * KWS_MELS + j] = fast_log(acc);
+                sm.mel[(f_base + fr) * KWS_MELS + t] = fast_log(acc);
             }
             WAVE_SYNC();
+            PH(4);
         }
 
         // ---- DCT-II via 32-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
@@ -320,42 +377,90 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
             orow[0] = fast_log(sm.energy[lane]);                                       // feature.hpp:425-429
         }
         WAVE_SYNC();
+        PH(5);
 
-        // ---- cmvnw (processing.hpp:326-389): padded matrix in LDS, then per (row, col) the reference's sums -----
-        const int prow = nfr + 2 * P.pad;
-        float *padm = sm.p;
-        for (int idx = lane; idx < prow * ncep; idx += KWS_WAVE) {
-            const int pr = idx / ncep, c = idx - pr * ncep;
-            padm[idx] = sm.mfcc[P.pad_map[pr] * ncep + c];
-        }
-        WAVE_SYNC();
+        // ---- cmvnw (processing.hpp:326-389) -------------------------------------------------------------------
+        // A lane owns column c and KWS_CR consecutive rows r0..r0+CR-1.  Row r's window is padded rows r..r+win-1, so
+        // the CR windows overlap: one walk over padded rows r0..r0+win+CR-2 feeds all CR running sums, each of which
+        // still receives its win terms in the reference's ascending order (fp32 sum; fp64 square-accumulate rounded
+        // to fp32 after every term, numpy.hpp:818-824).  13 independent chains per lane hide the fp64 latency.
         const int win = P.win_size;
         const float fwin = (float)win;
         float *fout = features + (size_t)clip * (nfr * ncep);
-        for (int idx = lane; idx < nfr * ncep; idx += KWS_WAVE) {
-            const float *col = padm + idx;                       // (r + j) * ncep + c == idx + j * ncep
-            float sum = 0.0f;
-            for (int j = 0; j < win; ++j) sum += col[j * ncep];
-            const float mean = sum / fwin;
-            float sd = 0.0f;
-            for (int j = 0; j < win; ++j) {
-                float d = col[j * ncep] - mean;
-                double dd = (double)d;
-                sd = (float)__fma_rn(dd, dd, (double)sd);        // std += pow(d, 2): fp64 square-accumulate, fp32 store
+        const int cgrp = lane >> 4, cl = lane & 15;
+        const int r0 = cgrp * KWS_CR;
+        for (int cb = 0; cb < ncep; cb += 16) {
+            const int c = cb + cl;
+            const bool act = (c < ncep) && (r0 < nfr);
+            const int cc = min(c, ncep - 1);
+            auto val = [&](int p) { return sm.mfcc[sm.map[min(r0 + p, prow - 1)] * ncep + cc]; };
+            float sum[KWS_CR], mean[KWS_CR], sd[KWS_CR];
+#pragma unroll
+            for (int r = 0; r < KWS_CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
+#pragma unroll
+            for (int p = 0; p < KWS_CR - 1; ++p) {               // ramp-up: rows 0..p have started
+                const float x = val(p);
+#pragma unroll
+                for (int r = 0; r <= p; ++r) sum[r] += x;
             }
-            const float dev = sqrtf(sd / fwin);            // correctly rounded (clang expands v_sqrt_f32 + fix-up)
-            const float xv = sm.mfcc[idx];
-            const float o = (xv - mean) / (dev + FLT_EPSILON);
-            fout[idx] = o;
-            if (q_out) {
-                // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
-                float qv = roundf(o / in_scale) + (float)in_zp;
-                int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
-                q_out[(size_t)clip * (nfr * ncep) + idx] = (int8_t)(iv & 0xff);
+            for (int p = KWS_CR - 1; p < win; ++p) {             // every row's window is open
+                const float x = val(p);
+#pragma unroll
+                for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
+            }
+#pragma unroll
+            for (int q = 0; q < KWS_CR - 1; ++q) {               // ramp-down: rows 0..q have finished
+                const float x = val(win + q);
+#pragma unroll
+                for (int r = q + 1; r < KWS_CR; ++r) sum[r] += x;
+            }
+#pragma unroll
+            for (int r = 0; r < KWS_CR; ++r) mean[r] = sum[r] / fwin;
+            auto sq_acc = [&](float x, int r) {
+                const float d = x - mean[r];
+                const double dd = (double)d;
+                sd[r] = (float)__fma_rn(dd, dd, (double)sd[r]);   // std += pow(d, 2)
+            };
+#pragma unroll
+            for (int p = 0; p < KWS_CR - 1; ++p) {
+                const float x = val(p);
+#pragma unroll
+                for (int r = 0; r <= p; ++r) sq_acc(x, r);
+            }
+            for (int p = KWS_CR - 1; p < win; ++p) {
+                const float x = val(p);
+#pragma unroll
+                for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
+            }
+#pragma unroll
+            for (int q = 0; q < KWS_CR - 1; ++q) {
+                const float x = val(win + q);
+#pragma unroll
+                for (int r = q + 1; r < KWS_CR; ++r) sq_acc(x, r);
+            }
+#pragma unroll
+            for (int r = 0; r < KWS_CR; ++r) {
+                const int row = r0 + r;
+                if (act && row < nfr) {
+                    const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
+                    const int idx = row * ncep + c;
+                    const float xv = sm.mfcc[idx];
+                    const float o = (xv - mean[r]) / (dev + FLT_EPSILON);
+                    fout[idx] = o;
+                    if (q_out) {
+                        // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
+                        float qv = roundf(o / in_scale) + (float)in_zp;
+                        int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
+                        q_out[(size_t)clip * (nfr * ncep) + idx] = (int8_t)(iv & 0xff);
+                    }
+                }
             }
         }
         WAVE_SYNC();
+        PH(7);
     }
+    if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
+        for (int i = 0; i < KWS_NPHASE; ++i) prof_out[i] = ph[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -587,7 +692,9 @@ __global__ void kws_synth_kernel(uint32_t seed, uint32_t first_clip, uint32_t n_
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KWS_CHP = 9;
 
-int kws_mfcc_p_capacity(void) { return KWS_NBINS * 2 * KWS_CHP; }   // floats available for the padded CMVN matrix
+int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
+int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
+int kws_mfcc_cmvn_rows(void) { return KWS_CR; }
 
 int kws_launch_mfcc(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                     float in_scale, int in_zp, int grid_cap, hipStream_t stream)
@@ -596,10 +703,19 @@ int kws_launch_mfcc(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int 
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
     if (pcm_is_float)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, features,
-                           q_out, in_scale, in_zp);
+                           q_out, in_scale, in_zp, (long long *)nullptr);
     else
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, false>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, features,
-                           q_out, in_scale, in_zp);
+                           q_out, in_scale, in_zp, (long long *)nullptr);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_mfcc_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
+                         int in_zp, int grid_cap, long long *prof_out, hipStream_t stream)
+{
+    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
+    hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, false, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
+                       features, q_out, in_scale, in_zp, prof_out);
     return (int)hipGetLastError();
 }
 
