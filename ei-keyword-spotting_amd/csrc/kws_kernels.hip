@@ -112,11 +112,18 @@ template <int CHP>   // frame PAIRS per chunk
 struct MfccSmem {
     static constexpr int CHF = 2 * CHP;
     float z[2][KWS_FFT];                 // per half-wave: pre-emphasised frame, then the in-place complex FFT
-    float p[KWS_NBINS * CHF];            // power spectrum [bin][frame in chunk]
+    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the cepstra
+    // before CMVN ([frame][coef], row stride n_cepstral) followed by the pad_1d_symmetric row map
+    union {
+        float p[KWS_NBINS * CHF];
+        struct {
+            float mfcc[KWS_MAXF * KWS_MAXCEP];
+            int map[KWS_MAXPROW];
+        } c;
+    } u;
     float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
-    float mfcc[KWS_MAXF * KWS_MAXCEP];   // cepstra before CMVN [frame][coef] (row stride = n_cepstral)
     float energy[KWS_MAXF];
-    int map[KWS_MAXPROW];                // numpy::pad_1d_symmetric row map (numpy.hpp:479-541)
+    static_assert(sizeof(float) * (KWS_MAXF * KWS_MAXCEP + KWS_MAXPROW) <= sizeof(float) * KWS_NBINS * CHF, "alias");
 };
 
 // one frame pair's worth of samples for this lane: 8 samples + the sample before them
@@ -157,7 +164,6 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
     const int half = lane >> 5, t = lane & 31;
 
     // ---- per-lane constants, fixed for the whole launch --------------------------------------------------
-    const cf tw0 = to_cf(P.tw[0]);
     const int k01 = t & 1, g01 = t >> 1;
     const int n0 = (g01 >> 2) + 4 * (g01 & 3);            // digit-reversed input base of this lane's radix-4 group
     const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
@@ -177,12 +183,13 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
 #pragma unroll
         for (int n = 0; n < KWS_MAXNZ; ++n) {
             const bool on = b0 + n < b1e;
-            fbin[n] = on ? P.filt_bin[b0 + n] * CHF : -1;
+            fbin[n] = on ? P.filt_bin[b0 + n] * CHF : 0;
             fwt[n] = on ? P.filt_w[b0 + n] : 0.0f;
         }
     }
-    for (int i = lane; i < prow; i += KWS_WAVE) sm.map[i] = P.pad_map[i];
-    WAVE_SYNC();
+    int mapreg[KWS_MAXPROW / KWS_WAVE];    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541), KWS_WAVE entries apart
+#pragma unroll
+    for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) mapreg[i] = (lane + i * KWS_WAVE < prow) ? P.pad_map[lane + i * KWS_WAVE] : 0;
     long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
@@ -233,8 +240,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     cf a = ld_cf(zb, n0 + 16 * i), b = ld_cf(zb, n0 + 16 * i + 64);
-                    cf tt = cmul(b, tw0);
-                    u[i] = k01 ? csub(a, tt) : cadd(a, tt);
+                    u[i] = k01 ? csub(a, b) : cadd(a, b);       // b * tw[0], tw[0] = (1, -0)
                 }
                 bfly4(u[0], u[1], u[2], u[3], a1, a2, a3);
 #pragma unroll
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 PH(1);
                 // ---- kiss_fftr split (kiss_fftr.cpp:84-119) + power spectrum -------------------------------
                 const int fr = f - 2 * pair0;                 // frame slot in the chunk
-                float *pcol = sm.p + fr;
+                float *pcol = sm.u.p + fr;
                 const bool live = f < nfr;
 #pragma unroll
                 for (int rep = 0; rep < 2; ++rep) {
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
             const int nfc = min(2 * pair1, nfr) - f_base;
             if (lane < nfc) {
                 float e = 0.0f;
-                const float *pl = sm.p + lane;
+                const float *pl = sm.u.p + lane;
 #pragma unroll 16
                 for (int k = 0; k < KWS_NBINS - 1; ++k) e += pl[k * CHF];
                 e += pl[(KWS_NBINS - 1) * CHF];
@@ -309,8 +315,8 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 float acc = 0.0f;
 #pragma unroll
                 for (int n = 0; n < KWS_MAXNZ; ++n) {
-                    if (fbin[n] >= 0) {
-                        float prod = sm.p[fbin[n] + fr] * fwt[n];
+                    if (n < P.max_nz) {                    // wave-uniform; taps beyond a filter's end have weight 0:
+                        float prod = sm.u.p[fbin[n] + fr] * fwt[n];   // power >= 0 is finite, so they add an exact +0
                         acc += prod;
                     }
                 }
@@ -322,6 +328,8 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
         }
 
         // ---- DCT-II via 32-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
+#pragma unroll
+        for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) sm.u.c.map[lane + i * KWS_WAVE] = mapreg[i];
         if (lane < nfr) {
             float v[KWS_NF];
             const float *mrow = sm.mel + lane * KWS_MELS;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 R[16 - k].r = (f1k.r - twv.r) * 0.5f;
                 R[16 - k].i = (twv.i - f1k.i) * 0.5f;
             }
-            float *orow = sm.mfcc + lane * ncep;
+            float *orow = sm.u.c.mfcc + lane * ncep;
 #pragma unroll
             for (int i = 0; i < KWS_MAXCEP; ++i) {
                 if (i < ncep) {
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
             const int c = cb + cl;
             const bool act = (c < ncep) && (r0 < nfr);
             const int cc = min(c, ncep - 1);
-            auto val = [&](int p) { return sm.mfcc[sm.map[min(r0 + p, prow - 1)] * ncep + cc]; };
+            auto val = [&](int p) { return sm.u.c.mfcc[sm.u.c.map[min(r0 + p, prow - 1)] * ncep + cc]; };
             float sum[KWS_CR], mean[KWS_CR], sd[KWS_CR];
 #pragma unroll
             for (int r = 0; r < KWS_CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
@@ -403,10 +411,14 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
 #pragma unroll
                 for (int r = 0; r <= p; ++r) sum[r] += x;
             }
-            for (int p = KWS_CR - 1; p < win; ++p) {             // every row's window is open
-                const float x = val(p);
+            {
+                float xn = val(KWS_CR - 1);
+                for (int p = KWS_CR - 1; p < win; ++p) {         // every row's window is open
+                    const float x = xn;
+                    xn = val(p + 1);                             // next term is in flight while this one is added
 #pragma unroll
-                for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
+                    for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
+                }
             }
 #pragma unroll
             for (int q = 0; q < KWS_CR - 1; ++q) {               // ramp-down: rows 0..q have finished
@@ -427,10 +439,14 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
 #pragma unroll
                 for (int r = 0; r <= p; ++r) sq_acc(x, r);
             }
-            for (int p = KWS_CR - 1; p < win; ++p) {
-                const float x = val(p);
+            {
+                float xn = val(KWS_CR - 1);
+                for (int p = KWS_CR - 1; p < win; ++p) {
+                    const float x = xn;
+                    xn = val(p + 1);
 #pragma unroll
-                for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
+                    for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
+                }
             }
 #pragma unroll
             for (int q = 0; q < KWS_CR - 1; ++q) {
@@ -444,7 +460,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 if (act && row < nfr) {
                     const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
                     const int idx = row * ncep + c;
-                    const float xv = sm.mfcc[idx];
+                    const float xv = sm.u.c.mfcc[idx];
                     const float o = (xv - mean[r]) / (dev + FLT_EPSILON);
                     fout[idx] = o;
                     if (q_out) {
