@@ -32,6 +32,7 @@ int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint3
 size_t kws_nn_smem_bytes(const KwsNnPlan &N);
 int kws_launch_mfcc_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
                          int in_zp, int grid_cap, long long *prof_out, hipStream_t stream);
+extern int kws_force_scalar_nn;
 int kws_mfcc_max_prow(void);
 int kws_mfcc_max_nz(void);
 int kws_mfcc_cmvn_rows(void);
@@ -779,6 +780,9 @@ EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm
     HIP_TRY(hipSetDevice(h->device));
     return mfcc_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
 }
+
+// development/test aid (not in the public headers): force the generic dot4 NN kernel
+void kws_dev_force_scalar_nn(int on) { kws_force_scalar_nn = on; }
 
 // development aid (not in the public headers): per-phase shader-clock totals of workgroup 0
 EI_IMPULSE_ERROR kws_dev_mfcc_phase_profile(kws_handle *h, const int16_t *pcm, size_t B, float *features, int8_t *q_in, long long *prof_dev)

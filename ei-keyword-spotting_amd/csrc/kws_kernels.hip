@@ -538,6 +538,54 @@ struct NnTaps {            // optional debug outputs for the parity tests (all i
     int8_t *out_q;         // [n_labels]
 };
 
+// FULLY_CONNECTED (integer_ops/fully_connected.h:23-63) + SOFTMAX int8->int8 (reference/softmax.h:66-144) for one clip.
+// vec: per-wave LDS scratch; bytes [0,64) hold the last pooled vector (int8), ints [16, 16+fc_out) receive the logits.
+__device__ __forceinline__ void nn_head(const KwsNnPlan &N, int *vec, int lane, int clip, float *__restrict__ scores,
+                                        const NnTaps &taps)
+{
+    // ---- FULLY_CONNECTED (integer_ops/fully_connected.h:23-63): input = last pooled vector ------------------
+    const int8_t *xin = (const int8_t *)vec;
+    int logit = 0;
+    if (lane < N.fc_out) {
+        int acc = 0;
+        for (int d = 0; d < N.fc_in; ++d)
+            acc += ((int)N.fc_w[lane * N.fc_in + d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
+        acc += N.fc_bias[lane];
+        acc = mbqm(acc, N.fc_mult, N.fc_shift) + N.fc_out_zp;
+        logit = min(max(acc, N.fc_act_min), N.fc_act_max);
+    }
+    WAVE_SYNC();
+    int *lg = vec + 16;     // logits as int32, after the (<=64 byte) pooled vector
+    if (lane < N.fc_out) {
+        lg[lane] = logit;
+        if (taps.fc) taps.fc[(size_t)clip * N.fc_out + lane] = (int8_t)logit;
+    }
+    WAVE_SYNC();
+    // ---- SOFTMAX int8 -> int8 (reference/softmax.h:66-144), every lane < n_labels redundantly ---------------
+    if (lane < N.fc_out) {
+        int mx = -128;
+        for (int c = 0; c < N.fc_out; ++c) mx = max(mx, lg[c]);
+        int sum = 0;
+        for (int c = 0; c < N.fc_out; ++c) {
+            const int d = mx - lg[c];
+            if (N.sm_valid[d]) sum = (int)((unsigned)sum + (unsigned)rdivpot(N.sm_exp[d], 12));
+        }
+        const int hp1 = sum ? __clz(sum) : 32;                                  // GetReciprocal, common.h:530-546
+        const int nbits = 12 - hp1;
+        const int ssm1 = (int)(((unsigned)sum << hp1) - (1u << 31));
+        const int scale = one_over_one_plus_x(ssm1);
+        const int d = mx - logit;
+        int o = -128;
+        if (N.sm_valid[d]) {
+            const int unsat = rdivpot(srdhm(scale, N.sm_exp[d]), nbits + 31 - 8);
+            o = min(max(unsat - 128, -128), 127);
+        }
+        if (taps.out_q) taps.out_q[(size_t)clip * N.fc_out + lane] = (int8_t)o;
+        scores[(size_t)clip * N.fc_out + lane] = (float)(o - N.out_zp) * N.out_scale;   // ei_run_classifier.h:470
+    }
+    WAVE_SYNC();
+}
+
 __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                          float *__restrict__ scores, NnTaps taps)
 {
@@ -635,48 +683,160 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
             WAVE_SYNC();
             int8_t *tmp = cur; cur = nxt; nxt = tmp;
         }
-        // ---- FULLY_CONNECTED (integer_ops/fully_connected.h:23-63): input = last pooled vector ------------------
-        const int8_t *xin = (const int8_t *)vec;
-        int logit = 0;
-        if (lane < N.fc_out) {
-            int acc = 0;
-            for (int d = 0; d < N.fc_in; ++d)
-                acc += ((int)N.fc_w[lane * N.fc_in + d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
-            acc += N.fc_bias[lane];
-            acc = mbqm(acc, N.fc_mult, N.fc_shift) + N.fc_out_zp;
-            logit = min(max(acc, N.fc_act_min), N.fc_act_max);
-        }
-        WAVE_SYNC();
-        int *lg = vec + 16;     // logits as int32, after the (<=64 byte) pooled vector
-        if (lane < N.fc_out) {
-            lg[lane] = logit;
-            if (taps.fc) taps.fc[(size_t)clip * N.fc_out + lane] = (int8_t)logit;
-        }
-        WAVE_SYNC();
-        // ---- SOFTMAX int8 -> int8 (reference/softmax.h:66-144), every lane < n_labels redundantly ---------------
-        if (lane < N.fc_out) {
-            int mx = -128;
-            for (int c = 0; c < N.fc_out; ++c) mx = max(mx, lg[c]);
-            int sum = 0;
-            for (int c = 0; c < N.fc_out; ++c) {
-                const int d = mx - lg[c];
-                if (N.sm_valid[d]) sum = (int)((unsigned)sum + (unsigned)rdivpot(N.sm_exp[d], 12));
-            }
-            const int hp1 = sum ? __clz(sum) : 32;                                  // GetReciprocal, common.h:530-546
-            const int nbits = 12 - hp1;
-            const int ssm1 = (int)(((unsigned)sum << hp1) - (1u << 31));
-            const int scale = one_over_one_plus_x(ssm1);
-            const int d = mx - logit;
-            int o = -128;
-            if (N.sm_valid[d]) {
-                const int unsat = rdivpot(srdhm(scale, N.sm_exp[d]), nbits + 31 - 8);
-                o = min(max(unsat - 128, -128), 127);
-            }
-            if (taps.out_q) taps.out_q[(size_t)clip * N.fc_out + lane] = (int8_t)o;
-            scores[(size_t)clip * N.fc_out + lane] = (float)(o - N.out_zp) * N.out_scale;   // ei_run_classifier.h:470
-        }
-        WAVE_SYNC();
+        nn_head(N, vec, lane, clip, scores, taps);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 2, matrix-core path for the shipped graph shape (two conv blocks: time<=64 x 16ch x <=8 taps -> <=32 ch,
+//  pool 7/7; then time<=16 x 32ch x <=8 taps -> <=16 ch, global pool).  The 1xK convolutions are genuine
+//  contractions: per clip  [time x (taps*16)] x [(taps*16) x out_c]  on v_mfma_i32_32x32x32_i8 (8 per clip) and
+//  [time x (taps*32)] x [(taps*32) x out_c] on v_mfma_i32_16x16x64_i8 (4 per clip).  int32 accumulation is exact, so
+//  the result is bit-identical to the reference's scalar loops whatever the summation order.  One wave per clip;
+//  weight fragments stay in registers for the whole launch; activations are read from LDS as aligned 16-byte rows.
+// ---------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int KWS_A1_ROWS = 72;    // >= 63 + 8 + 1 rows of 16 B: activations of block 1, row = time + tap
+constexpr int KWS_A2_ROWS = 24;    // >= 15 + 8 + 1 rows of 32 B
+constexpr int KWS_MFMA_POOL = 7;
+
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+                                                                              float *__restrict__ scores, NnTaps taps)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_lut1[32 * 256];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut2[16 * 256];
+    __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][KWS_A1_ROWS * 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][KWS_A2_ROWS * 32];
+    __shared__ int s_vec[KWS_NN_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+
+    for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
+    for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
+    int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
+    int *vec = s_vec[wave];
+    // padding rows/columns hold the input zero point ((x + input_offset) == 0) for the whole launch
+    {
+        const int z1 = (int)((unsigned)(k1.in_zp & 0xff) * 0x01010101u), z2 = (int)((unsigned)(k2.in_zp & 0xff) * 0x01010101u);
+        for (int i = lane; i < KWS_A1_ROWS * 4; i += 64) ((int *)act1)[i] = z1;
+        for (int i = lane; i < KWS_A2_ROWS * 8; i += 64) ((int *)act2)[i] = z2;
+    }
+    // ---- weight fragments.  k-slot (h, j) of k-step s is tap 2s+h, channel j (block 1); 16-byte group G = 4s+g of
+    //      k-step s is tap G>>1, channel half G&1 (block 2).  A and B use the same slot->k map, so any internal
+    //      ordering of k inside the instruction is irrelevant.
+    v4i wb1[4], wb2[4];
+    {
+        const int oc = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tap = 2 * s + h;
+            v4i w = { 0, 0, 0, 0 };
+            if (oc < k1.out_c && tap < k1.taps) w = *(const v4i *)(k1.w + ((size_t)oc * k1.taps + tap) * 16);
+            wb1[s] = w;
+        }
+        const int oc2 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int G = 4 * s + g, tap = G >> 1, ch = G & 1;
+            v4i w = { 0, 0, 0, 0 };
+            if (oc2 < k2.out_c && tap < k2.taps) w = *(const v4i *)(k2.w + ((size_t)oc2 * k2.taps + tap) * 32 + ch * 16);
+            wb2[s] = w;
+        }
+    }
+    const int oc1 = lane & 31, hh = lane >> 5;
+    const bool oc1_ok = oc1 < k1.out_c;
+    const int b1 = oc1_ok ? k1.bias_eff[oc1] : 0, m1 = oc1_ok ? k1.mult[oc1] : 0, sh1 = oc1_ok ? k1.shift[oc1] : 0;
+    const int oc2 = lane & 15, g4 = lane >> 4;
+    const bool oc2_ok = oc2 < k2.out_c;
+    const int b2 = oc2_ok ? k2.bias_eff[oc2] : 0, m2 = oc2_ok ? k2.mult[oc2] : 0, sh2 = oc2_ok ? k2.shift[oc2] : 0;
+    __syncthreads();
+
+    const int F = N.n_features;
+    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+        // ---- int8 input tensor [time][in_c] -> LDS rows of 16 B at row (time + pad_left) ------------------------
+        const int8_t *src = q_in + (size_t)clip * F;
+        for (int i = lane; i < F; i += 64) {
+            const int tt = i / k1.in_c, c = i - tt * k1.in_c;
+            act1[(tt + k1.pad_left) * 16 + c] = src[i];
+        }
+        WAVE_SYNC();
+        // ---- conv 1: two 32-row tiles x four k-steps -------------------------------------------------------------
+        v16i acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const v4i a0 = *(const v4i *)(act1 + (oc1 + 2 * s + hh) * 16);            // row = time (lane&31) + tap
+            const v4i a1 = *(const v4i *)(act1 + (32 + oc1 + 2 * s + hh) * 16);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wb1[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wb1[s], acc1, 0, 0, 0);
+        }
+        // ---- max-pool 7/7 on the raw accumulators (monotone requantisation, see the scalar kernel) --------------
+        // accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+        int pm[KWS_MFMA_POOL];
+#pragma unroll
+        for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = (int)0x80000000;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = mt ? acc1[r] : acc0[r];
+                const int t0 = 32 * mt + (r & 3) + 8 * (r >> 2), t1 = t0 + 4;       // time if lane>>5 is 0 / 1
+                if (t0 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t0 / KWS_MFMA_POOL] = max(pm[t0 / KWS_MFMA_POOL], hh == 0 ? v : (int)0x80000000);
+                if (t1 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t1 / KWS_MFMA_POOL] = max(pm[t1 / KWS_MFMA_POOL], hh == 1 ? v : (int)0x80000000);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = max(pm[i], __shfl_xor(pm[i], 32));
+        // requantise + ADD/ReLU table: half-wave 0 takes pooled rows 0..3, half-wave 1 rows 4..6
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pw = i + 4 * hh;
+            const int m = (hh == 0) ? pm[i] : pm[(i + 4 < KWS_MFMA_POOL) ? i + 4 : 0];
+            if (oc1_ok && pw < k1.pool_w) {
+                int rq = mbqm(m + b1, m1, sh1) + k1.out_zp;
+                rq = min(max(rq, k1.act_min), k1.act_max);
+                const int8_t o = s_lut1[oc1 * 256 + (rq + 128)];
+                act2[(pw + k2.pad_left) * 32 + oc1] = o;
+                if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pw * k1.out_c + oc1] = o;
+            }
+        }
+        WAVE_SYNC();
+        // ---- conv 2: one 16-row tile x four k-steps of 64 ----------------------------------------------------------
+        v4i c2 = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int G = 4 * s + g4;
+            const v4i a = *(const v4i *)(act2 + (oc2 + (G >> 1)) * 32 + (G & 1) * 16);  // row = time (lane&15) + tap
+            c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, wb2[s], c2, 0, 0, 0);
+        }
+        // accumulator register r of a 16x16 tile holds row 4*(lane>>4) + r, column lane&15; global max-pool over time
+        int pm2 = (int)0x80000000;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g4 + r < k2.out_w) pm2 = max(pm2, c2[r]);
+        pm2 = max(pm2, __shfl_xor(pm2, 16));
+        pm2 = max(pm2, __shfl_xor(pm2, 32));
+        if (lane < 16 && oc2_ok) {
+            int rq = mbqm(pm2 + b2, m2, sh2) + k2.out_zp;
+            rq = min(max(rq, k2.act_min), k2.act_max);
+            const int8_t o = s_lut2[oc2 * 256 + (rq + 128)];
+            ((int8_t *)vec)[oc2] = o;
+            if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + k1.pool_w * k1.out_c + oc2] = o;
+        }
+        WAVE_SYNC();
+        nn_head(N, vec, lane, clip, scores, taps);
+    }
+}
+
+// the matrix-core kernel covers this graph shape; anything else runs on kws_nn_kernel
+static bool nn_fits_mfma(const KwsNnPlan &N)
+{
+    if (N.n_blocks != 2) return false;
+    const KwsConvBlock &a = N.blk[0], &b = N.blk[1];
+    return a.in_cpad == 16 && a.taps <= 8 && a.out_c <= 32 && a.in_w <= 64 && a.pool == KWS_MFMA_POOL && a.pool_stride == KWS_MFMA_POOL &&
+           a.pool_w <= KWS_MFMA_POOL && b.in_cpad == 32 && b.taps <= 8 && b.out_c <= 16 && b.in_w <= 16 && b.pool_w == 1 &&
+           b.pool >= b.out_w && N.fc_in == b.out_c;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -750,6 +910,8 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N)
     return s + (size_t)KWS_NN_WAVES * (2 * act + 64 * 4);
 }
 
+int kws_force_scalar_nn = 0;   // tests: run the generic (dot4) kernel even when the matrix-core kernel applies
+
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream)
 {
@@ -757,6 +919,10 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
     NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
+    if (nn_fits_mfma(N) && !kws_force_scalar_nn) {
+        hipLaunchKernelGGL(kws_nn_mfma_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), kws_nn_smem_bytes(N), stream, N, q_in,
                        n_clips, scores, taps);
     return (int)hipGetLastError();

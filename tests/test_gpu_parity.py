@@ -181,3 +181,21 @@ def test_bad_inputs(pkg):
         pkg.Model("/nonexistent.kwsm")
     h = ctypes.c_void_p()
     assert pkg.lib().kws_create(b"XXXXXXXXXXXXXXXX", 16, 0, ctypes.byref(h)) == -20
+
+
+def test_generic_nn_kernel_also_bit_exact(pkg, gpu476, l476):
+    """The shipped graph runs on the matrix-core kernel; the generic (dot4) kernel that serves other graph shapes
+    must give the same bits."""
+    rng = np.random.default_rng(9)
+    qs = rng.integers(-128, 128, (300, 637)).astype(np.int8)
+    L = pkg.lib()
+    L.kws_dev_force_scalar_nn(1)
+    try:
+        s, pooled, fc, out = gpu476.nn_batch(qs)
+    finally:
+        L.kws_dev_force_scalar_nn(0)
+    s2, pooled2, fc2, out2 = gpu476.nn_batch(qs)
+    assert (pooled == pooled2).all() and (fc == fc2).all() and (out == out2).all() and (s == s2).all()
+    for i in range(0, 300, 7):
+        o, taps = l476.nn_invoke(qs[i], taps=True)
+        assert (out[i] == o).all() and (pooled[i][:210] == taps[21]).all() and (pooled[i][210:] == taps[27]).all()
