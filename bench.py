@@ -132,10 +132,10 @@ def main():
     def step(k=None):
         if k is not None:
             ev[k][0].record()
-        model.extract_mfcc_batch_device(pcm.data_ptr(), B, feats.data_ptr(), q.data_ptr(), stream)
+        model.extract_mfcc_batch_device(pcm.data_ptr(), B, feats.data_ptr(), q.data_ptr(), stream)   # extract_mfcc_features
         if k is not None:
             ev[k][1].record()
-        model.nn_batch_device(q.data_ptr(), B, scores.data_ptr(), stream)
+        model.nn_batch_device(q.data_ptr(), B, scores.data_ptr(), stream)                             # the int8 network
         if k is not None:
             ev[k][2].record()
         if world > 1:
@@ -175,10 +175,10 @@ def main():
                        "clips_per_gpu": B, "global_batch": world * B, "model": os.path.basename(a.model),
                        "parity": "bit-exact vs reference (tests/test_gpu_parity.py)",
                        "collective": "all_gather(scores) over RCCL" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "kws_mfcc_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "kws_mfcc_fused_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": None, "algorithmic_bytes_per_clip": ALGO_BYTES_PER_CLIP,
-                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), "kws_nn_kernel": round(ms_nn, 4)}},
+                         "kernel_ms": {"kws_mfcc_fused_kernel": round(ms_mfcc, 4), "kws_nn_mfma_kernel": round(ms_nn, 4)}},
             "checksum": checksum,
         }
         if cpu is not None:

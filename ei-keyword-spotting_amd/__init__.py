@@ -34,7 +34,8 @@ EXPORTED_SYMBOLS = [
     "kws_create", "kws_create_from_file", "kws_destroy", "kws_last_error", "kws_label_count", "kws_label",
     "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes", "kws_set_default_model",
     "kws_default_model", "kws_run_classifier_batch_device", "kws_run_classifier_batch",
-    "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
+    "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
+    "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
     "kws_synth_clips_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
@@ -79,6 +80,8 @@ def lib():
         L.kws_run_classifier_batch.argtypes = [vp, vp, sz, vp, vp, vp]
         L.kws_extract_mfcc_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.kws_run_inference_batch_device.argtypes = [vp, vp, sz, vp, vp]
+        L.kws_mfcc_batch_device.argtypes = [vp, vp, sz, vp, vp]
+        L.kws_cmvn_inference_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.kws_nn_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
         L.kws_nn_batch.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
@@ -182,6 +185,12 @@ class Model:
 
     def extract_mfcc_batch_device(self, pcm_ptr, B, features_ptr, q_ptr=None, stream=None):
         _check(self.L.kws_extract_mfcc_batch_device(self.h, pcm_ptr, B, features_ptr, q_ptr, stream))
+
+    def mfcc_batch_device(self, pcm_ptr, B, mfcc_ptr, stream=None):
+        _check(self.L.kws_mfcc_batch_device(self.h, pcm_ptr, B, mfcc_ptr, stream))
+
+    def cmvn_inference_batch_device(self, mfcc_ptr, B, scores_ptr, features_ptr=None, q_ptr=None, stream=None):
+        _check(self.L.kws_cmvn_inference_batch_device(self.h, mfcc_ptr, B, scores_ptr, features_ptr, q_ptr, stream))
 
     def run_inference_batch_device(self, features_ptr, B, scores_ptr, stream=None):
         _check(self.L.kws_run_inference_batch_device(self.h, features_ptr, B, scores_ptr, stream))

@@ -23,19 +23,27 @@
 #include "kws_plan.h"
 
 // launchers in kws_kernels.hip
-int kws_launch_mfcc(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
-                    float in_scale, int in_zp, int grid_cap, hipStream_t stream);
+int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
+                        int grid_cap, hipStream_t stream);
+int kws_launch_spectral_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *mfcc_out, int grid_cap, long long *prof_out,
+                             hipStream_t stream);
+int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
+                          float in_scale, int in_zp, int grid_cap, hipStream_t stream);
+int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
+                               int in_zp, int grid_cap, long long *prof_out, hipStream_t stream);
+int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
+                       float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
+                       int *ran_nn, hipStream_t stream);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
 size_t kws_nn_smem_bytes(const KwsNnPlan &N);
-int kws_launch_mfcc_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
-                         int in_zp, int grid_cap, long long *prof_out, hipStream_t stream);
 extern int kws_force_scalar_nn;
 int kws_mfcc_max_prow(void);
 int kws_mfcc_max_nz(void);
 int kws_mfcc_cmvn_rows(void);
+int kws_mfcc_max_frames(void);
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -381,7 +389,7 @@ struct kws_handle {
     int pooled_tap_bytes = 0;
     std::vector<void *> dev_allocs;
     // scratch for the combined entry points (grown on demand)
-    float *s_features = nullptr;
+    float *s_mfcc = nullptr;      // cepstra before CMVN, [B][n_features]
     int8_t *s_q = nullptr;
     size_t s_cap = 0;
     std::mutex mu;
@@ -438,7 +446,7 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     if (c.fft_length != 256 || c.num_filters != 32)
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC kernel is built for fft_length 256 / 32 filters (got %d / %d)",
                     c.fft_length, c.num_filters);
-    if (frame_len < c.fft_length || c.pre_shift != 1 || (c.win_size & 1) == 0 || nfr < 1 || nfr > 52 ||
+    if (frame_len < c.fft_length || c.pre_shift != 1 || (c.win_size & 1) == 0 || nfr < 1 || nfr > kws_mfcc_max_frames() ||
         c.num_cepstral < 1 || c.num_cepstral > c.num_filters || (stride * 2) % 16 != 0 || (P.n_samples * 2) % 16 != 0 ||
         (nfr - 1) * stride + c.fft_length > P.n_samples || nfr + 2 * P.pad > kws_mfcc_max_prow() || c.win_size < kws_mfcc_cmvn_rows() ||
         nfr > 4 * kws_mfcc_cmvn_rows() ||
@@ -737,7 +745,7 @@ void kws_destroy(kws_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void *p : h->dev_allocs) (void)hipFree(p);
-    if (h->s_features) (void)hipFree(h->s_features);
+    if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
     delete h;
 }
@@ -752,11 +760,11 @@ int kws_pooled_tap_bytes(const kws_handle *h) { return h->pooled_tap_bytes; }
 static EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B)
 {
     if (B <= h->s_cap) return EI_IMPULSE_OK;
-    if (h->s_features) (void)hipFree(h->s_features);
+    if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
-    h->s_features = nullptr; h->s_q = nullptr; h->s_cap = 0;
+    h->s_mfcc = nullptr; h->s_q = nullptr; h->s_cap = 0;
     const size_t F = h->model.nn_input_frame_size;
-    HIP_TRY(hipMalloc((void **)&h->s_features, B * F * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&h->s_mfcc, B * F * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&h->s_q, B * F));
     h->s_cap = B;
     return EI_IMPULSE_OK;
@@ -765,30 +773,82 @@ static EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B)
 static int grid_cap_mfcc(const kws_handle *h) { return h->n_cu * 8; }
 static int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 
-static EI_IMPULSE_ERROR mfcc_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s)
+// speechpy::feature::mfcc for B windows (kernel 1)
+static EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
+                                        const float *wrap, hipStream_t s)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
-    int rc = kws_launch_mfcc(h->dsp, pcm, is_float, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, grid_cap_mfcc(h), s);
+    int rc = kws_launch_spectral(P, pcm, is_float, (int)B, mfcc, wrap, grid_cap_mfcc(h), s);
     if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
+}
+
+// extract_mfcc_features + quantisation in one launch (fused kernel)
+static EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s)
+{
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
+    int rc = kws_launch_mfcc_fused(h->dsp, pcm, is_float, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s);
+    if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
+}
+
+// cmvnw + quantise + (optionally) the network (kernel 2; the generic NN kernel follows when the graph does not fit
+// the matrix-core path)
+static EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, float *features, int8_t *q, float *scores,
+                                       int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out, hipStream_t s)
+{
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    int ran_nn = 0;
+    int8_t *qq = q;
+    if (scores && !qq) qq = h->s_q;           // the generic NN kernel reads the quantised tensor from HBM
+    int rc = kws_launch_cmvn_nn(h->dsp, h->nn, mfcc, (int)B, features, qq, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out,
+                                grid_cap_nn(h), &ran_nn, s);
+    if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (scores && !ran_nn) {
+        rc = kws_launch_nn(h->nn, qq, (int)B, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out, grid_cap_nn(h), s);
+        if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *mfcc, void *stream)
+{
+    if (!h || !pcm || !mfcc) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return spectral_device(h, h->dsp, pcm, 0, B, mfcc, nullptr, (hipStream_t)stream);
+}
+
+EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfcc, size_t B, float *scores, float *features,
+                                                 int8_t *q_in, void *stream)
+{
+    if (!h || !mfcc || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    EI_IMPULSE_ERROR e = ensure_scratch(h, B);
+    if (e) return e;
+    return cmvn_nn_device(h, mfcc, B, features, q_in, scores, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features, int8_t *q_in, void *stream)
 {
     if (!h || !pcm || !features) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    return mfcc_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
+    std::lock_guard<std::mutex> lk(h->mu);
+    EI_IMPULSE_ERROR e = ensure_scratch(h, B);
+    if (e) return e;
+    return mfcc_fused_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
 }
 
 // development/test aid (not in the public headers): force the generic dot4 NN kernel
 void kws_dev_force_scalar_nn(int on) { kws_force_scalar_nn = on; }
 
-// development aid (not in the public headers): per-phase shader-clock totals of workgroup 0
-EI_IMPULSE_ERROR kws_dev_mfcc_phase_profile(kws_handle *h, const int16_t *pcm, size_t B, float *features, int8_t *q_in, long long *prof_dev)
+// development aid (not in the public headers): per-phase shader-clock totals of workgroup 0 of kernel 1
+EI_IMPULSE_ERROR kws_dev_mfcc_phase_profile(kws_handle *h, const int16_t *pcm, size_t B, float *features, long long *prof_dev)
 {
     HIP_TRY(hipSetDevice(h->device));
-    int rc = kws_launch_mfcc_prof(h->dsp, pcm, (int)B, features, q_in, h->nn.in_scale, h->nn.in_zp, grid_cap_mfcc(h), prof_dev, nullptr);
+    int rc = kws_launch_mfcc_fused_prof(h->dsp, pcm, (int)B, features, nullptr, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, prof_dev, nullptr);
     if (rc) return fail(KWS_ERROR_HIP, "launch failed");
     return EI_IMPULSE_OK;
 }
@@ -822,13 +882,12 @@ EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *p
     if (!h || !pcm || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!features || !q_in) {
-        EI_IMPULSE_ERROR e = ensure_scratch(h, B);
-        if (e) return e;
-    }
-    float *f = features ? features : h->s_features;
+    EI_IMPULSE_ERROR e = ensure_scratch(h, B);
+    if (e) return e;
+    // one fused launch for extract_mfcc_features + quantisation (the cepstra stay in LDS), then the network
+    float *f = features ? features : h->s_mfcc;
     int8_t *q = q_in ? q_in : h->s_q;
-    EI_IMPULSE_ERROR e = mfcc_device(h, pcm, 0, B, f, q, (hipStream_t)stream);
+    e = mfcc_fused_device(h, pcm, 0, B, f, q, (hipStream_t)stream);
     if (e) return e;
     return kws_nn_batch_device(h, q, B, scores, nullptr, nullptr, nullptr, stream);
 }
@@ -1001,7 +1060,7 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     if (hipMalloc((void **)&d_q, F) != hipSuccess) return alloc_fail();
     EI_IMPULSE_ERROR e = EI_IMPULSE_OK;
     if (hipMemcpy(d_x, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
-    if (!e) e = mfcc_device(h, d_x, 1, 1, d_f, d_q, nullptr);
+    if (!e) e = mfcc_fused_device(h, d_x, 1, 1, d_f, d_q, nullptr);
     if (!e && hipDeviceSynchronize() != hipSuccess) e = fail(KWS_ERROR_HIP, "MFCC kernel failed");
     if (e) { cleanup(); return e; }
     if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) { cleanup(); return EI_IMPULSE_CANCELED; }   // ei_run_classifier.h:689-691

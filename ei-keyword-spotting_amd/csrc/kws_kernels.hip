@@ -102,28 +102,19 @@ constexpr int KWS_NBINS = 129;
 constexpr int KWS_NF = 32;         // mel filters
 constexpr int KWS_MAXF = 52;       // frames per clip supported by the lane=frame stages
 constexpr int KWS_MAXCEP = 17;     // DCT only produces outputs 0..N/2 (fast-dct-fft.cpp:71)
-constexpr int KWS_MELS = KWS_NF + 1;   // padded row stride of the log-mel buffer
 
+constexpr int KWS_MELS = KWS_NF + 1;   // padded row stride of the fused kernel's log-mel buffer
 constexpr int KWS_MAXNZ = 12;      // longest mel filter kept in registers
 constexpr int KWS_MAXPROW = 256;   // rows of the symmetric-padded CMVN matrix (n_frames + win_size - 1)
 constexpr int KWS_CR = 13;         // CMVN: consecutive rows owned by one lane
 
 template <int CHP>   // frame PAIRS per chunk
-struct MfccSmem {
+struct SpectralSmem {
     static constexpr int CHF = 2 * CHP;
     float z[2][KWS_FFT];                 // per half-wave: pre-emphasised frame, then the in-place complex FFT
-    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the cepstra
-    // before CMVN ([frame][coef], row stride n_cepstral) followed by the pad_1d_symmetric row map
-    union {
-        float p[KWS_NBINS * CHF];
-        struct {
-            float mfcc[KWS_MAXF * KWS_MAXCEP];
-            int map[KWS_MAXPROW];
-        } c;
-    } u;
-    float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
+    float p[KWS_NBINS * CHF];            // power spectrum [bin][frame in chunk]
+    float mel[KWS_MAXF * KWS_NF];        // log-mel energies, element (frame f, filter j) at f*32 + (j ^ (f & 31))
     float energy[KWS_MAXF];
-    static_assert(sizeof(float) * (KWS_MAXF * KWS_MAXCEP + KWS_MAXPROW) <= sizeof(float) * KWS_NBINS * CHF, "alias");
 };
 
 // one frame pair's worth of samples for this lane: 8 samples + the sample before them
@@ -134,7 +125,8 @@ template <> struct RawSamples<true> { float4 v0, v1; float prev; };
 template <bool F32IN>
 __device__ __forceinline__ RawSamples<F32IN> fetch_samples(const void *clip_base, int s0, int n_samples)
 {
-    // x[n-1] for the first of the 8 samples; wraps to x[N-1] at n = 0 (processing.hpp:68, 104-106)
+    // x[n-1] for the first of the 8 samples; at n = 0 the reference uses the LAST sample of the window
+    // (processing.hpp:68, 104-106); the caller may override that value (continuous mode), see wrap below
     const int ip = (s0 == 0) ? (n_samples - 1) : (s0 - 1);
     RawSamples<F32IN> r;
     if constexpr (F32IN) {
@@ -153,8 +145,276 @@ __device__ __forceinline__ RawSamples<F32IN> fetch_samples(const void *clip_base
 // PROF: development aid -- per-phase shader-clock totals of block 0 are written to prof_out (tools/gpu_phase_profile.py)
 #define KWS_NPHASE 10
 #define PH(i) do { if (PROF) { long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 1: speechpy::feature::mfcc (feature.hpp:370-439) for one window per wavefront: the cepstra BEFORE cmvnw.
+//  F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM.
+//  wrap (optional, one float per window): the value the reference's pre-emphasis uses as x[-1]; NULL = x[N-1].
+// ---------------------------------------------------------------------------------------------------------
+template <int CHP, bool F32IN, bool PROF = false>
+__global__ __launch_bounds__(KWS_WAVE) void kws_spectral_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
+                                                                   float *__restrict__ mfcc_out, const float *__restrict__ wrap,
+                                                                   long long *prof_out = nullptr)
+{
+    constexpr int CHF = 2 * CHP;
+    __shared__ SpectralSmem<CHP> sm;
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, t = lane & 31;
+
+    // ---- per-lane constants, fixed for the whole launch --------------------------------------------------
+    const int k01 = t & 1, g01 = t >> 1;
+    const int n0 = (g01 >> 2) + 4 * (g01 & 3);            // digit-reversed input base of this lane's radix-4 group
+    const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
+    const int K2 = t & 7, G2 = t >> 3;
+    const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
+    const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
+    const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
+    const int nfr = P.n_frames, ncep = P.n_cepstral;
+    const int n_pairs = (nfr + 1) >> 1;
+    float *zb = sm.z[half];
+    // this lane's mel filter (filter index = lane & 31 in every pass of the mel stage): ascending-bin taps in registers
+    int fbin[KWS_MAXNZ];
+    float fwt[KWS_MAXNZ];
+    {
+        const int b0 = P.filt_start[t], b1e = P.filt_start[t + 1];
+#pragma unroll
+        for (int n = 0; n < KWS_MAXNZ; ++n) {
+            const bool on = b0 + n < b1e;
+            fbin[n] = on ? P.filt_bin[b0 + n] * CHF : 0;
+            fwt[n] = on ? P.filt_w[b0 + n] : 0.0f;
+        }
+    }
+    long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
+
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+        const void *xbase = F32IN ? (const void *)((const float *)pcm_v + (size_t)clip * P.n_samples)
+                                  : (const void *)((const int16_t *)pcm_v + (size_t)clip * P.n_samples);
+        // software prefetch: the samples of pair p+1 are requested before pair p is transformed
+        RawSamples<F32IN> nxt = fetch_samples<F32IN>(xbase, min(half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+        const bool has_wrap = wrap != nullptr;
+        const float wrapv = has_wrap ? wrap[clip] : 0.0f;
+
+        for (int pair0 = 0; pair0 < n_pairs; pair0 += CHP) {
+            const int pair1 = min(pair0 + CHP, n_pairs);
+            for (int pr = pair0; pr < pair1; ++pr) {
+                // ---- 8 samples/lane (16 B, coalesced: 32 lanes = the 256 samples of a frame that rfft keeps) -----
+                const int f = 2 * pr + half;
+                const RawSamples<F32IN> cur = nxt;
+                if (pr + 1 < n_pairs)
+                    nxt = fetch_samples<F32IN>(xbase, min(f + 2, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+                const bool first_sample = has_wrap && (min(f, nfr - 1) * P.frame_stride + 8 * t == 0);
+                float y[8];
+                if constexpr (F32IN) {
+                    const float v[8] = { cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w };
+                    float prev = first_sample ? wrapv : cur.prev;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float pl = P.pre_cof * prev;                                   // cof * prev, then subtract
+                        y[j] = v[j] - pl;
+                        prev = v[j];
+                    }
+                } else {
+                    float prev = first_sample ? wrapv : (float)cur.prev * (1.0f / 32768.0f);
+                    const int w[4] = { cur.v.x, cur.v.y, cur.v.z, cur.v.w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);   // numpy::int16_to_float
+                        float hi = (float)(short)(w[j] >> 16) * (1.0f / 32768.0f);
+                        float pl = P.pre_cof * prev;
+                        y[2 * j] = lo - pl;
+                        float ph_ = P.pre_cof * lo;
+                        y[2 * j + 1] = hi - ph_;
+                        prev = hi;
+                    }
+                }
+                *(float4 *)(zb + 8 * t) = make_float4(y[0], y[1], y[2], y[3]);
+                *(float4 *)(zb + 8 * t + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                WAVE_SYNC();
+                PH(0);
+
+                // ---- kf_bfly2 (m=1) fused with kf_bfly4 (m=2): kiss_fft.cpp:232-296 levels 4 and 3 ---------
+                cf u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cf a = ld_cf(zb, n0 + 16 * i), b = ld_cf(zb, n0 + 16 * i + 64);
+                    // b * tw[0] with tw[0] = (1, -0) returns b up to the sign of a zero, which no later operation can
+                    // observe (only sums, products, magnitudes and == 0 tests follow)
+                    u[i] = k01 ? csub(a, b) : cadd(a, b);
+                }
+                bfly4(u[0], u[1], u[2], u[3], a1, a2, a3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, 8 * g01 + k01 + 2 * i, u[i]);
+                WAVE_SYNC();
+                // ---- kf_bfly4 m=8, fstride=4 ----------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
+                bfly4(u[0], u[1], u[2], u[3], b1, b2, b3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, u[i]);
+                WAVE_SYNC();
+                // ---- kf_bfly4 m=32, fstride=1 ---------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, t + 32 * i);
+                bfly4(u[0], u[1], u[2], u[3], c1, c2, c3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
+                WAVE_SYNC();
+
+                PH(1);
+                // ---- kiss_fftr split (kiss_fftr.cpp:84-119) + power spectrum -------------------------------
+                const int fr = f - 2 * pair0;                 // frame slot in the chunk
+                float *pcol = sm.p + fr;
+                const bool live = f < nfr;
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;            // 1..64
+                    const cf stw = rep ? st2 : st1;
+                    cf fpk = ld_cf(zb, k), fq = ld_cf(zb, KWS_NC - k);
+                    cf fpnk; fpnk.r = fq.r; fpnk.i = -fq.i;
+                    cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    cf twv = cmul(f2k, stw);
+                    cf lo, hi;
+                    lo.r = (f1k.r + twv.r) * 0.5f;             // HALF_OF
+                    lo.i = (f1k.i + twv.i) * 0.5f;
+                    hi.r = (f1k.r - twv.r) * 0.5f;
+                    hi.i = (twv.i - f1k.i) * 0.5f;
+                    if (live) {
+                        if (k != KWS_NC / 2) pcol[k * CHF] = bin_power(lo, P.inv_fft);   // k == 64: overwritten by the
+                        pcol[(KWS_NC - k) * CHF] = bin_power(hi, P.inv_fft);            // "ncfft-k" store
+                    }
+                }
+                if (t == 0 && live) {
+                    cf d = ld_cf(zb, 0);
+                    cf dc, ny;
+                    dc.r = d.r + d.i; dc.i = 0.0f;
+                    ny.r = d.r - d.i; ny.i = 0.0f;
+                    pcol[0] = bin_power(dc, P.inv_fft);
+                    pcol[KWS_NC * CHF] = bin_power(ny, P.inv_fft);
+                }
+                WAVE_SYNC();
+                PH(2);
+            }
+
+            // ---- per chunk: frame energy (sequential fp32 sum, numpy.hpp:88-94) -------------------------------
+            const int f_base = 2 * pair0;
+            const int nfc = min(2 * pair1, nfr) - f_base;
+            if (lane < nfc) {
+                float e = 0.0f;
+                const float *pl = sm.p + lane;
+#pragma unroll 16
+                for (int k = 0; k < KWS_NBINS - 1; ++k) e += pl[k * CHF];
+                e += pl[(KWS_NBINS - 1) * CHF];
+                if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
+                sm.energy[f_base + lane] = e;
+            }
+            PH(3);
+            // ---- mel: sparse ascending-bin gather == dot_by_row (numpy.hpp:183-211), zero_handling, log ------
+            for (int idx = lane; idx < nfc * KWS_NF; idx += KWS_WAVE) {
+                const int fr = idx >> 5;                                              // filter j == lane & 31 == t
+                float acc = 0.0f;
+#pragma unroll
+                for (int n = 0; n < KWS_MAXNZ; ++n) {
+                    if (n < P.max_nz) {                    // wave-uniform; taps beyond a filter's end have weight 0:
+                        float prod = sm.p[fbin[n] + fr] * fwt[n];     // power >= 0 is finite, so they add an exact +0
+                        acc += prod;
+                    }
+                }
+                if (acc == 0.0f) acc = FLT_EPSILON;                                    // functions.hpp:63-69
+                const int fa = f_base + fr;
+                sm.mel[fa * KWS_NF + (t ^ (fa & 31))] = fast_log(acc);
+            }
+            WAVE_SYNC();
+            PH(4);
+        }
+
+        // ---- DCT-II via 32-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
+        if (lane < nfr) {
+            const float *mrow = sm.mel + lane * KWS_NF;
+            const int sw = lane & 31;
+            // even/odd reorder, then packed as 16 complex points: in[i] = v[2i], in[31-i] = v[2i+1]
+            cf F[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = q + 4 * j;                       // complex input index
+                    const int i0 = 2 * n, i1 = 2 * n + 1;          // real input indices
+                    const int v0 = (i0 < 16) ? 2 * i0 : 2 * (31 - i0) + 1, v1 = (i1 < 16) ? 2 * i1 : 2 * (31 - i1) + 1;
+                    F[4 * q + j].r = mrow[v0 ^ sw];
+                    F[4 * q + j].i = mrow[v1 ^ sw];
+                }
+            }
+            // first level: every twiddle is tw[0] = (1, -0): x * tw[0] == x up to the sign of a zero (see above)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cf &f0 = F[4 * q], &f1 = F[4 * q + 1], &f2 = F[4 * q + 2], &f3 = F[4 * q + 3];
+                cf s5 = csub(f0, f2);
+                f0 = cadd(f0, f2);
+                cf s3 = cadd(f1, f3), s4 = csub(f1, f3);
+                f2 = csub(f0, s3);
+                f0 = cadd(f0, s3);
+                f1.r = s5.r + s4.i; f1.i = s5.i - s4.r;
+                f3.r = s5.r - s4.i; f3.i = s5.i + s4.r;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+            float *orow = mfcc_out + (size_t)clip * (nfr * ncep) + lane * ncep;
+            auto emit = [&](int i, float re, float im) {           // v[i] = re*cos + im*sin, x2, ortho scale
+                if (i < ncep) {
+                    float a = re * P.dct_cos[i];
+                    float b = im * P.dct_sin[i];
+                    float d = (a + b) * 2.0f;
+                    orow[i] = d * (i == 0 ? P.dct_s0 : P.dct_s1);
+                }
+            };
+            // coefficient 0 is replaced by log(frame energy) (feature.hpp:425-429); bin 16 = F0.r - F0.i
+            orow[0] = fast_log(sm.energy[lane]);
+            emit(16, F[0].r - F[0].i, 0.0f);
+#pragma unroll
+            for (int k = 1; k <= 8; ++k) {
+                cf fpk = F[k], fpnk;
+                fpnk.r = F[16 - k].r; fpnk.i = -F[16 - k].i;
+                cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
+                if (k != 8) emit(k, (f1k.r + twv.r) * 0.5f, (f1k.i + twv.i) * 0.5f);
+                emit(16 - k, (f1k.r - twv.r) * 0.5f, (twv.i - f1k.i) * 0.5f);
+            }
+            // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
+            for (int i = KWS_MAXCEP; i < ncep; ++i) orow[i] = (mrow[i ^ sw] * 2.0f) * P.dct_s1;
+        }
+        WAVE_SYNC();
+        PH(5);
+    }
+    if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
+        for (int i = 0; i < KWS_NPHASE; ++i) prof_out[i] = ph[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 1+2 fused (the batch hot path): extract_mfcc_features = mfcc + cmvnw + input quantisation in ONE launch,
+//  the cepstra never leave LDS.  (kws_spectral_kernel + kws_cmvn_nn_kernel above are the same arithmetic split at the
+//  cmvnw boundary; they serve the stage API and the continuous mode, where CMVN runs over a rolling window.)
+// ---------------------------------------------------------------------------------------------------------
+template <int CHP>   // frame PAIRS per chunk
+struct MfccSmem {
+    static constexpr int CHF = 2 * CHP;
+    float z[2][KWS_FFT];                 // per half-wave: pre-emphasised frame, then the in-place complex FFT
+    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the cepstra
+    // before CMVN ([frame][coef], row stride n_cepstral) followed by the pad_1d_symmetric row map
+    union {
+        float p[KWS_NBINS * CHF];
+        struct {
+            float mfcc[KWS_MAXF * KWS_MAXCEP];
+            int map[KWS_MAXPROW];
+        } c;
+    } u;
+    float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
+    float energy[KWS_MAXF];
+    static_assert(sizeof(float) * (KWS_MAXF * KWS_MAXCEP + KWS_MAXPROW) <= sizeof(float) * KWS_NBINS * CHF, "alias");
+};
+
 template <int CHP, bool F32IN, bool PROF = false>   // F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM
-__global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
+__global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_fused_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
                                                             float *__restrict__ features, int8_t *__restrict__ q_out,
                                                             float in_scale, int in_zp, long long *prof_out = nullptr)
 {
@@ -702,6 +962,122 @@ constexpr int KWS_A1_ROWS = 72;    // >= 63 + 8 + 1 rows of 16 B: activations of
 constexpr int KWS_A2_ROWS = 24;    // >= 15 + 8 + 1 rows of 32 B
 constexpr int KWS_MFMA_POOL = 7;
 
+// per-wave constants of the matrix-core path, fixed for the whole launch
+struct NnMfmaCtx {
+    v4i wb1[4], wb2[4];          // weight fragments
+    int b1, m1, sh1, b2, m2, sh2;
+    bool oc1_ok, oc2_ok;
+};
+
+// Weight fragments: k-slot (h, j) of k-step s is tap 2s+h, channel j (block 1); the 16-byte group G = 4s+g of k-step s
+// is tap G>>1, channel half G&1 (block 2).  A and B use the same slot->k map, so the instruction's internal ordering of
+// k is irrelevant.
+__device__ __forceinline__ void nn_mfma_init(NnMfmaCtx &c, const KwsNnPlan &N, int lane)
+{
+    const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+    const int oc = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int tap = 2 * s + h;
+        v4i w = { 0, 0, 0, 0 };
+        if (oc < k1.out_c && tap < k1.taps) w = *(const v4i *)(k1.w + ((size_t)oc * k1.taps + tap) * 16);
+        c.wb1[s] = w;
+    }
+    const int oc2 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int G = 4 * s + g, tap = G >> 1, ch = G & 1;
+        v4i w = { 0, 0, 0, 0 };
+        if (oc2 < k2.out_c && tap < k2.taps) w = *(const v4i *)(k2.w + ((size_t)oc2 * k2.taps + tap) * 32 + ch * 16);
+        c.wb2[s] = w;
+    }
+    c.oc1_ok = oc < k1.out_c;
+    c.b1 = c.oc1_ok ? k1.bias_eff[oc] : 0; c.m1 = c.oc1_ok ? k1.mult[oc] : 0; c.sh1 = c.oc1_ok ? k1.shift[oc] : 0;
+    c.oc2_ok = oc2 < k2.out_c;
+    c.b2 = c.oc2_ok ? k2.bias_eff[oc2] : 0; c.m2 = c.oc2_ok ? k2.mult[oc2] : 0; c.sh2 = c.oc2_ok ? k2.shift[oc2] : 0;
+}
+
+// padding rows/columns of the activation buffers hold the input zero point ((x + input_offset) == 0) for the whole launch
+__device__ __forceinline__ void nn_mfma_fill_padding(const KwsNnPlan &N, int8_t *act1, int8_t *act2, int lane)
+{
+    const int z1 = (int)((unsigned)(N.blk[0].in_zp & 0xff) * 0x01010101u), z2 = (int)((unsigned)(N.blk[1].in_zp & 0xff) * 0x01010101u);
+    for (int i = lane; i < KWS_A1_ROWS * 4; i += 64) ((int *)act1)[i] = z1;
+    for (int i = lane; i < KWS_A2_ROWS * 8; i += 64) ((int *)act2)[i] = z2;
+}
+
+// One clip through both conv blocks, FC and softmax; act1 already holds the int8 input rows.
+__device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx &c, const KwsNnPlan &N, const int8_t *act1, int8_t *act2, int *vec,
+                                             const int8_t *s_lut1, const int8_t *s_lut2, int lane, int clip,
+                                             float *__restrict__ scores, const NnTaps &taps)
+{
+    const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+    const int oc1 = lane & 31, hh = lane >> 5, oc2 = lane & 15, g4 = lane >> 4;
+    // ---- conv 1: two 32-row tiles x four k-steps -------------------------------------------------------------
+    v16i acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const v4i a0 = *(const v4i *)(act1 + (oc1 + 2 * s + hh) * 16);            // row = time (lane&31) + tap
+        const v4i a1 = *(const v4i *)(act1 + (32 + oc1 + 2 * s + hh) * 16);
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, c.wb1[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, c.wb1[s], acc1, 0, 0, 0);
+    }
+    // ---- max-pool 7/7 on the raw accumulators (monotone requantisation, see the scalar kernel) --------------
+    // accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+    int pm[KWS_MFMA_POOL];
+#pragma unroll
+    for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = (int)0x80000000;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = mt ? acc1[r] : acc0[r];
+            const int t0 = 32 * mt + (r & 3) + 8 * (r >> 2), t1 = t0 + 4;       // time if lane>>5 is 0 / 1
+            if (t0 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t0 / KWS_MFMA_POOL] = max(pm[t0 / KWS_MFMA_POOL], hh == 0 ? v : (int)0x80000000);
+            if (t1 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t1 / KWS_MFMA_POOL] = max(pm[t1 / KWS_MFMA_POOL], hh == 1 ? v : (int)0x80000000);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = max(pm[i], __shfl_xor(pm[i], 32));
+    // requantise + ADD/ReLU table: half-wave 0 takes pooled rows 0..3, half-wave 1 rows 4..6
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pw = i + 4 * hh;
+        const int m = (hh == 0) ? pm[i] : pm[(i + 4 < KWS_MFMA_POOL) ? i + 4 : 0];
+        if (c.oc1_ok && pw < k1.pool_w) {
+            int rq = mbqm(m + c.b1, c.m1, c.sh1) + k1.out_zp;
+            rq = min(max(rq, k1.act_min), k1.act_max);
+            const int8_t o = s_lut1[oc1 * 256 + (rq + 128)];
+            act2[(pw + k2.pad_left) * 32 + oc1] = o;
+            if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pw * k1.out_c + oc1] = o;
+        }
+    }
+    WAVE_SYNC();
+    // ---- conv 2: one 16-row tile x four k-steps of 64 ----------------------------------------------------------
+    v4i c2 = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int G = 4 * s + g4;
+        const v4i a = *(const v4i *)(act2 + (oc2 + (G >> 1)) * 32 + (G & 1) * 16);  // row = time (lane&15) + tap
+        c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c.wb2[s], c2, 0, 0, 0);
+    }
+    // accumulator register r of a 16x16 tile holds row 4*(lane>>4) + r, column lane&15; global max-pool over time
+    int pm2 = (int)0x80000000;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * g4 + r < k2.out_w) pm2 = max(pm2, c2[r]);
+    pm2 = max(pm2, __shfl_xor(pm2, 16));
+    pm2 = max(pm2, __shfl_xor(pm2, 32));
+    if (lane < 16 && c.oc2_ok) {
+        int rq = mbqm(pm2 + c.b2, c.m2, c.sh2) + k2.out_zp;
+        rq = min(max(rq, k2.act_min), k2.act_max);
+        const int8_t o = s_lut2[oc2 * 256 + (rq + 128)];
+        ((int8_t *)vec)[oc2] = o;
+        if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + k1.pool_w * k1.out_c + oc2] = o;
+    }
+    WAVE_SYNC();
+    nn_head(N, vec, lane, clip, scores, taps);
+}
+
 __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                               float *__restrict__ scores, NnTaps taps)
 {
@@ -712,47 +1088,13 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
     __shared__ int s_vec[KWS_NN_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
-
     for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
     for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
     int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
-    int *vec = s_vec[wave];
-    // padding rows/columns hold the input zero point ((x + input_offset) == 0) for the whole launch
-    {
-        const int z1 = (int)((unsigned)(k1.in_zp & 0xff) * 0x01010101u), z2 = (int)((unsigned)(k2.in_zp & 0xff) * 0x01010101u);
-        for (int i = lane; i < KWS_A1_ROWS * 4; i += 64) ((int *)act1)[i] = z1;
-        for (int i = lane; i < KWS_A2_ROWS * 8; i += 64) ((int *)act2)[i] = z2;
-    }
-    // ---- weight fragments.  k-slot (h, j) of k-step s is tap 2s+h, channel j (block 1); 16-byte group G = 4s+g of
-    //      k-step s is tap G>>1, channel half G&1 (block 2).  A and B use the same slot->k map, so any internal
-    //      ordering of k inside the instruction is irrelevant.
-    v4i wb1[4], wb2[4];
-    {
-        const int oc = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int tap = 2 * s + h;
-            v4i w = { 0, 0, 0, 0 };
-            if (oc < k1.out_c && tap < k1.taps) w = *(const v4i *)(k1.w + ((size_t)oc * k1.taps + tap) * 16);
-            wb1[s] = w;
-        }
-        const int oc2 = lane & 15, g = lane >> 4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int G = 4 * s + g, tap = G >> 1, ch = G & 1;
-            v4i w = { 0, 0, 0, 0 };
-            if (oc2 < k2.out_c && tap < k2.taps) w = *(const v4i *)(k2.w + ((size_t)oc2 * k2.taps + tap) * 32 + ch * 16);
-            wb2[s] = w;
-        }
-    }
-    const int oc1 = lane & 31, hh = lane >> 5;
-    const bool oc1_ok = oc1 < k1.out_c;
-    const int b1 = oc1_ok ? k1.bias_eff[oc1] : 0, m1 = oc1_ok ? k1.mult[oc1] : 0, sh1 = oc1_ok ? k1.shift[oc1] : 0;
-    const int oc2 = lane & 15, g4 = lane >> 4;
-    const bool oc2_ok = oc2 < k2.out_c;
-    const int b2 = oc2_ok ? k2.bias_eff[oc2] : 0, m2 = oc2_ok ? k2.mult[oc2] : 0, sh2 = oc2_ok ? k2.shift[oc2] : 0;
+    nn_mfma_fill_padding(N, act1, act2, lane);
+    NnMfmaCtx ctx;
+    nn_mfma_init(ctx, N, lane);
     __syncthreads();
-
     const int F = N.n_features;
     for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
         // ---- int8 input tensor [time][in_c] -> LDS rows of 16 B at row (time + pad_left) ------------------------
@@ -762,70 +1104,133 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
             act1[(tt + k1.pad_left) * 16 + c] = src[i];
         }
         WAVE_SYNC();
-        // ---- conv 1: two 32-row tiles x four k-steps -------------------------------------------------------------
-        v16i acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
+        nn_mfma_clip(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 2': cmvnw (processing.hpp:326-389) + input quantisation (ei_run_classifier.h:436-444) [+ the network when
+//  FUSE and the graph fits the matrix-core path].  One wave per window, 4 waves per workgroup.
+//  CMVN: a lane owns column c and KWS_CR consecutive rows r0..r0+CR-1.  Row r's window is padded rows r..r+win-1, so the
+//  CR windows overlap: one walk over padded rows r0..r0+win+CR-2 feeds all CR running sums, each of which still
+//  receives its win terms in the reference's ascending order (fp32 sum; fp64 square-accumulate rounded to fp32 after
+//  every term, numpy.hpp:818-824).  13 independent chains per lane hide the fp64 latency.
+// ---------------------------------------------------------------------------------------------------------
+template <bool FUSE>
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel(KwsDspPlan P, KwsNnPlan N, const float *__restrict__ mfcc,
+                                                                              int n_clips, float *__restrict__ features,
+                                                                              int8_t *__restrict__ q_out, float *__restrict__ scores,
+                                                                              NnTaps taps)
+{
+    __shared__ int s_map[KWS_MAXPROW];                                    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541)
+    __shared__ float s_mfcc[KWS_NN_WAVES][KWS_MAXF * KWS_MAXCEP];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut1[FUSE ? 32 * 256 : 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut2[FUSE ? 16 * 256 : 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][FUSE ? KWS_A1_ROWS * 16 : 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][FUSE ? KWS_A2_ROWS * 32 : 16];
+    __shared__ int s_vec[KWS_NN_WAVES][FUSE ? 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nfr = P.n_frames, ncep = P.n_cepstral, nfeat = nfr * ncep;
+    const int prow = nfr + 2 * P.pad;
+    for (int i = threadIdx.x; i < prow; i += blockDim.x) s_map[i] = P.pad_map[i];
+    NnMfmaCtx ctx;
+    int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
+    if constexpr (FUSE) {
+        const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+        for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
+        for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
+        nn_mfma_fill_padding(N, act1, act2, lane);
+        nn_mfma_init(ctx, N, lane);
+    }
+    __syncthreads();
+    float *mf = s_mfcc[wave];
+    const int win = P.win_size;
+    const float fwin = (float)win;
+    const int cgrp = lane >> 4, cl = lane & 15;
+    const int r0 = cgrp * KWS_CR;
+    const float in_scale = N.in_scale;
+    const int in_zp = N.in_zp;
+
+    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+        const float *src = mfcc + (size_t)clip * nfeat;
+        for (int i = lane; i < nfeat; i += 64) mf[i] = src[i];
+        WAVE_SYNC();
+        for (int cb = 0; cb < ncep; cb += 16) {
+            const int c = cb + cl;
+            const bool act = (c < ncep) && (r0 < nfr);
+            const int cc = min(c, ncep - 1);
+            auto val = [&](int p) { return mf[s_map[min(r0 + p, prow - 1)] * ncep + cc]; };
+            float sum[KWS_CR], mean[KWS_CR], sd[KWS_CR];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const v4i a0 = *(const v4i *)(act1 + (oc1 + 2 * s + hh) * 16);            // row = time (lane&31) + tap
-            const v4i a1 = *(const v4i *)(act1 + (32 + oc1 + 2 * s + hh) * 16);
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wb1[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wb1[s], acc1, 0, 0, 0);
-        }
-        // ---- max-pool 7/7 on the raw accumulators (monotone requantisation, see the scalar kernel) --------------
-        // accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
-        int pm[KWS_MFMA_POOL];
+            for (int r = 0; r < KWS_CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
 #pragma unroll
-        for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = (int)0x80000000;
+            for (int p = 0; p < KWS_CR - 1; ++p) {               // ramp-up: rows 0..p have started
+                const float x = val(p);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int v = mt ? acc1[r] : acc0[r];
-                const int t0 = 32 * mt + (r & 3) + 8 * (r >> 2), t1 = t0 + 4;       // time if lane>>5 is 0 / 1
-                if (t0 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t0 / KWS_MFMA_POOL] = max(pm[t0 / KWS_MFMA_POOL], hh == 0 ? v : (int)0x80000000);
-                if (t1 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t1 / KWS_MFMA_POOL] = max(pm[t1 / KWS_MFMA_POOL], hh == 1 ? v : (int)0x80000000);
+                for (int r = 0; r <= p; ++r) sum[r] += x;
             }
-        }
+            {
+                float xn = val(KWS_CR - 1);
+                for (int p = KWS_CR - 1; p < win; ++p) {         // every row's window is open
+                    const float x = xn;
+                    xn = val(p + 1);                             // next term is in flight while this one is added
 #pragma unroll
-        for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = max(pm[i], __shfl_xor(pm[i], 32));
-        // requantise + ADD/ReLU table: half-wave 0 takes pooled rows 0..3, half-wave 1 rows 4..6
+                    for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
+                }
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pw = i + 4 * hh;
-            const int m = (hh == 0) ? pm[i] : pm[(i + 4 < KWS_MFMA_POOL) ? i + 4 : 0];
-            if (oc1_ok && pw < k1.pool_w) {
-                int rq = mbqm(m + b1, m1, sh1) + k1.out_zp;
-                rq = min(max(rq, k1.act_min), k1.act_max);
-                const int8_t o = s_lut1[oc1 * 256 + (rq + 128)];
-                act2[(pw + k2.pad_left) * 32 + oc1] = o;
-                if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pw * k1.out_c + oc1] = o;
+            for (int q = 0; q < KWS_CR - 1; ++q) {               // ramp-down: rows 0..q have finished
+                const float x = val(win + q);
+#pragma unroll
+                for (int r = q + 1; r < KWS_CR; ++r) sum[r] += x;
+            }
+#pragma unroll
+            for (int r = 0; r < KWS_CR; ++r) mean[r] = sum[r] / fwin;
+            auto sq_acc = [&](float x, int r) {
+                const float d = x - mean[r];
+                const double dd = (double)d;
+                sd[r] = (float)__fma_rn(dd, dd, (double)sd[r]);   // std += pow(d, 2)
+            };
+#pragma unroll
+            for (int p = 0; p < KWS_CR - 1; ++p) {
+                const float x = val(p);
+#pragma unroll
+                for (int r = 0; r <= p; ++r) sq_acc(x, r);
+            }
+            {
+                float xn = val(KWS_CR - 1);
+                for (int p = KWS_CR - 1; p < win; ++p) {
+                    const float x = xn;
+                    xn = val(p + 1);
+#pragma unroll
+                    for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < KWS_CR - 1; ++q) {
+                const float x = val(win + q);
+#pragma unroll
+                for (int r = q + 1; r < KWS_CR; ++r) sq_acc(x, r);
+            }
+#pragma unroll
+            for (int r = 0; r < KWS_CR; ++r) {
+                const int row = r0 + r;
+                if (act && row < nfr) {
+                    const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
+                    const int idx = row * ncep + c;
+                    const float o = (mf[idx] - mean[r]) / (dev + FLT_EPSILON);
+                    if (features) features[(size_t)clip * nfeat + idx] = o;
+                    // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
+                    float qv = roundf(o / in_scale) + (float)in_zp;
+                    int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
+                    const int8_t qb = (int8_t)(iv & 0xff);
+                    if (q_out) q_out[(size_t)clip * nfeat + idx] = qb;
+                    if constexpr (FUSE) act1[(row + N.blk[0].pad_left) * 16 + c] = qb;
+                }
             }
         }
         WAVE_SYNC();
-        // ---- conv 2: one 16-row tile x four k-steps of 64 ----------------------------------------------------------
-        v4i c2 = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int G = 4 * s + g4;
-            const v4i a = *(const v4i *)(act2 + (oc2 + (G >> 1)) * 32 + (G & 1) * 16);  // row = time (lane&15) + tap
-            c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, wb2[s], c2, 0, 0, 0);
-        }
-        // accumulator register r of a 16x16 tile holds row 4*(lane>>4) + r, column lane&15; global max-pool over time
-        int pm2 = (int)0x80000000;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * g4 + r < k2.out_w) pm2 = max(pm2, c2[r]);
-        pm2 = max(pm2, __shfl_xor(pm2, 16));
-        pm2 = max(pm2, __shfl_xor(pm2, 32));
-        if (lane < 16 && oc2_ok) {
-            int rq = mbqm(pm2 + b2, m2, sh2) + k2.out_zp;
-            rq = min(max(rq, k2.act_min), k2.act_max);
-            const int8_t o = s_lut2[oc2 * 256 + (rq + 128)];
-            ((int8_t *)vec)[oc2] = o;
-            if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + k1.pool_w * k1.out_c + oc2] = o;
-        }
-        WAVE_SYNC();
-        nn_head(N, vec, lane, clip, scores, taps);
+        if constexpr (FUSE) nn_mfma_clip(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
     }
 }
 
@@ -871,30 +1276,81 @@ constexpr int KWS_CHP = 9;
 int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
 int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
 int kws_mfcc_cmvn_rows(void) { return KWS_CR; }
+int kws_mfcc_max_frames(void) { return KWS_MAXF; }
 
-int kws_launch_mfcc(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
-                    float in_scale, int in_zp, int grid_cap, hipStream_t stream)
+constexpr int KWS_CHP_FUSED = 9;
+// extract_mfcc_features (+ quantisation) for n_clips windows in one launch
+int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
+                          float in_scale, int in_zp, int grid_cap, hipStream_t stream)
 {
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
     if (pcm_is_float)
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, features,
-                           q_out, in_scale, in_zp, (long long *)nullptr);
+        hipLaunchKernelGGL((kws_mfcc_fused_kernel<KWS_CHP_FUSED, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
+                           features, q_out, in_scale, in_zp, (long long *)nullptr);
     else
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, false>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, features,
-                           q_out, in_scale, in_zp, (long long *)nullptr);
+        hipLaunchKernelGGL((kws_mfcc_fused_kernel<KWS_CHP_FUSED, false>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
+                           features, q_out, in_scale, in_zp, (long long *)nullptr);
     return (int)hipGetLastError();
 }
 
-int kws_launch_mfcc_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
-                         int in_zp, int grid_cap, long long *prof_out, hipStream_t stream)
+int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
+                               int in_zp, int grid_cap, long long *prof_out, hipStream_t stream)
 {
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, false, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
+    hipLaunchKernelGGL((kws_mfcc_fused_kernel<KWS_CHP_FUSED, false, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
                        features, q_out, in_scale, in_zp, prof_out);
     return (int)hipGetLastError();
 }
 
+// speechpy::feature::mfcc for n_clips windows -> mfcc_out[n_clips][n_frames*n_cepstral]
+int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
+                        int grid_cap, hipStream_t stream)
+{
+    if (n_clips <= 0) return 0;
+    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
+    if (pcm_is_float)
+        hipLaunchKernelGGL((kws_spectral_kernel<KWS_CHP, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, mfcc_out,
+                           wrap, (long long *)nullptr);
+    else
+        hipLaunchKernelGGL((kws_spectral_kernel<KWS_CHP, false>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, mfcc_out,
+                           wrap, (long long *)nullptr);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_spectral_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *mfcc_out, int grid_cap, long long *prof_out,
+                             hipStream_t stream)
+{
+    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
+    hipLaunchKernelGGL((kws_spectral_kernel<KWS_CHP, false, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, mfcc_out,
+                       (const float *)nullptr, prof_out);
+    return (int)hipGetLastError();
+}
+
+static bool nn_fits_mfma(const KwsNnPlan &N);
+int kws_force_scalar_nn = 0;   // tests: run the generic (dot4) kernel even when the matrix-core kernel applies
+
+// cmvnw + quantise (+ the network when it fits the matrix-core path and scores != NULL).  Returns 1 in *ran_nn if the
+// network ran inside this launch.
+int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
+                       float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
+                       int *ran_nn, hipStream_t stream)
+{
+    *ran_nn = 0;
+    if (n_clips <= 0) return 0;
+    int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
+    if (grid > grid_cap) grid = grid_cap;
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
+    if (scores && nn_fits_mfma(N) && !kws_force_scalar_nn) {
+        hipLaunchKernelGGL((kws_cmvn_nn_kernel<true>), dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, P, N, mfcc, n_clips,
+                           features, q_out, scores, taps);
+        *ran_nn = 1;
+    } else {
+        hipLaunchKernelGGL((kws_cmvn_nn_kernel<false>), dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, P, N, mfcc, n_clips,
+                           features, q_out, scores, taps);
+    }
+    return (int)hipGetLastError();
+}
 size_t kws_nn_smem_bytes(const KwsNnPlan &N)
 {
     size_t s = 0;
@@ -909,8 +1365,6 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N)
     act = (act + 15) & ~15;
     return s + (size_t)KWS_NN_WAVES * (2 * act + 64 * 4);
 }
-
-int kws_force_scalar_nn = 0;   // tests: run the generic (dot4) kernel even when the matrix-core kernel applies
 
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream)

@@ -54,7 +54,14 @@ EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *p
 EI_IMPULSE_ERROR kws_run_classifier_batch(kws_handle *h, const int16_t *pcm, size_t B, float *scores,
                                           float *features, int8_t *q_in);
 
-/* ---- the two halves, for callers that hold features already (run_inference) and for parity tests --- */
+/* ---- the stages, for callers that hold intermediate data already and for parity tests ------------- */
+/* speechpy::feature::mfcc for B windows (dsp/speechpy/feature.hpp:370-439): cepstra BEFORE cmvnw,
+ * mfcc [B][feature_count] float, device */
+EI_IMPULSE_ERROR kws_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *mfcc, void *stream);
+/* processing::cmvnw (processing.hpp:326-389) + run_inference (ei_run_classifier.h:293-493) on B cepstral
+ * matrices; features / q_in optional outputs as above */
+EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfcc, size_t B, float *scores,
+                                                 float *features, int8_t *q_in, void *stream);
 /* extract_mfcc_features for B clips (classifier/ei_run_dsp.h:256-308) */
 EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features,
                                                int8_t *q_in, void *stream);

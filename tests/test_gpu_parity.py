@@ -199,3 +199,38 @@ def test_generic_nn_kernel_also_bit_exact(pkg, gpu476, l476):
     for i in range(0, 300, 7):
         o, taps = l476.nn_invoke(qs[i], taps=True)
         assert (out[i] == o).all() and (pooled[i][:210] == taps[21]).all() and (pooled[i][210:] == taps[27]).all()
+
+
+@pytest.mark.parametrize("which", ["l476", "l432"])
+def test_stage_api_split_at_cmvn(which, pkg, gpu476, gpu432, l476, l432, oracle):
+    """kws_mfcc_batch_device = speechpy::feature::mfcc (cepstra before cmvnw); kws_cmvn_inference_batch_device =
+    cmvnw + run_inference.  Both halves bit-exact against the oracle; together they equal the fused path."""
+    import torch
+    gm, om = (gpu476, l476) if which == "l476" else (gpu432, l432)
+    B = 130
+    clips = oracle.synth(91, 40, B)
+    pcm = torch.from_numpy(clips).cuda()
+    mfcc = torch.empty((B, 637), dtype=torch.float32, device="cuda")
+    feats = torch.empty((B, 637), dtype=torch.float32, device="cuda")
+    q = torch.empty((B, 637), dtype=torch.int8, device="cuda")
+    scores = torch.empty((B, gm.n_labels), dtype=torch.float32, device="cuda")
+    gm.mfcc_batch_device(pcm.data_ptr(), B, mfcc.data_ptr())
+    gm.cmvn_inference_batch_device(mfcc.data_ptr(), B, scores.data_ptr(), feats.data_ptr(), q.data_ptr())
+    torch.cuda.synchronize()
+    so, fo, qo = om.run_batch(clips, want_features=True)
+    m = mfcc.cpu().numpy()
+    for i in range(0, B, 13):
+        assert (bits(m[i].reshape(49, 13)) == bits(oracle.mfcc_nocmvn(clips[i], om.cfg))).all()
+    assert (bits(feats.cpu().numpy()) == bits(fo)).all()
+    assert (q.cpu().numpy() == qo).all()
+    assert (bits(scores.cpu().numpy()) == bits(so)).all()
+    # CMVN-only + generic NN kernel route
+    L = pkg.lib()
+    L.kws_dev_force_scalar_nn(1)
+    try:
+        scores2 = torch.empty_like(scores)
+        gm.cmvn_inference_batch_device(mfcc.data_ptr(), B, scores2.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        L.kws_dev_force_scalar_nn(0)
+    assert torch.equal(scores2, scores)

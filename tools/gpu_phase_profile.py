@@ -9,18 +9,18 @@ m = pkg.Model(pkg.DEFAULT_MODEL)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda")
 pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
-f = torch.empty((B, 637), dtype=torch.float32, device="cuda"); q = torch.empty((B, 637), dtype=torch.int8, device="cuda")
+f = torch.empty((B, 637), dtype=torch.float32, device="cuda")
 prof = torch.zeros(16, dtype=torch.int64, device="cuda")
 L = pkg.lib()
 L.kws_dev_mfcc_phase_profile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 3
-L.kws_dev_mfcc_phase_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+L.kws_dev_mfcc_phase_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
 for _ in range(2):
-    rc = L.kws_dev_mfcc_phase_profile(m.h, pcm.data_ptr(), B, f.data_ptr(), q.data_ptr(), prof.data_ptr())
+    rc = L.kws_dev_mfcc_phase_profile(m.h, pcm.data_ptr(), B, f.data_ptr(), prof.data_ptr())
     torch.cuda.synchronize()
 p = prof.cpu().numpy()[:10]
 names = ["load+preemph", "fft", "split+power", "energy", "mel+log", "dct", "cmvn pad", "cmvn", "-", "-"]
 tot = p.sum()
-nclips = (B + 2047) // 2048 if B > 2048 else 1
+nclips = (B + 3071) // 3072 if B > 3072 else 1
 print("rc", rc, "clips by wg0 ~", nclips, "total cycles", tot, "per clip", tot / max(1, nclips))
 for n, v in zip(names, p):
     print("%-14s %12d  %5.1f%%" % (n, v, 100.0 * v / tot))
