@@ -25,8 +25,6 @@
 // launchers in kws_kernels.hip
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
                         int grid_cap, hipStream_t stream);
-int kws_launch_spectral_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *mfcc_out, int grid_cap, long long *prof_out,
-                             hipStream_t stream);
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                           float in_scale, int in_zp, int grid_cap, hipStream_t stream);
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,

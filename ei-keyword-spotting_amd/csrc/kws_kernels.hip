@@ -60,8 +60,8 @@ __device__ __forceinline__ void bfly4(cf &f0, cf &f1, cf &f2, cf &f3, cf t1, cf 
     f3.i = s5.i + s4.r;
 }
 
-__device__ __forceinline__ cf ld_cf(const float *b, int n) { float2 v = *(const float2 *)(b + 2 * n); cf c; c.r = v.x; c.i = v.y; return c; }
-__device__ __forceinline__ void st_cf(float *b, int n, cf c) { *(float2 *)(b + 2 * n) = make_float2(c.r, c.i); }
+__device__ __forceinline__ cf ld_cf(const float *b, int n) { n += 8 * (n >> 5); float2 v = *(const float2 *)(b + 2 * n); cf c; c.r = v.x; c.i = v.y; return c; }
+__device__ __forceinline__ void st_cf(float *b, int n, cf c) { n += 8 * (n >> 5); *(float2 *)(b + 2 * n) = make_float2(c.r, c.i); }
 __device__ __forceinline__ cf to_cf(float2 v) { cf c; c.r = v.x; c.i = v.y; return c; }
 
 // numpy::log (SDK/dsp/numpy.hpp:1350-1371): the fmaf() calls are the reference's own
@@ -96,7 +96,7 @@ __device__ __forceinline__ float bin_power(cf f, float inv_fft)
 // ---------------------------------------------------------------------------------------------------------
 //  Kernel 1: MFCC + CMVN + input quantisation.  FFT 256, 32 mel filters (shipped configs); 64 threads = 1 clip.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int KWS_FFT = 256;
+constexpr int KWS_FFT = 256;      // real FFT length the kernel is specialised for (host checks the model)
 constexpr int KWS_NC = 128;        // complex FFT size
 constexpr int KWS_NBINS = 129;
 constexpr int KWS_NF = 32;         // mel filters
@@ -107,15 +107,6 @@ constexpr int KWS_MELS = KWS_NF + 1;   // padded row stride of the fused kernel'
 constexpr int KWS_MAXNZ = 12;      // longest mel filter kept in registers
 constexpr int KWS_MAXPROW = 256;   // rows of the symmetric-padded CMVN matrix (n_frames + win_size - 1)
 constexpr int KWS_CR = 13;         // CMVN: consecutive rows owned by one lane
-
-template <int CHP>   // frame PAIRS per chunk
-struct SpectralSmem {
-    static constexpr int CHF = 2 * CHP;
-    float z[2][KWS_FFT];                 // per half-wave: pre-emphasised frame, then the in-place complex FFT
-    float p[KWS_NBINS * CHF];            // power spectrum [bin][frame in chunk]
-    float mel[KWS_MAXF * KWS_NF];        // log-mel energies, element (frame f, filter j) at f*32 + (j ^ (f & 31))
-    float energy[KWS_MAXF];
-};
 
 // one frame pair's worth of samples for this lane: 8 samples + the sample before them
 template <bool F32IN> struct RawSamples;
@@ -147,17 +138,42 @@ __device__ __forceinline__ RawSamples<F32IN> fetch_samples(const void *clip_base
 #define PH(i) do { if (PROF) { long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
-//  Kernel 1: speechpy::feature::mfcc (feature.hpp:370-439) for one window per wavefront: the cepstra BEFORE cmvnw.
-//  F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM.
+//  Kernel 1: MFCC.  WITH_CMVN = true is the batch hot path: extract_mfcc_features = mfcc + cmvnw + input
+//  quantisation in ONE launch, the cepstra never leave LDS.  WITH_CMVN = false stops after speechpy::feature::mfcc
+//  (feature.hpp:370-439) and writes the cepstra BEFORE cmvnw to HBM (stage API, continuous mode: there cmvnw runs
+//  over a rolling window, in kws_cmvn_nn_kernel).
+//  F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM.  NZ: mel taps kept in registers.
 //  wrap (optional, one float per window): the value the reference's pre-emphasis uses as x[-1]; NULL = x[N-1].
 // ---------------------------------------------------------------------------------------------------------
-template <int CHP, bool F32IN, bool PROF = false>
-__global__ __launch_bounds__(KWS_WAVE) void kws_spectral_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
-                                                                   float *__restrict__ mfcc_out, const float *__restrict__ wrap,
-                                                                   long long *prof_out = nullptr)
+// complex FFT slot of element c: 8 slots of padding after every 32 make every butterfly stage bank-conflict free
+__device__ __forceinline__ int zi(int c) { return c + 8 * (c >> 5); }
+constexpr int KWS_ZF = 2 * (KWS_NC + 8 * (KWS_NC / 32));   // floats per frame buffer
+template <int CHP>   // frame PAIRS per chunk
+struct MfccSmem {
+    static constexpr int CHF = 2 * CHP;
+    float z[2][KWS_ZF];                  // per half-wave: pre-emphasised frame, then the in-place complex FFT
+    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the cepstra
+    // before CMVN ([frame][coef], row stride n_cepstral) followed by the pad_1d_symmetric row map
+    union {
+        float p[KWS_NBINS * CHF];
+        struct {
+            float mfcc[KWS_MAXF * KWS_MAXCEP];
+            int map[KWS_MAXPROW];
+        } c;
+    } u;
+    float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
+    float energy[KWS_MAXF];
+    static_assert(sizeof(float) * (KWS_MAXF * KWS_MAXCEP + KWS_MAXPROW) <= sizeof(float) * KWS_NBINS * CHF, "alias");
+};
+
+template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, bool PROF = false>
+__global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
+                                                            float *__restrict__ features, int8_t *__restrict__ q_out,
+                                                            float in_scale, int in_zp, const float *__restrict__ wrap,
+                                                            long long *prof_out = nullptr)
 {
     constexpr int CHF = 2 * CHP;
-    __shared__ SpectralSmem<CHP> sm;
+    __shared__ MfccSmem<CHP> sm;
     const int lane = threadIdx.x;
     const int half = lane >> 5, t = lane & 31;
 
@@ -171,19 +187,23 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_spectral_kernel(KwsDspPlan P, co
     const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
     const int nfr = P.n_frames, ncep = P.n_cepstral;
     const int n_pairs = (nfr + 1) >> 1;
+    const int prow = nfr + 2 * P.pad;
     float *zb = sm.z[half];
     // this lane's mel filter (filter index = lane & 31 in every pass of the mel stage): ascending-bin taps in registers
-    int fbin[KWS_MAXNZ];
-    float fwt[KWS_MAXNZ];
+    int fbin[NZ];
+    float fwt[NZ];
     {
         const int b0 = P.filt_start[t], b1e = P.filt_start[t + 1];
 #pragma unroll
-        for (int n = 0; n < KWS_MAXNZ; ++n) {
+        for (int n = 0; n < NZ; ++n) {
             const bool on = b0 + n < b1e;
             fbin[n] = on ? P.filt_bin[b0 + n] * CHF : 0;
             fwt[n] = on ? P.filt_w[b0 + n] : 0.0f;
         }
     }
+    int mapreg[KWS_MAXPROW / KWS_WAVE];    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541), KWS_WAVE entries apart
+#pragma unroll
+    for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) mapreg[i] = (lane + i * KWS_WAVE < prow) ? P.pad_map[lane + i * KWS_WAVE] : 0;
     long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
@@ -227,271 +247,8 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_spectral_kernel(KwsDspPlan P, co
                         prev = hi;
                     }
                 }
-                *(float4 *)(zb + 8 * t) = make_float4(y[0], y[1], y[2], y[3]);
-                *(float4 *)(zb + 8 * t + 4) = make_float4(y[4], y[5], y[6], y[7]);
-                WAVE_SYNC();
-                PH(0);
-
-                // ---- kf_bfly2 (m=1) fused with kf_bfly4 (m=2): kiss_fft.cpp:232-296 levels 4 and 3 ---------
-                cf u[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    cf a = ld_cf(zb, n0 + 16 * i), b = ld_cf(zb, n0 + 16 * i + 64);
-                    // b * tw[0] with tw[0] = (1, -0) returns b up to the sign of a zero, which no later operation can
-                    // observe (only sums, products, magnitudes and == 0 tests follow)
-                    u[i] = k01 ? csub(a, b) : cadd(a, b);
-                }
-                bfly4(u[0], u[1], u[2], u[3], a1, a2, a3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st_cf(zb, 8 * g01 + k01 + 2 * i, u[i]);
-                WAVE_SYNC();
-                // ---- kf_bfly4 m=8, fstride=4 ----------------------------------------------------------------
-#pragma unroll
-                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
-                bfly4(u[0], u[1], u[2], u[3], b1, b2, b3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, u[i]);
-                WAVE_SYNC();
-                // ---- kf_bfly4 m=32, fstride=1 ---------------------------------------------------------------
-#pragma unroll
-                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, t + 32 * i);
-                bfly4(u[0], u[1], u[2], u[3], c1, c2, c3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
-                WAVE_SYNC();
-
-                PH(1);
-                // ---- kiss_fftr split (kiss_fftr.cpp:84-119) + power spectrum -------------------------------
-                const int fr = f - 2 * pair0;                 // frame slot in the chunk
-                float *pcol = sm.p + fr;
-                const bool live = f < nfr;
-#pragma unroll
-                for (int rep = 0; rep < 2; ++rep) {
-                    const int k = t + 1 + 32 * rep;            // 1..64
-                    const cf stw = rep ? st2 : st1;
-                    cf fpk = ld_cf(zb, k), fq = ld_cf(zb, KWS_NC - k);
-                    cf fpnk; fpnk.r = fq.r; fpnk.i = -fq.i;
-                    cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
-                    cf twv = cmul(f2k, stw);
-                    cf lo, hi;
-                    lo.r = (f1k.r + twv.r) * 0.5f;             // HALF_OF
-                    lo.i = (f1k.i + twv.i) * 0.5f;
-                    hi.r = (f1k.r - twv.r) * 0.5f;
-                    hi.i = (twv.i - f1k.i) * 0.5f;
-                    if (live) {
-                        if (k != KWS_NC / 2) pcol[k * CHF] = bin_power(lo, P.inv_fft);   // k == 64: overwritten by the
-                        pcol[(KWS_NC - k) * CHF] = bin_power(hi, P.inv_fft);            // "ncfft-k" store
-                    }
-                }
-                if (t == 0 && live) {
-                    cf d = ld_cf(zb, 0);
-                    cf dc, ny;
-                    dc.r = d.r + d.i; dc.i = 0.0f;
-                    ny.r = d.r - d.i; ny.i = 0.0f;
-                    pcol[0] = bin_power(dc, P.inv_fft);
-                    pcol[KWS_NC * CHF] = bin_power(ny, P.inv_fft);
-                }
-                WAVE_SYNC();
-                PH(2);
-            }
-
-            // ---- per chunk: frame energy (sequential fp32 sum, numpy.hpp:88-94) -------------------------------
-            const int f_base = 2 * pair0;
-            const int nfc = min(2 * pair1, nfr) - f_base;
-            if (lane < nfc) {
-                float e = 0.0f;
-                const float *pl = sm.p + lane;
-#pragma unroll 16
-                for (int k = 0; k < KWS_NBINS - 1; ++k) e += pl[k * CHF];
-                e += pl[(KWS_NBINS - 1) * CHF];
-                if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
-                sm.energy[f_base + lane] = e;
-            }
-            PH(3);
-            // ---- mel: sparse ascending-bin gather == dot_by_row (numpy.hpp:183-211), zero_handling, log ------
-            for (int idx = lane; idx < nfc * KWS_NF; idx += KWS_WAVE) {
-                const int fr = idx >> 5;                                              // filter j == lane & 31 == t
-                float acc = 0.0f;
-#pragma unroll
-                for (int n = 0; n < KWS_MAXNZ; ++n) {
-                    if (n < P.max_nz) {                    // wave-uniform; taps beyond a filter's end have weight 0:
-                        float prod = sm.p[fbin[n] + fr] * fwt[n];     // power >= 0 is finite, so they add an exact +0
-                        acc += prod;
-                    }
-                }
-                if (acc == 0.0f) acc = FLT_EPSILON;                                    // functions.hpp:63-69
-                const int fa = f_base + fr;
-                sm.mel[fa * KWS_NF + (t ^ (fa & 31))] = fast_log(acc);
-            }
-            WAVE_SYNC();
-            PH(4);
-        }
-
-        // ---- DCT-II via 32-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
-        if (lane < nfr) {
-            const float *mrow = sm.mel + lane * KWS_NF;
-            const int sw = lane & 31;
-            // even/odd reorder, then packed as 16 complex points: in[i] = v[2i], in[31-i] = v[2i+1]
-            cf F[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = q + 4 * j;                       // complex input index
-                    const int i0 = 2 * n, i1 = 2 * n + 1;          // real input indices
-                    const int v0 = (i0 < 16) ? 2 * i0 : 2 * (31 - i0) + 1, v1 = (i1 < 16) ? 2 * i1 : 2 * (31 - i1) + 1;
-                    F[4 * q + j].r = mrow[v0 ^ sw];
-                    F[4 * q + j].i = mrow[v1 ^ sw];
-                }
-            }
-            // first level: every twiddle is tw[0] = (1, -0): x * tw[0] == x up to the sign of a zero (see above)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                cf &f0 = F[4 * q], &f1 = F[4 * q + 1], &f2 = F[4 * q + 2], &f3 = F[4 * q + 3];
-                cf s5 = csub(f0, f2);
-                f0 = cadd(f0, f2);
-                cf s3 = cadd(f1, f3), s4 = csub(f1, f3);
-                f2 = csub(f0, s3);
-                f0 = cadd(f0, s3);
-                f1.r = s5.r + s4.i; f1.i = s5.i - s4.r;
-                f3.r = s5.r - s4.i; f3.i = s5.i + s4.r;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
-            float *orow = mfcc_out + (size_t)clip * (nfr * ncep) + lane * ncep;
-            auto emit = [&](int i, float re, float im) {           // v[i] = re*cos + im*sin, x2, ortho scale
-                if (i < ncep) {
-                    float a = re * P.dct_cos[i];
-                    float b = im * P.dct_sin[i];
-                    float d = (a + b) * 2.0f;
-                    orow[i] = d * (i == 0 ? P.dct_s0 : P.dct_s1);
-                }
-            };
-            // coefficient 0 is replaced by log(frame energy) (feature.hpp:425-429); bin 16 = F0.r - F0.i
-            orow[0] = fast_log(sm.energy[lane]);
-            emit(16, F[0].r - F[0].i, 0.0f);
-#pragma unroll
-            for (int k = 1; k <= 8; ++k) {
-                cf fpk = F[k], fpnk;
-                fpnk.r = F[16 - k].r; fpnk.i = -F[16 - k].i;
-                cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
-                cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
-                if (k != 8) emit(k, (f1k.r + twv.r) * 0.5f, (f1k.i + twv.i) * 0.5f);
-                emit(16 - k, (f1k.r - twv.r) * 0.5f, (twv.i - f1k.i) * 0.5f);
-            }
-            // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
-            for (int i = KWS_MAXCEP; i < ncep; ++i) orow[i] = (mrow[i ^ sw] * 2.0f) * P.dct_s1;
-        }
-        WAVE_SYNC();
-        PH(5);
-    }
-    if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
-        for (int i = 0; i < KWS_NPHASE; ++i) prof_out[i] = ph[i];
-}
-
-// ---------------------------------------------------------------------------------------------------------
-//  Kernel 1+2 fused (the batch hot path): extract_mfcc_features = mfcc + cmvnw + input quantisation in ONE launch,
-//  the cepstra never leave LDS.  (kws_spectral_kernel + kws_cmvn_nn_kernel above are the same arithmetic split at the
-//  cmvnw boundary; they serve the stage API and the continuous mode, where CMVN runs over a rolling window.)
-// ---------------------------------------------------------------------------------------------------------
-template <int CHP>   // frame PAIRS per chunk
-struct MfccSmem {
-    static constexpr int CHF = 2 * CHP;
-    float z[2][KWS_FFT];                 // per half-wave: pre-emphasised frame, then the in-place complex FFT
-    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the cepstra
-    // before CMVN ([frame][coef], row stride n_cepstral) followed by the pad_1d_symmetric row map
-    union {
-        float p[KWS_NBINS * CHF];
-        struct {
-            float mfcc[KWS_MAXF * KWS_MAXCEP];
-            int map[KWS_MAXPROW];
-        } c;
-    } u;
-    float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
-    float energy[KWS_MAXF];
-    static_assert(sizeof(float) * (KWS_MAXF * KWS_MAXCEP + KWS_MAXPROW) <= sizeof(float) * KWS_NBINS * CHF, "alias");
-};
-
-template <int CHP, bool F32IN, bool PROF = false>   // F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM
-__global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_fused_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
-                                                            float *__restrict__ features, int8_t *__restrict__ q_out,
-                                                            float in_scale, int in_zp, long long *prof_out = nullptr)
-{
-    constexpr int CHF = 2 * CHP;
-    __shared__ MfccSmem<CHP> sm;
-    const int lane = threadIdx.x;
-    const int half = lane >> 5, t = lane & 31;
-
-    // ---- per-lane constants, fixed for the whole launch --------------------------------------------------
-    const int k01 = t & 1, g01 = t >> 1;
-    const int n0 = (g01 >> 2) + 4 * (g01 & 3);            // digit-reversed input base of this lane's radix-4 group
-    const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
-    const int K2 = t & 7, G2 = t >> 3;
-    const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
-    const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
-    const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
-    const int nfr = P.n_frames, ncep = P.n_cepstral;
-    const int n_pairs = (nfr + 1) >> 1;
-    const int prow = nfr + 2 * P.pad;
-    float *zb = sm.z[half];
-    // this lane's mel filter (filter index = lane & 31 in every pass of the mel stage): ascending-bin taps in registers
-    int fbin[KWS_MAXNZ];
-    float fwt[KWS_MAXNZ];
-    {
-        const int b0 = P.filt_start[t], b1e = P.filt_start[t + 1];
-#pragma unroll
-        for (int n = 0; n < KWS_MAXNZ; ++n) {
-            const bool on = b0 + n < b1e;
-            fbin[n] = on ? P.filt_bin[b0 + n] * CHF : 0;
-            fwt[n] = on ? P.filt_w[b0 + n] : 0.0f;
-        }
-    }
-    int mapreg[KWS_MAXPROW / KWS_WAVE];    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541), KWS_WAVE entries apart
-#pragma unroll
-    for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) mapreg[i] = (lane + i * KWS_WAVE < prow) ? P.pad_map[lane + i * KWS_WAVE] : 0;
-    long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
-
-    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
-        const void *xbase = F32IN ? (const void *)((const float *)pcm_v + (size_t)clip * P.n_samples)
-                                  : (const void *)((const int16_t *)pcm_v + (size_t)clip * P.n_samples);
-        // software prefetch: the samples of pair p+1 are requested before pair p is transformed
-        RawSamples<F32IN> nxt = fetch_samples<F32IN>(xbase, min(half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
-
-        for (int pair0 = 0; pair0 < n_pairs; pair0 += CHP) {
-            const int pair1 = min(pair0 + CHP, n_pairs);
-            for (int pr = pair0; pr < pair1; ++pr) {
-                // ---- 8 samples/lane (16 B, coalesced: 32 lanes = the 256 samples of a frame that rfft keeps) -----
-                const int f = 2 * pr + half;
-                const RawSamples<F32IN> cur = nxt;
-                if (pr + 1 < n_pairs)
-                    nxt = fetch_samples<F32IN>(xbase, min(f + 2, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
-                float y[8];
-                if constexpr (F32IN) {
-                    const float v[8] = { cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w };
-                    float prev = cur.prev;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float pl = P.pre_cof * prev;                                   // cof * prev, then subtract
-                        y[j] = v[j] - pl;
-                        prev = v[j];
-                    }
-                } else {
-                    float prev = (float)cur.prev * (1.0f / 32768.0f);
-                    const int w[4] = { cur.v.x, cur.v.y, cur.v.z, cur.v.w };
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float lo = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);   // numpy::int16_to_float
-                        float hi = (float)(short)(w[j] >> 16) * (1.0f / 32768.0f);
-                        float pl = P.pre_cof * prev;
-                        y[2 * j] = lo - pl;
-                        float ph_ = P.pre_cof * lo;
-                        y[2 * j + 1] = hi - ph_;
-                        prev = hi;
-                    }
-                }
-                *(float4 *)(zb + 8 * t) = make_float4(y[0], y[1], y[2], y[3]);
-                *(float4 *)(zb + 8 * t + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);        // complex slots 4t..4t+3
+                *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
                 WAVE_SYNC();
                 PH(0);
 
@@ -574,11 +331,9 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_fused_kernel(KwsDspPlan P, 
                 const int fr = idx >> 5;                                              // filter j == lane & 31 == t
                 float acc = 0.0f;
 #pragma unroll
-                for (int n = 0; n < KWS_MAXNZ; ++n) {
-                    if (n < P.max_nz) {                    // wave-uniform; taps beyond a filter's end have weight 0:
-                        float prod = sm.u.p[fbin[n] + fr] * fwt[n];   // power >= 0 is finite, so they add an exact +0
-                        acc += prod;
-                    }
+                for (int n = 0; n < NZ; ++n) {             // taps beyond a filter's end have weight 0: power >= 0 is
+                    float prod = sm.u.p[fbin[n] + fr] * fwt[n];       // finite, so they add an exact +0
+                    acc += prod;
                 }
                 if (acc == 0.0f) acc = FLT_EPSILON;                                    // functions.hpp:63-69
                 sm.mel[(f_base + fr) * KWS_MELS + t] = fast_log(acc);
@@ -629,7 +384,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_fused_kernel(KwsDspPlan P, 
                 R[16 - k].r = (f1k.r - twv.r) * 0.5f;
                 R[16 - k].i = (twv.i - f1k.i) * 0.5f;
             }
-            float *orow = sm.u.c.mfcc + lane * ncep;
+            float *orow = WITH_CMVN ? sm.u.c.mfcc + lane * ncep : features + (size_t)clip * (nfr * ncep) + lane * ncep;
 #pragma unroll
             for (int i = 0; i < KWS_MAXCEP; ++i) {
                 if (i < ncep) {
@@ -646,6 +401,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_fused_kernel(KwsDspPlan P, 
         }
         WAVE_SYNC();
         PH(5);
+        if constexpr (!WITH_CMVN) continue;
 
         // ---- cmvnw (processing.hpp:326-389) -------------------------------------------------------------------
         // A lane owns column c and KWS_CR consecutive rows r0..r0+CR-1.  Row r's window is padded rows r..r+win-1, so
@@ -1271,60 +1027,49 @@ __global__ void kws_synth_kernel(uint32_t seed, uint32_t first_clip, uint32_t n_
 // ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int KWS_CHP = 9;
-
 int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
 int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
 int kws_mfcc_cmvn_rows(void) { return KWS_CR; }
 int kws_mfcc_max_frames(void) { return KWS_MAXF; }
+int kws_mfcc_fft_length(void) { return KWS_FFT; }
 
-constexpr int KWS_CHP_FUSED = 9;
+constexpr int KWS_CHP = 9;
+
+template <bool F32IN, bool WITH_CMVN, bool PROF>
+static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, float *out, int8_t *q_out, float in_scale, int in_zp,
+                         const float *wrap, int grid_cap, long long *prof, hipStream_t stream)
+{
+    if (n_clips <= 0) return 0;
+    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
+    if (P.max_nz <= 4)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 4, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
+                           out, q_out, in_scale, in_zp, wrap, prof);
+    else
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
+                           n_clips, out, q_out, in_scale, in_zp, wrap, prof);
+    return (int)hipGetLastError();
+}
+
 // extract_mfcc_features (+ quantisation) for n_clips windows in one launch
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                           float in_scale, int in_zp, int grid_cap, hipStream_t stream)
 {
-    if (n_clips <= 0) return 0;
-    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    if (pcm_is_float)
-        hipLaunchKernelGGL((kws_mfcc_fused_kernel<KWS_CHP_FUSED, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
-                           features, q_out, in_scale, in_zp, (long long *)nullptr);
-    else
-        hipLaunchKernelGGL((kws_mfcc_fused_kernel<KWS_CHP_FUSED, false>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
-                           features, q_out, in_scale, in_zp, (long long *)nullptr);
-    return (int)hipGetLastError();
+    return pcm_is_float ? launch_mfcc_t<true, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, grid_cap, nullptr, stream)
+                        : launch_mfcc_t<false, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, grid_cap, nullptr, stream);
 }
 
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
                                int in_zp, int grid_cap, long long *prof_out, hipStream_t stream)
 {
-    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    hipLaunchKernelGGL((kws_mfcc_fused_kernel<KWS_CHP_FUSED, false, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
-                       features, q_out, in_scale, in_zp, prof_out);
-    return (int)hipGetLastError();
+    return launch_mfcc_t<false, true, true>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, grid_cap, prof_out, stream);
 }
 
-// speechpy::feature::mfcc for n_clips windows -> mfcc_out[n_clips][n_frames*n_cepstral]
+// speechpy::feature::mfcc for n_clips windows -> mfcc_out[n_clips][n_frames*n_cepstral] (cepstra before cmvnw)
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
                         int grid_cap, hipStream_t stream)
 {
-    if (n_clips <= 0) return 0;
-    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    if (pcm_is_float)
-        hipLaunchKernelGGL((kws_spectral_kernel<KWS_CHP, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, mfcc_out,
-                           wrap, (long long *)nullptr);
-    else
-        hipLaunchKernelGGL((kws_spectral_kernel<KWS_CHP, false>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, mfcc_out,
-                           wrap, (long long *)nullptr);
-    return (int)hipGetLastError();
-}
-
-int kws_launch_spectral_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *mfcc_out, int grid_cap, long long *prof_out,
-                             hipStream_t stream)
-{
-    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    hipLaunchKernelGGL((kws_spectral_kernel<KWS_CHP, false, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips, mfcc_out,
-                       (const float *)nullptr, prof_out);
-    return (int)hipGetLastError();
+    return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, grid_cap, nullptr, stream)
+                        : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, grid_cap, nullptr, stream);
 }
 
 static bool nn_fits_mfma(const KwsNnPlan &N);
