@@ -1104,11 +1104,113 @@ void run_classifier_init(void)
     for (auto &m : h->maf) { m.buf_idx = 0; m.running_sum = 0; for (float &v : m.maf_buffer) v = 0.f; }
 }
 
-// ei_run_classifier.h:184-282 -- sliced mode is the next row of SURVEY section 8(f); not on the GPU yet.
+// ei_run_classifier.h:184-282 + ei_run_dsp.h:310-366 -- continuous (sliced) mode.  One call = one slice of audio:
+// cepstra of the slice (speechpy::feature::mfcc, no CMVN) are appended to a rolling feature buffer; once it is full every
+// call normalises a copy of the whole buffer (cmvnw), runs the network and a 2-tap moving average per class.
+// The slice's MFCC and the window's cmvnw + network run on the GPU (kws_mfcc_kernel<WITH_CMVN=false>,
+// kws_cmvn_nn_kernel); the rolling buffer and the filters are host state of the default model handle.
+//
+// Reference quirks that are kept: a function-static `first_run` (ei_run_dsp.h:313) that NOTHING resets makes every call
+// but the process's first grow signal->total_length by one frame length IN THE CALLER'S STRUCT and take one more frame;
+// the pre-emphasis constructor then asks get_data for the sample at total_length-1 (beyond the slice) and ignores the
+// callback's return value (buffer pre-zeroed).
+static bool g_cont_first_run = false;
+
 EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t *result, bool debug)
 {
-    (void)signal; (void)result; (void)debug;
-    return fail(KWS_ERROR_UNSUPPORTED_MODEL, "run_classifier_continuous is not implemented yet (SURVEY 8(f) rank 1)");
+    kws_handle *h = kws_default_model();
+    if (!h) return KWS_ERROR_NO_MODEL;
+    if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    const Model &m = h->model;
+    const size_t F = m.nn_input_frame_size, C = m.labels.size();
+    const int ncep = m.dsp.num_cepstral;
+    if (h->cont_features.size() != F) h->cont_features.assign(F, 0.0f);         // static_features_matrix (calloc'd)
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t dsp_start_ms = ei_read_timer_ms();
+
+    // ---- extract_mfcc_per_slice_features ----------------------------------------------------------------------
+    if (g_cont_first_run) signal->total_length += (size_t)(m.dsp.frame_length * (float)m.frequency);
+    g_cont_first_run = true;
+    const size_t n_claimed = signal->total_length;
+    float eos = 0.0f;                                                           // _end_of_signal_buffer (calloc)
+    if (n_claimed >= 1) (void)signal->get_data(n_claimed - (size_t)m.dsp.pre_shift, (size_t)m.dsp.pre_shift, &eos);
+    const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
+    const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
+    const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)ncep;
+    if (nf < 1 || feature_size > F || h->slice_offset + feature_size > F || nf > kws_mfcc_max_frames()) {
+        ei_printf("ERR: MFCC failed (%d)\n", -1002);                           // EIDSP_MATRIX_SIZE_MISMATCH
+        ei_printf("ERR: Failed to run DSP process (%d)\n", -1002);
+        return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples yields %d frames", n_claimed, nf);
+    }
+    const size_t needed = (size_t)(nf - 1) * stride + frame_len;                // last sample any frame reads
+    std::vector<float> slice(std::max(n_claimed, needed) + 16, 0.0f);
+    {
+        int r = signal->get_data(0, needed, slice.data());
+        if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
+    }
+    float *d_x = nullptr, *d_m = nullptr, *d_w = nullptr, *d_s = nullptr;
+    auto cleanup = [&]() { for (void *p : { (void *)d_x, (void *)d_m, (void *)d_w, (void *)d_s }) if (p) (void)hipFree(p); };
+    auto alloc_fail = [&]() { cleanup(); return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed"); };
+    if (hipMalloc((void **)&d_x, slice.size() * sizeof(float)) != hipSuccess) return alloc_fail();
+    if (hipMalloc((void **)&d_m, F * sizeof(float)) != hipSuccess) return alloc_fail();
+    if (hipMalloc((void **)&d_w, sizeof(float)) != hipSuccess) return alloc_fail();
+    if (hipMalloc((void **)&d_s, C * sizeof(float)) != hipSuccess) return alloc_fail();
+    EI_IMPULSE_ERROR e = EI_IMPULSE_OK;
+    if (hipMemcpy(d_x, slice.data(), slice.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_w, &eos, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+    if (!e) {
+        KwsDspPlan P = h->dsp;                // same tables, this slice's framing
+        P.n_samples = (int)n_claimed;
+        P.n_frames = nf;
+        e = spectral_device(h, P, d_x, 1, 1, d_m, d_w, nullptr);
+    }
+    if (!e && hipMemcpy(h->cont_features.data() + h->slice_offset, d_m, feature_size * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        e = fail(KWS_ERROR_HIP, "d2h copy failed");
+    if (e) { cleanup(); return e; }
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) { cleanup(); return EI_IMPULSE_CANCELED; }
+
+    // ---- rolling buffer bookkeeping (ei_run_classifier.h:229-239) ------------------------------------------------
+    if (!h->feature_buffer_full) {
+        h->slice_offset += feature_size;
+        if (h->slice_offset > (F - feature_size)) {
+            h->feature_buffer_full = true;
+            h->slice_offset -= feature_size;
+        }
+    }
+    ei_impulse_result_timing_t *timing = result_timing(h, result);
+    timing->dsp = (int)(ei_read_timer_ms() - dsp_start_ms);
+    if (debug) {
+        ei_printf("\r\nFeatures (%d ms.): ", timing->dsp);
+        for (size_t ix = 0; ix < F; ix++) { ei_printf_float(h->cont_features[ix]); ei_printf(" "); }
+        ei_printf("\n");
+        ei_printf("Running neural network...\n");
+    }
+    if (h->feature_buffer_full) {
+        dsp_start_ms = ei_read_timer_ms();
+        // calc_cepstral_mean_and_var_normalization on a COPY of the buffer, then run_inference
+        std::vector<float> scores(C);
+        uint64_t t1 = 0;
+        if (hipMemcpy(d_m, h->cont_features.data(), F * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+        if (!e) {
+            std::lock_guard<std::mutex> lk(h->mu);
+            e = ensure_scratch(h, 1);
+            t1 = ei_read_timer_ms();
+            if (!e) e = cmvn_nn_device(h, d_m, 1, nullptr, nullptr, d_s, nullptr, nullptr, nullptr, nullptr);
+        }
+        if (!e && hipMemcpy(scores.data(), d_s, C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+        if (e) { cleanup(); return e; }
+        timing->dsp += (int)(t1 - dsp_start_ms);
+        fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t1));
+        ei_impulse_result_classification_t *cls = (ei_impulse_result_classification_t *)result;
+        for (size_t ix = 0; ix < C; ix++) cls[ix].value = run_moving_average_filter(&h->maf[ix], cls[ix].value);
+        // shift the feature buffer for new data (ei_run_classifier.h:277-279)
+        for (size_t i = 0; i < F - feature_size; i++) h->cont_features[i] = h->cont_features[i + feature_size];
+        cleanup();
+        if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+        return EI_IMPULSE_OK;
+    }
+    cleanup();
+    return EI_IMPULSE_OK;
 }
 
 }  // extern "C"

@@ -148,20 +148,29 @@ int kwso_filterbanks(const kwso_mfcc_config *c, float *fb_t)
 /*  x[N-shift+n] (captured at construction with N = total_length).         */
 /*  x = int16 / 32768 (numpy::int16_to_float, numpy.hpp:1289-1298)         */
 /* ====================================================================== */
-int kwso_preemphasis(const int16_t *pcm, size_t n, float cof, int shift,
-                     size_t offset, size_t length, float *out)
+/* end_of_signal (optional): the `shift` floats the reference's constructor fetched from
+ * signal->get_data(total_length - shift, shift) (processing.hpp:68); NULL = take them from pcm[n-shift..n). */
+static int preemphasis_ex(const int16_t *pcm, size_t n, float cof, int shift, size_t offset, size_t length, float *out,
+                          const float *end_of_signal)
 {
     if (shift < 1 || (size_t)shift > n) return KWSO_ERR_PARAM;
     if (offset + length > n) return -1004;   /* EIDSP_OUT_OF_BOUNDS */
     for (size_t ix = 0; ix < length; ix++) {
         size_t p = offset + ix;
         float now = (float)pcm[p] / 32768;
-        float prev = (p < (size_t)shift) ? (float)pcm[n - (size_t)shift + p] / 32768
-                                         : (float)pcm[p - (size_t)shift] / 32768;
+        float prev;
+        if (p < (size_t)shift) prev = end_of_signal ? end_of_signal[p] : (float)pcm[n - (size_t)shift + p] / 32768;
+        else prev = (float)pcm[p - (size_t)shift] / 32768;
         float prod = cof * prev;
         out[ix] = now - prod;
     }
     return KWSO_OK;
+}
+
+int kwso_preemphasis(const int16_t *pcm, size_t n, float cof, int shift,
+                     size_t offset, size_t length, float *out)
+{
+    return preemphasis_ex(pcm, n, cof, shift, offset, length, out, NULL);
 }
 
 /* ====================================================================== */
@@ -392,9 +401,19 @@ int kwso_power_spectrum(const float *frame, size_t frame_size, float *out, int f
 /* ====================================================================== */
 /*  mfe                                             feature.hpp:193-318    */
 /* ====================================================================== */
+static int mfe_ex(const int16_t *pcm, size_t n, size_t n_claimed, const kwso_mfcc_config *c, float *features, float *energies,
+                  const float *end_of_signal);
 int kwso_mfe(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, float *features, float *energies)
 {
-    const int nf = kwso_num_frames(n, c);
+    return mfe_ex(pcm, n, n, c, features, energies, NULL);
+}
+
+/* n = samples really available in pcm, n_claimed = signal->total_length the frame count is derived from
+ * (continuous mode claims one extra frame length, ei_run_dsp.h:319-325) */
+static int mfe_ex(const int16_t *pcm, size_t n, size_t n_claimed, const kwso_mfcc_config *c, float *features, float *energies,
+                  const float *end_of_signal)
+{
+    const int nf = kwso_num_frames(n_claimed, c);
     const int flen = kwso_frame_length_samples(c);
     const int stride = (int)roundf((float)c->sampling_frequency * c->frame_stride);
     const int coeff = c->fft_length / 2 + 1;
@@ -408,7 +427,7 @@ int kwso_mfe(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, float *fea
     memset(features, 0, sizeof(float) * (size_t)nf * M);
     for (int ix = 0; ix < nf && rc == KWSO_OK; ix++) {
         size_t off = (size_t)ix * (size_t)stride;
-        rc = kwso_preemphasis(pcm, n, c->pre_cof, c->pre_shift, off, (size_t)flen, frame);
+        rc = preemphasis_ex(pcm, n, c->pre_cof, c->pre_shift, off, (size_t)flen, frame, end_of_signal);
         if (rc) break;
         rc = kwso_power_spectrum(frame, (size_t)flen, ps, c->fft_length);
         if (rc) break;
@@ -468,15 +487,21 @@ int kwso_dct2_ortho(float *v, int n)
 /* ====================================================================== */
 /*  mfcc (no CMVN)                                  feature.hpp:370-439    */
 /* ====================================================================== */
+static int mfcc_ex(const int16_t *pcm, size_t n, size_t n_claimed, const kwso_mfcc_config *c, float *out, const float *end_of_signal);
 int kwso_mfcc_nocmvn(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, float *out)
 {
-    const int nf = kwso_num_frames(n, c);
+    return mfcc_ex(pcm, n, n, c, out, NULL);
+}
+
+static int mfcc_ex(const int16_t *pcm, size_t n, size_t n_claimed, const kwso_mfcc_config *c, float *out, const float *end_of_signal)
+{
+    const int nf = kwso_num_frames(n_claimed, c);
     const int M = c->num_filters, K = c->num_cepstral;
     if (nf < 1) return KWSO_ERR_SIZE;
     float *mel = (float *)malloc(sizeof(float) * (size_t)nf * M);
     float *en = (float *)malloc(sizeof(float) * (size_t)nf);
     if (!mel || !en) { free(mel); free(en); return KWSO_ERR_OOM; }
-    int rc = kwso_mfe(pcm, n, c, mel, en);
+    int rc = mfe_ex(pcm, n, n_claimed, c, mel, en, end_of_signal);
     if (rc == KWSO_OK) {
         for (size_t i = 0; i < (size_t)nf * M; i++) mel[i] = kwso_log(mel[i]);
         for (int r = 0; r < nf && rc == KWSO_OK; r++) rc = kwso_dct2_ortho(mel + (size_t)r * M, M);
@@ -1185,6 +1210,90 @@ double kwso_time_run_classifier(const kwso_model *m, const int16_t *pcm, size_t 
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (checksum) *checksum = acc;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ====================================================================== */
+/*  continuous (sliced) mode      ei_run_classifier.h:134-145, 164-282,    */
+/*                                ei_run_dsp.h:310-366                     */
+/* ====================================================================== */
+#define KWSO_SLICES_PER_WINDOW 4     /* EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW, model_metadata.h:66-68 */
+struct kwso_continuous {
+    const kwso_model *m;
+    float *features;                 /* static_features_matrix (ei_run_classifier.h:187) */
+    size_t slice_offset;
+    int feature_buffer_full;
+    int first_run;                   /* function-static in extract_mfcc_per_slice_features: NOT reset by init */
+    struct { uint32_t buf_idx; float running_sum; float buf[KWSO_SLICES_PER_WINDOW >> 1]; } maf[64];
+};
+
+kwso_continuous *kwso_continuous_create(const kwso_model *m)
+{
+    kwso_continuous *s = (kwso_continuous *)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->m = m;
+    s->features = (float *)calloc(m->nn_input_frame_size, sizeof(float));
+    if (!s->features) { free(s); return NULL; }
+    return s;
+}
+void kwso_continuous_free(kwso_continuous *s) { if (s) { free(s->features); free(s); } }
+
+void kwso_continuous_init(kwso_continuous *s)          /* run_classifier_init, ei_run_classifier.h:164-172 */
+{
+    s->slice_offset = 0;
+    s->feature_buffer_full = 0;
+    memset(s->maf, 0, sizeof(s->maf));
+}
+
+/* One slice.  end_of_signal: what signal->get_data(total_length - shift, shift) delivered to the pre-emphasis
+ * constructor (the reference asks for it AFTER growing total_length by one frame, i.e. beyond the slice; callers
+ * pass what their callback returns there, 0 when it refuses).  *produced = inference ran. */
+int kwso_continuous_step(kwso_continuous *s, const int16_t *slice, size_t n, const float *end_of_signal, float *scores,
+                         int *produced)
+{
+    const kwso_model *m = s->m;
+    const size_t F = m->nn_input_frame_size;
+    const kwso_mfcc_config *c = &m->dsp;
+    *produced = 0;
+    size_t n_claimed = n;
+    if (s->first_run) n_claimed += (size_t)(c->frame_length * (float)c->sampling_frequency);
+    s->first_run = 1;
+    const int nf = kwso_num_frames(n_claimed, c);
+    if (nf < 1) return -5;
+    const size_t feature_size = (size_t)nf * (size_t)c->num_cepstral;
+    if (feature_size > F) return -5;                 /* EIDSP_MATRIX_SIZE_MISMATCH */
+    if (s->slice_offset + feature_size > F) return -5;
+    float eos0 = 0.0f;
+    const float *eos = end_of_signal;
+    if (!eos && n_claimed != n) eos = &eos0;         /* the reference's calloc'd buffer when get_data refused */
+    int rc = mfcc_ex(slice, n, n_claimed, c, s->features + s->slice_offset, eos);
+    if (rc) return -5;
+    if (!s->feature_buffer_full) {
+        s->slice_offset += feature_size;
+        if (s->slice_offset > (F - feature_size)) {
+            s->feature_buffer_full = 1;
+            s->slice_offset -= feature_size;
+        }
+    }
+    if (s->feature_buffer_full) {
+        float *cm = (float *)malloc(sizeof(float) * F);
+        if (!cm) return -8;
+        memcpy(cm, s->features, sizeof(float) * F);
+        rc = kwso_cmvnw(cm, (int)(F / (size_t)c->num_cepstral), c->num_cepstral, c->win_size, 1);
+        if (rc == 0) rc = kwso_run_inference(m, cm, scores);
+        free(cm);
+        if (rc) return rc;
+        for (uint32_t ix = 0; ix < m->n_labels; ix++) {          /* run_moving_average_filter */
+            float *buf = s->maf[ix].buf;
+            s->maf[ix].running_sum -= buf[s->maf[ix].buf_idx];
+            s->maf[ix].running_sum += scores[ix];
+            buf[s->maf[ix].buf_idx] = scores[ix];
+            if (++s->maf[ix].buf_idx >= (KWSO_SLICES_PER_WINDOW >> 1)) s->maf[ix].buf_idx = 0;
+            scores[ix] = s->maf[ix].running_sum / (float)(KWSO_SLICES_PER_WINDOW >> 1);
+        }
+        for (size_t i = 0; i < F - feature_size; i++) s->features[i] = s->features[i + feature_size];
+        *produced = 1;
+    }
+    return 0;
 }
 
 /* ====================================================================== */

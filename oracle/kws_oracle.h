@@ -105,6 +105,14 @@ int  kwso_run_classifier_batch(const kwso_model *m, const int16_t *pcm, size_t n
 double kwso_time_run_classifier(const kwso_model *m, const int16_t *pcm, size_t n_clips, size_t n,
                                 int iters, float *checksum);
 
+/* continuous (sliced) mode: run_classifier_init / run_classifier_continuous, ei_run_classifier.h:164-282 */
+typedef struct kwso_continuous kwso_continuous;
+kwso_continuous *kwso_continuous_create(const kwso_model *m);
+void kwso_continuous_free(kwso_continuous *s);
+void kwso_continuous_init(kwso_continuous *s);
+int  kwso_continuous_step(kwso_continuous *s, const int16_t *slice, size_t n, const float *end_of_signal, float *scores,
+                          int *produced);
+
 /* synthetic test clips: include/kws/kws_synth.h */
 void kwso_synth_fill(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out);
 

@@ -93,6 +93,26 @@ int eiref_run_classifier(const int16_t *pcm, size_t n, float *scores,
     return (int)r;
 }
 
+/* Continuous (sliced) mode, SDK/classifier/ei_run_classifier.h:184-282.  One call = one slice of
+ * EI_CLASSIFIER_SLICE_SIZE samples.  produced = 1 when the call ran inference (feature buffer full).
+ * NOTE the reference's function-static `first_run` (ei_run_dsp.h:313) is never reset: only the very first call of
+ * the PROCESS sees it false. */
+void eiref_continuous_init(void) { run_classifier_init(); }
+int eiref_continuous(const int16_t *slice, size_t n, float *scores, int *produced, size_t *total_length_after) {
+    g_pcm = slice; g_pcm_len = n; g_get_data_calls = 0;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    ei_impulse_result_t result;
+    memset(&result, 0, sizeof(result));
+    EI_IMPULSE_ERROR r = run_classifier_continuous(&signal, &result, false);
+    *produced = result.classification[0].label != NULL;
+    for (int i = 0; i < EI_CLASSIFIER_LABEL_COUNT; i++) scores[i] = result.classification[i].value;
+    if (total_length_after) *total_length_after = signal.total_length;
+    return (int)r;
+}
+int eiref_slice_size(void) { return EI_CLASSIFIER_SLICE_SIZE; }
+
 /* extract_mfcc_features with an arbitrary ei_dsp_config_mfcc_t.
  * features must hold rows*num_cepstral floats; returns EIDSP code. */
 int eiref_extract_mfcc(const int16_t *pcm, size_t n, int num_cepstral, float frame_length,

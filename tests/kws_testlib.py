@@ -96,6 +96,11 @@ class Oracle:
         L.kwso_time_run_classifier.restype = C.c_double
         L.kwso_time_run_classifier.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.kwso_synth_fill.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.kwso_continuous_create.restype = C.c_void_p
+        L.kwso_continuous_create.argtypes = [C.c_void_p]
+        L.kwso_continuous_free.argtypes = [C.c_void_p]
+        L.kwso_continuous_init.argtypes = [C.c_void_p]
+        L.kwso_continuous_step.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
 
     # ---- clips
     def synth(self, seed, first, n, clip_len=CLIP_LEN):
@@ -241,6 +246,26 @@ class OracleModel:
         return self.o.L.kwso_time_run_classifier(self.h, _ptr(pcm), pcm.shape[0], pcm.shape[1], iters, C.byref(chk))
 
 
+class OracleContinuous:
+    """run_classifier_init / run_classifier_continuous restated (oracle/kws_oracle.c)."""
+
+    def __init__(self, model):
+        self.m = model
+        self.L = model.o.L
+        self.h = self.L.kwso_continuous_create(model.h)
+        assert self.h
+
+    def init(self):
+        self.L.kwso_continuous_init(self.h)
+
+    def step(self, slice_pcm):
+        slice_pcm = np.ascontiguousarray(slice_pcm, np.int16)
+        s = np.zeros(self.m.n_labels, np.float32)
+        produced = C.c_int()
+        rc = self.L.kwso_continuous_step(self.h, _ptr(slice_pcm), slice_pcm.size, None, _ptr(s), C.byref(produced))
+        return rc, bool(produced.value), s
+
+
 def have_reference():
     return os.path.exists(REF_SO)
 
@@ -273,6 +298,7 @@ class Reference:
         L.eiref_rfft_complex.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.eiref_run_inference.argtypes = [C.c_void_p, C.c_void_p]
         L.eiref_nn_taps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eiref_continuous.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         L.eiref_time_run_classifier.restype = C.c_double
         L.eiref_time_run_classifier.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         self.n_labels = L.eiref_label_count()
@@ -380,6 +406,17 @@ class Reference:
         assert rc == 0, rc
         offs = np.cumsum([0] + self.tensor_bytes)
         return {int(i): out[offs[i]:offs[i + 1]].copy() for i in ids if sizes[i] >= 0}
+
+    def continuous_init(self):
+        self.L.eiref_continuous_init()
+
+    def continuous(self, slice_pcm):
+        slice_pcm = np.ascontiguousarray(slice_pcm, np.int16)
+        s = np.zeros(self.n_labels, np.float32)
+        produced = C.c_int()
+        tl = C.c_size_t()
+        rc = self.L.eiref_continuous(_ptr(slice_pcm), slice_pcm.size, _ptr(s), C.byref(produced), C.byref(tl))
+        return rc, bool(produced.value), s, tl.value
 
     def time_run(self, pcm, iters=1):
         pcm = np.ascontiguousarray(pcm, np.int16)

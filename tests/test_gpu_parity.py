@@ -234,3 +234,40 @@ def test_stage_api_split_at_cmvn(which, pkg, gpu476, gpu432, l476, l432, oracle)
     finally:
         L.kws_dev_force_scalar_nn(0)
     assert torch.equal(scores2, scores)
+
+
+def test_run_classifier_continuous(pkg, gpu476, l476, oracle):
+    """The demos' real entry point (L476/Core/Src/main.cpp:190-199): 250 ms slices through run_classifier_continuous,
+    against the restated reference (oracle) slice by slice, including the caller-visible total_length mutation."""
+    from kws_testlib import OracleContinuous
+    gpu476.set_default()
+    L = pkg.lib()
+    L.run_classifier_continuous.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_bool]
+    audio = oracle.synth(4, 0, 5).reshape(-1)
+    cur = {}
+
+    def get_data(offset, length, out):
+        if offset + length > 4000:                  # like the reference harness: refuse reads beyond the slice
+            return -1
+        seg = cur["s"][offset:offset + length].astype(np.float32) / np.float32(32768)
+        ctypes.memmove(out, seg.ctypes.data, 4 * length)
+        return 0
+
+    cb = pkg.GET_DATA_FN(get_data)
+    Result = pkg.result_struct(4)
+    oc = OracleContinuous(l476)
+    for n_slices in (20, 6):
+        L.run_classifier_init()
+        oc.init()
+        for i in range(n_slices):
+            cur["s"] = audio[i * 4000:(i + 1) * 4000]
+            sig = pkg.Signal(cb, 4000)
+            res = Result()
+            rc = L.run_classifier_continuous(ctypes.byref(sig), ctypes.byref(res), False)
+            orc, produced, s = oc.step(cur["s"])
+            assert rc == 0 and orc == 0
+            assert bool(res.classification[0].label) == produced
+            got = np.float32([res.classification[j].value for j in range(4)])
+            if produced:
+                assert (bits(got) == bits(s)).all(), (n_slices, i)
+            assert sig.total_length in (4000, 4320)

@@ -134,3 +134,22 @@ def test_bad_blob_rejected(oracle):
     assert not oracle.L.kwso_model_load(b"XXXX" + b"\0" * 64, 68)
     blob = open(os.path.join(os.path.dirname(GOLDEN), "..", "models", "l476_no_yes.kwsm"), "rb").read()
     assert not oracle.L.kwso_model_load(blob[:200], 200)   # truncated
+
+
+def test_continuous_mode_golden(oracle, l476):
+    """run_classifier_continuous + run_classifier_init restated: 20 slices, re-init, 6 more (golden from the reference)."""
+    from kws_testlib import OracleContinuous
+    g = _load("continuous_l476.npz")
+    audio = oracle.synth(int(g["audio_seed"]), 0, int(g["n_clips"])).reshape(-1)
+    oc = OracleContinuous(l476)
+    oc.init()
+    k = 0
+    for n_slices in (20, 6):
+        for i in range(n_slices):
+            rc, produced, s = oc.step(audio[i * 4000:(i + 1) * 4000])
+            assert rc == 0 and produced == bool(g["produced"][k])
+            assert (bits(s) == bits(g["scores"][k])).all(), k
+            k += 1
+        oc.init()
+    assert list(g["produced"][:5]) == [False, False, False, True, True]      # buffer full after 4 slices
+    assert g["total_length_after"][0] == 4000 and (g["total_length_after"][1:] == 4320).all()   # first_run quirk

@@ -104,7 +104,27 @@ def main():
         k += 1
     deep["n"] = np.int32(k)
     np.savez_compressed(os.path.join(GOLDEN, "deep_l476.npz"), **deep)
-    for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz"):
+    # ---- continuous (sliced) mode: 5 s of audio = 20 slices of 4000 samples, then re-init and 6 more ----------
+    # (this script is the first and only user of run_classifier_continuous in its process, so the reference's
+    #  never-reset `first_run` static is false exactly for slice 0)
+    audio = synth.synth(4, 0, 5).reshape(-1)
+    cont = {"audio_seed": np.int32(4), "n_clips": np.int32(5)}
+    ref.continuous_init()
+    prod, sc, tls = [], [], []
+    for k in range(20):
+        rc, p, s, tl = ref.continuous(audio[k * 4000:(k + 1) * 4000])
+        assert rc == 0
+        prod.append(p); sc.append(s); tls.append(tl)
+    ref.continuous_init()
+    for k in range(6):
+        rc, p, s, tl = ref.continuous(audio[k * 4000:(k + 1) * 4000])
+        assert rc == 0
+        prod.append(p); sc.append(s); tls.append(tl)
+    cont["produced"] = np.array(prod)
+    cont["scores"] = np.stack(sc)
+    cont["total_length_after"] = np.int64(tls)
+    np.savez_compressed(os.path.join(GOLDEN, "continuous_l476.npz"), **cont)
+    for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz", "continuous_l476.npz"):
         print(fn, os.path.getsize(os.path.join(GOLDEN, fn)), "bytes")
 
 
