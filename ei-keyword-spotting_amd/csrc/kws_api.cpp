@@ -45,8 +45,10 @@ int kws_mfcc_max_frames(void);
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static thread_local EI_IMPULSE_ERROR g_err_code = EI_IMPULSE_OK;
 static EI_IMPULSE_ERROR fail(EI_IMPULSE_ERROR code, const char *fmt, ...)
 {
+    g_err_code = code;
     char buf[512];
     va_list a;
     va_start(a, fmt);
@@ -61,6 +63,7 @@ static EI_IMPULSE_ERROR fail(EI_IMPULSE_ERROR code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(KWS_ERROR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+#pragma GCC visibility push(default)     // the library is built with -fvisibility=hidden: only the C ABI is exported
 extern "C" const char *kws_last_error(void) { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -882,10 +885,10 @@ EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *p
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
-    // one fused launch for extract_mfcc_features + quantisation (the cepstra stay in LDS), then the network
-    float *f = features ? features : h->s_mfcc;
+    // one fused launch for extract_mfcc_features + quantisation (the cepstra stay in LDS), then the network;
+    // the float feature matrix only leaves the chip when the caller asks for it
     int8_t *q = q_in ? q_in : h->s_q;
-    e = mfcc_fused_device(h, pcm, 0, B, f, q, (hipStream_t)stream);
+    e = mfcc_fused_device(h, pcm, 0, B, features, q, (hipStream_t)stream);
     if (e) return e;
     return kws_nn_batch_device(h, q, B, scores, nullptr, nullptr, nullptr, stream);
 }
@@ -1009,7 +1012,7 @@ static ei_impulse_result_timing_t *result_timing(const kws_handle *h, ei_impulse
 EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result, bool debug)
 {
     kws_handle *h = kws_default_model();
-    if (!h) return KWS_ERROR_NO_MODEL;
+    if (!h) return g_err_code != EI_IMPULSE_OK ? g_err_code : KWS_ERROR_NO_MODEL;   // why the default model is missing
     if (!fmatrix || !fmatrix->buffer || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
     if ((size_t)fmatrix->rows * fmatrix->cols != F) return fail(EI_IMPULSE_ERROR_SHAPES_DONT_MATCH, "feature matrix is %ux%u, model needs %zu", fmatrix->rows, fmatrix->cols, F);
@@ -1032,7 +1035,7 @@ EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result
 EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, bool debug)
 {
     kws_handle *h = kws_default_model();
-    if (!h) return KWS_ERROR_NO_MODEL;
+    if (!h) return g_err_code != EI_IMPULSE_OK ? g_err_code : KWS_ERROR_NO_MODEL;   // why the default model is missing
     if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     const size_t n = h->model.raw_sample_count, F = h->model.nn_input_frame_size, C = h->model.labels.size();
     // The reference sizes its frame count from signal->total_length (ei_run_dsp.h:277-286); a length that yields another
@@ -1119,7 +1122,7 @@ static bool g_cont_first_run = false;
 EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t *result, bool debug)
 {
     kws_handle *h = kws_default_model();
-    if (!h) return KWS_ERROR_NO_MODEL;
+    if (!h) return g_err_code != EI_IMPULSE_OK ? g_err_code : KWS_ERROR_NO_MODEL;   // why the default model is missing
     if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     const Model &m = h->model;
     const size_t F = m.nn_input_frame_size, C = m.labels.size();

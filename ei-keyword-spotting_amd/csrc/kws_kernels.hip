@@ -478,7 +478,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                     const int idx = row * ncep + c;
                     const float xv = sm.u.c.mfcc[idx];
                     const float o = (xv - mean[r]) / (dev + FLT_EPSILON);
-                    fout[idx] = o;
+                    if (features) fout[idx] = o;           // optional output (extract_mfcc_features' matrix)
                     if (q_out) {
                         // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
                         float qv = roundf(o / in_scale) + (float)in_zp;
