@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "kws_default_model", "kws_run_classifier_batch_device", "kws_run_classifier_batch",
     "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
+    "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
     "kws_synth_clips_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
@@ -85,6 +86,10 @@ def lib():
         L.kws_nn_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
         L.kws_nn_batch.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
+        L.kws_streams_create.argtypes = [vp, sz, C.POINTER(vp)]
+        L.kws_streams_destroy.argtypes = [vp]
+        L.kws_streams_init.argtypes = [vp]
+        L.kws_streams_step_device.argtypes = [vp, vp, sz, vp, vp, C.POINTER(C.c_int), vp]
         L.kws_device_malloc.argtypes = [C.POINTER(vp), sz]
         L.kws_device_free.argtypes = [vp]
         L.kws_memcpy_h2d.argtypes = [vp, vp, sz]
@@ -197,6 +202,32 @@ class Model:
 
     def nn_batch_device(self, q_ptr, B, scores_ptr, stream=None):
         _check(self.L.kws_nn_batch_device(self.h, q_ptr, B, scores_ptr, None, None, None, stream))
+
+
+class StreamBatch:
+    """S audio streams in continuous mode, state in HBM (kws_stream_batch)."""
+
+    def __init__(self, model, n_streams):
+        self.model = model
+        self.L = model.L
+        sb = C.c_void_p()
+        _check(self.L.kws_streams_create(model.h, n_streams, C.byref(sb)))
+        self.sb = sb
+        self.n_streams = n_streams
+
+    def init(self):
+        _check(self.L.kws_streams_init(self.sb))
+
+    def step_device(self, slices_ptr, slice_samples, scores_ptr, end_of_signal_ptr=None, stream=None):
+        produced = C.c_int()
+        _check(self.L.kws_streams_step_device(self.sb, slices_ptr, slice_samples, end_of_signal_ptr, scores_ptr,
+                                              C.byref(produced), stream))
+        return bool(produced.value)
+
+    def close(self):
+        if getattr(self, "sb", None):
+            self.L.kws_streams_destroy(self.sb)
+            self.sb = None
 
 
 def synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream=None):

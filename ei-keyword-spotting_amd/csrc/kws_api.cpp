@@ -24,7 +24,9 @@
 
 // launchers in kws_kernels.hip
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
-                        int grid_cap, hipStream_t stream);
+                        int out_stride, int grid_cap, hipStream_t stream);
+int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream);
+int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream);
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                           float in_scale, int in_zp, int grid_cap, hipStream_t stream);
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
@@ -776,11 +778,11 @@ static int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 
 // speechpy::feature::mfcc for B windows (kernel 1)
 static EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
-                                        const float *wrap, hipStream_t s)
+                                        const float *wrap, hipStream_t s, int out_stride = 0)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
-    int rc = kws_launch_spectral(P, pcm, is_float, (int)B, mfcc, wrap, grid_cap_mfcc(h), s);
+    int rc = kws_launch_spectral(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, grid_cap_mfcc(h), s);
     if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
 }
@@ -956,6 +958,115 @@ EI_IMPULSE_ERROR kws_device_free(void *ptr) { HIP_TRY(hipFree(ptr)); return EI_I
 EI_IMPULSE_ERROR kws_memcpy_h2d(void *dst, const void *src, size_t n) { HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); return EI_IMPULSE_OK; }
 EI_IMPULSE_ERROR kws_memcpy_d2h(void *dst, const void *src, size_t n) { HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); return EI_IMPULSE_OK; }
 EI_IMPULSE_ERROR kws_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EI_IMPULSE_OK; }
+
+// ------------------------------------------------------------------------------------------------------------
+//  continuous mode for S streams in lock step ("many concurrent streams, per-stream state in HBM")
+// ------------------------------------------------------------------------------------------------------------
+struct kws_stream_batch {
+    kws_handle *h = nullptr;
+    size_t S = 0;
+    float *feat[2] = { nullptr, nullptr };   // rolling cepstra buffers [S][F] (ping-pong for the shift)
+    int cur = 0;
+    float *running_sum = nullptr, *maf_buf = nullptr;   // [S][C], [S][C][taps]
+    float *zeros = nullptr;                   // [S] end-of-signal samples when the caller gives none
+    size_t slice_offset = 0;
+    bool full = false, first_run = false;     // first_run: like the reference's function-static, never reset
+    uint32_t buf_idx = 0;
+};
+static const int kMafTaps = EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW >> 1;
+
+void kws_streams_destroy(kws_stream_batch *sb)
+{
+    if (!sb) return;
+    for (void *p : { (void *)sb->feat[0], (void *)sb->feat[1], (void *)sb->running_sum, (void *)sb->maf_buf, (void *)sb->zeros })
+        if (p) (void)hipFree(p);
+    delete sb;
+}
+
+EI_IMPULSE_ERROR kws_streams_init(kws_stream_batch *sb)          // run_classifier_init for every stream
+{
+    if (!sb) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(sb->h->device));
+    const size_t C = sb->h->model.labels.size();
+    sb->slice_offset = 0;
+    sb->full = false;
+    sb->buf_idx = 0;
+    HIP_TRY(hipMemset(sb->running_sum, 0, sb->S * C * sizeof(float)));
+    HIP_TRY(hipMemset(sb->maf_buf, 0, sb->S * C * kMafTaps * sizeof(float)));
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_streams_create(kws_handle *h, size_t S, kws_stream_batch **out)
+{
+    if (!h || !out || S == 0 || S > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "bad argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(h->device));
+    kws_stream_batch *sb = new kws_stream_batch();
+    sb->h = h; sb->S = S;
+    const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
+    bool ok = hipMalloc((void **)&sb->feat[0], S * F * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->feat[1], S * F * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->running_sum, S * C * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->maf_buf, S * C * kMafTaps * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->zeros, S * sizeof(float)) == hipSuccess;
+    if (ok) ok = hipMemset(sb->feat[0], 0, S * F * sizeof(float)) == hipSuccess && hipMemset(sb->feat[1], 0, S * F * sizeof(float)) == hipSuccess &&
+                 hipMemset(sb->zeros, 0, S * sizeof(float)) == hipSuccess;
+    if (!ok) { kws_streams_destroy(sb); return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed"); }
+    EI_IMPULSE_ERROR e = kws_streams_init(sb);
+    if (e) { kws_streams_destroy(sb); return e; }
+    *out = sb;
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *slices, size_t slice_samples, const float *end_of_signal,
+                                         float *scores, int *produced, void *stream)
+{
+    if (!sb || !slices || !scores || !produced) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    kws_handle *h = sb->h;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const Model &m = h->model;
+    const size_t F = m.nn_input_frame_size, C = m.labels.size(), S = sb->S;
+    *produced = 0;
+    // extract_mfcc_per_slice_features: every step but the first claims one more frame length (ei_run_dsp.h:319-325)
+    size_t n_claimed = slice_samples;
+    const bool grown = sb->first_run;
+    if (grown) n_claimed += (size_t)(m.dsp.frame_length * (float)m.frequency);
+    sb->first_run = true;
+    const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
+    const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
+    const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)m.dsp.num_cepstral;
+    if (nf < 1 || nf > kws_mfcc_max_frames() || feature_size > F || sb->slice_offset + feature_size > F ||
+        (size_t)(nf - 1) * stride + h->dsp.fft_len > slice_samples || (slice_samples * 2) % 16 != 0)
+        return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples (claimed %zu) yields %d frames", slice_samples, n_claimed, nf);
+    KwsDspPlan P = h->dsp;
+    P.n_samples = (int)slice_samples;      // memory stride between the streams' slices
+    P.n_frames = nf;
+    // x[-1] of the slice: the reference takes the sample at total_length-1, which lies beyond the slice once it has grown
+    const float *wrap = grown ? (end_of_signal ? end_of_signal : sb->zeros) : nullptr;
+    float *feat = sb->feat[sb->cur];
+    EI_IMPULSE_ERROR e = spectral_device(h, P, slices, 0, S, feat + sb->slice_offset, wrap, st, (int)F);
+    if (e) return e;
+    if (!sb->full) {
+        sb->slice_offset += feature_size;
+        if (sb->slice_offset > (F - feature_size)) { sb->full = true; sb->slice_offset -= feature_size; }
+    }
+    if (!sb->full) return EI_IMPULSE_OK;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        e = ensure_scratch(h, S);
+        if (!e) e = cmvn_nn_device(h, feat, S, nullptr, nullptr, scores, nullptr, nullptr, nullptr, st);
+    }
+    if (e) return e;
+    int rc = kws_launch_maf(scores, sb->running_sum, sb->maf_buf, (int)(S * C), (int)sb->buf_idx, kMafTaps, st);
+    if (rc) return fail(KWS_ERROR_HIP, "moving-average kernel launch failed");
+    if (++sb->buf_idx >= (uint32_t)kMafTaps) sb->buf_idx = 0;
+    rc = kws_launch_shift(feat, sb->feat[sb->cur ^ 1], (int)S, (int)F, (int)feature_size, st);
+    if (rc) return fail(KWS_ERROR_HIP, "shift kernel launch failed");
+    sb->cur ^= 1;
+    *produced = 1;
+    return EI_IMPULSE_OK;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 //  SDK-compatible single-clip entry points

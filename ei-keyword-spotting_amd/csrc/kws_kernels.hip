@@ -169,7 +169,7 @@ struct MfccSmem {
 template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, bool PROF = false>
 __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
                                                             float *__restrict__ features, int8_t *__restrict__ q_out,
-                                                            float in_scale, int in_zp, const float *__restrict__ wrap,
+                                                            float in_scale, int in_zp, const float *__restrict__ wrap, int out_stride,
                                                             long long *prof_out = nullptr)
 {
     constexpr int CHF = 2 * CHP;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 R[16 - k].r = (f1k.r - twv.r) * 0.5f;
                 R[16 - k].i = (twv.i - f1k.i) * 0.5f;
             }
-            float *orow = WITH_CMVN ? sm.u.c.mfcc + lane * ncep : features + (size_t)clip * (nfr * ncep) + lane * ncep;
+            float *orow = WITH_CMVN ? sm.u.c.mfcc + lane * ncep : features + (size_t)clip * out_stride + lane * ncep;
 #pragma unroll
             for (int i = 0; i < KWS_MAXCEP; ++i) {
                 if (i < ncep) {
@@ -1037,16 +1037,16 @@ constexpr int KWS_CHP = 9;
 
 template <bool F32IN, bool WITH_CMVN, bool PROF>
 static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, float *out, int8_t *q_out, float in_scale, int in_zp,
-                         const float *wrap, int grid_cap, long long *prof, hipStream_t stream)
+                         const float *wrap, int out_stride, int grid_cap, long long *prof, hipStream_t stream)
 {
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
     if (P.max_nz <= 4)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 4, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
-                           out, q_out, in_scale, in_zp, wrap, prof);
+                           out, q_out, in_scale, in_zp, wrap, out_stride, prof);
     else
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
-                           n_clips, out, q_out, in_scale, in_zp, wrap, prof);
+                           n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
     return (int)hipGetLastError();
 }
 
@@ -1054,22 +1054,65 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                           float in_scale, int in_zp, int grid_cap, hipStream_t stream)
 {
-    return pcm_is_float ? launch_mfcc_t<true, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, grid_cap, nullptr, stream)
-                        : launch_mfcc_t<false, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, grid_cap, nullptr, stream);
+    return pcm_is_float ? launch_mfcc_t<true, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream)
+                        : launch_mfcc_t<false, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream);
 }
 
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
                                int in_zp, int grid_cap, long long *prof_out, hipStream_t stream)
 {
-    return launch_mfcc_t<false, true, true>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, grid_cap, prof_out, stream);
+    return launch_mfcc_t<false, true, true>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, prof_out, stream);
 }
 
 // speechpy::feature::mfcc for n_clips windows -> mfcc_out[n_clips][n_frames*n_cepstral] (cepstra before cmvnw)
+// out_stride: floats between consecutive windows' outputs (0 = packed, n_frames*n_cepstral)
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
-                        int grid_cap, hipStream_t stream)
+                        int out_stride, int grid_cap, hipStream_t stream)
 {
-    return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, grid_cap, nullptr, stream)
-                        : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, grid_cap, nullptr, stream);
+    if (out_stride == 0) out_stride = P.n_frames * P.n_cepstral;
+    return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream)
+                        : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream);
+}
+
+// ---- continuous mode, many streams: per-class 2-tap moving average (ei_run_classifier.h:134-145) and the feature-buffer
+//      shift (ei_run_classifier.h:277-279) for S streams advancing in lock step
+__global__ void kws_maf_kernel(float *__restrict__ scores, float *__restrict__ running_sum, float *__restrict__ maf_buf, int n,
+                               int buf_idx, int taps)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float rs = running_sum[i];
+        const float v = scores[i];
+        rs -= maf_buf[(size_t)i * taps + buf_idx];
+        rs += v;
+        maf_buf[(size_t)i * taps + buf_idx] = v;
+        running_sum[i] = rs;
+        scores[i] = rs / (float)taps;
+    }
+}
+
+__global__ void kws_shift_kernel(const float *__restrict__ src, float *__restrict__ dst, int n_streams, int F, int shift)
+{
+    const size_t total = (size_t)n_streams * F;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % F);
+        dst[i] = (k < F - shift) ? src[i + shift] : src[i];     // the tail keeps its old values, as in the reference
+    }
+}
+
+int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(kws_maf_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, stream, scores, running_sum,
+                       maf_buf, n, buf_idx, taps);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream)
+{
+    if (n_streams <= 0) return 0;
+    size_t blocks = ((size_t)n_streams * F + 255) / 256;
+    hipLaunchKernelGGL(kws_shift_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, dst, n_streams, F, shift);
+    return (int)hipGetLastError();
 }
 
 static bool nn_fits_mfma(const KwsNnPlan &N);

@@ -77,6 +77,21 @@ EI_IMPULSE_ERROR kws_nn_batch_device(kws_handle *h, const int8_t *q_in, size_t B
 EI_IMPULSE_ERROR kws_nn_batch(kws_handle *h, const int8_t *q_in, size_t B, float *scores, int8_t *tap_pooled,
                               int8_t *tap_fc, int8_t *tap_out);
 
+/* ---- continuous mode for S streams in lock step ----------------------------------------------------
+ * Each stream follows run_classifier_continuous() (classifier/ei_run_classifier.h:184-282): one slice of audio per
+ * step, a rolling cepstra buffer, whole-window cmvnw + network once it is full, 2-tap moving average per class
+ * (ei_run_classifier.h:134-145).  All per-stream state lives in HBM.  As in the reference, every step of a batch
+ * but its very first claims one extra frame length (ei_run_dsp.h:319-325; not reset by kws_streams_init) and
+ * pre-emphasis then needs the sample one frame beyond the slice: pass those S floats in end_of_signal (device),
+ * or NULL for 0 (what the reference sees when the application's get_data refuses the read).
+ *   slices [S][slice_samples] int16 (device), scores [S][label_count] float (device), *produced = inference ran. */
+typedef struct kws_stream_batch kws_stream_batch;
+EI_IMPULSE_ERROR kws_streams_create(kws_handle *h, size_t S, kws_stream_batch **out);
+void kws_streams_destroy(kws_stream_batch *sb);
+EI_IMPULSE_ERROR kws_streams_init(kws_stream_batch *sb);            /* run_classifier_init, ei_run_classifier.h:164 */
+EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *slices, size_t slice_samples,
+                                         const float *end_of_signal, float *scores, int *produced, void *stream);
+
 /* deterministic synthetic clips generated directly in HBM (include/kws/kws_synth.h) */
 EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len,
                                         int16_t *out, void *stream);

@@ -271,3 +271,33 @@ def test_run_classifier_continuous(pkg, gpu476, l476, oracle):
             if produced:
                 assert (bits(got) == bits(s)).all(), (n_slices, i)
             assert sig.total_length in (4000, 4320)
+
+
+def test_many_streams_continuous_mode(pkg, gpu476, l476, oracle):
+    """kws_streams_*: S streams in lock step, state in HBM; every stream must follow run_classifier_continuous()
+    (restated reference) slice by slice, across a run_classifier_init()."""
+    import torch
+    from kws_testlib import OracleContinuous
+    S, n_steps = 37, 11
+    audio = oracle.synth(12, 0, S * 3).reshape(S, 3 * 16000)            # 3 s per stream
+    sb = pkg.StreamBatch(gpu476, S)
+    ocs = [OracleContinuous(l476) for _ in range(S)]
+    for oc in ocs:
+        oc.init()
+    scores = torch.empty((S, 4), dtype=torch.float32, device="cuda")
+    for phase in range(2):
+        for k in range(n_steps if phase == 0 else 6):
+            sl = np.ascontiguousarray(audio[:, k * 4000:(k + 1) * 4000])
+            d = torch.from_numpy(sl).cuda()
+            produced = sb.step_device(d.data_ptr(), 4000, scores.data_ptr())
+            torch.cuda.synchronize()
+            got = scores.cpu().numpy()
+            for s in range(S):
+                rc, p, want = ocs[s].step(sl[s])
+                assert rc == 0 and p == produced, (phase, k, s)
+                if p:
+                    assert (bits(got[s]) == bits(want)).all(), (phase, k, s)
+        sb.init()
+        for oc in ocs:
+            oc.init()
+    sb.close()
