@@ -84,11 +84,27 @@ __device__ __forceinline__ float fast_log(float a)
 
 // software_rfft's magnitude + power_spectrum's scaling (numpy.hpp:1410, processing.hpp:306-309):
 //   mag = (float)sqrt(pow(re,2) + pow(im,2))  [double];  P = (1.0/fft) * (mag*mag)
+// Correctly rounded fp64 sqrt for x == 0 or x >= 2^-298 (a sum of two squared floats): clang's own expansion of
+// sqrt(double) -- v_rsq_f64 + Goldschmidt -- minus the rescaling it needs only for inputs below 2^-767.
+__device__ __forceinline__ double dsqrt_sumsq(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __fma_rn(-h, g, 0.5);
+    g = __fma_rn(g, r, g);
+    h = __fma_rn(h, r, h);
+    double d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    return x == 0.0 ? x : g;
+}
+
 __device__ __forceinline__ float bin_power(cf f, float inv_fft)
 {
     double re = (double)f.r, im = (double)f.i;
     double s = __fma_rn(re, re, im * im);     // both squares are exact in fp64: one rounding, as re*re + im*im
-    float mag = (float)__dsqrt_rn(s);
+    float mag = (float)dsqrt_sumsq(s);
     float sq = mag * mag;
     return sq * inv_fft;                       // power-of-two fft length: exact scaling
 }
@@ -163,6 +179,7 @@ struct MfccSmem {
     } u;
     float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
     float energy[KWS_MAXF];
+    float dcny[2 * CHF];                 // tmp[0] of each frame of the chunk (DC / Nyquist source)
     static_assert(sizeof(float) * (KWS_MAXF * KWS_MAXCEP + KWS_MAXPROW) <= sizeof(float) * KWS_NBINS * CHF, "alias");
 };
 
@@ -301,14 +318,9 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                         pcol[(KWS_NC - k) * CHF] = bin_power(hi, P.inv_fft);            // "ncfft-k" store
                     }
                 }
-                if (t == 0 && live) {
-                    cf d = ld_cf(zb, 0);
-                    cf dc, ny;
-                    dc.r = d.r + d.i; dc.i = 0.0f;
-                    ny.r = d.r - d.i; ny.i = 0.0f;
-                    pcol[0] = bin_power(dc, P.inv_fft);
-                    pcol[KWS_NC * CHF] = bin_power(ny, P.inv_fft);
-                }
+                // DC / Nyquist bins (kiss_fftr.cpp:84-96) need tmp[0] only: parked per frame, evaluated once per chunk
+                // with one frame per lane instead of one lane per wave here
+                if (t == 0 && live) *(float2 *)(sm.dcny + 2 * fr) = *(const float2 *)zb;
                 WAVE_SYNC();
                 PH(2);
             }
@@ -317,6 +329,14 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
             const int f_base = 2 * pair0;
             const int nfc = min(2 * pair1, nfr) - f_base;
             if (lane < nfc) {
+                {
+                    const float2 d = *(const float2 *)(sm.dcny + 2 * lane);
+                    cf dc, ny;
+                    dc.r = d.x + d.y; dc.i = 0.0f;
+                    ny.r = d.x - d.y; ny.i = 0.0f;
+                    sm.u.p[lane] = bin_power(dc, P.inv_fft);
+                    sm.u.p[KWS_NC * CHF + lane] = bin_power(ny, P.inv_fft);
+                }
                 float e = 0.0f;
                 const float *pl = sm.u.p + lane;
 #pragma unroll 16
