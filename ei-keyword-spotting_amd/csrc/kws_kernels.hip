@@ -226,8 +226,9 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
         const void *xbase = F32IN ? (const void *)((const float *)pcm_v + (size_t)clip * P.n_samples)
                                   : (const void *)((const int16_t *)pcm_v + (size_t)clip * P.n_samples);
-        // software prefetch: the samples of pair p+1 are requested before pair p is transformed
+        // software prefetch, two frame pairs deep: the samples of pair p+2 are requested before pair p is transformed
         RawSamples<F32IN> nxt = fetch_samples<F32IN>(xbase, min(half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+        RawSamples<F32IN> nxt2 = fetch_samples<F32IN>(xbase, min(2 + half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
         const bool has_wrap = wrap != nullptr;
         const float wrapv = has_wrap ? wrap[clip] : 0.0f;
 
@@ -237,8 +238,9 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 // ---- 8 samples/lane (16 B, coalesced: 32 lanes = the 256 samples of a frame that rfft keeps) -----
                 const int f = 2 * pr + half;
                 const RawSamples<F32IN> cur = nxt;
-                if (pr + 1 < n_pairs)
-                    nxt = fetch_samples<F32IN>(xbase, min(f + 2, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+                nxt = nxt2;
+                if (pr + 2 < n_pairs)
+                    nxt2 = fetch_samples<F32IN>(xbase, min(f + 4, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
                 const bool first_sample = has_wrap && (min(f, nfr - 1) * P.frame_stride + 8 * t == 0);
                 float y[8];
                 if constexpr (F32IN) {
