@@ -1092,6 +1092,192 @@ static int op_softmax(const kwso_model *m, const o_node *nd, int8_t **buf)
     return 0;
 }
 
+/* ====================================================================== */
+/*  NN ops, float32 variants (TFLite-Micro float reference kernels)        */
+/* ====================================================================== */
+/* CalculateActivationRange (TFL/kernels/kernel_util.h): none -> [lowest, max], relu -> [0, max], ... */
+static void act_range_f32(int activation, float *amin, float *amax)
+{
+    *amin = -FLT_MAX; *amax = FLT_MAX;
+    if (activation == 1) *amin = 0.f;
+    else if (activation == 3) { *amin = 0.f; *amax = 6.f; }
+    else if (activation == 2) { *amin = -1.f; *amax = 1.f; }
+}
+static float clampf(float x, float lo, float hi)   /* ActivationFunctionWithMinMax: std::min(std::max(x, lo), hi) */
+{
+    float a = x < lo ? lo : x;        /* std::max(x, lo): returns x unless x < lo */
+    return hi < a ? hi : a;           /* std::min(a, hi): returns a unless hi < a */
+}
+
+/* CONV_2D float: TFL/kernels/internal/reference/conv.h:28-99 (sequential total += in * filter, then + bias, clamp) */
+static int op_conv_f32(const kwso_model *m, const o_node *nd, float **buf)
+{
+    const o_tensor *in = &m->t[nd->in[0]], *flt = &m->t[nd->in[1]], *out = &m->t[nd->out[0]];
+    const o_tensor *bias = nd->n_in > 2 && nd->in[2] >= 0 ? &m->t[nd->in[2]] : NULL;
+    const float *x = buf[nd->in[0]], *w = (const float *)flt->data, *b = bias ? (const float *)bias->data : NULL;
+    float *y = buf[nd->out[0]];
+    const int padding = nd->p[0], stride_w = nd->p[1], stride_h = nd->p[2], activation = nd->p[3];
+    const int dil_w = nd->p[4], dil_h = nd->p[5];
+    const int batches = dim4(in, 0), in_h = dim4(in, 1), in_w = dim4(in, 2), in_d = dim4(in, 3);
+    const int f_h = dim4(flt, 1), f_w = dim4(flt, 2);
+    const int out_h = dim4(out, 1), out_w = dim4(out, 2), out_d = dim4(out, 3);
+    int oh = out_size(padding, in_h, f_h, stride_h, dil_h), ow = out_size(padding, in_w, f_w, stride_w, dil_w);
+    const int pad_h = pad_amount(stride_h, dil_h, in_h, f_h, oh), pad_w = pad_amount(stride_w, dil_w, in_w, f_w, ow);
+    float amin, amax;
+    act_range_f32(activation, &amin, &amax);
+    for (int bt = 0; bt < batches; ++bt)
+        for (int oy = 0; oy < out_h; ++oy)
+            for (int ox = 0; ox < out_w; ++ox)
+                for (int oc = 0; oc < out_d; ++oc) {
+                    const int x0 = ox * stride_w - pad_w, y0 = oy * stride_h - pad_h;
+                    float total = 0.f;
+                    for (int fy = 0; fy < f_h; ++fy)
+                        for (int fx = 0; fx < f_w; ++fx)
+                            for (int ic = 0; ic < in_d; ++ic) {
+                                const int ix = x0 + dil_w * fx, iy = y0 + dil_h * fy;
+                                if (ix >= 0 && ix < in_w && iy >= 0 && iy < in_h) {
+                                    float prod = x[((bt * in_h + iy) * in_w + ix) * in_d + ic] * w[((oc * f_h + fy) * f_w + fx) * in_d + ic];
+                                    total += prod;
+                                }
+                            }
+                    float bv = b ? b[oc] : 0.0f;
+                    y[((bt * out_h + oy) * out_w + ox) * out_d + oc] = clampf(total + bv, amin, amax);
+                }
+    return 0;
+}
+
+/* ADD float: add.cc:101-120, reference/add.h:179-215 */
+static int op_add_f32(const kwso_model *m, const o_node *nd, float **buf)
+{
+    const o_tensor *t1 = &m->t[nd->in[0]], *t2 = &m->t[nd->in[1]], *out = &m->t[nd->out[0]];
+    const float *a = buf[nd->in[0]], *bq = buf[nd->in[1]];
+    float *y = buf[nd->out[0]];
+    float amin, amax;
+    act_range_f32(nd->p[0], &amin, &amax);
+    int od[4], d1[4], d2[4];
+    for (int i = 0; i < 4; i++) { od[i] = dim4(out, i); d1[i] = dim4(t1, i); d2[i] = dim4(t2, i); }
+    for (int b0 = 0; b0 < od[0]; ++b0)
+        for (int yy = 0; yy < od[1]; ++yy)
+            for (int xx = 0; xx < od[2]; ++xx)
+                for (int c = 0; c < od[3]; ++c) {
+                    int i1 = (((d1[0] == 1 ? 0 : b0) * d1[1] + (d1[1] == 1 ? 0 : yy)) * d1[2] + (d1[2] == 1 ? 0 : xx)) * d1[3] + (d1[3] == 1 ? 0 : c);
+                    int i2 = (((d2[0] == 1 ? 0 : b0) * d2[1] + (d2[1] == 1 ? 0 : yy)) * d2[2] + (d2[2] == 1 ? 0 : xx)) * d2[3] + (d2[3] == 1 ? 0 : c);
+                    y[((b0 * od[1] + yy) * od[2] + xx) * od[3] + c] = clampf(a[i1] + bq[i2], amin, amax);
+                }
+    return 0;
+}
+
+/* MAX_POOL_2D float: reference/pooling.h:189-237 */
+static int op_maxpool_f32(const kwso_model *m, const o_node *nd, float **buf)
+{
+    const o_tensor *in = &m->t[nd->in[0]], *out = &m->t[nd->out[0]];
+    const float *x = buf[nd->in[0]];
+    float *y = buf[nd->out[0]];
+    const int padding = nd->p[0], stride_w = nd->p[1], stride_h = nd->p[2], f_w = nd->p[3], f_h = nd->p[4];
+    const int batches = dim4(in, 0), in_h = dim4(in, 1), in_w = dim4(in, 2), depth = dim4(in, 3);
+    const int out_h = dim4(out, 1), out_w = dim4(out, 2);
+    int oh = out_size(padding, in_h, f_h, stride_h, 1), ow = out_size(padding, in_w, f_w, stride_w, 1);
+    const int pad_h = pad_amount(stride_h, 1, in_h, f_h, oh), pad_w = pad_amount(stride_w, 1, in_w, f_w, ow);
+    float amin, amax;
+    act_range_f32(nd->p[5], &amin, &amax);
+    for (int bt = 0; bt < batches; ++bt)
+        for (int oy = 0; oy < out_h; ++oy)
+            for (int ox = 0; ox < out_w; ++ox)
+                for (int c = 0; c < depth; ++c) {
+                    const int x0 = ox * stride_w - pad_w, y0 = oy * stride_h - pad_h;
+                    const int fxs = 0 > -x0 ? 0 : -x0, fxe = f_w < in_w - x0 ? f_w : in_w - x0;
+                    const int fys = 0 > -y0 ? 0 : -y0, fye = f_h < in_h - y0 ? f_h : in_h - y0;
+                    float mx = -FLT_MAX;
+                    for (int fy = fys; fy < fye; ++fy)
+                        for (int fx = fxs; fx < fxe; ++fx) {
+                            float v = x[((bt * in_h + (y0 + fy)) * in_w + (x0 + fx)) * depth + c];
+                            mx = mx < v ? v : mx;                     /* std::max(mx, v) */
+                        }
+                    y[((bt * out_h + oy) * out_w + ox) * depth + c] = clampf(mx, amin, amax);
+                }
+    return 0;
+}
+
+/* FULLY_CONNECTED float: reference/fully_connected.h:26-60 */
+static int op_fc_f32(const kwso_model *m, const o_node *nd, float **buf)
+{
+    const o_tensor *flt = &m->t[nd->in[1]], *out = &m->t[nd->out[0]];
+    const o_tensor *bias = nd->n_in > 2 && nd->in[2] >= 0 ? &m->t[nd->in[2]] : NULL;
+    const float *x = buf[nd->in[0]], *w = (const float *)flt->data, *b = bias ? (const float *)bias->data : NULL;
+    float *y = buf[nd->out[0]];
+    float amin, amax;
+    act_range_f32(nd->p[0], &amin, &amax);
+    const int out_d = out->dims[out->ndims - 1];
+    int batches = 1;
+    for (uint32_t i = 0; i + 1 < out->ndims; i++) batches *= out->dims[i];
+    const int accum = flt->dims[flt->ndims - 1];
+    for (int bt = 0; bt < batches; ++bt)
+        for (int oc = 0; oc < out_d; ++oc) {
+            float total = 0.f;
+            for (int d = 0; d < accum; ++d) {
+                float prod = x[bt * accum + d] * w[oc * accum + d];
+                total += prod;
+            }
+            float bv = b ? b[oc] : 0.0f;
+            y[oc + out_d * bt] = clampf(total + bv, amin, amax);
+        }
+    return 0;
+}
+
+/* SOFTMAX float: reference/softmax.h:31-63 (std::exp on float = expf) */
+static int op_softmax_f32(const kwso_model *m, const o_node *nd, float **buf)
+{
+    const o_tensor *in = &m->t[nd->in[0]];
+    const float *x = buf[nd->in[0]];
+    float *y = buf[nd->out[0]];
+    const int depth = in->dims[in->ndims - 1];
+    int outer = 1;
+    for (uint32_t i = 0; i + 1 < in->ndims; i++) outer *= in->dims[i];
+    const float beta = nd->beta;
+    for (int i = 0; i < outer; ++i) {
+        float mx = -FLT_MAX;
+        for (int c = 0; c < depth; ++c) mx = mx < x[i * depth + c] ? x[i * depth + c] : mx;
+        float sum = 0.f;
+        for (int c = 0; c < depth; ++c) sum += expf((x[i * depth + c] - mx) * beta);
+        for (int c = 0; c < depth; ++c) y[i * depth + c] = expf((x[i * depth + c] - mx) * beta) / sum;
+    }
+    return 0;
+}
+
+int kwso_model_is_float(const kwso_model *m) { return m->t[m->t_in].type == TYPE_F32; }
+
+/* float graph: input[nn_input_frame_size] -> out[label_count]; taps (optional) = every tensor, tensor-id order */
+int kwso_nn_invoke_f32(const kwso_model *m, const float *input, float *out, float *taps)
+{
+    float **buf = (float **)calloc(m->n_tensors, sizeof(float *));
+    float *own = (float *)calloc(m->tap_bytes / 4 + 1, sizeof(float));
+    if (!buf || !own) { free(buf); free(own); return -6; }
+    for (uint32_t i = 0; i < m->n_tensors; i++) {
+        buf[i] = own + m->t[i].tap_offset / 4;
+        if (m->t[i].is_const) memcpy(buf[i], m->t[i].data, m->t[i].nbytes);
+    }
+    memcpy(buf[m->t_in], input, m->t[m->t_in].nbytes);
+    int rc = 0;
+    for (uint32_t i = 0; i < m->n_nodes && rc == 0; i++) {
+        const o_node *nd = &m->n[i];
+        switch (nd->op) {
+        case OP_RESHAPE: memcpy(buf[nd->out[0]], buf[nd->in[0]], m->t[nd->out[0]].nbytes); break;
+        case OP_CONV_2D: rc = op_conv_f32(m, nd, buf); break;
+        case OP_ADD: rc = op_add_f32(m, nd, buf); break;
+        case OP_MAX_POOL_2D: rc = op_maxpool_f32(m, nd, buf); break;
+        case OP_FULLY_CONNECTED: rc = op_fc_f32(m, nd, buf); break;
+        case OP_SOFTMAX: rc = op_softmax_f32(m, nd, buf); break;
+        default: rc = -3;
+        }
+    }
+    if (rc == 0) {
+        memcpy(out, buf[m->t_out], m->t[m->t_out].nbytes);
+        if (taps) memcpy(taps, own, m->tap_bytes);
+    }
+    free(buf); free(own);
+    return rc;
+}
+
 /* ei_run_classifier.h:436-444 : static_cast<int8_t>(round(f / scale) + zero_point), no clamp.
  * x86 semantics of the out-of-range cast: cvttss2si to int32 (INT_MIN when unrepresentable),
  * then the low 8 bits. */
@@ -1154,6 +1340,7 @@ int kwso_nn_invoke(const kwso_model *m, const int8_t *input_q, int8_t *out_q, in
 
 int kwso_run_inference(const kwso_model *m, const float *features, float *scores)
 {
+    if (kwso_model_is_float(m)) return kwso_nn_invoke_f32(m, features, scores, NULL);   /* ei_run_classifier.h:441-443, 475 */
     int8_t *q = (int8_t *)malloc(m->nn_input_frame_size);
     int8_t oq[1024];
     if (!q) return -8;
@@ -1179,10 +1366,16 @@ int kwso_run_classifier_batch(const kwso_model *m, const int16_t *pcm, size_t n,
         memset(feat, 0, sizeof(float) * F);
         rc = kwso_extract_mfcc(pcm + b * n, n, &m->dsp, feat);
         if (rc) { rc = -5; break; }   /* EI_IMPULSE_DSP_ERROR */
-        kwso_quantize_input(m, feat, q);
-        rc = kwso_nn_invoke(m, q, oq, NULL);
-        if (rc) break;
-        kwso_dequantize_output(m, oq, scores + b * C);
+        if (kwso_model_is_float(m)) {
+            memset(q, 0, F);
+            rc = kwso_nn_invoke_f32(m, feat, scores + b * C, NULL);
+            if (rc) break;
+        } else {
+            kwso_quantize_input(m, feat, q);
+            rc = kwso_nn_invoke(m, q, oq, NULL);
+            if (rc) break;
+            kwso_dequantize_output(m, oq, scores + b * C);
+        }
         if (features_out) memcpy(features_out + b * F, feat, sizeof(float) * F);
         if (q_out) memcpy(q_out + b * F, q, F);
     }

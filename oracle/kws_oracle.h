@@ -92,6 +92,10 @@ void kwso_quantize_input(const kwso_model *m, const float *features, int8_t *q);
  * tensors (tensor id order, kwso_model_tensor_bytes each); every op output is copied there.
  * out_q[label_count] = int8 output tensor.    trained_model_compiled.cpp:457-465 + TFL kernels */
 int  kwso_nn_invoke(const kwso_model *m, const int8_t *input_q, int8_t *out_q, int8_t *taps);
+/* float32 models (TFLM float reference kernels): conv.h:28-99, add.h:179-215, pooling.h:189-237,
+ * fully_connected.h:26-60, softmax.h:31-63 */
+int  kwso_model_is_float(const kwso_model *m);
+int  kwso_nn_invoke_f32(const kwso_model *m, const float *input, float *out, float *taps);
 /* dequantise                                  ei_run_classifier.h:466-482 */
 void kwso_dequantize_output(const kwso_model *m, const int8_t *out_q, float *scores);
 /* run_inference = quantise + invoke + dequantise         ei_run_classifier.h:293-493 */

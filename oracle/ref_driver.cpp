@@ -32,6 +32,12 @@
 #include "tflite-model/trained_model_compiled.cpp"
 #include "edge-impulse-sdk/classifier/ei_run_classifier.h"
 
+#include "edge-impulse-sdk/tensorflow/lite/kernels/internal/reference/conv.h"
+#include "edge-impulse-sdk/tensorflow/lite/kernels/internal/reference/add.h"
+#include "edge-impulse-sdk/tensorflow/lite/kernels/internal/reference/pooling.h"
+#include "edge-impulse-sdk/tensorflow/lite/kernels/internal/reference/fully_connected.h"
+#include "edge-impulse-sdk/tensorflow/lite/kernels/internal/reference/softmax.h"
+
 using namespace ei;
 
 /* ---- porting hooks (SDK/porting/ei_classifier_porting.h:45-76) ---------- */
@@ -255,6 +261,51 @@ int eiref_nn_taps(const int8_t *input, int n_taps, const int *tensor_ids, int8_t
 
 int eiref_tensor_count(void) { return (int)(sizeof(tensorData) / sizeof(tensorData[0])); }
 int eiref_tensor_bytes(int id) { return (int)tensorData[id].bytes; }
+
+/* ---- float32 TFLite-Micro reference kernels, called as leaves (no float model is shipped) ----
+ * TFL/kernels/internal/reference/{conv.h:28-99, add.h:179-215, pooling.h:189-237, fully_connected.h:26-60,
+ * softmax.h:31-63} */
+void eiref_f32_conv(const float *in, int in_h, int in_w, int in_c, const float *flt, int out_c, int f_h, int f_w,
+                    const float *bias, int pad_w, int pad_h, float amin, float amax, float *out, int out_h, int out_w) {
+    tflite::ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.padding_values.width = pad_w; p.padding_values.height = pad_h;
+    p.stride_width = 1; p.stride_height = 1; p.dilation_width_factor = 1; p.dilation_height_factor = 1;
+    p.float_activation_min = amin; p.float_activation_max = amax;
+    tflite::reference_ops::Conv(p, tflite::RuntimeShape({1, in_h, in_w, in_c}), in, tflite::RuntimeShape({out_c, f_h, f_w, in_c}), flt,
+                                tflite::RuntimeShape({out_c}), bias, tflite::RuntimeShape({1, out_h, out_w, out_c}), out,
+                                tflite::RuntimeShape(), nullptr);
+}
+void eiref_f32_add_bcast(const float *a, const int *da /*[4]*/, const float *b, const int *db /*[4]*/, const int *dout,
+                         float amin, float amax, float *out) {
+    tflite::ArithmeticParams p;
+    memset(&p, 0, sizeof(p));
+    p.float_activation_min = amin; p.float_activation_max = amax;
+    tflite::reference_ops::BroadcastAdd4DSlow(p, tflite::RuntimeShape({da[0], da[1], da[2], da[3]}), a,
+                                              tflite::RuntimeShape({db[0], db[1], db[2], db[3]}), b,
+                                              tflite::RuntimeShape({dout[0], dout[1], dout[2], dout[3]}), out);
+}
+void eiref_f32_maxpool(const float *in, int in_h, int in_w, int c, int f_h, int f_w, int stride_h, int stride_w,
+                       float amin, float amax, float *out, int out_h, int out_w) {
+    tflite::PoolParams p;
+    memset(&p, 0, sizeof(p));
+    p.stride_height = stride_h; p.stride_width = stride_w; p.filter_height = f_h; p.filter_width = f_w;
+    p.float_activation_min = amin; p.float_activation_max = amax;
+    tflite::reference_ops::MaxPool(p, tflite::RuntimeShape({1, in_h, in_w, c}), in, tflite::RuntimeShape({1, out_h, out_w, c}), out);
+}
+void eiref_f32_fc(const float *in, int accum, const float *w, int out_d, const float *bias, float amin, float amax, float *out) {
+    tflite::FullyConnectedParams p;
+    memset(&p, 0, sizeof(p));
+    p.float_activation_min = amin; p.float_activation_max = amax;
+    tflite::reference_ops::FullyConnected(p, tflite::RuntimeShape({1, accum}), in, tflite::RuntimeShape({out_d, accum}), w,
+                                          tflite::RuntimeShape({out_d}), bias, tflite::RuntimeShape({1, out_d}), out);
+}
+void eiref_f32_softmax(const float *in, int depth, float beta, float *out) {
+    tflite::SoftmaxParams p;
+    memset(&p, 0, sizeof(p));
+    p.beta = beta;
+    tflite::reference_ops::Softmax(p, tflite::RuntimeShape({1, depth}), in, tflite::RuntimeShape({1, depth}), out);
+}
 
 /* CPU baseline: loop run_classifier over n_clips clips ([n_clips][len] int16), `iters` passes.
  * Returns seconds of wall time; checksum defeats dead-code elimination. */

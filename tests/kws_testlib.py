@@ -96,6 +96,8 @@ class Oracle:
         L.kwso_time_run_classifier.restype = C.c_double
         L.kwso_time_run_classifier.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.kwso_synth_fill.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.kwso_model_is_float.argtypes = [C.c_void_p]
+        L.kwso_nn_invoke_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kwso_continuous_create.restype = C.c_void_p
         L.kwso_continuous_create.argtypes = [C.c_void_p]
         L.kwso_continuous_free.argtypes = [C.c_void_p]
@@ -212,6 +214,18 @@ class OracleModel:
         if not taps:
             return out
         offs = np.cumsum([0] + self.tensor_bytes)
+        return out, [tp[offs[i]:offs[i + 1]] for i in range(len(self.tensor_bytes))]
+
+    def nn_invoke_f32(self, feat, taps=False):
+        """float graph; taps -> list of float32 arrays, one per tensor (tensor-id order)"""
+        feat = np.ascontiguousarray(feat, np.float32)
+        out = np.zeros(self.n_labels, np.float32)
+        tp = np.zeros(sum(self.tensor_bytes) // 4 + 1, np.float32) if taps else None
+        rc = self.o.L.kwso_nn_invoke_f32(self.h, _ptr(feat), _ptr(out), _ptr(tp) if taps else None)
+        assert rc == 0, rc
+        if not taps:
+            return out
+        offs = np.cumsum([0] + [b // 4 for b in self.tensor_bytes])
         return out, [tp[offs[i]:offs[i + 1]] for i in range(len(self.tensor_bytes))]
 
     def dequantize(self, out_q):
@@ -422,6 +436,42 @@ class Reference:
         pcm = np.ascontiguousarray(pcm, np.int16)
         chk = C.c_float()
         return self.L.eiref_time_run_classifier(_ptr(pcm), pcm.shape[0], pcm.shape[1], iters, C.byref(chk))
+
+
+def reference_float_twin(reference, tensors, feat):
+    """Run the fp32 twin of the shipped graph through the REFERENCE's float TFLite-Micro kernels,
+    called leaf by leaf (oracle/ref_driver.cpp eiref_f32_*).  tensors: constant tensors of the .kwsm (id -> float array).
+    Returns (logits[4], scores[4])."""
+    L = reference.L
+    fp = C.POINTER(C.c_float)
+    FLT_MAX = float(np.finfo(np.float32).max)
+
+    def P(a):
+        return a.ctypes.data_as(fp)
+
+    def F(x):
+        return C.c_float(x)
+
+    x = np.ascontiguousarray(feat, np.float32)
+    y1 = np.zeros(49 * 30, np.float32)
+    L.eiref_f32_conv(P(x), 1, 49, 13, P(tensors[7]), 30, 1, 7, P(tensors[6]), 3, 0, F(-FLT_MAX), F(FLT_MAX), P(y1), 1, 49)
+    y2 = np.zeros(49 * 30, np.float32)
+    L.eiref_f32_add_bcast(P(y1), (C.c_int * 4)(1, 1, 49, 30), P(tensors[2]), (C.c_int * 4)(1, 1, 1, 30),
+                          (C.c_int * 4)(1, 1, 49, 30), F(0.0), F(FLT_MAX), P(y2))
+    y3 = np.zeros(7 * 30, np.float32)
+    L.eiref_f32_maxpool(P(y2), 49, 1, 30, 7, 1, 7, 1, F(-FLT_MAX), F(FLT_MAX), P(y3), 7, 1)
+    y4 = np.zeros(70, np.float32)
+    L.eiref_f32_conv(P(y3), 1, 7, 30, P(tensors[9]), 10, 1, 7, P(tensors[8]), 3, 0, F(-FLT_MAX), F(FLT_MAX), P(y4), 1, 7)
+    y5 = np.zeros(70, np.float32)
+    L.eiref_f32_add_bcast(P(y4), (C.c_int * 4)(1, 1, 7, 10), P(tensors[3]), (C.c_int * 4)(1, 1, 1, 10),
+                          (C.c_int * 4)(1, 1, 7, 10), F(0.0), F(FLT_MAX), P(y5))
+    y6 = np.zeros(10, np.float32)
+    L.eiref_f32_maxpool(P(y5), 7, 1, 10, 7, 1, 7, 1, F(-FLT_MAX), F(FLT_MAX), P(y6), 1, 1)
+    lg = np.zeros(4, np.float32)
+    L.eiref_f32_fc(P(y6), 10, P(tensors[5]), 4, P(tensors[4]), F(-FLT_MAX), F(FLT_MAX), P(lg))
+    sc = np.zeros(4, np.float32)
+    L.eiref_f32_softmax(P(lg), 4, F(1.0), P(sc))
+    return lg, sc
 
 
 def bits(a):

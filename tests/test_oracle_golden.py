@@ -153,3 +153,16 @@ def test_continuous_mode_golden(oracle, l476):
         oc.init()
     assert list(g["produced"][:5]) == [False, False, False, True, True]      # buffer full after 4 slices
     assert g["total_length_after"][0] == 4000 and (g["total_length_after"][1:] == 4320).all()   # first_run quirk
+
+
+def test_fp32_twin_golden(oracle):
+    """fp32 twin of the shipped model (BASELINE config "fp32"): golden = the reference's float kernels chained leaf by
+    leaf on the reference's own MFCC features (tools/make_golden.py)."""
+    from kws_testlib import MODELS, OracleModel
+    g = _load("f32_twin_l476.npz")
+    mf = OracleModel(oracle, os.path.join(MODELS, "l476_no_yes_f32.kwsm"))
+    clips = oracle.synth(int(g["seed"]), 0, int(g["n"]))
+    s = mf.run_batch(clips)
+    assert np.abs(s - g["scores"]).max() <= 1e-7        # expf of the host libm is the only non-replayed operation
+    out, taps = mf.nn_invoke_f32(oracle.extract_mfcc(clips[3], mf.cfg), taps=True)
+    assert (bits(taps[29]) == bits(g["logits"][3])).all()

@@ -111,3 +111,53 @@ def test_run_classifier_end_to_end(oracle, reference, l476):
         assert (bits(s[i]) == bits(rs)).all()
     for name, c in special_clips().items():
         assert (bits(l476.run_batch(c)[0]) == bits(reference.run_classifier(c)[1])).all(), name
+
+
+def test_float_kernels_pinned_leaf_by_leaf(oracle, reference):
+    """No float model ships with the reference, but its SDK carries the float TFLite-Micro kernels.
+    The restated float graph (fp32 twin of the shipped model, tools/dequantize_model.py) is pinned op by op: each
+    reference kernel is fed the oracle's input tensor of that op and must reproduce the oracle's output tensor."""
+    import ctypes as C
+    import os
+    from kws_testlib import MODELS, OracleModel
+    mf = OracleModel(oracle, os.path.join(MODELS, "l476_no_yes_f32.kwsm"))
+    assert oracle.L.kwso_model_is_float(mf.h) == 1
+    L = reference.L
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    FLT_MAX = float(np.finfo(np.float32).max)
+
+    def P(a):
+        return np.ascontiguousarray(a, np.float32).ctypes.data_as(fp)
+
+    rng = np.random.default_rng(2)
+    for trial in range(6):
+        feat = (rng.standard_normal(637) * (1 + trial)).astype(np.float32)
+        out, t = mf.nn_invoke_f32(feat, taps=True)
+        # tensor ids as in SURVEY appendix A: conv1 16->17 (W=7, B=6), add 18+2->19, pool 20->21, conv2 22->23 (W=9, B=8),
+        # add 24+3->25, pool 26->27, fc 28->29 (W=5, B=4), softmax 29->30
+        y = np.zeros(49 * 30, np.float32)
+        L.eiref_f32_conv(P(t[16]), 1, 49, 13, P(t[7]), 30, 1, 7, P(t[6]), 3, 0, C.c_float(-FLT_MAX), C.c_float(FLT_MAX), P(y), 1, 49)
+        assert (bits(y) == bits(t[17])).all()
+        y = np.zeros(49 * 30, np.float32)
+        L.eiref_f32_add_bcast(P(t[18]), (C.c_int * 4)(1, 1, 49, 30), P(t[2]), (C.c_int * 4)(1, 1, 1, 30), (C.c_int * 4)(1, 1, 49, 30),
+                              C.c_float(0.0), C.c_float(FLT_MAX), P(y))
+        assert (bits(y) == bits(t[19])).all()
+        y = np.zeros(7 * 30, np.float32)
+        L.eiref_f32_maxpool(P(t[20]), 49, 1, 30, 7, 1, 7, 1, C.c_float(-FLT_MAX), C.c_float(FLT_MAX), P(y), 7, 1)
+        assert (bits(y) == bits(t[21])).all()
+        y = np.zeros(7 * 10, np.float32)
+        L.eiref_f32_conv(P(t[22]), 1, 7, 30, P(t[9]), 10, 1, 7, P(t[8]), 3, 0, C.c_float(-FLT_MAX), C.c_float(FLT_MAX), P(y), 1, 7)
+        assert (bits(y) == bits(t[23])).all()
+        y = np.zeros(70, np.float32)
+        L.eiref_f32_add_bcast(P(t[24]), (C.c_int * 4)(1, 1, 7, 10), P(t[3]), (C.c_int * 4)(1, 1, 1, 10), (C.c_int * 4)(1, 1, 7, 10),
+                              C.c_float(0.0), C.c_float(FLT_MAX), P(y))
+        assert (bits(y) == bits(t[25])).all()
+        y = np.zeros(10, np.float32)
+        L.eiref_f32_maxpool(P(t[26]), 7, 1, 10, 7, 1, 7, 1, C.c_float(-FLT_MAX), C.c_float(FLT_MAX), P(y), 1, 1)
+        assert (bits(y) == bits(t[27])).all()
+        y = np.zeros(4, np.float32)
+        L.eiref_f32_fc(P(t[28]), 10, P(t[5]), 4, P(t[4]), C.c_float(-FLT_MAX), C.c_float(FLT_MAX), P(y))
+        assert (bits(y) == bits(t[29])).all()
+        y = np.zeros(4, np.float32)
+        L.eiref_f32_softmax(P(t[29]), 4, C.c_float(1.0), P(y))
+        assert (bits(y) == bits(t[30])).all() and (bits(y) == bits(out)).all()

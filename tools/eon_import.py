@@ -156,6 +156,54 @@ def serialise(tensors, nodes, t_in, t_out, meta):
     return b"".join(out)
 
 
+def parse_blob(blob):
+    """Inverse of serialise(): .kwsm bytes -> (tensors, nodes, t_in, t_out, meta)."""
+    assert blob[:4] == b"KWSM"
+    off = [4]
+
+    def rd(fmt):
+        v = struct.unpack_from("<" + fmt, blob, off[0])
+        off[0] += struct.calcsize("<" + fmt)
+        return v
+
+    (version,) = rd("I")
+    assert version == 1
+    nt, nn, nl, t_in, t_out = rd("5I")
+    raw, freq, nnin = rd("3I")
+    d = rd("8i3f")
+    dsp = dict(zip(("axes", "num_cepstral", "num_filters", "fft_length", "win_size", "low_frequency", "high_frequency",
+                    "pre_shift", "frame_length", "frame_stride", "pre_cof"), d))
+    labels = []
+    for _ in range(nl):
+        (ln,) = rd("I")
+        labels.append(blob[off[0]:off[0] + ln].decode())
+        off[0] += (ln + 3) & ~3
+    tensors = []
+    for _ in range(nt):
+        ttype, nd = rd("2I")
+        dims = list(rd("%di" % nd)) if nd else []
+        const, nq = rd("2I")
+        scale = list(rd("%df" % nq)) if nq else []
+        zero = list(rd("%di" % nq)) if nq else []
+        qdim, nbytes = rd("iI")
+        data = b""
+        if const:
+            data = blob[off[0]:off[0] + nbytes]
+            off[0] += (nbytes + 3) & ~3
+        tensors.append({"type": ttype, "dims": dims, "nbytes": nbytes, "const": bool(const), "scale": scale, "zero": zero,
+                        "qdim": qdim, "data": data})
+    nodes = []
+    for _ in range(nn):
+        op, ni = rd("2I")
+        ins = list(rd("%di" % ni)) if ni else []
+        (no,) = rd("I")
+        outs = list(rd("%di" % no)) if no else []
+        pb = rd("8if")
+        nodes.append({"op": op, "in": ins, "out": outs, "p": list(pb[:8]), "beta": pb[8]})
+    meta = {"labels": labels, "dsp": dsp, "raw_sample_count": raw, "frequency": freq, "nn_input_frame_size": nnin}
+    return tensors, nodes, t_in, t_out, meta
+
+
 def import_export(export_dir):
     with open(f"{export_dir}/tflite-model/trained_model_compiled.cpp") as f:
         tensors, nodes, t_in, t_out = parse_compiled_model(f.read())

@@ -124,7 +124,21 @@ def main():
     cont["scores"] = np.stack(sc)
     cont["total_length_after"] = np.int64(tls)
     np.savez_compressed(os.path.join(GOLDEN, "continuous_l476.npz"), **cont)
-    for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz", "continuous_l476.npz"):
+    # ---- fp32 twin (tools/dequantize_model.py) through the reference's FLOAT kernels, leaf by leaf --------------
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import eon_import
+    from kws_testlib import reference_float_twin
+    tens, _, _, _, _ = eon_import.parse_blob(open(os.path.join(MODELS, "l476_no_yes_f32.kwsm"), "rb").read())
+    consts = {i: np.frombuffer(t["data"], np.float32).copy() for i, t in enumerate(tens) if t["const"] and t["type"] == 1}
+    clips = synth.synth(6, 0, 24)
+    f32 = {"seed": np.int32(6), "n": np.int32(24)}
+    lg, sc = [], []
+    for c in clips:
+        a, b = reference_float_twin(ref, consts, ref.extract_mfcc(c, cfg))
+        lg.append(a); sc.append(b)
+    f32["logits"], f32["scores"] = np.stack(lg), np.stack(sc)
+    np.savez_compressed(os.path.join(GOLDEN, "f32_twin_l476.npz"), **f32)
+    for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz", "continuous_l476.npz", "f32_twin_l476.npz"):
         print(fn, os.path.getsize(os.path.join(GOLDEN, fn)), "bytes")
 
 
