@@ -20,13 +20,16 @@ ALGO_BYTES_PER_CLIP = 16000 * 2 + 4 * 4      # int16 PCM in + C=4 f
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_worker(kind, n_clips, seconds):
+DEFAULT_MODEL = os.path.join(ROOT, "models", "l476_no_yes.kwsm")
+
+
+def cpu_worker(kind, n_clips, seconds, model_path=DEFAULT_MODEL):
     """Child process: run the CPU path over n_clips synthetic clips again and again for ~`seconds`; prints clips/s."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from kws_testlib import MODELS, Oracle, OracleModel, Reference
     o = Oracle()
     clips = o.synth(0, 0, n_clips)
-    runner = Reference() if kind == "reference" else OracleModel(o, os.path.join(MODELS, "l476_no_yes.kwsm"))
+    runner = Reference() if kind == "reference" else OracleModel(o, model_path)
     runner.time_run(clips[:4], 1)
     done, spent = 0, 0.0
     while spent < seconds:
@@ -54,15 +57,16 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(seconds=8.0):
+def cpu_baseline(seconds=8.0, model_path=DEFAULT_MODEL):
     """The reference SDK (oracle/_ref, compiled from the unmodified sources) on the host cores, one PROCESS per core
     (the reference keeps state in globals: non-reentrant), for a bounded time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from kws_testlib import have_reference
-    kind = "reference" if have_reference() else "port"
+    # oracle/_ref is the reference built around ITS shipped model; any other model file is timed on the C restatement
+    kind = "reference" if have_reference() and os.path.samefile(model_path, DEFAULT_MODEL) else "port"
     cores = usable_cores()
     n_clips = 64
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, str(n_clips)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--model", model_path, "--cpu-worker", kind, str(n_clips)]
     single = subprocess.run(cmd + ["2.0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     try:
         single = float(single.stdout.strip().splitlines()[-1])
@@ -91,12 +95,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="clips per GPU per step")
-    ap.add_argument("--model", default=os.path.join(ROOT, "models", "l476_no_yes.kwsm"))
+    ap.add_argument("--model", default=DEFAULT_MODEL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", nargs=3, metavar=("KIND", "N_CLIPS", "SECONDS"))
     a = ap.parse_args()
     if a.cpu_worker:
-        cpu_worker(a.cpu_worker[0], int(a.cpu_worker[1]), float(a.cpu_worker[2]))
+        cpu_worker(a.cpu_worker[0], int(a.cpu_worker[1]), float(a.cpu_worker[2]), a.model)
         return
 
     rank = int(os.environ.get("RANK", 0))
@@ -104,7 +108,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline()                     # before the GPU is touched: children never see a HIP context
+        cpu = cpu_baseline(model_path=a.model)                     # before the GPU is touched: children never see a HIP context
 
     import torch
     import torch.distributed as dist
@@ -123,7 +127,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     pkg.synth_clips_device(0, rank * B, B, n, pcm.data_ptr(), stream)
     feats = torch.empty((B, F), dtype=torch.float32, device=dev)
-    q = torch.empty((B, F), dtype=torch.int8, device=dev)
+    is_float = model.is_float
+    q = None if is_float else torch.empty((B, F), dtype=torch.int8, device=dev)
     scores = torch.empty((B, C), dtype=torch.float32, device=dev)
     gathered = torch.empty((world * B, C), dtype=torch.float32, device=dev) if world > 1 else scores
 
@@ -132,10 +137,13 @@ def main():
     def step(k=None):
         if k is not None:
             ev[k][0].record()
-        model.extract_mfcc_batch_device(pcm.data_ptr(), B, feats.data_ptr(), q.data_ptr(), stream)   # extract_mfcc_features
+        model.extract_mfcc_batch_device(pcm.data_ptr(), B, feats.data_ptr(), None if is_float else q.data_ptr(), stream)   # extract_mfcc_features
         if k is not None:
             ev[k][1].record()
-        model.nn_batch_device(q.data_ptr(), B, scores.data_ptr(), stream)                             # the int8 network
+        if is_float:
+            model.run_inference_batch_device(feats.data_ptr(), B, scores.data_ptr(), stream)          # the float network
+        else:
+            model.nn_batch_device(q.data_ptr(), B, scores.data_ptr(), stream)                         # the int8 network
         if k is not None:
             ev[k][2].record()
         if world > 1:
@@ -177,17 +185,19 @@ def main():
             "metric": "1s@16kHz clips/sec (MFCC+CNN)", "value": round(world * B * a.steps / dt, 1), "unit": "clips/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32+f64 (MFCC) / i8 (CNN)", "data": "synthetic",
-            "config": {"workload": "shipped 4-class no/noise/unknown/yes impulse (MFCC 49x13: 32 mel, fft 256, CMVN 101; "
-                                   "int8 2-Conv CNN), %d clips of 1 s @ 16 kHz int16 per GPU resident in HBM" % B,
+            "dtype": "f32+f64 (MFCC) / %s (CNN)" % ("f32" if is_float else "i8"), "data": "synthetic",
+            "config": {"workload": "%s 4-class no/noise/unknown/yes impulse (MFCC 49x13: 32 mel, fft 256, CMVN 101; "
+                                   "%s 2-Conv CNN), %d clips of 1 s @ 16 kHz int16 per GPU resident in HBM"
+                                   % ("de-quantised fp32 twin of the shipped" if is_float else "shipped", "fp32" if is_float else "int8", B),
                        "clips_per_gpu": B, "global_batch": world * B, "model": os.path.basename(a.model),
-                       "parity": "bit-exact vs reference (tests/test_gpu_parity.py)",
+                       "parity": ("features+logits bit-exact, scores <= 1e-6 vs reference float kernels" if is_float
+                                  else "bit-exact vs reference") + " (tests/test_gpu_parity.py)",
                        "collective": "all_gather(scores) over RCCL" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "kws_mfcc_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CLIP * B, "algorithmic_bytes_per_clip": ALGO_BYTES_PER_CLIP,
-                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), "kws_nn_mfma_kernel": round(ms_nn, 4)}},
+                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), ("kws_nn_f32_kernel" if is_float else "kws_nn_mfma_kernel"): round(ms_nn, 4)}},
             "checksum": checksum,
         }
         if cpu is not None:

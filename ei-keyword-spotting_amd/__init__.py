@@ -32,7 +32,8 @@ EXPORTED_SYMBOLS = [
     "run_moving_average_filter", "ei_run_impulse_check_canceled", "ei_sleep", "ei_read_timer_ms",
     "ei_read_timer_us", "ei_printf", "ei_printf_float",
     "kws_create", "kws_create_from_file", "kws_destroy", "kws_last_error", "kws_label_count", "kws_label",
-    "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes", "kws_set_default_model",
+    "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes", "kws_model_is_float",
+    "kws_nn_f32_batch_device", "kws_set_default_model",
     "kws_default_model", "kws_run_classifier_batch_device", "kws_run_classifier_batch",
     "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
@@ -71,7 +72,8 @@ def lib():
         L.kws_create.argtypes = [vp, sz, i32, C.POINTER(vp)]
         L.kws_create_from_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         L.kws_destroy.argtypes = [vp]
-        for f in ("kws_label_count", "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes"):
+        for f in ("kws_label_count", "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes",
+                  "kws_model_is_float"):
             getattr(L, f).argtypes = [vp]
         L.kws_label.restype = C.c_char_p
         L.kws_label.argtypes = [vp, i32]
@@ -85,6 +87,7 @@ def lib():
         L.kws_cmvn_inference_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.kws_nn_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
         L.kws_nn_batch.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+        L.kws_nn_f32_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
         L.kws_streams_create.argtypes = [vp, sz, C.POINTER(vp)]
         L.kws_streams_destroy.argtypes = [vp]
@@ -155,6 +158,7 @@ class Model:
         self.clip_samples = self.L.kws_clip_samples(h)
         self.n_frames = self.L.kws_frame_count(h)
         self.pooled_tap_bytes = self.L.kws_pooled_tap_bytes(h)
+        self.is_float = bool(self.L.kws_model_is_float(h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -173,8 +177,8 @@ class Model:
         assert pcm.shape[1] == self.clip_samples
         s = np.zeros((B, self.n_labels), np.float32)
         f = np.zeros((B, self.n_features), np.float32)
-        q = np.zeros((B, self.n_features), np.int8)
-        _check(self.L.kws_run_classifier_batch(self.h, _p(pcm), B, _p(s), _p(f), _p(q)))
+        q = None if self.is_float else np.zeros((B, self.n_features), np.int8)     # float models have no int8 tensor
+        _check(self.L.kws_run_classifier_batch(self.h, _p(pcm), B, _p(s), _p(f), None if q is None else _p(q)))
         return (s, f, q) if want_features else s
 
     def nn_batch(self, q):
@@ -202,6 +206,9 @@ class Model:
 
     def run_inference_batch_device(self, features_ptr, B, scores_ptr, stream=None):
         _check(self.L.kws_run_inference_batch_device(self.h, features_ptr, B, scores_ptr, stream))
+
+    def nn_f32_batch_device(self, features_ptr, B, scores_ptr, logits_ptr=None, stream=None):
+        _check(self.L.kws_nn_f32_batch_device(self.h, features_ptr, B, scores_ptr, logits_ptr, stream))
 
     def nn_batch_device(self, q_ptr, B, scores_ptr, stream=None):
         _check(self.L.kws_nn_batch_device(self.h, q_ptr, B, scores_ptr, None, None, None, stream))

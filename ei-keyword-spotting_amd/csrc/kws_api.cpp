@@ -34,6 +34,9 @@ int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips
 int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
                        int *ran_nn, hipStream_t stream);
+int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int grid_cap,
+                      hipStream_t stream);
+size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
@@ -389,6 +392,8 @@ struct kws_handle {
     int n_cu = 256;
     KwsDspPlan dsp{};
     KwsNnPlan nn{};
+    bool is_float = false;        // float32 model: nnf is the plan, nn only carries a neutral input quantisation
+    KwsNnPlanF32 nnf{};
     int pooled_tap_bytes = 0;
     std::vector<void *> dev_allocs;
     // scratch for the combined entry points (grown on demand)
@@ -502,6 +507,8 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     return EI_IMPULSE_OK;
 }
 
+static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h);
+
 // Recognise the Edge Impulse 1-D CNN family and fold its per-model constants.
 static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
 {
@@ -509,8 +516,9 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
     KwsNnPlan &N = h->nn;
     memset(&N, 0, sizeof(N));
     const Tensor &tin = m.t[m.t_in], &tout = m.t[m.t_out];
+    if (tin.type == TYPE_F32 && tout.type == TYPE_F32) return build_nn_plan_f32(h);
     if (tin.type != TYPE_I8 || tout.type != TYPE_I8 || tin.scale.empty() || tout.scale.empty())
-        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "only int8-quantised models are implemented");
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "only int8-quantised and float32 models are implemented");
     N.n_features = (int)m.nn_input_frame_size;
     N.in_scale = tin.scale[0]; N.in_zp = tin.zero[0];
     N.out_scale = tout.scale[0]; N.out_zp = tout.zero[0];
@@ -703,6 +711,137 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
     return EI_IMPULSE_OK;
 }
 
+// The same graph family with float32 tensors (the "fp32" configuration of BASELINE.json): constants are uploaded as they
+// are, the fused activations become clamp ranges (kernel_util_lite.h:79-97 CalculateActivationRange<float>).
+static void h_act_range_f32(int act, float *lo, float *hi)
+{
+    *lo = -FLT_MAX; *hi = FLT_MAX;                       // kTfLiteActNone: numeric_limits lowest()/max()
+    if (act == 1) { *lo = 0.f; }                         // kTfLiteActRelu
+    else if (act == 2) { *lo = -1.f; *hi = 1.f; }        // kTfLiteActReluN1To1
+    else if (act == 3) { *lo = 0.f; *hi = 6.f; }         // kTfLiteActRelu6
+}
+
+static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
+{
+    const Model &m = h->model;
+    KwsNnPlanF32 &N = h->nnf;
+    memset(&N, 0, sizeof(N));
+    h->is_float = true;
+    memset(&h->nn, 0, sizeof(h->nn));
+    h->nn.in_scale = 1.0f;                               // never used for a result: float models have no int8 input tensor
+    h->nn.n_features = (int)m.nn_input_frame_size;
+    N.n_features = (int)m.nn_input_frame_size;
+    N.n_labels = (int)m.labels.size();
+    for (const Tensor &t : m.t)
+        if (t.type != TYPE_F32 && !(t.type == TYPE_I32 && t.is_const))     // int32 constants: RESHAPE shape operands
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "mixed float/integer graphs are not implemented");
+
+    int cur = (int)m.t_in, cur_w = 0, cur_c = 0;
+    size_t i = 0;
+    auto skip_reshapes = [&]() {
+        while (i < m.n.size() && m.n[i].op == OP_RESHAPE && m.n[i].in[0] == cur) { cur = m.n[i].out[0]; i++; }
+    };
+    auto floats = [](const Tensor &t) { return std::vector<float>((const float *)t.data.data(), (const float *)t.data.data() + t.nbytes / 4); };
+    skip_reshapes();
+    while (i < m.n.size() && m.n[i].op == OP_CONV_2D) {
+        if (N.n_blocks >= KWS_MAX_BLOCKS) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "more than %d conv blocks", KWS_MAX_BLOCKS);
+        const Node &cv = m.n[i];
+        if (cv.in[0] != cur || cv.in.size() < 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv input is not the flowing tensor");
+        const Tensor &x = m.t[cur], &w = m.t[cv.in[1]], &y = m.t[cv.out[0]];
+        const Tensor *bias = (cv.in.size() > 2 && cv.in[2] >= 0) ? &m.t[cv.in[2]] : nullptr;
+        const int in_h = x.dim4(1), in_w = x.dim4(2), in_c = x.dim4(3);
+        const int out_c = w.dim4(0), f_h = w.dim4(1), f_w = w.dim4(2);
+        const int padding = cv.p[0], stride_w = cv.p[1], stride_h = cv.p[2], act = cv.p[3], dil_w = cv.p[4], dil_h = cv.p[5];
+        if (x.dim4(0) != 1 || in_h != 1 || f_h != 1 || stride_w != 1 || stride_h != 1 || dil_w != 1 || dil_h != 1 || !w.is_const ||
+            w.dim4(3) != in_c || (bias && !bias->is_const) || f_w > 16 || out_c > 64)
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu is not a stride-1 1xK convolution over time", i);
+        if (cur_w && (cur_w != in_w || cur_c != in_c)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "shape mismatch into conv %zu", i);
+        const int out_w = h_out_size(padding, in_w, f_w, 1, 1);
+        const int pad_left = h_pad_amount(1, 1, in_w, f_w, out_w);
+        if (out_w != y.dim4(2) || y.dim4(3) != out_c) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu output shape", i);
+        KwsConvBlockF32 &k = N.blk[N.n_blocks];
+        k.in_w = in_w; k.in_c = in_c; k.out_c = out_c; k.taps = f_w; k.pad_left = pad_left; k.out_w = out_w;
+        h_act_range_f32(act, &k.conv_min, &k.conv_max);
+        std::vector<float> wv = floats(w), bv(out_c, 0.0f), av(out_c, 0.0f);
+        if ((int)wv.size() != out_c * f_w * in_c) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu filter size", i);
+        if (bias) { if ((int)bias->nbytes != out_c * 4) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu bias size", i); bv = floats(*bias); }
+        cur = cv.out[0]; cur_w = out_w; cur_c = out_c;
+        i++;
+        skip_reshapes();
+        k.has_add = 0;
+        h_act_range_f32(0, &k.add_min, &k.add_max);
+        if (i < m.n.size() && m.n[i].op == OP_ADD) {
+            const Node &ad = m.n[i];
+            int a_id = ad.in[0], b_id = ad.in[1];
+            if (a_id != cur && b_id == cur) std::swap(a_id, b_id);
+            const Tensor &cb = m.t[b_id];
+            if (a_id != cur || !cb.is_const || (int)cb.nbytes != out_c * 4 || cb.dims.back() != out_c)
+                return fail(KWS_ERROR_UNSUPPORTED_MODEL, "ADD %zu is not a per-channel constant add", i);
+            av = floats(cb);                              // x + c == c + x in IEEE arithmetic: operand order is immaterial
+            k.has_add = 1;
+            h_act_range_f32(ad.p[0], &k.add_min, &k.add_max);
+            cur = ad.out[0];
+            i++;
+            skip_reshapes();
+        }
+        k.pool = 1; k.pool_stride = 1; k.pool_w = out_w;
+        h_act_range_f32(0, &k.pool_min, &k.pool_max);
+        if (i < m.n.size() && m.n[i].op == OP_MAX_POOL_2D) {
+            const Node &pl = m.n[i];
+            const Tensor &px = m.t[pl.in[0]], &py = m.t[pl.out[0]];
+            if (pl.in[0] != cur) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "pool %zu input", i);
+            const int ph = px.dim4(1), pw = px.dim4(2);
+            int f, s, out_n;
+            if (pw == 1 && ph == cur_w) { f = pl.p[4]; s = pl.p[2]; if (pl.p[3] != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "2-D pool"); out_n = py.dim4(1); }
+            else if (ph == 1 && pw == cur_w) { f = pl.p[3]; s = pl.p[1]; if (pl.p[4] != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "2-D pool"); out_n = py.dim4(2); }
+            else return fail(KWS_ERROR_UNSUPPORTED_MODEL, "pool %zu is not over the time axis", i);
+            const int po = h_out_size(pl.p[0], cur_w, f, s, 1);
+            if (po != out_n || h_pad_amount(s, 1, cur_w, f, po) != 0 || (po - 1) * s + f > cur_w || f > 8)
+                return fail(KWS_ERROR_UNSUPPORTED_MODEL, "pool %zu window/padding outside the kernel's limits", i);
+            k.pool = f; k.pool_stride = s; k.pool_w = po;
+            h_act_range_f32(pl.p[5], &k.pool_min, &k.pool_max);
+            cur = pl.out[0]; cur_w = po;
+            i++;
+            skip_reshapes();
+        }
+        EI_IMPULSE_ERROR e;
+        if ((e = h->upload(wv, &k.w))) return e;
+        if ((e = h->upload(bv, &k.bias))) return e;
+        if ((e = h->upload(av, &k.addc))) return e;
+        N.n_blocks++;
+    }
+    if (N.n_blocks == 0) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "graph does not start with a convolution block");
+    if (N.blk[0].in_w * N.blk[0].in_c != N.n_features) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "first conv does not consume the feature vector");
+    for (int b = 0; b + 1 < N.n_blocks; b++)
+        if (N.blk[b].pool_w != N.blk[b + 1].in_w || N.blk[b].out_c != N.blk[b + 1].in_c)
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv blocks do not chain");
+    if (i >= m.n.size() || m.n[i].op != OP_FULLY_CONNECTED || m.n[i].in[0] != cur)
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "expected FULLY_CONNECTED after the conv blocks");
+    {
+        const Node &fc = m.n[i];
+        const Tensor &w = m.t[fc.in[1]];
+        const Tensor *bias = (fc.in.size() > 2 && fc.in[2] >= 0) ? &m.t[fc.in[2]] : nullptr;
+        N.fc_in = w.dims.back(); N.fc_out = w.dims[0];
+        const KwsConvBlockF32 &lb = N.blk[N.n_blocks - 1];
+        if (N.fc_in != lb.pool_w * lb.out_c || N.fc_in > 64 || N.fc_out > 48 || N.fc_out != N.n_labels || !w.is_const ||
+            (int)w.nbytes != N.fc_in * N.fc_out * 4)
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "FULLY_CONNECTED shape %dx%d outside the kernel's limits", N.fc_out, N.fc_in);
+        h_act_range_f32(fc.p[0], &N.fc_min, &N.fc_max);
+        std::vector<float> wv = floats(w), bv(N.fc_out, 0.0f);
+        if (bias) { if ((int)bias->nbytes != N.fc_out * 4) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "FULLY_CONNECTED bias size"); bv = floats(*bias); }
+        EI_IMPULSE_ERROR e;
+        if ((e = h->upload(wv, &N.fc_w))) return e;
+        if ((e = h->upload(bv, &N.fc_bias))) return e;
+        cur = fc.out[0];
+        i++;
+    }
+    if (i >= m.n.size() || m.n[i].op != OP_SOFTMAX || m.n[i].in[0] != cur || m.n[i].out[0] != (int)m.t_out || i + 1 != m.n.size())
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "expected a final SOFTMAX");
+    N.beta = m.n[i].beta;
+    if (kws_nn_f32_smem_bytes(N) > 64 * 1024) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "float model too large for the kernel's LDS budget");
+    return EI_IMPULSE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 //  C ABI
 // ------------------------------------------------------------------------------------------------------------
@@ -759,6 +898,7 @@ int kws_feature_count(const kws_handle *h) { return (int)h->model.nn_input_frame
 int kws_clip_samples(const kws_handle *h) { return (int)h->model.raw_sample_count; }
 int kws_frame_count(const kws_handle *h) { return h->dsp.n_frames; }
 int kws_pooled_tap_bytes(const kws_handle *h) { return h->pooled_tap_bytes; }
+int kws_model_is_float(const kws_handle *h) { return h->is_float ? 1 : 0; }
 
 static EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B)
 {
@@ -797,6 +937,16 @@ static EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is
     return EI_IMPULSE_OK;
 }
 
+// float32 models: the network reads the feature matrix itself (ei_run_classifier.h:447-452 copies it into the input tensor)
+static EI_IMPULSE_ERROR nn_f32_device(kws_handle *h, const float *features, size_t B, float *scores, float *tap_logits, hipStream_t s)
+{
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    int rc = kws_launch_nn_f32(h->nnf, features, (int)B, scores, tap_logits, grid_cap_nn(h), s);
+    if (rc) return fail(KWS_ERROR_HIP, "float NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
+}
+#define KWS_INT8_ONLY(h) do { if ((h)->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%s takes an int8 tensor; the loaded model is float32", __func__); } while (0)
+
 // cmvnw + quantise + (optionally) the network (kernel 2; the generic NN kernel follows when the graph does not fit
 // the matrix-core path)
 static EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, float *features, int8_t *q, float *scores,
@@ -804,6 +954,13 @@ static EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t 
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     int ran_nn = 0;
+    if (h->is_float) {
+        if (q || tap_pooled || tap_fc || tap_out) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 outputs requested from a float32 model");
+        float *f = features ? features : h->s_mfcc;
+        int rc = kws_launch_cmvn_nn(h->dsp, h->nn, mfcc, (int)B, f, nullptr, nullptr, nullptr, 0, nullptr, nullptr, grid_cap_nn(h), &ran_nn, s);
+        if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return scores ? nn_f32_device(h, f, B, scores, nullptr, s) : EI_IMPULSE_OK;
+    }
     int8_t *qq = q;
     if (scores && !qq) qq = h->s_q;           // the generic NN kernel reads the quantised tensor from HBM
     int rc = kws_launch_cmvn_nn(h->dsp, h->nn, mfcc, (int)B, features, qq, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out,
@@ -837,6 +994,7 @@ EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfc
 EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features, int8_t *q_in, void *stream)
 {
     if (!h || !pcm || !features) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (q_in) KWS_INT8_ONLY(h);
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
@@ -860,6 +1018,7 @@ EI_IMPULSE_ERROR kws_nn_batch_device(kws_handle *h, const int8_t *q_in, size_t B
                                      int8_t *tap_out, void *stream)
 {
     if (!h || !q_in || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    KWS_INT8_ONLY(h);
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     HIP_TRY(hipSetDevice(h->device));
     int rc = kws_launch_nn(h->nn, q_in, (int)B, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out, grid_cap_nn(h), (hipStream_t)stream);
@@ -867,10 +1026,19 @@ EI_IMPULSE_ERROR kws_nn_batch_device(kws_handle *h, const int8_t *q_in, size_t B
     return EI_IMPULSE_OK;
 }
 
+EI_IMPULSE_ERROR kws_nn_f32_batch_device(kws_handle *h, const float *features, size_t B, float *scores, float *tap_logits, void *stream)
+{
+    if (!h || !features || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (!h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "kws_nn_f32_batch_device needs a float32 model; the loaded model is int8");
+    HIP_TRY(hipSetDevice(h->device));
+    return nn_f32_device(h, features, B, scores, tap_logits, (hipStream_t)stream);
+}
+
 EI_IMPULSE_ERROR kws_run_inference_batch_device(kws_handle *h, const float *features, size_t B, float *scores, void *stream)
 {
     if (!h || !features || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->is_float) return nn_f32_device(h, features, B, scores, nullptr, (hipStream_t)stream);
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
@@ -887,6 +1055,12 @@ EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *p
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
+    if (h->is_float) {                       // features -> HBM (caller's buffer or scratch) -> float network
+        if (q_in) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 input tensor requested from a float32 model");
+        float *f = features ? features : h->s_mfcc;
+        e = mfcc_fused_device(h, pcm, 0, B, f, nullptr, (hipStream_t)stream);
+        return e ? e : nn_f32_device(h, f, B, scores, nullptr, (hipStream_t)stream);
+    }
     // one fused launch for extract_mfcc_features + quantisation (the cepstra stay in LDS), then the network;
     // the float feature matrix only leaves the chip when the caller asks for it
     int8_t *q = q_in ? q_in : h->s_q;
@@ -908,7 +1082,8 @@ EI_IMPULSE_ERROR kws_run_classifier_batch(kws_handle *h, const int16_t *pcm, siz
     TRY_OR_CLEAN(hipMalloc((void **)&d_pcm, B * n * sizeof(int16_t)));
     TRY_OR_CLEAN(hipMalloc((void **)&d_s, B * C * sizeof(float)));
     TRY_OR_CLEAN(hipMalloc((void **)&d_f, B * F * sizeof(float)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_q, B * F));
+    if (h->is_float && q_in) { cleanup(); return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 input tensor requested from a float32 model"); }
+    if (!h->is_float) TRY_OR_CLEAN(hipMalloc((void **)&d_q, B * F));
     TRY_OR_CLEAN(hipMemcpy(d_pcm, pcm, B * n * sizeof(int16_t), hipMemcpyHostToDevice));
     e = kws_run_classifier_batch_device(h, d_pcm, B, d_s, d_f, d_q, nullptr);
     if (e == EI_IMPULSE_OK) {
@@ -1172,7 +1347,7 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     if (hipMalloc((void **)&d_q, F) != hipSuccess) return alloc_fail();
     EI_IMPULSE_ERROR e = EI_IMPULSE_OK;
     if (hipMemcpy(d_x, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
-    if (!e) e = mfcc_fused_device(h, d_x, 1, 1, d_f, d_q, nullptr);
+    if (!e) e = mfcc_fused_device(h, d_x, 1, 1, d_f, h->is_float ? nullptr : d_q, nullptr);
     if (!e && hipDeviceSynchronize() != hipSuccess) e = fail(KWS_ERROR_HIP, "MFCC kernel failed");
     if (e) { cleanup(); return e; }
     if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) { cleanup(); return EI_IMPULSE_CANCELED; }   // ei_run_classifier.h:689-691
@@ -1187,7 +1362,7 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
         ei_printf("Running neural network...\n");
     }
     uint64_t t1 = ei_read_timer_ms();
-    e = kws_nn_batch_device(h, d_q, 1, d_s, nullptr, nullptr, nullptr, nullptr);
+    e = h->is_float ? nn_f32_device(h, d_f, 1, d_s, nullptr, nullptr) : kws_nn_batch_device(h, d_q, 1, d_s, nullptr, nullptr, nullptr, nullptr);
     if (!e && hipMemcpy(scores.data(), d_s, C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
     cleanup();
     if (e) return e;

@@ -1023,6 +1023,138 @@ static bool nn_fits_mfma(const KwsNnPlan &N)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+//  Kernel 2f: float32 models.  One wave per clip; every accumulation replays the reference's sequential
+//  `total += input * filter` order (tap outer, channel inner; products and sums rounded separately), so everything up
+//  to the logits is bit-identical to the float TFLite-Micro kernels; only softmax's expf is the device's.
+//  Zero-padded activation rows stand in for the reference's skipped out-of-image taps: they add an exact 0.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_clamp(float x, float lo, float hi)   // ActivationFunctionWithMinMax
+{
+    const float a = x < lo ? lo : x;
+    return hi < a ? hi : a;
+}
+
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(KwsNnPlanF32 N, const float *__restrict__ features,
+                                                                             int n_clips, float *__restrict__ scores,
+                                                                             float *__restrict__ tap_logits)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *sp = (float *)smem_raw;
+    const float *s_w[KWS_MAX_BLOCKS];
+    int act_floats = 0;
+    for (int b = 0; b < N.n_blocks; ++b) {
+        const KwsConvBlockF32 &k = N.blk[b];
+        const int wn = k.out_c * k.taps * k.in_c;
+        for (int i = threadIdx.x; i < wn; i += blockDim.x) sp[i] = k.w[i];
+        s_w[b] = sp;
+        sp += (wn + 3) & ~3;
+        act_floats = max(act_floats, (k.in_w + k.taps) * k.in_c);
+    }
+    act_floats = (act_floats + 3) & ~3;
+    float *actA = sp + wave * (2 * act_floats + 128);
+    float *actB = actA + act_floats;
+    float *vec = actB + act_floats;
+    __syncthreads();
+
+    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+        {
+            const KwsConvBlockF32 &k = N.blk[0];
+            const int rows = k.in_w + k.taps;
+            for (int i = lane; i < rows * k.in_c; i += 64) actA[i] = 0.0f;
+            WAVE_SYNC();
+            const float *src = features + (size_t)clip * N.n_features;
+            for (int i = lane; i < k.in_w * k.in_c; i += 64) actA[k.pad_left * k.in_c + i] = src[i];
+            WAVE_SYNC();
+        }
+        float *cur = actA, *nxt = actB;
+        for (int b = 0; b < N.n_blocks; ++b) {
+            const KwsConvBlockF32 &k = N.blk[b];
+            const bool last = (b + 1 == N.n_blocks);
+            const int ncp = last ? k.out_c : N.blk[b + 1].in_c;
+            const int npl = last ? 0 : N.blk[b + 1].pad_left;
+            if (!last) {
+                const int nrows = N.blk[b + 1].in_w + N.blk[b + 1].taps;
+                for (int i = lane; i < nrows * ncp; i += 64) nxt[i] = 0.0f;
+                WAVE_SYNC();
+            }
+            const int n_out = k.pool_w * k.out_c;
+            for (int idx = lane; idx < n_out; idx += 64) {
+                const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                const float *wrow = s_w[b] + (size_t)oc * k.taps * k.in_c;
+                const float bv = k.bias[oc];
+                const float av = k.has_add ? k.addc[oc] : 0.0f;
+                float mx = -FLT_MAX;
+                for (int i = 0; i < k.pool; ++i) {
+                    const int tt = pw * k.pool_stride + i;
+                    if (tt >= k.out_w) break;
+                    const float *xr = cur + tt * k.in_c;              // row (time + tap), already offset by pad_left
+                    float total = 0.0f;
+                    for (int j = 0; j < k.taps * k.in_c; ++j) {
+                        const float prod = xr[j] * wrow[j];           // rows are contiguous: (tap, channel) order
+                        total += prod;
+                    }
+                    float v = act_clamp(total + bv, k.conv_min, k.conv_max);
+                    if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
+                    mx = mx < v ? v : mx;                              // std::max(max, v)
+                }
+                mx = act_clamp(mx, k.pool_min, k.pool_max);
+                if (last) vec[idx] = mx;
+                else nxt[(npl + pw) * ncp + oc] = mx;
+            }
+            WAVE_SYNC();
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        // FULLY_CONNECTED + SOFTMAX
+        float *lg = vec + 64;
+        if (lane < N.fc_out) {
+            float total = 0.0f;
+            for (int d = 0; d < N.fc_in; ++d) {
+                const float prod = vec[d] * N.fc_w[lane * N.fc_in + d];
+                total += prod;
+            }
+            const float lgt = act_clamp(total + N.fc_bias[lane], N.fc_min, N.fc_max);
+            lg[lane] = lgt;
+            if (tap_logits) tap_logits[(size_t)clip * N.fc_out + lane] = lgt;
+        }
+        WAVE_SYNC();
+        if (lane < N.fc_out) {
+            float mx = -FLT_MAX;
+            for (int c = 0; c < N.fc_out; ++c) mx = mx < lg[c] ? lg[c] : mx;
+            float sum = 0.0f;
+            for (int c = 0; c < N.fc_out; ++c) sum += expf((lg[c] - mx) * N.beta);
+            scores[(size_t)clip * N.fc_out + lane] = expf((lg[lane] - mx) * N.beta) / sum;
+        }
+        WAVE_SYNC();
+    }
+}
+
+size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N)
+{
+    size_t fl = 0;
+    int act = 0;
+    for (int b = 0; b < N.n_blocks; ++b) {
+        const KwsConvBlockF32 &k = N.blk[b];
+        fl += ((size_t)k.out_c * k.taps * k.in_c + 3) & ~(size_t)3;
+        const int a = (k.in_w + k.taps) * k.in_c;
+        act = a > act ? a : act;
+    }
+    act = (act + 3) & ~3;
+    return (fl + (size_t)KWS_NN_WAVES * (2 * act + 128)) * sizeof(float);
+}
+
+int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int grid_cap,
+                      hipStream_t stream)
+{
+    if (n_clips <= 0) return 0;
+    int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
+    if (grid > grid_cap) grid = grid_cap;
+    hipLaunchKernelGGL(kws_nn_f32_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), kws_nn_f32_smem_bytes(N), stream, N, features,
+                       n_clips, scores, tap_logits);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 //  float features -> int8 input tensor (the quantise loop of run_inference, ei_run_classifier.h:436-444)
 // ---------------------------------------------------------------------------------------------------------
 __global__ void kws_quantize_kernel(const float *__restrict__ f, int8_t *__restrict__ q, size_t n, float scale, int zp)

@@ -69,3 +69,26 @@ struct KwsNnPlan {
     int out_zp;
     int n_labels;
 };
+
+// ---- float32 models (the reference's float TFLite-Micro kernels: reference/conv.h:28-99, add.h:179-215,
+//      pooling.h:189-237, fully_connected.h:26-60, softmax.h:31-63) -------------------------------------------
+struct KwsConvBlockF32 {
+    int in_w, in_c, out_c, taps, pad_left, out_w;
+    int pool, pool_stride, pool_w;
+    int has_add;
+    float conv_min, conv_max;      // fused activation range of the convolution
+    float add_min, add_max;        // fused activation range of the ADD (ReLU: [0, max])
+    float pool_min, pool_max;
+    const float *w;                // [out_c][taps][in_c]
+    const float *bias;             // [out_c]
+    const float *addc;             // [out_c] constant operand of the ADD
+};
+
+struct KwsNnPlanF32 {
+    int n_blocks;
+    KwsConvBlockF32 blk[KWS_MAX_BLOCKS];
+    int n_features, fc_in, fc_out, n_labels;
+    float fc_min, fc_max, beta;
+    const float *fc_w;             // [fc_out][fc_in]
+    const float *fc_bias;          // [fc_out]
+};

@@ -37,6 +37,7 @@ int kws_feature_count(const kws_handle *h);              /* EI_CLASSIFIER_NN_INP
 int kws_clip_samples(const kws_handle *h);               /* EI_CLASSIFIER_RAW_SAMPLE_COUNT */
 int kws_frame_count(const kws_handle *h);                /* MFCC rows (49) */
 int kws_pooled_tap_bytes(const kws_handle *h);           /* bytes/clip of the pooled-activation tap */
+int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI_CLASSIFIER_TFLITE_INPUT_QUANTIZED == 0) */
 
 /* The model used by the SDK-style entry points run_classifier()/run_inference().  If none was set,
  * the first call loads the file named by the environment variable KWS_MODEL on device KWS_DEVICE (0). */
@@ -76,6 +77,14 @@ EI_IMPULSE_ERROR kws_nn_batch_device(kws_handle *h, const int8_t *q_in, size_t B
                                      int8_t *tap_fc, int8_t *tap_out, void *stream);
 EI_IMPULSE_ERROR kws_nn_batch(kws_handle *h, const int8_t *q_in, size_t B, float *scores, int8_t *tap_pooled,
                               int8_t *tap_fc, int8_t *tap_out);
+/* float32 models (the reference's float kernels: TFL/kernels/internal/reference/conv.h:28-99, add.h:179-215,
+ * pooling.h:189-237, fully_connected.h:26-60, softmax.h:31-63): network only, from float feature vectors; optional tap
+ *   tap_logits [B][label_count]  FULLY_CONNECTED output (bit-identical to the reference; softmax uses the device expf).
+ * The int8 entry points above return KWS_ERROR_UNSUPPORTED_MODEL for a float model, and this one for an int8 model;
+ * kws_run_classifier_batch*, kws_run_inference_batch_device, kws_cmvn_inference_batch_device, the stream API and the
+ * SDK entry points serve both kinds (int8 outputs must then be NULL). */
+EI_IMPULSE_ERROR kws_nn_f32_batch_device(kws_handle *h, const float *features, size_t B, float *scores,
+                                         float *tap_logits, void *stream);
 
 /* ---- continuous mode for S streams in lock step ----------------------------------------------------
  * Each stream follows run_classifier_continuous() (classifier/ei_run_classifier.h:184-282): one slice of audio per

@@ -357,3 +357,142 @@ def test_soak_8192_clips_bit_exact(gpu476, l476, oracle):
     so, fo, qo = l476.run_batch(clips, want_features=True)
     assert int((bits(f) != bits(fo)).sum()) == 0
     assert (q == qo).all() and (bits(s) == bits(so)).all()
+
+
+# ---- float32 models (BASELINE.json config "fp32": the de-quantised twin of the shipped model) -------------------------------
+# Bar: MFCC features and every tensor up to the logits BIT-EXACT (the float kernels' sequential accumulation order is
+# replayed); softmax scores within 1e-6 absolute (expf: device libm vs host libm, both ~1 ulp; tolerance per BASELINE's
+# north_star "fp32 scores within 1e-4" with two orders of margin).
+F32_SCORE_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def gpu476f(pkg):
+    return pkg.Model(os.path.join(MODELS, "l476_no_yes_f32.kwsm"), device=0)
+
+
+@pytest.fixture(scope="module")
+def l476f(oracle):
+    from kws_testlib import OracleModel
+    return OracleModel(oracle, os.path.join(MODELS, "l476_no_yes_f32.kwsm"))
+
+
+def _f32_logits(pkg, gm, feats):
+    import torch
+    f = torch.from_numpy(np.ascontiguousarray(feats, np.float32)).to("cuda:0")
+    B = f.shape[0]
+    s = torch.empty((B, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    lg = torch.empty((B, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    gm.nn_f32_batch_device(f.data_ptr(), B, s.data_ptr(), lg.data_ptr())
+    torch.cuda.synchronize()
+    return s.cpu().numpy(), lg.cpu().numpy()
+
+
+def test_fp32_twin_golden_and_oracle(pkg, gpu476f, l476f, oracle):
+    assert gpu476f.is_float and gpu476f.labels == ["no", "noise", "unknown", "yes"]
+    g = np.load(os.path.join(GOLDEN, "f32_twin_l476.npz"))
+    clips = oracle.synth(int(g["seed"]), 0, int(g["n"]))
+    s, f, q = gpu476f.run_classifier_batch(clips, want_features=True)
+    assert q is None
+    assert np.abs(s - g["scores"]).max() <= F32_SCORE_TOL
+    s2, lg = _f32_logits(pkg, gpu476f, f)
+    assert (bits(lg) == bits(g["logits"])).all()                 # logits: the reference's float kernels, bit for bit
+    assert (bits(s2) == bits(s)).all()
+    # random clips against the oracle's float graph
+    clips = oracle.synth(77, 500, 300)
+    s, f, _ = gpu476f.run_classifier_batch(clips, want_features=True)
+    so, fo, _ = l476f.run_batch(clips, want_features=True)
+    assert (bits(f) == bits(fo)).all()
+    assert np.abs(s - so).max() <= F32_SCORE_TOL
+    _, lg = _f32_logits(pkg, gpu476f, f)
+    n_t = len(l476f.tensor_bytes)
+    for i in range(0, 300, 13):
+        _, taps = l476f.nn_invoke_f32(fo[i], taps=True)
+        assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), i
+    # adversarial feature vectors: huge / tiny / signed zeros / denormals exercise ReLU clamps and max-pool ordering
+    rng = np.random.default_rng(5)
+    feats = (rng.standard_normal((64, 637)) * np.float32(10.0) ** rng.integers(-3, 3, (64, 1))).astype(np.float32)
+    feats[0] = 0.0; feats[1] = -0.0; feats[2] = 1e-41; feats[3, ::2] = 3e4
+    sg, lg = _f32_logits(pkg, gpu476f, feats)
+    for i in range(64):
+        so_i, taps = l476f.nn_invoke_f32(feats[i], taps=True)
+        assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), i
+        assert np.abs(sg[i] - so_i).max() <= F32_SCORE_TOL, i
+
+
+def test_fp32_entry_points(pkg, gpu476f, gpu476, l476f, oracle):
+    """Every entry point that serves both kinds of model, plus the loud failures of the int8-only ones."""
+    import torch
+    B = 130
+    clips = oracle.synth(31, 0, B)
+    so, fo, _ = l476f.run_batch(clips, want_features=True)
+    pcm = torch.from_numpy(clips).to("cuda:0")
+    s = torch.empty((B, 4), dtype=torch.float32, device="cuda:0")
+    # run_classifier_batch_device without a feature buffer (scratch), then stage-split APIs
+    gpu476f.run_classifier_batch_device(pcm.data_ptr(), B, s.data_ptr())
+    torch.cuda.synchronize()
+    s_ref = s.cpu().numpy().copy()
+    assert np.abs(s_ref - so).max() <= F32_SCORE_TOL
+    f = torch.empty((B, 637), dtype=torch.float32, device="cuda:0")
+    gpu476f.extract_mfcc_batch_device(pcm.data_ptr(), B, f.data_ptr())
+    gpu476f.run_inference_batch_device(f.data_ptr(), B, s.data_ptr())
+    torch.cuda.synchronize()
+    assert (bits(f.cpu().numpy()) == bits(fo)).all() and (bits(s.cpu().numpy()) == bits(s_ref)).all()
+    m = torch.empty((B, 637), dtype=torch.float32, device="cuda:0")
+    gpu476f.mfcc_batch_device(pcm.data_ptr(), B, m.data_ptr())
+    s.zero_()
+    gpu476f.cmvn_inference_batch_device(m.data_ptr(), B, s.data_ptr())
+    torch.cuda.synchronize()
+    assert (bits(s.cpu().numpy()) == bits(s_ref)).all()
+    # int8-only entry points refuse a float model, and the float one refuses an int8 model
+    q = torch.zeros((B, 637), dtype=torch.int8, device="cuda:0")
+    for call in (lambda: gpu476f.nn_batch_device(q.data_ptr(), B, s.data_ptr()),
+                 lambda: gpu476f.extract_mfcc_batch_device(pcm.data_ptr(), B, f.data_ptr(), q.data_ptr()),
+                 lambda: gpu476f.run_classifier_batch_device(pcm.data_ptr(), B, s.data_ptr(), None, q.data_ptr()),
+                 lambda: gpu476.nn_f32_batch_device(f.data_ptr(), B, s.data_ptr())):
+        with pytest.raises(pkg.KwsError) as e:
+            call()
+        assert e.value.code == -18
+    # SDK entry point with the float model as the default model
+    gpu476f.set_default()
+    try:
+        buf = clips[5].astype(np.float32) / np.float32(32768)
+
+        @pkg.GET_DATA_FN
+        def get_data(offset, length, out):
+            ctypes.memmove(out, buf[offset:offset + length].ctypes.data, 4 * length)
+            return 0
+        sig = pkg.Signal(get_data=get_data, total_length=16000)
+        res = pkg.result_struct(4)()
+        rc = pkg.lib().run_classifier(ctypes.byref(sig), ctypes.byref(res), False)
+        assert rc == 0
+        got = np.float32([res.classification[i].value for i in range(4)])
+        assert (bits(got) == bits(s_ref[5])).all()
+    finally:
+        gpu476.set_default()
+
+
+def test_fp32_twins_of_synthetic_models(pkg, oracle, tmp_path):
+    """De-quantised twins of other members of the graph family (different widths / taps / pools / labels)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dequantize_model import dequantize
+    from kws_testlib import OracleModel, synth_model_blob
+    for kw in SYNTH_MODELS[:3]:
+        blob = dequantize(synth_model_blob(**kw))
+        p = tmp_path / ("f32_%d.kwsm" % kw["seed"])
+        p.write_bytes(blob)
+        om = OracleModel(oracle, str(p))
+        gm = pkg.Model(blob=blob)
+        assert gm.is_float
+        clips = oracle.synth(kw["seed"], 0, 40)
+        so, fo, _ = om.run_batch(clips, want_features=True)
+        s, f, _ = gm.run_classifier_batch(clips, want_features=True)
+        assert (bits(f) == bits(fo)).all()
+        assert np.abs(s - so).max() <= F32_SCORE_TOL
+        _, lg = _f32_logits(pkg, gm, f)
+        n_t = len(om.tensor_bytes)
+        for i in range(0, 40, 7):
+            _, taps = om.nn_invoke_f32(fo[i], taps=True)
+            assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), (kw, i)
+        gm.close()
