@@ -37,6 +37,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int grid_cap,
                       hipStream_t stream);
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N);
+void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
@@ -808,6 +809,7 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
         if ((e = h->upload(wv, &k.w))) return e;
         if ((e = h->upload(bv, &k.bias))) return e;
         if ((e = h->upload(av, &k.addc))) return e;
+        kws_nn_f32_pick_blocking(&k);
         N.n_blocks++;
     }
     if (N.n_blocks == 0) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "graph does not start with a convolution block");
@@ -838,7 +840,7 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
     if (i >= m.n.size() || m.n[i].op != OP_SOFTMAX || m.n[i].in[0] != cur || m.n[i].out[0] != (int)m.t_out || i + 1 != m.n.size())
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "expected a final SOFTMAX");
     N.beta = m.n[i].beta;
-    if (kws_nn_f32_smem_bytes(N) > 64 * 1024) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "float model too large for the kernel's LDS budget");
+    if (kws_nn_f32_smem_bytes(N) > 150 * 1024) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "float model too large for the kernel's LDS budget");
     return EI_IMPULSE_OK;
 }
 

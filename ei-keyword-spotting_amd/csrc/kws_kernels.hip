@@ -1023,15 +1023,85 @@ static bool nn_fits_mfma(const KwsNnPlan &N)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-//  Kernel 2f: float32 models.  One wave per clip; every accumulation replays the reference's sequential
-//  `total += input * filter` order (tap outer, channel inner; products and sums rounded separately), so everything up
-//  to the logits is bit-identical to the float TFLite-Micro kernels; only softmax's expf is the device's.
-//  Zero-padded activation rows stand in for the reference's skipped out-of-image taps: they add an exact 0.
+//  Kernel 2f: float32 models.  One wave per clip.  Every accumulation replays the reference's sequential
+//  `total += input * filter` order (tap outer, channel inner; product and sum rounded separately -- the build has
+//  -ffp-contract=off), so everything up to the logits is bit-identical to the float TFLite-Micro kernels; only softmax's
+//  expf is the device's.  Zero-padded activation rows stand in for the reference's skipped out-of-image taps: they add
+//  an exact 0 (x*0 = +-0, and total + (+-0) == total for every total the chain can hold, +0 included).
+//
+//  The 148 k multiply-adds per clip are order-constrained only WITHIN one output's chain, so a lane runs TB x OB chains
+//  (TB consecutive time steps x OB consecutive output channels) side by side: per chain step it reads TB activations and
+//  one OB-wide weight vector from LDS for TB*OB independent mul+add pairs (packed v_pk_mul_f32 / v_pk_add_f32).  The plan
+//  picks (TB, OB) per conv block so that the work items fill the 64 lanes (conv1 49x30: 7x4 -> 56 lanes, 91 steps;
+//  conv2 7x10: 1x2 -> 35 lanes, 210 steps).
+//  LDS: weights transposed to [tap*in_c + c][out_c padded to 4] once per workgroup; per wave X (block input, rows
+//  zero-padded), Y (conv+bias+ADD output before pooling) and a small vector for the FULLY_CONNECTED input / logits.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_clamp(float x, float lo, float hi)   // ActivationFunctionWithMinMax
 {
     const float a = x < lo ? lo : x;
     return hi < a ? hi : a;
+}
+
+__host__ __device__ inline int nnf_rows(const KwsConvBlockF32 &k)          // rows of the zero-padded input image
+{
+    const int a = k.in_w + k.taps, b = k.out_w + 7 + k.taps;     // ceil(out_w / TB) * TB <= out_w + 7 for every TB <= 8
+    return a > b ? a : b;
+}
+__host__ __device__ inline int nnf_ocp(const KwsConvBlockF32 &k) { return (k.out_c + 3) & ~3; }
+
+template <int TB, int OB>
+__device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *__restrict__ x, const float *__restrict__ wt,
+                                         float *__restrict__ y, int lane)
+{
+    const int J = k.taps * k.in_c, ocp = nnf_ocp(k);
+    const int n_ob = (k.out_c + OB - 1) / OB, n_tb = (k.out_w + TB - 1) / TB;
+    for (int item = lane; item < n_tb * n_ob; item += 64) {
+        const int tb = item / n_ob, ob = item - tb * n_ob;
+        const int t0 = tb * TB, oc0 = ob * OB;
+        float acc[TB][OB];
+#pragma unroll
+        for (int i = 0; i < TB; ++i)
+#pragma unroll
+            for (int o = 0; o < OB; ++o) acc[i][o] = 0.0f;
+        const float *xp = x + t0 * k.in_c;          // rows are contiguous: x[(t+tap)*in_c + c] == x[t*in_c + (tap*in_c + c)]
+        const float *wp = wt + oc0;
+        for (int j = 0; j < J; ++j) {
+            float w[OB];
+#pragma unroll
+            for (int o = 0; o < OB; ++o) w[o] = wp[j * ocp + o];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const float xv = xp[i * k.in_c + j];
+#pragma unroll
+                for (int o = 0; o < OB; ++o) {
+                    const float prod = xv * w[o];
+                    acc[i][o] += prod;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+            const int oc = oc0 + o;
+            if (oc >= k.out_c) break;
+            const float bv = k.bias[oc], av = k.addc[oc];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                if (t0 + i >= k.out_w) break;
+                float v = act_clamp(acc[i][o] + bv, k.conv_min, k.conv_max);
+                if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
+                y[(t0 + i) * k.out_c + oc] = v;
+            }
+        }
+    }
+}
+
+template <int TB>
+__device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const float *x, const float *wt, float *y, int lane)
+{
+    if (k.ob == 4) nnf_conv<TB, 4>(k, x, wt, y, lane);
+    else if (k.ob == 2) nnf_conv<TB, 2>(k, x, wt, y, lane);
+    else nnf_conv<TB, 1>(k, x, wt, y, lane);
 }
 
 __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(KwsNnPlanF32 N, const float *__restrict__ features,
@@ -1042,70 +1112,78 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(Kws
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *sp = (float *)smem_raw;
     const float *s_w[KWS_MAX_BLOCKS];
-    int act_floats = 0;
+    int x_floats = 0, y_floats = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlockF32 &k = N.blk[b];
-        const int wn = k.out_c * k.taps * k.in_c;
-        for (int i = threadIdx.x; i < wn; i += blockDim.x) sp[i] = k.w[i];
+        const int J = k.taps * k.in_c, ocp = nnf_ocp(k);
+        for (int i = threadIdx.x; i < J * ocp; i += blockDim.x) {      // [oc][j] -> [j][oc], zero in the padding channels
+            const int j = i / ocp, oc = i - j * ocp;
+            sp[i] = oc < k.out_c ? k.w[oc * J + j] : 0.0f;
+        }
         s_w[b] = sp;
-        sp += (wn + 3) & ~3;
-        act_floats = max(act_floats, (k.in_w + k.taps) * k.in_c);
+        sp += J * ocp;
+        x_floats = max(x_floats, nnf_rows(k) * k.in_c);
+        y_floats = max(y_floats, k.out_w * k.out_c);
     }
-    act_floats = (act_floats + 3) & ~3;
-    float *actA = sp + wave * (2 * act_floats + 128);
-    float *actB = actA + act_floats;
-    float *vec = actB + act_floats;
+    x_floats = (x_floats + 3) & ~3;
+    y_floats = (y_floats + 3) & ~3;
+    float *X = sp + wave * (x_floats + y_floats + 128);
+    float *Y = X + x_floats;
+    float *vec = Y + y_floats;
     __syncthreads();
 
     for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
         {
             const KwsConvBlockF32 &k = N.blk[0];
-            const int rows = k.in_w + k.taps;
-            for (int i = lane; i < rows * k.in_c; i += 64) actA[i] = 0.0f;
-            WAVE_SYNC();
+            const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
             const float *src = features + (size_t)clip * N.n_features;
-            for (int i = lane; i < k.in_w * k.in_c; i += 64) actA[k.pad_left * k.in_c + i] = src[i];
+            for (int i = lane; i < tot; i += 64) X[i] = (i >= lo && i < hi) ? src[i - lo] : 0.0f;
             WAVE_SYNC();
         }
-        float *cur = actA, *nxt = actB;
         for (int b = 0; b < N.n_blocks; ++b) {
             const KwsConvBlockF32 &k = N.blk[b];
-            const bool last = (b + 1 == N.n_blocks);
-            const int ncp = last ? k.out_c : N.blk[b + 1].in_c;
-            const int npl = last ? 0 : N.blk[b + 1].pad_left;
-            if (!last) {
-                const int nrows = N.blk[b + 1].in_w + N.blk[b + 1].taps;
-                for (int i = lane; i < nrows * ncp; i += 64) nxt[i] = 0.0f;
-                WAVE_SYNC();
-            }
-            const int n_out = k.pool_w * k.out_c;
-            for (int idx = lane; idx < n_out; idx += 64) {
-                const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
-                const float *wrow = s_w[b] + (size_t)oc * k.taps * k.in_c;
-                const float bv = k.bias[oc];
-                const float av = k.has_add ? k.addc[oc] : 0.0f;
-                float mx = -FLT_MAX;
-                for (int i = 0; i < k.pool; ++i) {
-                    const int tt = pw * k.pool_stride + i;
-                    if (tt >= k.out_w) break;
-                    const float *xr = cur + tt * k.in_c;              // row (time + tap), already offset by pad_left
-                    float total = 0.0f;
-                    for (int j = 0; j < k.taps * k.in_c; ++j) {
-                        const float prod = xr[j] * wrow[j];           // rows are contiguous: (tap, channel) order
-                        total += prod;
-                    }
-                    float v = act_clamp(total + bv, k.conv_min, k.conv_max);
-                    if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
-                    mx = mx < v ? v : mx;                              // std::max(max, v)
-                }
-                mx = act_clamp(mx, k.pool_min, k.pool_max);
-                if (last) vec[idx] = mx;
-                else nxt[(npl + pw) * ncp + oc] = mx;
+            switch (k.tb) {
+            case 8: nnf_conv_ob<8>(k, X, s_w[b], Y, lane); break;
+            case 7: nnf_conv_ob<7>(k, X, s_w[b], Y, lane); break;
+            case 4: nnf_conv_ob<4>(k, X, s_w[b], Y, lane); break;
+            case 2: nnf_conv_ob<2>(k, X, s_w[b], Y, lane); break;
+            default: nnf_conv_ob<1>(k, X, s_w[b], Y, lane); break;
             }
             WAVE_SYNC();
-            float *tmp = cur; cur = nxt; nxt = tmp;
+            // MAX_POOL_2D over time (pooling.h:189-237) into the next block's zero-padded input, or the FC input vector
+            const bool last = (b + 1 == N.n_blocks);
+            const int n_out = k.pool_w * k.out_c;
+            if (!last) {
+                const KwsConvBlockF32 &nk = N.blk[b + 1];
+                const int lo = nk.pad_left * nk.in_c, tot = nnf_rows(nk) * nk.in_c;
+                for (int i = lane; i < tot; i += 64) {
+                    const int idx = i - lo;
+                    float mx = 0.0f;
+                    if (idx >= 0 && idx < n_out) {
+                        const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                        mx = -FLT_MAX;
+                        for (int q = 0; q < k.pool; ++q) {
+                            const float v = Y[(pw * k.pool_stride + q) * k.out_c + oc];
+                            mx = mx < v ? v : mx;                      // std::max(max, v)
+                        }
+                        mx = act_clamp(mx, k.pool_min, k.pool_max);
+                    }
+                    X[i] = mx;
+                }
+            } else {
+                for (int idx = lane; idx < n_out; idx += 64) {
+                    const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                    float mx = -FLT_MAX;
+                    for (int q = 0; q < k.pool; ++q) {
+                        const float v = Y[(pw * k.pool_stride + q) * k.out_c + oc];
+                        mx = mx < v ? v : mx;
+                    }
+                    vec[idx] = act_clamp(mx, k.pool_min, k.pool_max);
+                }
+            }
+            WAVE_SYNC();
         }
-        // FULLY_CONNECTED + SOFTMAX
+        // FULLY_CONNECTED (fully_connected.h:26-60) + SOFTMAX (softmax.h:31-63)
         float *lg = vec + 64;
         if (lane < N.fc_out) {
             float total = 0.0f;
@@ -1132,15 +1210,30 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(Kws
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N)
 {
     size_t fl = 0;
-    int act = 0;
+    int xf = 0, yf = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlockF32 &k = N.blk[b];
-        fl += ((size_t)k.out_c * k.taps * k.in_c + 3) & ~(size_t)3;
-        const int a = (k.in_w + k.taps) * k.in_c;
-        act = a > act ? a : act;
+        fl += (size_t)k.taps * k.in_c * nnf_ocp(k);
+        xf = std::max(xf, nnf_rows(k) * k.in_c);
+        yf = std::max(yf, k.out_w * k.out_c);
     }
-    act = (act + 3) & ~3;
-    return (fl + (size_t)KWS_NN_WAVES * (2 * act + 128)) * sizeof(float);
+    xf = (xf + 3) & ~3;
+    yf = (yf + 3) & ~3;
+    return (fl + (size_t)KWS_NN_WAVES * (xf + yf + 128)) * sizeof(float);
+}
+
+// (TB, OB) of a conv block: fewest lane passes x chain work, LDS reads as the tie breaker
+void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k)
+{
+    static const int tbs[] = { 1, 2, 4, 7, 8 }, obs[] = { 1, 2, 4 };
+    float best = 1e30f;
+    for (int tb : tbs)
+        for (int ob : obs) {
+            const int items = ((k->out_w + tb - 1) / tb) * ((k->out_c + ob - 1) / ob);
+            const int passes = (items + 63) / 64;
+            const float cost = (float)passes * (2.0f * tb * ob + 1.0f * (tb + 1));
+            if (cost < best) { best = cost; k->tb = tb; k->ob = ob; }
+        }
 }
 
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int grid_cap,
@@ -1149,8 +1242,13 @@ int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips,
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
-    hipLaunchKernelGGL(kws_nn_f32_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), kws_nn_f32_smem_bytes(N), stream, N, features,
-                       n_clips, scores, tap_logits);
+    const size_t smem = kws_nn_f32_smem_bytes(N);
+    if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute((const void *)kws_nn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kws_nn_f32_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), smem, stream, N, features, n_clips, scores,
+                       tap_logits);
     return (int)hipGetLastError();
 }
 

@@ -76,6 +76,7 @@ struct KwsConvBlockF32 {
     int in_w, in_c, out_c, taps, pad_left, out_w;
     int pool, pool_stride, pool_w;
     int has_add;
+    int tb, ob;                    // register blocking of the conv: time steps x output channels per lane
     float conv_min, conv_max;      // fused activation range of the convolution
     float add_min, add_max;        // fused activation range of the ADD (ReLU: [0, max])
     float pool_min, pool_max;

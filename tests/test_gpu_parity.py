@@ -478,7 +478,7 @@ def test_fp32_twins_of_synthetic_models(pkg, oracle, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from dequantize_model import dequantize
     from kws_testlib import OracleModel, synth_model_blob
-    for kw in SYNTH_MODELS[:3]:
+    for kw in SYNTH_MODELS:
         blob = dequantize(synth_model_blob(**kw))
         p = tmp_path / ("f32_%d.kwsm" % kw["seed"])
         p.write_bytes(blob)
