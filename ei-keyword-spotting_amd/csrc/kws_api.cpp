@@ -47,7 +47,7 @@ extern int kws_force_scalar_nn;
 int kws_mfcc_max_prow(void);
 int kws_mfcc_max_nz(void);
 int kws_mfcc_cmvn_rows(void);
-int kws_mfcc_max_frames(void);
+int kws_mfcc_max_frames(int n_filters);
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -452,10 +452,10 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
 
     // what the gfx950 kernels implement (kws_kernels.hip: KWS_FFT, KWS_NF, KWS_MAXF ...)
     if (c.axes != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC block with %d axes", c.axes);
-    if (c.fft_length != 256 || c.num_filters != 32)
-        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC kernel is built for fft_length 256 / 32 filters (got %d / %d)",
+    if (c.fft_length != 256 || (c.num_filters != 32 && c.num_filters != 40))
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC kernel is built for fft_length 256 and 32 or 40 filters (got %d / %d)",
                     c.fft_length, c.num_filters);
-    if (frame_len < c.fft_length || c.pre_shift != 1 || (c.win_size & 1) == 0 || nfr < 1 || nfr > kws_mfcc_max_frames() ||
+    if (frame_len < c.fft_length || c.pre_shift != 1 || (c.win_size & 1) == 0 || nfr < 1 || nfr > kws_mfcc_max_frames(c.num_filters) ||
         c.num_cepstral < 1 || c.num_cepstral > c.num_filters || (stride * 2) % 16 != 0 || (P.n_samples * 2) % 16 != 0 ||
         (nfr - 1) * stride + c.fft_length > P.n_samples || nfr + 2 * P.pad > kws_mfcc_max_prow() || c.win_size < kws_mfcc_cmvn_rows() ||
         nfr > 4 * kws_mfcc_cmvn_rows() ||
@@ -489,7 +489,7 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     }
     fstart[N] = (int)fbin.size();
     P.max_nz = max_nz;
-    if (max_nz > kws_mfcc_max_nz())
+    if (c.num_filters == 32 && max_nz > kws_mfcc_max_nz())
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "mel filter with %d taps (kernel keeps at most %d in registers)", max_nz, kws_mfcc_max_nz());
     std::vector<int> pmap;
     h_pad_map(nfr, P.pad, pmap);
@@ -1213,7 +1213,7 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
     const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)m.dsp.num_cepstral;
-    if (nf < 1 || nf > kws_mfcc_max_frames() || feature_size > F || sb->slice_offset + feature_size > F ||
+    if (nf < 1 || nf > kws_mfcc_max_frames(h->dsp.n_filters) || feature_size > F || sb->slice_offset + feature_size > F ||
         (size_t)(nf - 1) * stride + h->dsp.fft_len > slice_samples || (slice_samples * 2) % 16 != 0)
         return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples (claimed %zu) yields %d frames", slice_samples, n_claimed, nf);
     KwsDspPlan P = h->dsp;
@@ -1428,7 +1428,7 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
     const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)ncep;
-    if (nf < 1 || feature_size > F || h->slice_offset + feature_size > F || nf > kws_mfcc_max_frames()) {
+    if (nf < 1 || feature_size > F || h->slice_offset + feature_size > F || nf > kws_mfcc_max_frames(h->dsp.n_filters)) {
         ei_printf("ERR: MFCC failed (%d)\n", -1002);                           // EIDSP_MATRIX_SIZE_MISMATCH
         ei_printf("ERR: Failed to run DSP process (%d)\n", -1002);
         return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples yields %d frames", n_claimed, nf);

@@ -115,14 +115,14 @@ __device__ __forceinline__ float bin_power(cf f, float inv_fft)
 constexpr int KWS_FFT = 256;      // real FFT length the kernel is specialised for (host checks the model)
 constexpr int KWS_NC = 128;        // complex FFT size
 constexpr int KWS_NBINS = 129;
-constexpr int KWS_NF = 32;         // mel filters
-constexpr int KWS_MAXF = 52;       // frames per clip supported by the lane=frame stages
-constexpr int KWS_MAXCEP = 17;     // DCT only produces outputs 0..N/2 (fast-dct-fft.cpp:71)
-
-constexpr int KWS_MELS = KWS_NF + 1;   // padded row stride of the fused kernel's log-mel buffer
+// mel filter counts the kernel is instantiated for: 32 (both shipped impulses) and 40 (BASELINE's 49x40 configs)
+constexpr int KWS_NF_MAX = 40;
+constexpr int KWS_MAXF = 52;       // frames per clip supported by the lane=frame stages (4 CMVN row groups x KWS_CR)
 constexpr int KWS_MAXNZ = 12;      // longest mel filter kept in registers
-constexpr int KWS_MAXPROW = 256;   // rows of the symmetric-padded CMVN matrix (n_frames + win_size - 1)
+constexpr int KWS_MAXPROW = 192;   // rows of the symmetric-padded CMVN matrix (n_frames + win_size - 1)
 constexpr int KWS_CR = 13;         // CMVN: consecutive rows owned by one lane
+// rows of the log-mel / cepstra buffer: LDS per wave must stay <= 20 KB (8 waves per CU)
+__host__ __device__ constexpr int kws_mel_rows(int nf) { return nf <= 32 ? 52 : 50; }
 
 // one frame pair's worth of samples for this lane: 8 samples + the sample before them
 template <bool F32IN> struct RawSamples;
@@ -149,6 +149,91 @@ __device__ __forceinline__ RawSamples<F32IN> fetch_samples(const void *clip_base
     return r;
 }
 
+// kf_bfly5 with m = 1 (kiss_fft.cpp:131-192): every product and sum in the reference's order
+__device__ __forceinline__ void bfly5(cf &F0, cf &F1, cf &F2, cf &F3, cf &F4, cf t1, cf t2, cf t3, cf t4, cf ya, cf yb)
+{
+    const cf s0 = F0;
+    const cf s1 = cmul(F1, t1), s2 = cmul(F2, t2), s3 = cmul(F3, t3), s4 = cmul(F4, t4);
+    const cf s7 = cadd(s1, s4), s10 = csub(s1, s4), s8 = cadd(s2, s3), s9 = csub(s2, s3);
+    float tt, a, b;
+    tt = s7.r + s8.r; F0.r = F0.r + tt;
+    tt = s7.i + s8.i; F0.i = F0.i + tt;
+    cf s5, s6, s11, s12;
+    a = s7.r * ya.r; b = s8.r * yb.r; s5.r = (s0.r + a) + b;
+    a = s7.i * ya.r; b = s8.i * yb.r; s5.i = (s0.i + a) + b;
+    a = s10.i * ya.i; b = s9.i * yb.i; s6.r = a + b;
+    a = s10.r * ya.i; b = s9.r * yb.i; s6.i = (-a) - b;
+    F1 = csub(s5, s6);
+    F4 = cadd(s5, s6);
+    a = s7.r * yb.r; b = s8.r * ya.r; s11.r = (s0.r + a) + b;
+    a = s7.i * yb.r; b = s8.i * ya.r; s11.i = (s0.i + a) + b;
+    a = s10.i * yb.i; b = s9.i * ya.i; s12.r = (-a) + b;
+    a = s10.r * yb.i; b = s9.r * ya.i; s12.i = a - b;
+    F2 = cadd(s11, s12);
+    F3 = csub(s11, s12);
+}
+
+// numpy::dct2 of one frame (numpy.hpp:378-401 -> dct::transform, fast-dct-fft.cpp:37-80 -> kiss_fftr(NF)): v holds the NF
+// log-mel energies; R receives the NF/2+1 spectrum points the transform reads.  The complex FFT of NF/2 points is
+// kf_work's recursion unrolled: NF = 32 -> 16 = 4 x 4 (kf_bfly4, kf_bfly4); NF = 40 -> 20 = 4 x 5 (kf_bfly5 leaves of
+// stride 4, then kf_bfly4 with m = 5).
+template <int NF>
+__device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspPlan &P, cf (&R)[NF / 2 + 1])
+{
+    constexpr int NC = NF / 2;
+    // even/odd reorder (in[i] = v[2i], in[NF-1-i] = v[2i+1]) read as NC complex points
+    auto rin = [&](int i) { return (i < NC) ? v[2 * i] : v[2 * (NF - 1 - i) + 1]; };
+    cf F[NC];
+    if constexpr (NF == 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = q + 4 * j;                           // complex input index of leaf q
+                F[4 * q + j].r = rin(2 * n);
+                F[4 * q + j].i = rin(2 * n + 1);
+            }
+        const cf d0 = to_cf(P.dct_tw[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfly4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3], d0, d0, d0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+    } else {
+        static_assert(NF == 40, "DCT sizes: 32, 40");
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = q + 4 * j;
+                F[5 * q + j].r = rin(2 * n);
+                F[5 * q + j].i = rin(2 * n + 1);
+            }
+        const cf d0 = to_cf(P.dct_tw[0]), ya = to_cf(P.dct_tw[4]), yb = to_cf(P.dct_tw[8]);   // tw[fstride*m], tw[2*fstride*m]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfly5(F[5 * q], F[5 * q + 1], F[5 * q + 2], F[5 * q + 3], F[5 * q + 4], d0, d0, d0, d0, ya, yb);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            bfly4(F[k], F[k + 5], F[k + 10], F[k + 15], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+    }
+    // kiss_fftr split (kiss_fftr.cpp:84-119)
+    R[0].r = F[0].r + F[0].i; R[0].i = 0.0f;
+    R[NC].r = F[0].r - F[0].i; R[NC].i = 0.0f;
+#pragma unroll
+    for (int k = 1; k <= NC / 2; ++k) {
+        cf fpk = F[k], fpnk;
+        fpnk.r = F[NC - k].r; fpnk.i = -F[NC - k].i;
+        cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+        cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
+        if (k != NC - k) {                                         // k == ncfft/2: overwritten by the "ncfft-k" store
+            R[k].r = (f1k.r + twv.r) * 0.5f;
+            R[k].i = (f1k.i + twv.i) * 0.5f;
+        }
+        R[NC - k].r = (f1k.r - twv.r) * 0.5f;
+        R[NC - k].i = (twv.i - f1k.i) * 0.5f;
+    }
+}
+
 // PROF: development aid -- per-phase shader-clock totals of block 0 are written to prof_out (tools/gpu_phase_profile.py)
 #define KWS_NPHASE 10
 #define PH(i) do { if (PROF) { long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
@@ -164,33 +249,33 @@ __device__ __forceinline__ RawSamples<F32IN> fetch_samples(const void *clip_base
 // complex FFT slot of element c: 8 slots of padding after every 32 make every butterfly stage bank-conflict free
 __device__ __forceinline__ int zi(int c) { return c + 8 * (c >> 5); }
 constexpr int KWS_ZF = 2 * (KWS_NC + 8 * (KWS_NC / 32));   // floats per frame buffer
-template <int CHP>   // frame PAIRS per chunk
+template <int CHP, int NF>   // frame PAIRS per chunk, mel filters
 struct MfccSmem {
     static constexpr int CHF = 2 * CHP;
+    static constexpr int MELS = NF + 1;  // padded (odd) row stride of the log-mel / cepstra buffer
     float z[2][KWS_ZF];                  // per half-wave: pre-emphasised frame, then the in-place complex FFT
-    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the cepstra
-    // before CMVN ([frame][coef], row stride n_cepstral) followed by the pad_1d_symmetric row map
+    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the
+    // pad_1d_symmetric row map for cmvnw
     union {
         float p[KWS_NBINS * CHF];
-        struct {
-            float mfcc[KWS_MAXF * KWS_MAXCEP];
-            int map[KWS_MAXPROW];
-        } c;
+        int map[KWS_MAXPROW];
     } u;
-    float mel[KWS_MAXF * KWS_MELS];      // log-mel energies [frame][filter]
-    float energy[KWS_MAXF];
+    // log-mel energies [frame][filter]; the DCT overwrites each row in place with that frame's cepstra
+    float mel[kws_mel_rows(NF) * MELS];
+    float energy[kws_mel_rows(NF)];
     float dcny[2 * CHF];                 // tmp[0] of each frame of the chunk (DC / Nyquist source)
-    static_assert(sizeof(float) * (KWS_MAXF * KWS_MAXCEP + KWS_MAXPROW) <= sizeof(float) * KWS_NBINS * CHF, "alias");
 };
+static_assert(sizeof(MfccSmem<9, 32>) <= 20 * 1024 && sizeof(MfccSmem<9, 40>) <= 20 * 1024, "8 waves per CU need <= 20 KB LDS each");
 
-template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, bool PROF = false>
-__global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
+template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF = 32, bool PROF = false>
+__global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
                                                             float *__restrict__ features, int8_t *__restrict__ q_out,
                                                             float in_scale, int in_zp, const float *__restrict__ wrap, int out_stride,
                                                             long long *prof_out = nullptr)
 {
     constexpr int CHF = 2 * CHP;
-    __shared__ MfccSmem<CHP> sm;
+    constexpr int MELS = NF + 1, NCEPT = NF / 2 + 1;     // DCT only produces outputs 0..NF/2 (fast-dct-fft.cpp:71)
+    __shared__ MfccSmem<CHP, NF> sm;
     const int lane = threadIdx.x;
     const int half = lane >> 5, t = lane & 31;
 
@@ -206,10 +291,11 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
     const int n_pairs = (nfr + 1) >> 1;
     const int prow = nfr + 2 * P.pad;
     float *zb = sm.z[half];
-    // this lane's mel filter (filter index = lane & 31 in every pass of the mel stage): ascending-bin taps in registers
+    // NF == 32: this lane's mel filter (filter index = lane & 31 in every pass of the mel stage) keeps its ascending-bin
+    // taps in registers; other filter counts walk the CSR table
     int fbin[NZ];
     float fwt[NZ];
-    {
+    if constexpr (NF == 32) {
         const int b0 = P.filt_start[t], b1e = P.filt_start[t + 1];
 #pragma unroll
         for (int n = 0; n < NZ; ++n) {
@@ -349,66 +435,48 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
             }
             PH(3);
             // ---- mel: sparse ascending-bin gather == dot_by_row (numpy.hpp:183-211), zero_handling, log ------
-            for (int idx = lane; idx < nfc * KWS_NF; idx += KWS_WAVE) {
-                const int fr = idx >> 5;                                              // filter j == lane & 31 == t
-                float acc = 0.0f;
+            if constexpr (NF == 32) {
+                for (int idx = lane; idx < nfc * NF; idx += KWS_WAVE) {
+                    const int fr = idx >> 5;                                          // filter j == lane & 31 == t
+                    float acc = 0.0f;
 #pragma unroll
-                for (int n = 0; n < NZ; ++n) {             // taps beyond a filter's end have weight 0: power >= 0 is
-                    float prod = sm.u.p[fbin[n] + fr] * fwt[n];       // finite, so they add an exact +0
-                    acc += prod;
+                    for (int n = 0; n < NZ; ++n) {         // taps beyond a filter's end have weight 0: power >= 0 is
+                        float prod = sm.u.p[fbin[n] + fr] * fwt[n];   // finite, so they add an exact +0
+                        acc += prod;
+                    }
+                    if (acc == 0.0f) acc = FLT_EPSILON;                                // functions.hpp:63-69
+                    sm.mel[(f_base + fr) * MELS + t] = fast_log(acc);
                 }
-                if (acc == 0.0f) acc = FLT_EPSILON;                                    // functions.hpp:63-69
-                sm.mel[(f_base + fr) * KWS_MELS + t] = fast_log(acc);
+            } else {
+                for (int idx = lane; idx < nfc * NF; idx += KWS_WAVE) {
+                    const int fr = idx / NF, j = idx - fr * NF;
+                    float acc = 0.0f;
+                    for (int n = P.filt_start[j]; n < P.filt_start[j + 1]; ++n) {
+                        float prod = sm.u.p[P.filt_bin[n] * CHF + fr] * P.filt_w[n];
+                        acc += prod;
+                    }
+                    if (acc == 0.0f) acc = FLT_EPSILON;
+                    sm.mel[(f_base + fr) * MELS + j] = fast_log(acc);
+                }
             }
             WAVE_SYNC();
             PH(4);
         }
 
-        // ---- DCT-II via 32-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
+        // ---- DCT-II via NF-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
+        // the cepstra of a frame replace its log-mel row in place (row stride MELS)
 #pragma unroll
-        for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) sm.u.c.map[lane + i * KWS_WAVE] = mapreg[i];
+        for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) sm.u.map[lane + i * KWS_WAVE] = mapreg[i];
         if (lane < nfr) {
-            float v[KWS_NF];
-            const float *mrow = sm.mel + lane * KWS_MELS;
+            float v[NF];
+            float *mrow = sm.mel + lane * MELS;
 #pragma unroll
-            for (int i = 0; i < KWS_NF; ++i) v[i] = mrow[i];
-            // even/odd reorder, then packed as 16 complex points: in[i] = v[2i], in[31-i] = v[2i+1]
-            cf F[16];
+            for (int i = 0; i < NF; ++i) v[i] = mrow[i];
+            cf R[NCEPT];
+            dct_spectrum<NF>(v, P, R);
+            float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + lane * ncep;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = q + 4 * j;                       // complex input index
-                    const int i0 = 2 * n, i1 = 2 * n + 1;          // real input indices
-                    F[4 * q + j].r = (i0 < 16) ? v[2 * i0] : v[2 * (31 - i0) + 1];
-                    F[4 * q + j].i = (i1 < 16) ? v[2 * i1] : v[2 * (31 - i1) + 1];
-                }
-            }
-            const cf d0 = to_cf(P.dct_tw[0]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bfly4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3], d0, d0, d0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
-            cf R[KWS_MAXCEP];
-            R[0].r = F[0].r + F[0].i; R[0].i = 0.0f;
-            R[16].r = F[0].r - F[0].i; R[16].i = 0.0f;
-#pragma unroll
-            for (int k = 1; k <= 8; ++k) {
-                cf fpk = F[k], fpnk;
-                fpnk.r = F[16 - k].r; fpnk.i = -F[16 - k].i;
-                cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
-                cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
-                if (k != 8) {
-                    R[k].r = (f1k.r + twv.r) * 0.5f;
-                    R[k].i = (f1k.i + twv.i) * 0.5f;
-                }
-                R[16 - k].r = (f1k.r - twv.r) * 0.5f;
-                R[16 - k].i = (twv.i - f1k.i) * 0.5f;
-            }
-            float *orow = WITH_CMVN ? sm.u.c.mfcc + lane * ncep : features + (size_t)clip * out_stride + lane * ncep;
-#pragma unroll
-            for (int i = 0; i < KWS_MAXCEP; ++i) {
+            for (int i = 0; i < NCEPT; ++i) {
                 if (i < ncep) {
                     float a = R[i].r * P.dct_cos[i];
                     float b = R[i].i * P.dct_sin[i];
@@ -418,7 +486,9 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 }
             }
             // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
-            for (int i = KWS_MAXCEP; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * P.dct_s1;
+#pragma unroll
+            for (int i = NCEPT; i < NF; ++i)
+                if (i < ncep) orow[i] = (v[i] * 2.0f) * P.dct_s1;
             orow[0] = fast_log(sm.energy[lane]);                                       // feature.hpp:425-429
         }
         WAVE_SYNC();
@@ -439,7 +509,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
             const int c = cb + cl;
             const bool act = (c < ncep) && (r0 < nfr);
             const int cc = min(c, ncep - 1);
-            auto val = [&](int p) { return sm.u.c.mfcc[sm.u.c.map[min(r0 + p, prow - 1)] * ncep + cc]; };
+            auto val = [&](int p) { return sm.mel[sm.u.map[min(r0 + p, prow - 1)] * MELS + cc]; };
             float sum[KWS_CR], mean[KWS_CR], sd[KWS_CR];
 #pragma unroll
             for (int r = 0; r < KWS_CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
@@ -498,7 +568,7 @@ __global__ __launch_bounds__(KWS_WAVE) void kws_mfcc_kernel(KwsDspPlan P, const 
                 if (act && row < nfr) {
                     const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
                     const int idx = row * ncep + c;
-                    const float xv = sm.u.c.mfcc[idx];
+                    const float xv = sm.mel[row * MELS + c];
                     const float o = (xv - mean[r]) / (dev + FLT_EPSILON);
                     if (features) fout[idx] = o;           // optional output (extract_mfcc_features' matrix)
                     if (q_out) {
@@ -901,7 +971,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
                                                                               NnTaps taps)
 {
     __shared__ int s_map[KWS_MAXPROW];                                    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541)
-    __shared__ float s_mfcc[KWS_NN_WAVES][KWS_MAXF * KWS_MAXCEP];
+    __shared__ float s_mfcc[KWS_NN_WAVES][KWS_MAXF * KWS_NF_MAX];       // cepstra before CMVN, [frame][coef] (coef <= filters)
     __shared__ __attribute__((aligned(16))) int8_t s_lut1[FUSE ? 32 * 256 : 16];
     __shared__ __attribute__((aligned(16))) int8_t s_lut2[FUSE ? 16 * 256 : 16];
     __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][FUSE ? KWS_A1_ROWS * 16 : 16];
@@ -1282,7 +1352,7 @@ __global__ void kws_synth_kernel(uint32_t seed, uint32_t first_clip, uint32_t n_
 int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
 int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
 int kws_mfcc_cmvn_rows(void) { return KWS_CR; }
-int kws_mfcc_max_frames(void) { return KWS_MAXF; }
+int kws_mfcc_max_frames(int n_filters) { return kws_mel_rows(n_filters); }
 int kws_mfcc_fft_length(void) { return KWS_FFT; }
 
 constexpr int KWS_CHP = 9;
@@ -1293,12 +1363,17 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
 {
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    if (P.max_nz <= 4)
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 4, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm, n_clips,
-                           out, q_out, in_scale, in_zp, wrap, out_stride, prof);
-    else
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
+    if (P.n_filters == 40)                                     // mel taps walked from the CSR table: NZ unused
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 1, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
                            n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else if (P.n_filters != 32)
+        return (int)hipErrorInvalidValue;
+    else if (P.max_nz <= 4)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 4, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
+                           n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
     return (int)hipGetLastError();
 }
 

@@ -496,3 +496,69 @@ def test_fp32_twins_of_synthetic_models(pkg, oracle, tmp_path):
             _, taps = om.nn_invoke_f32(fo[i], taps=True)
             assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), (kw, i)
         gm.close()
+
+
+# ---- 40 mel filters (BASELINE configs 2 and 5: "40-band MFCC (49x40)") ------------------------------------------------------
+MFCC40_MODELS = {          # golden key -> synthetic model around that MFCC block (weights random: only the DSP block is golden)
+    "f40c40": dict(seed=11, num_filters=40, ncep=40, low=300, high=0, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3),
+    "f40c13": dict(seed=12, num_filters=40, ncep=13, low=0, high=0),
+    "f40c30w51": dict(seed=13, num_filters=40, ncep=30, win_size=51, blocks=((24, 3, 7), (10, 7, 7)), n_labels=4),
+}
+
+
+@pytest.mark.parametrize("key", sorted(MFCC40_MODELS))
+def test_mfcc40_golden_and_oracle(key, pkg, oracle, tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dequantize_model import dequantize
+    from kws_testlib import OracleModel, synth_model_blob
+    g = np.load(os.path.join(GOLDEN, "mfcc40_l476.npz"))
+    sp = special_clips()
+    gclips = np.concatenate([oracle.synth(int(g["seed"]), 0, int(g["n"])), np.stack([sp[str(k)] for k in g["special_names"]])])
+    blob = synth_model_blob(**MFCC40_MODELS[key])
+    for kind, b in (("int8", blob), ("f32", dequantize(blob))):
+        p = tmp_path / ("m40_%s_%s.kwsm" % (key, kind))
+        p.write_bytes(b)
+        om = OracleModel(oracle, str(p))
+        gm = pkg.Model(blob=b)
+        s, f, q = gm.run_classifier_batch(gclips, want_features=True)
+        assert (bits(f) == bits(g[key])).all(), (key, kind)               # features: the reference itself
+        clips = oracle.synth(99, 40, 150)
+        so, fo, qo = om.run_batch(clips, want_features=True)
+        s, f, q = gm.run_classifier_batch(clips, want_features=True)
+        assert (bits(f) == bits(fo)).all(), (key, kind)
+        if kind == "int8":
+            assert (q == qo).all() and (bits(s) == bits(so)).all(), key
+        else:
+            assert np.abs(s - so).max() <= F32_SCORE_TOL, key
+            _, lg = _f32_logits(pkg, gm, f)
+            n_t = len(om.tensor_bytes)
+            for i in range(0, 150, 17):
+                _, taps = om.nn_invoke_f32(fo[i], taps=True)
+                assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), (key, i)
+        gm.close()
+
+
+def test_mfcc40_stage_api_and_streams(pkg, oracle, tmp_path):
+    """cepstra before CMVN (stage API) and cmvnw+network in kws_cmvn_nn_kernel for a 49x40 model."""
+    import torch
+    from kws_testlib import OracleModel, synth_model_blob
+    blob = synth_model_blob(**MFCC40_MODELS["f40c40"])
+    p = tmp_path / "m40.kwsm"
+    p.write_bytes(blob)
+    om = OracleModel(oracle, str(p))
+    gm = pkg.Model(blob=blob)
+    B = 70
+    clips = oracle.synth(3, 7, B)
+    so, fo, qo = om.run_batch(clips, want_features=True)
+    pcm = torch.from_numpy(clips).to("cuda:0")
+    m = torch.empty((B, gm.n_features), dtype=torch.float32, device="cuda:0")
+    s = torch.empty((B, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    f = torch.empty((B, gm.n_features), dtype=torch.float32, device="cuda:0")
+    gm.mfcc_batch_device(pcm.data_ptr(), B, m.data_ptr())
+    gm.cmvn_inference_batch_device(m.data_ptr(), B, s.data_ptr(), f.data_ptr())
+    torch.cuda.synchronize()
+    mo = np.stack([oracle.mfcc_nocmvn(c, om.cfg) for c in clips[:8]])
+    assert (bits(m.cpu().numpy()[:8]) == bits(mo.reshape(8, -1))).all()
+    assert (bits(f.cpu().numpy()) == bits(fo)).all() and (bits(s.cpu().numpy()) == bits(so)).all()
+    gm.close()

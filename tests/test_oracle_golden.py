@@ -166,3 +166,18 @@ def test_fp32_twin_golden(oracle):
     assert np.abs(s - g["scores"]).max() <= 1e-7        # expf of the host libm is the only non-replayed operation
     out, taps = mf.nn_invoke_f32(oracle.extract_mfcc(clips[3], mf.cfg), taps=True)
     assert (bits(taps[29]) == bits(g["logits"][3])).all()
+
+
+def test_mfcc40_golden(oracle):
+    """BASELINE's 40-band MFCC variants: reference extract_mfcc_features outputs (tools/make_golden.py mfcc40)."""
+    from kws_testlib import L476_CONFIG, special_clips
+    g = _load("mfcc40_l476.npz")
+    sp = special_clips()
+    clips = np.concatenate([oracle.synth(int(g["seed"]), 0, int(g["n"])), np.stack([sp[str(k)] for k in g["special_names"]])])
+    cfg = L476_CONFIG()
+    for name, kw in (("f40c40", dict(num_filters=40, num_cepstral=40, high_frequency=0)),
+                     ("f40c13", dict(num_filters=40, num_cepstral=13, low_frequency=0, high_frequency=0)),
+                     ("f40c30w51", dict(num_filters=40, num_cepstral=30, win_size=51))):
+        c = cfg.copy(**kw)
+        for i, x in enumerate(clips):
+            assert (bits(oracle.extract_mfcc(x, c)) == bits(g[name][i])).all(), (name, i)

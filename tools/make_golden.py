@@ -21,8 +21,26 @@ CLIPS_PER_SEED = 32      # end-to-end vectors
 DEEP_PER_SEED = 2        # clips with every intermediate stage stored
 
 
+def mfcc40(ref, synth, cfg):
+    """BASELINE's 40-band MFCC variants through the reference's extract_mfcc_features (radix-5 DCT FFT, and the
+    coefficients above N/2 that the transform never writes)."""
+    clips = synth.synth(8, 0, 12)
+    sp = special_clips()
+    clips = np.concatenate([clips, np.stack([sp[k] for k in sorted(sp)])])
+    out = {"seed": np.int32(8), "n": np.int32(12), "special_names": np.array(sorted(sp))}
+    for name, kw in (("f40c40", dict(num_filters=40, num_cepstral=40, high_frequency=0)),
+                     ("f40c13", dict(num_filters=40, num_cepstral=13, low_frequency=0, high_frequency=0)),
+                     ("f40c30w51", dict(num_filters=40, num_cepstral=30, win_size=51))):
+        c = cfg.copy(**kw)
+        out[name] = np.stack([ref.extract_mfcc(x, c) for x in clips])
+    np.savez_compressed(os.path.join(GOLDEN, "mfcc40_l476.npz"), **out)
+    print("mfcc40_l476.npz", os.path.getsize(os.path.join(GOLDEN, "mfcc40_l476.npz")), "bytes")
+
+
 def main():
     ref = Reference()
+    if "--only-mfcc40" in sys.argv:
+        return mfcc40(ref, Oracle(), L476_CONFIG())
     synth = Oracle()          # only used for kwso_synth_fill (shared integer generator)
     cfg = L476_CONFIG()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -138,6 +156,7 @@ def main():
         lg.append(a); sc.append(b)
     f32["logits"], f32["scores"] = np.stack(lg), np.stack(sc)
     np.savez_compressed(os.path.join(GOLDEN, "f32_twin_l476.npz"), **f32)
+    mfcc40(ref, synth, cfg)
     for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz", "continuous_l476.npz", "f32_twin_l476.npz"):
         print(fn, os.path.getsize(os.path.join(GOLDEN, fn)), "bytes")
 

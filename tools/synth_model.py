@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Synthetic members of the Edge Impulse 1-D CNN graph family, as .kwsm blobs (tools/eon_import.py layout).
+
+The reference ships two int8 models, both 32 mel filters / 13 cepstra.  BASELINE.json's other configurations
+("40-band MFCC (49x40) + 2-Conv CNN, fp32", ...) have NO model file in the reference, so their
+models are generated here: same graph (RESHAPE/CONV_2D/ADD/MAX_POOL_2D/FULLY_CONNECTED/SOFTMAX), seeded random int8
+weights and quantisation parameters; tools/dequantize_model.py turns one into its float32 twin.  The parity tests use
+the same generator for other widths / taps / pools / label counts.
+
+    python tools/synth_model.py models/cfg2_mfcc40_int8.kwsm --seed 40 --num-filters 40 --ncep 40 --low 300 --high 0
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import eon_import  # noqa: E402
+
+
+def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4,
+                     conv_bias=False, add_bias=True, num_filters=32):
+    """blocks: sequence of (out_channels, taps, pool).  Frame geometry is the shipped one (49 frames)."""
+    rng = np.random.default_rng(seed)
+    n_frames = 49
+    F = n_frames * ncep
+    tensors, nodes = [], []
+
+    def T(ttype, dims, const=False, scale=(), zero=(), data=b"", qdim=0):
+        nbytes = int(np.prod(dims)) * {1: 4, 2: 4, 9: 1}[ttype]
+        if const:
+            assert len(data) == nbytes
+        tensors.append({"type": ttype, "dims": list(dims), "nbytes": nbytes, "const": const, "scale": list(scale),
+                        "zero": list(zero), "qdim": qdim, "data": data})
+        return len(tensors) - 1
+
+    def node(op, ins, outs, p=None, beta=0.0):
+        pp = [0] * 8
+        if p:
+            pp[:len(p)] = p
+        nodes.append({"op": op, "in": list(ins), "out": list(outs), "p": pp, "beta": beta})
+
+    def shape_const(dims):
+        return T(2, [len(dims)], True, data=np.int32(dims).tobytes())
+
+    def rscale(lo, hi):
+        return float(np.float32(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
+
+    in_scale, in_zp = rscale(0.03, 0.06), int(rng.integers(-20, 5))
+    t_in = T(9, [1, F], scale=[in_scale], zero=[in_zp])
+    cur, cur_scale, cur_zp, w, c = t_in, in_scale, in_zp, n_frames, ncep
+    t = T(9, [1, 1, w, c], scale=[cur_scale], zero=[cur_zp])
+    node(0, [cur, shape_const([1, 1, w, c])], [t])
+    cur = t
+    for (oc, taps, pool) in blocks:
+        wq = rng.integers(-127, 128, (oc, 1, taps, c)).astype(np.int8)
+        wscales = [rscale(0.001, 0.005) for _ in range(oc)]
+        tw = T(9, [oc, 1, taps, c], True, wscales, [0] * oc, wq.tobytes())
+        bias = rng.integers(-200, 200, oc).astype(np.int32) if conv_bias else np.zeros(oc, np.int32)
+        tb = T(2, [oc], True, [cur_scale * s for s in wscales], [0] * oc, bias.tobytes())
+        out_scale, out_zp = rscale(0.03, 0.12), int(rng.integers(-30, 40))
+        tc = T(9, [1, 1, w, oc], scale=[out_scale], zero=[out_zp])
+        node(1, [cur, tw, tb], [tc], [1, 1, 1, 0, 1, 1])                    # SAME, stride 1, no activation
+        cur, cur_scale, cur_zp = tc, out_scale, out_zp
+        if add_bias:
+            t3 = T(9, [1, w, oc], scale=[cur_scale], zero=[cur_zp])
+            node(0, [cur, shape_const([1, w, oc])], [t3])
+            bq = rng.integers(-127, 1, oc).astype(np.int8)
+            tbq = T(9, [oc], True, [rscale(0.001, 0.01)], [0], bq.tobytes())
+            a_scale = rscale(0.02, 0.05)
+            ta = T(9, [1, w, oc], scale=[a_scale], zero=[-128])
+            node(2, [t3, tbq], [ta], [1])                                   # ReLU
+            cur, cur_scale, cur_zp = ta, a_scale, -128
+        if pool > 1:
+            t4 = T(9, [1, w, 1, oc], scale=[cur_scale], zero=[cur_zp])
+            node(0, [cur, shape_const([1, w, 1, oc])], [t4])
+            pw = (w + pool - 1) // pool
+            assert (pw - 1) * pool + pool <= w, "pool must tile the time axis"
+            tp = T(9, [1, pw, 1, oc], scale=[cur_scale], zero=[cur_zp])
+            node(3, [t4], [tp], [1, 1, pool, 1, pool, 0])                   # SAME, stride (w1,hP), filter (w1,hP)
+            w = pw
+            t5 = T(9, [1, 1, w, oc], scale=[cur_scale], zero=[cur_zp])
+            node(0, [tp, shape_const([1, 1, w, oc])], [t5])
+            cur = t5
+        c = oc
+    fc_in = w * c
+    tf = T(9, [1, fc_in], scale=[cur_scale], zero=[cur_zp])
+    node(0, [cur, shape_const([1, fc_in])], [tf])
+    fw = rng.integers(-127, 128, (n_labels, fc_in)).astype(np.int8)
+    fw_scale = rscale(0.005, 0.02)
+    tfw = T(9, [n_labels, fc_in], True, [fw_scale], [0], fw.tobytes())
+    tfb = T(2, [n_labels], True, [cur_scale * fw_scale], [0], rng.integers(-400, 400, n_labels).astype(np.int32).tobytes())
+    tfo = T(9, [1, n_labels], scale=[rscale(0.05, 0.2)], zero=[int(rng.integers(-10, 10))])
+    node(4, [tf, tfw, tfb], [tfo], [0])
+    tso = T(9, [1, n_labels], scale=[0.00390625], zero=[-128])
+    node(5, [tfo], [tso], beta=1.0)
+    meta = {"labels": ["label%d" % i for i in range(n_labels)],
+            "dsp": {"axes": 1, "num_cepstral": ncep, "frame_length": 0.02, "frame_stride": 0.02, "num_filters": num_filters,
+                    "fft_length": 256, "win_size": win_size, "low_frequency": low, "high_frequency": high,
+                    "pre_cof": 0.98, "pre_shift": 1},
+            "raw_sample_count": 16000, "frequency": 16000, "nn_input_frame_size": F}
+    return eon_import.serialise(tensors, nodes, t_in, tso, meta)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ncep", type=int, default=13)
+    ap.add_argument("--num-filters", type=int, default=32)
+    ap.add_argument("--win-size", type=int, default=101)
+    ap.add_argument("--low", type=int, default=300)
+    ap.add_argument("--high", type=int, default=4000)
+    ap.add_argument("--labels", type=int, default=4)
+    ap.add_argument("--blocks", default="30,7,7;10,7,7", help="out_channels,taps,pool per conv block")
+    a = ap.parse_args()
+    blocks = tuple(tuple(int(v) for v in b.split(",")) for b in a.blocks.split(";"))
+    blob = synth_model_blob(a.seed, ncep=a.ncep, win_size=a.win_size, low=a.low, high=a.high, blocks=blocks,
+                            n_labels=a.labels, num_filters=a.num_filters)
+    with open(a.out, "wb") as f:
+        f.write(blob)
+    print(a.out, len(blob), "bytes")
+
+
+if __name__ == "__main__":
+    main()
