@@ -197,7 +197,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CLIP * B, "algorithmic_bytes_per_clip": ALGO_BYTES_PER_CLIP,
-                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), ("kws_nn_f32_kernel" if is_float else "kws_nn_mfma_kernel"): round(ms_nn, 4)}},
+                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), model.nn_kernel: round(ms_nn, 4)}},
             "checksum": checksum,
         }
         if cpu is not None:

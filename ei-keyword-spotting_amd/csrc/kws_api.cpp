@@ -44,6 +44,7 @@ int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
 size_t kws_nn_smem_bytes(const KwsNnPlan &N);
 extern int kws_force_scalar_nn;
+int kws_nn_uses_mfma(const KwsNnPlan &N);
 int kws_mfcc_max_prow(void);
 int kws_mfcc_max_nz(void);
 int kws_mfcc_cmvn_rows(void);
@@ -901,6 +902,10 @@ int kws_clip_samples(const kws_handle *h) { return (int)h->model.raw_sample_coun
 int kws_frame_count(const kws_handle *h) { return h->dsp.n_frames; }
 int kws_pooled_tap_bytes(const kws_handle *h) { return h->pooled_tap_bytes; }
 int kws_model_is_float(const kws_handle *h) { return h->is_float ? 1 : 0; }
+const char *kws_nn_kernel_name(const kws_handle *h)
+{
+    return h->is_float ? "kws_nn_f32_kernel" : kws_nn_uses_mfma(h->nn) ? "kws_nn_mfma_kernel" : "kws_nn_kernel";
+}
 
 static EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B)
 {

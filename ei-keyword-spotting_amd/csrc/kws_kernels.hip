@@ -1444,6 +1444,7 @@ int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shi
 
 static bool nn_fits_mfma(const KwsNnPlan &N);
 int kws_force_scalar_nn = 0;   // tests: run the generic (dot4) kernel even when the matrix-core kernel applies
+int kws_nn_uses_mfma(const KwsNnPlan &N) { return nn_fits_mfma(N) && !kws_force_scalar_nn; }
 
 // cmvnw + quantise (+ the network when it fits the matrix-core path and scores != NULL).  Returns 1 in *ran_nn if the
 // network ran inside this launch.

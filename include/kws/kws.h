@@ -37,6 +37,7 @@ int kws_feature_count(const kws_handle *h);              /* EI_CLASSIFIER_NN_INP
 int kws_clip_samples(const kws_handle *h);               /* EI_CLASSIFIER_RAW_SAMPLE_COUNT */
 int kws_frame_count(const kws_handle *h);                /* MFCC rows (49) */
 int kws_pooled_tap_bytes(const kws_handle *h);           /* bytes/clip of the pooled-activation tap */
+const char *kws_nn_kernel_name(const kws_handle *h);    /* which network kernel serves this model (diagnostics) */
 int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI_CLASSIFIER_TFLITE_INPUT_QUANTIZED == 0) */
 
 /* The model used by the SDK-style entry points run_classifier()/run_inference().  If none was set,
