@@ -875,6 +875,9 @@ static int op_conv(const kwso_model *m, const o_node *nd, int8_t **buf, int dept
     }
     int32_t amin, amax;
     act_range(activation, out, &amin, &amax);
+    /* depthwise_conv.cc:618-620 (EvalQuantizedPerChannel): the int8 depthwise op clamps to the int8 range and IGNORES its
+     * fused activation ("TODO(b/130439627): Use calculated value for clamping") -- kept, it is what the reference computes */
+    if (depthwise) { amin = -128; amax = 127; }
     const int32_t input_offset = -in->zero[0], output_offset = out->zero[0];
     const int depth_mult = depthwise ? nd->p[6] : 1;
     for (int bt = 0; bt < batches; ++bt)
@@ -1110,7 +1113,7 @@ static float clampf(float x, float lo, float hi)   /* ActivationFunctionWithMinM
 }
 
 /* CONV_2D float: TFL/kernels/internal/reference/conv.h:28-99 (sequential total += in * filter, then + bias, clamp) */
-static int op_conv_f32(const kwso_model *m, const o_node *nd, float **buf)
+static int op_conv_f32(const kwso_model *m, const o_node *nd, float **buf, int depthwise)
 {
     const o_tensor *in = &m->t[nd->in[0]], *flt = &m->t[nd->in[1]], *out = &m->t[nd->out[0]];
     const o_tensor *bias = nd->n_in > 2 && nd->in[2] >= 0 ? &m->t[nd->in[2]] : NULL;
@@ -1125,6 +1128,29 @@ static int op_conv_f32(const kwso_model *m, const o_node *nd, float **buf)
     const int pad_h = pad_amount(stride_h, dil_h, in_h, f_h, oh), pad_w = pad_amount(stride_w, dil_w, in_w, f_w, ow);
     float amin, amax;
     act_range_f32(activation, &amin, &amax);
+    if (depthwise) {   /* reference/depthwiseconv_float.h:25-97, depthwise_conv.cc:582-603 (EvalFloat honours the activation) */
+        const int depth_mult = nd->p[6];
+        for (int bt = 0; bt < batches; ++bt)
+            for (int oy = 0; oy < out_h; ++oy)
+                for (int ox = 0; ox < out_w; ++ox)
+                    for (int ic = 0; ic < in_d; ++ic)
+                        for (int mm = 0; mm < depth_mult; ++mm) {
+                            const int oc = mm + ic * depth_mult;
+                            const int x0 = ox * stride_w - pad_w, y0 = oy * stride_h - pad_h;
+                            float total = 0.f;
+                            for (int fy = 0; fy < f_h; ++fy)
+                                for (int fx = 0; fx < f_w; ++fx) {
+                                    const int ix = x0 + dil_w * fx, iy = y0 + dil_h * fy;
+                                    if (ix >= 0 && ix < in_w && iy >= 0 && iy < in_h) {
+                                        float prod = x[((bt * in_h + iy) * in_w + ix) * in_d + ic] * w[(fy * f_w + fx) * out_d + oc];
+                                        total += prod;
+                                    }
+                                }
+                            float bv = b ? b[oc] : 0.0f;
+                            y[((bt * out_h + oy) * out_w + ox) * out_d + oc] = clampf(total + bv, amin, amax);
+                        }
+        return 0;
+    }
     for (int bt = 0; bt < batches; ++bt)
         for (int oy = 0; oy < out_h; ++oy)
             for (int ox = 0; ox < out_w; ++ox)
@@ -1262,7 +1288,8 @@ int kwso_nn_invoke_f32(const kwso_model *m, const float *input, float *out, floa
         const o_node *nd = &m->n[i];
         switch (nd->op) {
         case OP_RESHAPE: memcpy(buf[nd->out[0]], buf[nd->in[0]], m->t[nd->out[0]].nbytes); break;
-        case OP_CONV_2D: rc = op_conv_f32(m, nd, buf); break;
+        case OP_CONV_2D: rc = op_conv_f32(m, nd, buf, 0); break;
+        case OP_DEPTHWISE_CONV_2D: rc = op_conv_f32(m, nd, buf, 1); break;
         case OP_ADD: rc = op_add_f32(m, nd, buf); break;
         case OP_MAX_POOL_2D: rc = op_maxpool_f32(m, nd, buf); break;
         case OP_FULLY_CONNECTED: rc = op_fc_f32(m, nd, buf); break;

@@ -26,6 +26,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <time.h>
+#include <vector>
 
 /* The generated model is included (not linked) so that the per-op tensors in
  * its anonymous namespace (tflTensors[]) can be tapped. */
@@ -305,6 +306,161 @@ void eiref_f32_softmax(const float *in, int depth, float beta, float *out) {
     memset(&p, 0, sizeof(p));
     p.beta = beta;
     tflite::reference_ops::Softmax(p, tflite::RuntimeShape({1, depth}), in, tflite::RuntimeShape({1, depth}), out);
+}
+
+/* ---- a .kwsm graph (tools/eon_import.py layout) run through the reference's OWN TFLite-Micro op registrations ----------
+ * The same harness MODEL/tflite-model/trained_model_compiled.cpp:380-465 is (TfLiteContext with
+ * AllocatePersistentBuffer / RequestScratchBufferInArena / GetScratchBuffer, tensors + nodes tables, then
+ * init -> prepare -> invoke of TFL/micro/kernels/{reshape,conv,depthwise_conv,add,pooling,fully_connected,softmax}.cc),
+ * but driven by data, so that graphs the reference does not ship (float twins, depthwise graphs, other shapes) are still
+ * evaluated by the reference's op code, Prepare-time arithmetic included.
+ * input: the bytes of the graph's input tensor; taps (optional): every tensor, tensor-id order, concatenated. */
+namespace graphrun {
+struct Rd {
+    const uint8_t *p, *end; bool bad;
+    uint32_t u32() { if (p + 4 > end) { bad = true; return 0; } uint32_t v; memcpy(&v, p, 4); p += 4; return v; }
+    int32_t i32() { return (int32_t)u32(); }
+    float f32() { uint32_t u = u32(); float f; memcpy(&f, &u, 4); return f; }
+    const uint8_t *bytes(size_t n) { size_t pn = (n + 3) & ~(size_t)3; if (p + pn > end) { bad = true; return nullptr; } const uint8_t *q = p; p += pn; return q; }
+};
+static std::vector<void *> allocs;
+static void *keep(void *p) { allocs.push_back(p); return p; }
+static TfLiteIntArray *int_array(const std::vector<int> &v) {
+    TfLiteIntArray *a = (TfLiteIntArray *)keep(malloc(sizeof(int) * (v.size() + 1)));
+    a->size = (int)v.size();
+    for (size_t i = 0; i < v.size(); i++) a->data[i] = v[i];
+    return a;
+}
+static TfLiteFloatArray *float_array(const std::vector<float> &v) {
+    TfLiteFloatArray *a = (TfLiteFloatArray *)keep(malloc(sizeof(float) * (v.size() + 1)));
+    a->size = (int)v.size();
+    for (size_t i = 0; i < v.size(); i++) a->data[i] = v[i];
+    return a;
+}
+static TfLiteStatus alloc_persistent(TfLiteContext *, size_t bytes, void **ptr) { *ptr = keep(calloc(1, bytes ? bytes : 1)); return *ptr ? kTfLiteOk : kTfLiteError; }
+static std::vector<void *> scratch;
+static TfLiteStatus request_scratch(TfLiteContext *c, size_t bytes, int *idx) {
+    void *p; if (alloc_persistent(c, bytes, &p) != kTfLiteOk) return kTfLiteError;
+    scratch.push_back(p); *idx = (int)scratch.size() - 1; return kTfLiteOk;
+}
+static void *get_scratch(TfLiteContext *, int idx) { return idx >= 0 && idx < (int)scratch.size() ? scratch[idx] : nullptr; }
+static void report_error(TfLiteContext *, const char *fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
+}  // namespace graphrun
+
+int eiref_graph_run(const uint8_t *blob, size_t nbytes, const void *input, size_t input_bytes, void *output, size_t output_bytes,
+                    uint8_t *taps) {
+    using namespace graphrun;
+    if (nbytes < 8 || memcmp(blob, "KWSM", 4) != 0) return -1;
+    Rd r{ blob + 4, blob + nbytes, false };
+    if (r.u32() != 1) return -1;
+    const uint32_t nt = r.u32(), nn = r.u32(), nl = r.u32(), t_in = r.u32(), t_out = r.u32();
+    for (int i = 0; i < 3 + 8 + 3; i++) r.u32();                      /* sizes + dsp block: not needed here */
+    for (uint32_t i = 0; i < nl; i++) { uint32_t len = r.u32(); r.bytes(len); }
+    if (r.bad || nt > 4096 || nn > 4096 || t_in >= nt || t_out >= nt) return -1;
+    allocs.clear(); scratch.clear();
+    std::vector<TfLiteTensor> T(nt);
+    memset(T.data(), 0, sizeof(TfLiteTensor) * nt);
+    for (uint32_t i = 0; i < nt; i++) {
+        TfLiteTensor &t = T[i];
+        const uint32_t type = r.u32(), nd = r.u32();
+        std::vector<int> dims;
+        for (uint32_t k = 0; k < nd; k++) dims.push_back(r.i32());
+        const bool is_const = r.u32() != 0;
+        const uint32_t nq = r.u32();
+        std::vector<float> sc; std::vector<int> zp;
+        for (uint32_t k = 0; k < nq; k++) sc.push_back(r.f32());
+        for (uint32_t k = 0; k < nq; k++) zp.push_back(r.i32());
+        const int qdim = r.i32();
+        const uint32_t nb = r.u32();
+        if (r.bad) return -1;
+        t.type = (TfLiteType)type;                                    /* 1 f32, 2 i32, 9 i8: TfLiteType's own values */
+        t.dims = int_array(dims);
+        t.bytes = nb;
+        t.is_variable = 0;
+        if (is_const) {
+            const uint8_t *d = r.bytes(nb);
+            if (!d) return -1;
+            void *c = keep(malloc(nb ? nb : 1)); memcpy(c, d, nb);
+            t.data.data = c; t.allocation_type = kTfLiteMmapRo;
+        } else {
+            t.data.data = keep(calloc(1, nb ? nb : 1)); t.allocation_type = kTfLiteArenaRw;
+        }
+        if (nq) {
+            TfLiteAffineQuantization *q = (TfLiteAffineQuantization *)keep(malloc(sizeof(TfLiteAffineQuantization)));
+            q->scale = float_array(sc); q->zero_point = int_array(zp); q->quantized_dimension = qdim;
+            t.quantization.type = kTfLiteAffineQuantization; t.quantization.params = q;
+            t.params.scale = sc[0]; t.params.zero_point = zp[0];
+        } else {
+            t.quantization.type = kTfLiteNoQuantization; t.quantization.params = nullptr;
+        }
+    }
+    TfLiteContext c;
+    memset(&c, 0, sizeof(c));
+    c.AllocatePersistentBuffer = &alloc_persistent;
+    c.RequestScratchBufferInArena = &request_scratch;
+    c.GetScratchBuffer = &get_scratch;
+    c.ReportError = &report_error;
+    c.tensors = T.data();
+    c.tensors_size = nt;
+    std::vector<TfLiteNode> N(nn);
+    std::vector<TfLiteRegistration> reg(nn);
+    memset(N.data(), 0, sizeof(TfLiteNode) * nn);
+    int rc = 0;
+    for (uint32_t i = 0; i < nn && !rc; i++) {
+        const uint32_t op = r.u32(), ni = r.u32();
+        std::vector<int> in, out;
+        for (uint32_t k = 0; k < ni; k++) in.push_back(r.i32());
+        const uint32_t no = r.u32();
+        for (uint32_t k = 0; k < no; k++) out.push_back(r.i32());
+        int p[8];
+        for (int k = 0; k < 8; k++) p[k] = r.i32();
+        const float beta = r.f32();
+        if (r.bad) { rc = -1; break; }
+        N[i].inputs = int_array(in); N[i].outputs = int_array(out);
+        switch (op) {
+        case 0: { reg[i] = *tflite::ops::micro::Register_RESHAPE();
+                  N[i].builtin_data = keep(calloc(1, sizeof(TfLiteReshapeParams))); break; }
+        case 1: { reg[i] = *tflite::ops::micro::Register_CONV_2D();
+                  TfLiteConvParams *q = (TfLiteConvParams *)keep(calloc(1, sizeof(TfLiteConvParams)));
+                  q->padding = (TfLitePadding)p[0]; q->stride_width = p[1]; q->stride_height = p[2]; q->activation = (TfLiteFusedActivation)p[3];
+                  q->dilation_width_factor = p[4]; q->dilation_height_factor = p[5]; N[i].builtin_data = q; break; }
+        case 6: { reg[i] = *tflite::ops::micro::Register_DEPTHWISE_CONV_2D();
+                  TfLiteDepthwiseConvParams *q = (TfLiteDepthwiseConvParams *)keep(calloc(1, sizeof(TfLiteDepthwiseConvParams)));
+                  q->padding = (TfLitePadding)p[0]; q->stride_width = p[1]; q->stride_height = p[2]; q->activation = (TfLiteFusedActivation)p[3];
+                  q->dilation_width_factor = p[4]; q->dilation_height_factor = p[5]; q->depth_multiplier = p[6]; N[i].builtin_data = q; break; }
+        case 2: { reg[i] = *tflite::ops::micro::Register_ADD();
+                  TfLiteAddParams *q = (TfLiteAddParams *)keep(calloc(1, sizeof(TfLiteAddParams)));
+                  q->activation = (TfLiteFusedActivation)p[0]; N[i].builtin_data = q; break; }
+        case 3: { reg[i] = *tflite::ops::micro::Register_MAX_POOL_2D();
+                  TfLitePoolParams *q = (TfLitePoolParams *)keep(calloc(1, sizeof(TfLitePoolParams)));
+                  q->padding = (TfLitePadding)p[0]; q->stride_width = p[1]; q->stride_height = p[2]; q->filter_width = p[3];
+                  q->filter_height = p[4]; q->activation = (TfLiteFusedActivation)p[5]; N[i].builtin_data = q; break; }
+        case 4: { reg[i] = *tflite::ops::micro::Register_FULLY_CONNECTED();
+                  TfLiteFullyConnectedParams *q = (TfLiteFullyConnectedParams *)keep(calloc(1, sizeof(TfLiteFullyConnectedParams)));
+                  q->activation = (TfLiteFusedActivation)p[0]; N[i].builtin_data = q; break; }
+        case 5: { reg[i] = *tflite::ops::micro::Register_SOFTMAX();
+                  TfLiteSoftmaxParams *q = (TfLiteSoftmaxParams *)keep(calloc(1, sizeof(TfLiteSoftmaxParams)));
+                  q->beta = beta; N[i].builtin_data = q; break; }
+        default: rc = -2;
+        }
+    }
+    for (uint32_t i = 0; i < nn && !rc; i++)
+        if (reg[i].init) N[i].user_data = reg[i].init(&c, (const char *)N[i].builtin_data, 0);
+    for (uint32_t i = 0; i < nn && !rc; i++)
+        if (reg[i].prepare && reg[i].prepare(&c, &N[i]) != kTfLiteOk) rc = -3;
+    if (!rc) {
+        if (input_bytes != T[t_in].bytes || output_bytes != T[t_out].bytes) rc = -4;
+        else memcpy(T[t_in].data.data, input, input_bytes);
+    }
+    for (uint32_t i = 0; i < nn && !rc; i++)
+        if (reg[i].invoke(&c, &N[i]) != kTfLiteOk) rc = -5;
+    if (!rc) {
+        memcpy(output, T[t_out].data.data, output_bytes);
+        if (taps) { size_t off = 0; for (uint32_t i = 0; i < nt; i++) { memcpy(taps + off, T[i].data.data, T[i].bytes); off += T[i].bytes; } }
+    }
+    for (void *p : allocs) free(p);
+    allocs.clear(); scratch.clear();
+    return rc;
 }
 
 /* CPU baseline: loop run_classifier over n_clips clips ([n_clips][len] int16), `iters` passes.

@@ -316,10 +316,25 @@ class Reference:
         L.eiref_continuous.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         L.eiref_time_run_classifier.restype = C.c_double
         L.eiref_time_run_classifier.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.eiref_graph_run.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         self.n_labels = L.eiref_label_count()
         self.labels = [L.eiref_label(i).decode() for i in range(self.n_labels)]
         self.n_features = L.eiref_feature_count()
         self.tensor_bytes = [L.eiref_tensor_bytes(i) for i in range(L.eiref_tensor_count())]
+
+    def graph_run(self, blob, x):
+        """A .kwsm graph through the reference's own TFLite-Micro op registrations (init/prepare/invoke).
+        x: the input tensor (int8 or float32).  Returns (output, [every tensor as raw bytes, tensor-id order])."""
+        import eon_import
+        tens, _, t_in, t_out, _ = eon_import.parse_blob(blob)
+        x = np.ascontiguousarray(x)
+        np_t = {1: np.float32, 2: np.int32, 9: np.int8}
+        out = np.zeros(tens[t_out]["nbytes"] // np.dtype(np_t[tens[t_out]["type"]]).itemsize, np_t[tens[t_out]["type"]])
+        taps = np.zeros(sum(t["nbytes"] for t in tens), np.uint8)
+        rc = self.L.eiref_graph_run(blob, len(blob), _ptr(x), x.nbytes, _ptr(out), out.nbytes, _ptr(taps))
+        assert rc == 0, rc
+        offs = np.cumsum([0] + [t["nbytes"] for t in tens])
+        return out, [taps[offs[i]:offs[i + 1]].view(np_t[t["type"]]) for i, t in enumerate(tens)]
 
     def run_classifier(self, pcm):
         pcm = np.ascontiguousarray(pcm, np.int16)
@@ -501,3 +516,20 @@ def special_clips():
 # ---------------------------------------------------------------------------------------------------------------
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from synth_model import synth_model_blob  # noqa: E402,F401
+
+# Named synthetic graphs shared by the CPU pins (oracle vs the reference's op registrations), tools/make_golden.py and
+# the GPU parity tests.  `dw` / `pw` blocks: DEPTHWISE_CONV_2D / pointwise CONV_2D (BASELINE config 5).
+SYNTH_SPECS = {
+    "seed1": dict(seed=1),                                                                # shipped shape, random weights
+    "seed2": dict(seed=2, ncep=10, win_size=51, high=0, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3),
+    "seed4": dict(seed=4, ncep=16, blocks=((32, 8, 7), (16, 8, 7)), n_labels=5, add_bias=False),   # matrix-core limits, even taps
+    "seed5": dict(seed=5, ncep=13, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4, conv_bias=True),
+    "seed6": dict(seed=6, ncep=12, win_size=13, low=0, high=8000, blocks=((20, 3, 7), (12, 5, 1), (6, 3, 7)), n_labels=2),  # 3 blocks
+    "seed7": dict(seed=7, ncep=13, blocks=((40, 7, 7), (10, 7, 7)), n_labels=4),           # 40 channels
+    "f40c40": dict(seed=11, num_filters=40, ncep=40, low=300, high=0, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3),
+    "dscnn_a": dict(seed=21, blocks=((16, 5, 1), ("dw", 1, 3, 1, 1), ("pw", 24, 1), ("dw", 1, 5, 7, 0), ("pw", 8, 3), (8, 3, 7)), n_labels=5),
+    "dscnn_b": dict(seed=22, ncep=10, blocks=(("dw", 2, 7, 7, 3), ("pw", 12, 1), ("dw", 1, 3, 7, 1)), n_labels=3),
+    # BASELINE config 5 as worded: 49x40 MFCC, deeper depthwise-separable CNN, 10 keywords (+ noise/unknown); synthetic weights
+    "cfg5_dscnn": dict(seed=50, num_filters=40, ncep=40, low=300, high=0, n_labels=12,
+                       blocks=((32, 5, 1), ("dw", 1, 5, 1, 1), ("pw", 32, 1), ("dw", 1, 5, 7, 1), ("pw", 32, 1), ("dw", 1, 3, 7, 1), ("pw", 12, 0))),
+}

@@ -181,3 +181,28 @@ def test_mfcc40_golden(oracle):
         c = cfg.copy(**kw)
         for i, x in enumerate(clips):
             assert (bits(oracle.extract_mfcc(x, c)) == bits(g[name][i])).all(), (name, i)
+
+
+def test_synthetic_graph_goldens(oracle, tmp_path):
+    """Outputs of the reference's own op registrations for the synthetic graphs (tools/make_golden.py graphs)."""
+    from kws_testlib import SYNTH_SPECS, OracleModel, synth_model_blob
+    from dequantize_model import dequantize
+    g = _load("graphs_l476.npz")
+    for name in [str(n) for n in g["names"]]:
+        blob = synth_model_blob(**SYNTH_SPECS[name])
+        for kind, b in (("i8", blob), ("f32", dequantize(blob))):
+            p = tmp_path / (name + kind + ".kwsm")
+            p.write_bytes(b)
+            om = OracleModel(oracle, str(p))
+            rng = np.random.default_rng(int(g["rng_seed"]))
+            xi = rng.integers(-128, 128, (int(g["n"]), om.n_features)).astype(np.int8)
+            xf = (rng.standard_normal((int(g["n"]), om.n_features)) * 3).astype(np.float32)
+            n_t = len(om.tensor_bytes)
+            for k in range(int(g["n"])):
+                if kind == "i8":
+                    o, taps = om.nn_invoke(xi[k], taps=True)
+                    assert (o == g[name + "_i8_out"][k]).all() and (taps[n_t - 2] == g[name + "_i8_fc"][k]).all(), (name, k)
+                else:
+                    o, taps = om.nn_invoke_f32(xf[k], taps=True)
+                    assert (bits(taps[n_t - 2]) == bits(g[name + "_f32_logits"][k])).all(), (name, k)
+                    assert np.abs(o - g[name + "_f32_scores"][k]).max() <= 1e-7

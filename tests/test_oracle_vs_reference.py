@@ -161,3 +161,36 @@ def test_float_kernels_pinned_leaf_by_leaf(oracle, reference):
         y = np.zeros(4, np.float32)
         L.eiref_f32_softmax(P(t[29]), 4, C.c_float(1.0), P(y))
         assert (bits(y) == bits(t[30])).all() and (bits(y) == bits(out)).all()
+
+
+@pytest.mark.parametrize("name", sorted(__import__("kws_testlib").SYNTH_SPECS))
+def test_synthetic_graphs_through_reference_op_registrations(name, oracle, reference, tmp_path):
+    """Every synthetic graph (int8 and its float32 twin) evaluated by the reference's OWN TFLite-Micro op code
+    (init/prepare/invoke of Register_*(), driven by eiref_graph_run) == the restatement, every tensor, bit for bit.
+    Covers what no shipped model exercises: DEPTHWISE_CONV_2D (whose int8 path ignores its fused activation,
+    depthwise_conv.cc:618-620), pointwise convolutions, fused activations, conv biases, the float kernels."""
+    from kws_testlib import SYNTH_SPECS, OracleModel, synth_model_blob    # (puts tools/ on sys.path)
+    from dequantize_model import dequantize
+    blob = synth_model_blob(**SYNTH_SPECS[name])
+    rng = np.random.default_rng(3)
+    for kind, b in (("i8", blob), ("f32", dequantize(blob))):
+        p = tmp_path / (name + kind + ".kwsm")
+        p.write_bytes(b)
+        om = OracleModel(oracle, str(p))
+        for it in range(12):
+            if kind == "i8":
+                x = rng.integers(-128, 128, om.n_features).astype(np.int8)
+                out, taps = reference.graph_run(b, x)
+                oo, ot = om.nn_invoke(x, taps=True)
+                assert (out == oo).all()
+                for a, t in zip(taps, ot):
+                    if a.dtype == np.int8:
+                        assert (a == t).all(), (name, it)
+            else:
+                x = (rng.standard_normal(om.n_features) * np.float32(10.0) ** rng.integers(-2, 2)).astype(np.float32)
+                out, taps = reference.graph_run(b, x)
+                oo, ot = om.nn_invoke_f32(x, taps=True)
+                for a, t in zip(taps[:-1], ot[:-1]):
+                    if a.dtype == np.float32:
+                        assert (bits(a) == bits(t)).all(), (name, it)           # everything up to the logits
+                assert np.abs(out - oo).max() <= 1e-7                          # softmax: libm expf on both sides

@@ -37,10 +37,40 @@ def mfcc40(ref, synth, cfg):
     print("mfcc40_l476.npz", os.path.getsize(os.path.join(GOLDEN, "mfcc40_l476.npz")), "bytes")
 
 
+def graphs(ref):
+    """Synthetic graphs (kws_testlib.SYNTH_SPECS; int8 and float32 twins) evaluated by the reference's own TFLite-Micro
+    op registrations (eiref_graph_run): inputs are regenerated in the tests from the seed, outputs are stored."""
+    from kws_testlib import SYNTH_SPECS, synth_model_blob
+    from dequantize_model import dequantize
+    import eon_import
+    out = {"names": np.array(sorted(SYNTH_SPECS)), "n": np.int32(16), "rng_seed": np.int32(17)}
+    for name in sorted(SYNTH_SPECS):
+        blob = synth_model_blob(**SYNTH_SPECS[name])
+        tens, nodes, t_in, t_out, _ = eon_import.parse_blob(blob)
+        nfeat = tens[t_in]["nbytes"]
+        fc_t = nodes[-1]["in"][0]
+        rng = np.random.default_rng(17)
+        xi = rng.integers(-128, 128, (16, nfeat)).astype(np.int8)
+        xf = (rng.standard_normal((16, nfeat)) * 3).astype(np.float32)
+        bf = dequantize(blob)
+        qi, fi, lf, sf = [], [], [], []
+        for k in range(16):
+            o, taps = ref.graph_run(blob, xi[k])
+            qi.append(o); fi.append(taps[fc_t].copy())
+            o, taps = ref.graph_run(bf, xf[k])
+            sf.append(o); lf.append(taps[fc_t].copy())
+        out[name + "_i8_out"], out[name + "_i8_fc"] = np.stack(qi), np.stack(fi)
+        out[name + "_f32_scores"], out[name + "_f32_logits"] = np.stack(sf), np.stack(lf)
+    np.savez_compressed(os.path.join(GOLDEN, "graphs_l476.npz"), **out)
+    print("graphs_l476.npz", os.path.getsize(os.path.join(GOLDEN, "graphs_l476.npz")), "bytes")
+
+
 def main():
     ref = Reference()
     if "--only-mfcc40" in sys.argv:
         return mfcc40(ref, Oracle(), L476_CONFIG())
+    if "--only-graphs" in sys.argv:
+        return graphs(ref)
     synth = Oracle()          # only used for kwso_synth_fill (shared integer generator)
     cfg = L476_CONFIG()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -157,6 +187,7 @@ def main():
     f32["logits"], f32["scores"] = np.stack(lg), np.stack(sc)
     np.savez_compressed(os.path.join(GOLDEN, "f32_twin_l476.npz"), **f32)
     mfcc40(ref, synth, cfg)
+    graphs(ref)
     for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz", "continuous_l476.npz", "f32_twin_l476.npz"):
         print(fn, os.path.getsize(os.path.join(GOLDEN, fn)), "bytes")
 

@@ -21,7 +21,12 @@ import eon_import  # noqa: E402
 
 def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4,
                      conv_bias=False, add_bias=True, num_filters=32):
-    """blocks: sequence of (out_channels, taps, pool).  Frame geometry is the shipped one (49 frames)."""
+    """blocks: sequence of
+         (out_channels, taps, pool)              CONV_2D 1xK (+ optional int32 bias) -> ADD(int8 per-channel)+ReLU -> MAX_POOL
+         ("dw", depth_mult, taps, pool, act)     DEPTHWISE_CONV_2D 1xK with int32 bias and fused activation -> MAX_POOL
+         ("pw", out_channels, act)               CONV_2D 1x1 with int32 bias and fused activation (pointwise)
+       (pool 1 = no pooling node; act: TfLiteFusedActivation 0 none, 1 relu, 3 relu6).
+       Frame geometry is the shipped one (49 frames)."""
     rng = np.random.default_rng(seed)
     n_frames = 49
     F = n_frames * ncep
@@ -53,7 +58,52 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
     t = T(9, [1, 1, w, c], scale=[cur_scale], zero=[cur_zp])
     node(0, [cur, shape_const([1, 1, w, c])], [t])
     cur = t
-    for (oc, taps, pool) in blocks:
+    def add_pool(pool):
+        nonlocal cur, w
+        if pool <= 1:
+            return
+        t4 = T(9, [1, w, 1, c_out], scale=[cur_scale], zero=[cur_zp])
+        node(0, [cur, shape_const([1, w, 1, c_out])], [t4])
+        pw = (w + pool - 1) // pool
+        assert (pw - 1) * pool + pool <= w, "pool must tile the time axis"
+        tp = T(9, [1, pw, 1, c_out], scale=[cur_scale], zero=[cur_zp])
+        node(3, [t4], [tp], [1, 1, pool, 1, pool, 0])                   # SAME, stride (w1,hP), filter (w1,hP)
+        w = pw
+        t5 = T(9, [1, 1, w, c_out], scale=[cur_scale], zero=[cur_zp])
+        node(0, [tp, shape_const([1, 1, w, c_out])], [t5])
+        cur = t5
+
+    for blk in blocks:
+        if blk[0] == "dw":
+            _, mult, taps, pool, act = blk
+            c_out = c * mult
+            wq = rng.integers(-127, 128, (1, 1, taps, c_out)).astype(np.int8)
+            wscales = [rscale(0.002, 0.02) for _ in range(c_out)]
+            tw = T(9, [1, 1, taps, c_out], True, wscales, [0] * c_out, wq.tobytes(), qdim=3)
+            bias = rng.integers(-300, 300, c_out).astype(np.int32)
+            tb = T(2, [c_out], True, [cur_scale * s_ for s_ in wscales], [0] * c_out, bias.tobytes())
+            out_scale, out_zp = rscale(0.03, 0.12), int(rng.integers(-128, -90)) if act else int(rng.integers(-30, 40))
+            tc = T(9, [1, 1, w, c_out], scale=[out_scale], zero=[out_zp])
+            node(6, [cur, tw, tb], [tc], [1, 1, 1, act, 1, 1, mult])          # SAME, stride 1
+            cur, cur_scale, cur_zp = tc, out_scale, out_zp
+            add_pool(pool)
+            c = c_out
+            continue
+        if blk[0] == "pw":
+            _, c_out, act = blk
+            wq = rng.integers(-127, 128, (c_out, 1, 1, c)).astype(np.int8)
+            wscales = [rscale(0.001, 0.008) for _ in range(c_out)]
+            tw = T(9, [c_out, 1, 1, c], True, wscales, [0] * c_out, wq.tobytes())
+            bias = rng.integers(-300, 300, c_out).astype(np.int32)
+            tb = T(2, [c_out], True, [cur_scale * s_ for s_ in wscales], [0] * c_out, bias.tobytes())
+            out_scale, out_zp = rscale(0.03, 0.12), int(rng.integers(-128, -90)) if act else int(rng.integers(-30, 40))
+            tc = T(9, [1, 1, w, c_out], scale=[out_scale], zero=[out_zp])
+            node(1, [cur, tw, tb], [tc], [1, 1, 1, act, 1, 1])
+            cur, cur_scale, cur_zp = tc, out_scale, out_zp
+            c = c_out
+            continue
+        (oc, taps, pool) = blk
+        c_out = oc
         wq = rng.integers(-127, 128, (oc, 1, taps, c)).astype(np.int8)
         wscales = [rscale(0.001, 0.005) for _ in range(oc)]
         tw = T(9, [oc, 1, taps, c], True, wscales, [0] * oc, wq.tobytes())
@@ -73,16 +123,11 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
             node(2, [t3, tbq], [ta], [1])                                   # ReLU
             cur, cur_scale, cur_zp = ta, a_scale, -128
         if pool > 1:
-            t4 = T(9, [1, w, 1, oc], scale=[cur_scale], zero=[cur_zp])
-            node(0, [cur, shape_const([1, w, 1, oc])], [t4])
-            pw = (w + pool - 1) // pool
-            assert (pw - 1) * pool + pool <= w, "pool must tile the time axis"
-            tp = T(9, [1, pw, 1, oc], scale=[cur_scale], zero=[cur_zp])
-            node(3, [t4], [tp], [1, 1, pool, 1, pool, 0])                   # SAME, stride (w1,hP), filter (w1,hP)
-            w = pw
-            t5 = T(9, [1, 1, w, oc], scale=[cur_scale], zero=[cur_zp])
-            node(0, [tp, shape_const([1, 1, w, oc])], [t5])
-            cur = t5
+            add_pool(pool)
+        elif add_bias:                                                      # back to NHWC for the next convolution
+            t6 = T(9, [1, 1, w, oc], scale=[cur_scale], zero=[cur_zp])
+            node(0, [cur, shape_const([1, 1, w, oc])], [t6])
+            cur = t6
         c = oc
     fc_in = w * c
     tf = T(9, [1, fc_in], scale=[cur_scale], zero=[cur_zp])
@@ -113,9 +158,9 @@ def main():
     ap.add_argument("--low", type=int, default=300)
     ap.add_argument("--high", type=int, default=4000)
     ap.add_argument("--labels", type=int, default=4)
-    ap.add_argument("--blocks", default="30,7,7;10,7,7", help="out_channels,taps,pool per conv block")
+    ap.add_argument("--blocks", default="30,7,7;10,7,7", help="per block: out_channels,taps,pool | dw,depth_mult,taps,pool,act | pw,out_channels,act")
     a = ap.parse_args()
-    blocks = tuple(tuple(int(v) for v in b.split(",")) for b in a.blocks.split(";"))
+    blocks = tuple(tuple(v if v in ("dw", "pw") else int(v) for v in b.split(",")) for b in a.blocks.split(";"))
     blob = synth_model_blob(a.seed, ncep=a.ncep, win_size=a.win_size, low=a.low, high=a.high, blocks=blocks,
                             n_labels=a.labels, num_filters=a.num_filters)
     with open(a.out, "wb") as f:
