@@ -541,18 +541,21 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         return true;
     };
     if (!skip_reshapes()) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "reshape changes quantisation");
-    while (i < m.n.size() && m.n[i].op == OP_CONV_2D) {
+    while (i < m.n.size() && (m.n[i].op == OP_CONV_2D || m.n[i].op == OP_DEPTHWISE_CONV_2D)) {
         if (N.n_blocks >= KWS_MAX_BLOCKS) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "more than %d conv blocks", KWS_MAX_BLOCKS);
         const Node &cv = m.n[i];
+        const bool dw = cv.op == OP_DEPTHWISE_CONV_2D;
         if (cv.in[0] != cur || cv.in.size() < 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv input is not the flowing tensor");
         const Tensor &x = m.t[cur], &w = m.t[cv.in[1]], &y = m.t[cv.out[0]];
         const Tensor *bias = (cv.in.size() > 2 && cv.in[2] >= 0) ? &m.t[cv.in[2]] : nullptr;
         const int in_h = x.dim4(1), in_w = x.dim4(2), in_c = x.dim4(3);
-        const int out_c = w.dim4(0), f_h = w.dim4(1), f_w = w.dim4(2);
+        const int out_c = dw ? w.dim4(3) : w.dim4(0), f_h = w.dim4(1), f_w = w.dim4(2);
+        const int depth_mult = dw ? cv.p[6] : 1;
         const int padding = cv.p[0], stride_w = cv.p[1], stride_h = cv.p[2], act = cv.p[3], dil_w = cv.p[4], dil_h = cv.p[5];
         if (x.dim4(0) != 1 || in_h != 1 || f_h != 1 || stride_w != 1 || stride_h != 1 || dil_w != 1 || dil_h != 1 || !w.is_const ||
-            w.dim4(3) != in_c || (bias && !bias->is_const) || f_w > 16 || out_c > 64)
-            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu is not a stride-1 1xK convolution over time", i);
+            (dw ? (w.dim4(0) != 1 || depth_mult < 1 || out_c != in_c * depth_mult) : (w.dim4(3) != in_c)) || (bias && !bias->is_const) ||
+            f_w > 16 || out_c > 64 || x.dims.size() != 4 || (size_t)w.nbytes != (size_t)out_c * f_w * (dw ? 1 : in_c))
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu is not a stride-1 1xK (depthwise) convolution over time", i);
         if (cur_w && (cur_w != in_w || cur_c != in_c)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "shape mismatch into conv %zu", i);
         const int out_w = h_out_size(padding, in_w, f_w, 1, 1);
         const int pad_left = h_pad_amount(1, 1, in_w, f_w, out_w);
@@ -560,9 +563,16 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         KwsConvBlock &k = N.blk[N.n_blocks];
         k.in_w = in_w; k.in_c = in_c; k.in_cpad = (in_c + 15) & ~15; k.out_c = out_c; k.taps = f_w; k.pad_left = pad_left;
         k.out_w = out_w; k.in_zp = x.zero[0]; k.out_zp = y.zero[0];
+        k.depthwise = dw ? 1 : 0; k.depth_mult = depth_mult;
         h_act_range(act, y.scale[0], y.zero[0], &k.act_min, &k.act_max);
-        // weights -> [out_c][taps][in_cpad]; bias_eff = bias + input_offset * sum(w)   (integer_ops/conv.h:64-113)
-        std::vector<int8_t> wp((size_t)out_c * f_w * k.in_cpad, 0);
+        // the reference's int8 depthwise op clamps to the int8 range whatever its fused activation says
+        // (TFL/micro/kernels/depthwise_conv.cc:618-620, "TODO(b/130439627)") -- pinned in tests/test_oracle_vs_reference.py
+        if (dw) { k.act_min = -128; k.act_max = 127; }
+        // weights -> [out_c][taps][in_cpad] (depthwise: [out_c][taps padded to 4], from the filter's [taps][out_c]);
+        // bias_eff = bias + input_offset * sum(w)   (integer_ops/conv.h:64-113, depthwise_conv.h:64-106)
+        const int tp4 = (f_w + 3) & ~3;
+        std::vector<int8_t> wp(dw ? (size_t)out_c * tp4 : (size_t)out_c * f_w * k.in_cpad, 0);
+        k.w_bytes = (int)wp.size();
         std::vector<int32_t> beff(out_c), mult(out_c), shift(out_c);
         const int8_t *wd = (const int8_t *)w.data.data();
         const int32_t in_off = -x.zero[0];
@@ -570,12 +580,19 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         if (per_channel && (int)w.scale.size() != out_c) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "per-channel scale count");
         for (int oc = 0; oc < out_c; oc++) {
             int64_t wsum = 0;
-            for (int tap = 0; tap < f_w; tap++)
+            for (int tap = 0; tap < f_w; tap++) {
+                if (dw) {
+                    const int8_t v = wd[(size_t)tap * out_c + oc];
+                    wp[(size_t)oc * tp4 + tap] = v;
+                    wsum += v;
+                    continue;
+                }
                 for (int c = 0; c < in_c; c++) {
                     const int8_t v = wd[((size_t)oc * f_w + tap) * in_c + c];
                     wp[((size_t)oc * f_w + tap) * k.in_cpad + c] = v;
                     wsum += v;
                 }
+            }
             beff[oc] = (int32_t)((bias ? ((const int32_t *)bias->data.data())[oc] : 0) + (int64_t)in_off * wsum);
             const double eff = (double)x.scale[0] * (double)(per_channel ? w.scale[oc] : w.scale[0]) / (double)y.scale[0];
             int sh;
@@ -589,7 +606,9 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         // optional ADD(const per-channel tensor) with fused activation -> 256-entry table per channel
         std::vector<int8_t> lut((size_t)out_c * 256);
         for (int c = 0; c < out_c; c++) for (int v = 0; v < 256; v++) lut[(size_t)c * 256 + v] = (int8_t)(v - 128);
+        k.has_lut = 0;
         if (i < m.n.size() && m.n[i].op == OP_ADD) {
+            k.has_lut = 1;
             const Node &ad = m.n[i];
             int a_id = ad.in[0], b_id = ad.in[1];
             if (a_id != cur && b_id == cur) std::swap(a_id, b_id);
@@ -745,27 +764,31 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
     };
     auto floats = [](const Tensor &t) { return std::vector<float>((const float *)t.data.data(), (const float *)t.data.data() + t.nbytes / 4); };
     skip_reshapes();
-    while (i < m.n.size() && m.n[i].op == OP_CONV_2D) {
+    while (i < m.n.size() && (m.n[i].op == OP_CONV_2D || m.n[i].op == OP_DEPTHWISE_CONV_2D)) {
         if (N.n_blocks >= KWS_MAX_BLOCKS) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "more than %d conv blocks", KWS_MAX_BLOCKS);
         const Node &cv = m.n[i];
+        const bool dw = cv.op == OP_DEPTHWISE_CONV_2D;
         if (cv.in[0] != cur || cv.in.size() < 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv input is not the flowing tensor");
         const Tensor &x = m.t[cur], &w = m.t[cv.in[1]], &y = m.t[cv.out[0]];
         const Tensor *bias = (cv.in.size() > 2 && cv.in[2] >= 0) ? &m.t[cv.in[2]] : nullptr;
         const int in_h = x.dim4(1), in_w = x.dim4(2), in_c = x.dim4(3);
-        const int out_c = w.dim4(0), f_h = w.dim4(1), f_w = w.dim4(2);
+        const int out_c = dw ? w.dim4(3) : w.dim4(0), f_h = w.dim4(1), f_w = w.dim4(2);
+        const int depth_mult = dw ? cv.p[6] : 1;
         const int padding = cv.p[0], stride_w = cv.p[1], stride_h = cv.p[2], act = cv.p[3], dil_w = cv.p[4], dil_h = cv.p[5];
         if (x.dim4(0) != 1 || in_h != 1 || f_h != 1 || stride_w != 1 || stride_h != 1 || dil_w != 1 || dil_h != 1 || !w.is_const ||
-            w.dim4(3) != in_c || (bias && !bias->is_const) || f_w > 16 || out_c > 64)
-            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu is not a stride-1 1xK convolution over time", i);
+            (dw ? (w.dim4(0) != 1 || depth_mult < 1 || out_c != in_c * depth_mult) : (w.dim4(3) != in_c)) || (bias && !bias->is_const) ||
+            f_w > 16 || out_c > 64 || x.dims.size() != 4 || (size_t)w.nbytes != sizeof(float) * out_c * f_w * (dw ? 1 : in_c))
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu is not a stride-1 1xK (depthwise) convolution over time", i);
         if (cur_w && (cur_w != in_w || cur_c != in_c)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "shape mismatch into conv %zu", i);
         const int out_w = h_out_size(padding, in_w, f_w, 1, 1);
         const int pad_left = h_pad_amount(1, 1, in_w, f_w, out_w);
         if (out_w != y.dim4(2) || y.dim4(3) != out_c) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu output shape", i);
         KwsConvBlockF32 &k = N.blk[N.n_blocks];
         k.in_w = in_w; k.in_c = in_c; k.out_c = out_c; k.taps = f_w; k.pad_left = pad_left; k.out_w = out_w;
-        h_act_range_f32(act, &k.conv_min, &k.conv_max);
+        k.depthwise = dw ? 1 : 0; k.depth_mult = depth_mult;
+        h_act_range_f32(act, &k.conv_min, &k.conv_max);           // the float depthwise op honours its activation
         std::vector<float> wv = floats(w), bv(out_c, 0.0f), av(out_c, 0.0f);
-        if ((int)wv.size() != out_c * f_w * in_c) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu filter size", i);
+        if ((int)wv.size() != out_c * f_w * (dw ? 1 : in_c)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu filter size", i);
         if (bias) { if ((int)bias->nbytes != out_c * 4) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu bias size", i); bv = floats(*bias); }
         cur = cv.out[0]; cur_w = out_w; cur_c = out_c;
         i++;

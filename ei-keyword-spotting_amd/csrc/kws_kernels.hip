@@ -707,11 +707,11 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
     int act_bytes = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlock &k = N.blk[b];
-        const int wbytes = k.out_c * k.taps * k.in_cpad;
+        const int wbytes = k.w_bytes;
         for (int i = threadIdx.x * 4; i < wbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.w + i);
         s_w[b] = (const int8_t *)sp;
         sp += (wbytes + 15) & ~15;
-        const int lbytes = k.out_c * 256;
+        const int lbytes = k.has_lut ? k.out_c * 256 : 0;
         for (int i = threadIdx.x * 4; i < lbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.add_lut + i);
         s_lut[b] = (const int8_t *)sp;
         sp += lbytes;
@@ -762,15 +762,27 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
                 int acc[KWS_POOL_MAX];
 #pragma unroll
                 for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i] = 0;
-                const int *wrow = (const int *)(s_w[b] + (size_t)oc * k.taps * k.in_cpad);
-                for (int tap = 0; tap < k.taps; ++tap) {
-                    for (int c4 = 0; c4 < c4n; ++c4) {
-                        const int wv = wrow[tap * c4n + c4];
+                if (k.depthwise) {                       // integer_ops/depthwise_conv.h:64-103: one input channel per output
+                    const int tp4 = (k.taps + 3) & ~3;
+                    const int8_t *wrow = s_w[b] + oc * tp4;
+                    const int8_t *xcol = cur + t0 * k.in_cpad + oc / k.depth_mult;
+                    for (int tap = 0; tap < k.taps; ++tap) {
+                        const int wv = wrow[tap];
 #pragma unroll
-                        for (int i = 0; i < KWS_POOL_MAX; ++i) {
-                            if (i < k.pool) {
-                                const int xv = *(const int *)(cur + (t0 + i + tap) * k.in_cpad + 4 * c4);
-                                acc[i] = __builtin_amdgcn_sdot4(wv, xv, acc[i], false);
+                        for (int i = 0; i < KWS_POOL_MAX; ++i)
+                            if (i < k.pool) acc[i] += wv * (int)xcol[(i + tap) * k.in_cpad];
+                    }
+                } else {
+                    const int *wrow = (const int *)(s_w[b] + (size_t)oc * k.taps * k.in_cpad);
+                    for (int tap = 0; tap < k.taps; ++tap) {
+                        for (int c4 = 0; c4 < c4n; ++c4) {
+                            const int wv = wrow[tap * c4n + c4];
+#pragma unroll
+                            for (int i = 0; i < KWS_POOL_MAX; ++i) {
+                                if (i < k.pool) {
+                                    const int xv = *(const int *)(cur + (t0 + i + tap) * k.in_cpad + 4 * c4);
+                                    acc[i] = __builtin_amdgcn_sdot4(wv, xv, acc[i], false);
+                                }
                             }
                         }
                     }
@@ -782,7 +794,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
                 m += k.bias_eff[oc];
                 int r = mbqm(m, k.mult[oc], k.shift[oc]) + k.out_zp;          // integer_ops/conv.h:111-116
                 r = min(max(r, k.act_min), k.act_max);
-                const int8_t o = s_lut[b][oc * 256 + (r + 128)];               // ADD(bias)+ReLU, integer_ops/add.h
+                const int8_t o = k.has_lut ? s_lut[b][oc * 256 + (r + 128)] : (int8_t)r;   // ADD(bias)+ReLU, integer_ops/add.h
                 if (last) ((int8_t *)vec)[idx] = o;
                 else nxt[(npl + pw) * ncp + oc] = o;
                 if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
@@ -1087,6 +1099,7 @@ static bool nn_fits_mfma(const KwsNnPlan &N)
 {
     if (N.n_blocks != 2) return false;
     const KwsConvBlock &a = N.blk[0], &b = N.blk[1];
+    if (a.depthwise || b.depthwise) return false;
     return a.in_cpad == 16 && a.taps <= 8 && a.out_c <= 32 && a.in_w <= 64 && a.pool == KWS_MFMA_POOL && a.pool_stride == KWS_MFMA_POOL &&
            a.pool_w <= KWS_MFMA_POOL && b.in_cpad == 32 && b.taps <= 8 && b.out_c <= 16 && b.in_w <= 16 && b.pool_w == 1 &&
            b.pool >= b.out_w && N.fc_in == b.out_c;
@@ -1166,10 +1179,44 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
     }
 }
 
+// DEPTHWISE_CONV_2D float (reference/depthwiseconv_float.h:25-97): the chain of output (t, oc) runs over the taps of input
+// channel oc / depth_mult only.  A lane owns TB consecutive time steps of one output channel.
+template <int TB>
+__device__ __forceinline__ void nnf_dwconv(const KwsConvBlockF32 &k, const float *__restrict__ x, const float *__restrict__ wt,
+                                           float *__restrict__ y, int lane)
+{
+    const int ocp = nnf_ocp(k), n_tb = (k.out_w + TB - 1) / TB;
+    for (int item = lane; item < n_tb * k.out_c; item += 64) {
+        const int tb = item / k.out_c, oc = item - tb * k.out_c;
+        const int t0 = tb * TB;
+        const float *xp = x + t0 * k.in_c + oc / k.depth_mult;
+        float acc[TB];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) acc[i] = 0.0f;
+        for (int tap = 0; tap < k.taps; ++tap) {
+            const float w = wt[tap * ocp + oc];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const float prod = xp[(i + tap) * k.in_c] * w;
+                acc[i] += prod;
+            }
+        }
+        const float bv = k.bias[oc], av = k.addc[oc];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            if (t0 + i >= k.out_w) break;
+            float v = act_clamp(acc[i] + bv, k.conv_min, k.conv_max);
+            if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
+            y[(t0 + i) * k.out_c + oc] = v;
+        }
+    }
+}
+
 template <int TB>
 __device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const float *x, const float *wt, float *y, int lane)
 {
-    if (k.ob == 4) nnf_conv<TB, 4>(k, x, wt, y, lane);
+    if (k.depthwise) nnf_dwconv<TB>(k, x, wt, y, lane);
+    else if (k.ob == 4) nnf_conv<TB, 4>(k, x, wt, y, lane);
     else if (k.ob == 2) nnf_conv<TB, 2>(k, x, wt, y, lane);
     else nnf_conv<TB, 1>(k, x, wt, y, lane);
 }
@@ -1185,10 +1232,10 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(Kws
     int x_floats = 0, y_floats = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlockF32 &k = N.blk[b];
-        const int J = k.taps * k.in_c, ocp = nnf_ocp(k);
+        const int J = k.depthwise ? k.taps : k.taps * k.in_c, ocp = nnf_ocp(k);
         for (int i = threadIdx.x; i < J * ocp; i += blockDim.x) {      // [oc][j] -> [j][oc], zero in the padding channels
             const int j = i / ocp, oc = i - j * ocp;
-            sp[i] = oc < k.out_c ? k.w[oc * J + j] : 0.0f;
+            sp[i] = oc < k.out_c ? (k.depthwise ? k.w[j * k.out_c + oc] : k.w[oc * J + j]) : 0.0f;
         }
         s_w[b] = sp;
         sp += J * ocp;
@@ -1283,7 +1330,7 @@ size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N)
     int xf = 0, yf = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlockF32 &k = N.blk[b];
-        fl += (size_t)k.taps * k.in_c * nnf_ocp(k);
+        fl += (size_t)(k.depthwise ? k.taps : k.taps * k.in_c) * nnf_ocp(k);
         xf = std::max(xf, nnf_rows(k) * k.in_c);
         yf = std::max(yf, k.out_w * k.out_c);
     }
@@ -1299,6 +1346,7 @@ void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k)
     float best = 1e30f;
     for (int tb : tbs)
         for (int ob : obs) {
+            if (k->depthwise && ob != 1) continue;
             const int items = ((k->out_w + tb - 1) / tb) * ((k->out_c + ob - 1) / ob);
             const int passes = (items + 63) / 64;
             const float cost = (float)passes * (2.0f * tb * ob + 1.0f * (tb + 1));
@@ -1473,8 +1521,8 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N)
     int act = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlock &k = N.blk[b];
-        s += ((size_t)k.out_c * k.taps * k.in_cpad + 15) & ~(size_t)15;
-        s += (size_t)k.out_c * 256;
+        s += ((size_t)k.w_bytes + 15) & ~(size_t)15;
+        s += k.has_lut ? (size_t)k.out_c * 256 : 0;
         const int ab = (k.in_w + k.taps) * k.in_cpad;
         act = ab > act ? ab : act;
     }
@@ -1493,8 +1541,12 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
         hipLaunchKernelGGL(kws_nn_mfma_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), kws_nn_smem_bytes(N), stream, N, q_in,
-                       n_clips, scores, taps);
+    const size_t smem = kws_nn_smem_bytes(N);
+    if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute((const void *)kws_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), smem, stream, N, q_in, n_clips, scores, taps);
     return (int)hipGetLastError();
 }
 

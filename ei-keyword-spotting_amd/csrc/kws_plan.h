@@ -35,8 +35,8 @@ struct KwsDspPlan {
 };
 
 // One "conv block" of the Edge Impulse 1-D CNN family:
-//   RESHAPE -> CONV_2D(1xK) -> RESHAPE -> ADD(bias, ReLU) -> RESHAPE -> MAX_POOL_2D(P) -> RESHAPE
-#define KWS_MAX_BLOCKS 4
+//   RESHAPE -> CONV_2D(1xK) | DEPTHWISE_CONV_2D(1xK) -> RESHAPE -> [ADD(bias, ReLU)] -> RESHAPE -> [MAX_POOL_2D(P)] -> RESHAPE
+#define KWS_MAX_BLOCKS 8
 struct KwsConvBlock {
     int in_w, in_c, in_cpad;   // time steps, channels, channels padded to a multiple of 16
     int out_c;
@@ -45,7 +45,10 @@ struct KwsConvBlock {
     int pool, pool_stride, pool_w;   // pool window, stride, pooled width
     int in_zp;                 // input zero point (= padding value so that (x + offset) == 0)
     int out_zp, act_min, act_max;    // conv output zero point and clamp
-    const int8_t *w;           // [out_c][taps][in_cpad], zero padded
+    int depthwise, depth_mult; // DEPTHWISE_CONV_2D: output channel oc reads input channel oc / depth_mult
+    int has_lut;               // an ADD follows the convolution (add_lut is not the identity)
+    int w_bytes;               // bytes of w
+    const int8_t *w;           // conv: [out_c][taps][in_cpad], zero padded; depthwise: [out_c][taps padded to 4]
     const int32_t *bias_eff;   // [out_c] bias + input_offset * sum(w)
     const int32_t *mult;       // [out_c] per-channel quantized multiplier
     const int32_t *shift;      // [out_c]
@@ -76,11 +79,12 @@ struct KwsConvBlockF32 {
     int in_w, in_c, out_c, taps, pad_left, out_w;
     int pool, pool_stride, pool_w;
     int has_add;
+    int depthwise, depth_mult;     // DEPTHWISE_CONV_2D (filter [1][1][taps][out_c]); else CONV_2D (filter [out_c][1][taps][in_c])
     int tb, ob;                    // register blocking of the conv: time steps x output channels per lane
     float conv_min, conv_max;      // fused activation range of the convolution
     float add_min, add_max;        // fused activation range of the ADD (ReLU: [0, max])
     float pool_min, pool_max;
-    const float *w;                // [out_c][taps][in_c]
+    const float *w;                // conv: [out_c][taps][in_c]; depthwise: [taps][out_c]
     const float *bias;             // [out_c]
     const float *addc;             // [out_c] constant operand of the ADD
 };

@@ -303,14 +303,8 @@ def test_many_streams_continuous_mode(pkg, gpu476, l476, oracle):
     sb.close()
 
 
-SYNTH_MODELS = [
-    dict(seed=1),                                                                        # shipped shape, random weights
-    dict(seed=2, ncep=10, win_size=51, high=0, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3),
-    dict(seed=4, ncep=16, blocks=((32, 8, 7), (16, 8, 7)), n_labels=5, add_bias=False),   # matrix-core limits, even taps
-    dict(seed=5, ncep=13, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4, conv_bias=True),
-    dict(seed=6, ncep=12, win_size=13, low=0, high=8000, blocks=((20, 3, 7), (12, 5, 1), (6, 3, 7)), n_labels=2),  # 3 blocks -> generic kernel
-    dict(seed=7, ncep=13, blocks=((40, 7, 7), (10, 7, 7)), n_labels=4),                   # 40 channels -> generic kernel
-]
+from kws_testlib import SYNTH_SPECS  # noqa: E402
+SYNTH_MODELS = [SYNTH_SPECS[k] for k in ("seed1", "seed2", "seed4", "seed5", "seed6", "seed7")]
 
 
 @pytest.mark.parametrize("kw", SYNTH_MODELS, ids=lambda kw: "seed%d" % kw["seed"])
@@ -562,3 +556,40 @@ def test_mfcc40_stage_api_and_streams(pkg, oracle, tmp_path):
     assert (bits(m.cpu().numpy()[:8]) == bits(mo.reshape(8, -1))).all()
     assert (bits(f.cpu().numpy()) == bits(fo)).all() and (bits(s.cpu().numpy()) == bits(so)).all()
     gm.close()
+
+
+# ---- every synthetic graph incl. DEPTHWISE_CONV_2D (BASELINE config 5) ----------------------------------
+@pytest.mark.parametrize("name", sorted(SYNTH_SPECS))
+def test_graph_goldens_from_reference_op_registrations(name, pkg, oracle, tmp_path):
+    """Network only: golden outputs computed by the reference's own TFLite-Micro op code (tools/make_golden.py graphs),
+    then the whole pipeline against the oracle on audio."""
+    import torch
+    from dequantize_model import dequantize
+    from kws_testlib import OracleModel, synth_model_blob
+    g = np.load(os.path.join(GOLDEN, "graphs_l476.npz"))
+    blob = synth_model_blob(**SYNTH_SPECS[name])
+    n = int(g["n"])
+    for kind, b in (("i8", blob), ("f32", dequantize(blob))):
+        gm = pkg.Model(blob=b)
+        rng = np.random.default_rng(int(g["rng_seed"]))
+        xi = rng.integers(-128, 128, (n, gm.n_features)).astype(np.int8)
+        xf = (rng.standard_normal((n, gm.n_features)) * 3).astype(np.float32)
+        if kind == "i8":
+            s, pooled, fc, out = gm.nn_batch(xi)
+            assert (out == g[name + "_i8_out"]).all() and (fc == g[name + "_i8_fc"]).all(), name
+        else:
+            s, lg = _f32_logits(pkg, gm, xf)
+            assert (bits(lg) == bits(g[name + "_f32_logits"])).all(), name
+            assert np.abs(s - g[name + "_f32_scores"]).max() <= F32_SCORE_TOL, name
+        p = tmp_path / (name + kind + ".kwsm")
+        p.write_bytes(b)
+        om = OracleModel(oracle, str(p))
+        clips = oracle.synth(123, 0, 48)
+        so, fo, qo = om.run_batch(clips, want_features=True)
+        s, f, q = gm.run_classifier_batch(clips, want_features=True)
+        assert (bits(f) == bits(fo)).all(), (name, kind)
+        if kind == "i8":
+            assert (q == qo).all() and (bits(s) == bits(so)).all(), name
+        else:
+            assert np.abs(s - so).max() <= F32_SCORE_TOL, name
+        gm.close()
