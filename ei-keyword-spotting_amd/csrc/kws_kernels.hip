@@ -177,8 +177,8 @@ __device__ __forceinline__ void bfly5(cf &F0, cf &F1, cf &F2, cf &F3, cf &F4, cf
 // log-mel energies; R receives the NF/2+1 spectrum points the transform reads.  The complex FFT of NF/2 points is
 // kf_work's recursion unrolled: NF = 32 -> 16 = 4 x 4 (kf_bfly4, kf_bfly4); NF = 40 -> 20 = 4 x 5 (kf_bfly5 leaves of
 // stride 4, then kf_bfly4 with m = 5).
-template <int NF>
-__device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspPlan &P, cf (&R)[NF / 2 + 1])
+template <int NF, typename Emit>
+__device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspPlan &P, Emit emit)   // emit(i, R[i]), i = 0..NF/2
 {
     constexpr int NC = NF / 2;
     // even/odd reorder (in[i] = v[2i], in[NF-1-i] = v[2i+1]) read as NC complex points
@@ -216,21 +216,25 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
         for (int k = 0; k < 5; ++k)
             bfly4(F[k], F[k + 5], F[k + 10], F[k + 15], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
     }
-    // kiss_fftr split (kiss_fftr.cpp:84-119)
-    R[0].r = F[0].r + F[0].i; R[0].i = 0.0f;
-    R[NC].r = F[0].r - F[0].i; R[NC].i = 0.0f;
+    // kiss_fftr split (kiss_fftr.cpp:84-119); every spectrum point is handed on as soon as it exists
+    cf r0, rn;
+    r0.r = F[0].r + F[0].i; r0.i = 0.0f;
+    rn.r = F[0].r - F[0].i; rn.i = 0.0f;
+    emit(0, r0);
+    emit(NC, rn);
 #pragma unroll
     for (int k = 1; k <= NC / 2; ++k) {
         cf fpk = F[k], fpnk;
         fpnk.r = F[NC - k].r; fpnk.i = -F[NC - k].i;
         cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
         cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
-        if (k != NC - k) {                                         // k == ncfft/2: overwritten by the "ncfft-k" store
-            R[k].r = (f1k.r + twv.r) * 0.5f;
-            R[k].i = (f1k.i + twv.i) * 0.5f;
-        }
-        R[NC - k].r = (f1k.r - twv.r) * 0.5f;
-        R[NC - k].i = (twv.i - f1k.i) * 0.5f;
+        cf lo, hi;
+        lo.r = (f1k.r + twv.r) * 0.5f;
+        lo.i = (f1k.i + twv.i) * 0.5f;
+        hi.r = (f1k.r - twv.r) * 0.5f;
+        hi.i = (twv.i - f1k.i) * 0.5f;
+        if (k != NC - k) emit(k, lo);                              // k == ncfft/2: overwritten by the "ncfft-k" store
+        emit(NC - k, hi);
     }
 }
 
@@ -472,23 +476,30 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
             float *mrow = sm.mel + lane * MELS;
 #pragma unroll
             for (int i = 0; i < NF; ++i) v[i] = mrow[i];
-            cf R[NCEPT];
-            dct_spectrum<NF>(v, P, R);
             float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + lane * ncep;
-#pragma unroll
-            for (int i = 0; i < NCEPT; ++i) {
+            auto put = [&](int i, cf R) {
                 if (i < ncep) {
-                    float a = R[i].r * P.dct_cos[i];
-                    float b = R[i].i * P.dct_sin[i];
+                    float a = R.r * P.dct_cos[i];
+                    float b = R.i * P.dct_sin[i];
                     float d = (a + b) * 2.0f;
                     d = d * (i == 0 ? P.dct_s0 : P.dct_s1);
                     orow[i] = d;
                 }
-            }
+            };
             // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
+            if constexpr (NF == 32) {            // 17 spectrum points fit the register budget: scale + store after the split
+                cf R[NCEPT];
+                dct_spectrum<NF>(v, P, [&](int i, cf r) { R[i] = r; });
 #pragma unroll
-            for (int i = NCEPT; i < NF; ++i)
-                if (i < ncep) orow[i] = (v[i] * 2.0f) * P.dct_s1;
+                for (int i = 0; i < NCEPT; ++i) put(i, R[i]);
+#pragma unroll
+                for (int i = NCEPT; i < NF; ++i)
+                    if (i < ncep) orow[i] = (v[i] * 2.0f) * P.dct_s1;
+            } else {                              // 40 filters: hand every point on as soon as it exists (no spills);
+                // in place: element i >= NCEPT is read, then written, by this lane only
+                for (int i = NCEPT; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * P.dct_s1;
+                dct_spectrum<NF>(v, P, put);
+            }
             orow[0] = fast_log(sm.energy[lane]);                                       // feature.hpp:425-429
         }
         WAVE_SYNC();
