@@ -403,6 +403,16 @@ struct kws_handle {
     int8_t *s_q = nullptr;
     size_t s_cap = 0;
     std::mutex mu;
+    // single-clip workspace of the SDK entry points: allocated once, pinned host staging, own stream
+    struct Ws {
+        float *h_x = nullptr, *d_x = nullptr;     // samples / slice (host pinned, device)
+        size_t cap_x = 0;
+        float *d_f = nullptr, *d_s = nullptr, *d_w = nullptr;   // features (or cepstra), scores, wrap sample
+        int8_t *d_q = nullptr;
+        float *h_s = nullptr, *h_f = nullptr;     // pinned: scores, features
+        hipStream_t st = nullptr;
+    } ws;
+    std::mutex sdk_mu;            // the SDK entry points are serialised (the reference is non-reentrant)
     // continuous-mode state (ei_run_classifier.h:115-121, 187)
     std::vector<float> cont_features;
     size_t slice_offset = 0;
@@ -915,6 +925,11 @@ void kws_destroy(kws_handle *h)
     for (void *p : h->dev_allocs) (void)hipFree(p);
     if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
+    for (void *p : { (void *)h->ws.d_x, (void *)h->ws.d_f, (void *)h->ws.d_s, (void *)h->ws.d_w, (void *)h->ws.d_q })
+        if (p) (void)hipFree(p);
+    for (void *p : { (void *)h->ws.h_x, (void *)h->ws.h_s, (void *)h->ws.h_f })
+        if (p) (void)hipHostFree(p);
+    if (h->ws.st) (void)hipStreamDestroy(h->ws.st);
     delete h;
 }
 
@@ -1276,6 +1291,32 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
 // ------------------------------------------------------------------------------------------------------------
 //  SDK-compatible single-clip entry points
 // ------------------------------------------------------------------------------------------------------------
+// workspace for one window / slice of n_x float samples
+static EI_IMPULSE_ERROR ensure_ws(kws_handle *h, size_t n_x)
+{
+    kws_handle::Ws &w = h->ws;
+    const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
+    auto oom = [&]() { return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed"); };
+    if (!w.st) {
+        if (hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking) != hipSuccess) return fail(KWS_ERROR_HIP, "stream creation failed");
+        if (hipMalloc((void **)&w.d_f, F * sizeof(float)) != hipSuccess || hipMalloc((void **)&w.d_s, C * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&w.d_w, 16) != hipSuccess || hipMalloc((void **)&w.d_q, F + 16) != hipSuccess ||
+            hipHostMalloc((void **)&w.h_s, C * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&w.h_f, F * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return oom();
+    }
+    if (n_x > w.cap_x) {
+        if (w.d_x) (void)hipFree(w.d_x);
+        if (w.h_x) (void)hipHostFree(w.h_x);
+        w.d_x = nullptr; w.h_x = nullptr; w.cap_x = 0;
+        if (hipMalloc((void **)&w.d_x, n_x * sizeof(float)) != hipSuccess ||
+            hipHostMalloc((void **)&w.h_x, n_x * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return oom();
+        w.cap_x = n_x;
+    }
+    return EI_IMPULSE_OK;
+}
+
 static kws_handle *g_default = nullptr;
 static bool g_default_owned = false;
 static std::mutex g_default_mu;
@@ -1333,16 +1374,19 @@ EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result
     const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
     if ((size_t)fmatrix->rows * fmatrix->cols != F) return fail(EI_IMPULSE_ERROR_SHAPES_DONT_MATCH, "feature matrix is %ux%u, model needs %zu", fmatrix->rows, fmatrix->cols, F);
     HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
     uint64_t t0 = ei_read_timer_ms();
-    float *d_f = nullptr, *d_s = nullptr;
     std::vector<float> scores(C);
-    HIP_TRY(hipMalloc((void **)&d_f, F * sizeof(float)));
-    if (hipMalloc((void **)&d_s, C * sizeof(float)) != hipSuccess) { (void)hipFree(d_f); return fail(EI_IMPULSE_TFLITE_ARENA_ALLOC_FAILED, "device allocation failed"); }
-    hipError_t he = hipMemcpy(d_f, fmatrix->buffer, F * sizeof(float), hipMemcpyHostToDevice);
-    EI_IMPULSE_ERROR e = he == hipSuccess ? kws_run_inference_batch_device(h, d_f, 1, d_s, nullptr) : fail(KWS_ERROR_HIP, "h2d copy failed");
-    if (e == EI_IMPULSE_OK && hipMemcpy(scores.data(), d_s, C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
-    (void)hipFree(d_f); (void)hipFree(d_s);
+    EI_IMPULSE_ERROR e = ensure_ws(h, 1);
     if (e) return e;
+    kws_handle::Ws &w = h->ws;
+    memcpy(w.h_f, fmatrix->buffer, F * sizeof(float));
+    if (hipMemcpyAsync(w.d_f, w.h_f, F * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+    if (!e) e = kws_run_inference_batch_device(h, w.d_f, 1, w.d_s, w.st);
+    if (!e && (hipMemcpyAsync(w.h_s, w.d_s, C * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+               hipStreamSynchronize(w.st) != hipSuccess)) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+    if (e) return e;
+    memcpy(scores.data(), w.h_s, C * sizeof(float));
     fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t0));
     if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;     // ei_run_classifier.h:489-491
     return EI_IMPULSE_OK;
@@ -1358,44 +1402,40 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     // feature count than the model's is EIDSP_MATRIX_SIZE_MISMATCH there (-> EI_IMPULSE_DSP_ERROR).
     if (signal->total_length != n) { ei_printf("ERR: Failed to run DSP process (%d)\n", -1002); return fail(EI_IMPULSE_DSP_ERROR, "signal length %zu, model window %zu", signal->total_length, n); }
     HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
     uint64_t t0 = ei_read_timer_ms();
-    // gather the window through the caller's callback (float samples, as the SDK hands them to the DSP block)
-    std::vector<float> win(n);
+    EI_IMPULSE_ERROR e = ensure_ws(h, n);
+    if (e) return e;
+    kws_handle::Ws &w = h->ws;
+    // gather the window through the caller's callback (float samples, as the SDK hands them to the DSP block) straight
+    // into pinned memory
     const size_t chunk = 4000;
     for (size_t off = 0; off < n; off += chunk) {
         const size_t len = std::min(chunk, n - off);
-        int r = signal->get_data(off, len, win.data() + off);
+        int r = signal->get_data(off, len, w.h_x + off);
         if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
     }
-    float *d_x = nullptr, *d_f = nullptr, *d_s = nullptr; int8_t *d_q = nullptr;
-    std::vector<float> scores(C), feats(debug ? F : 0);
-    auto cleanup = [&]() { for (void *p : { (void *)d_x, (void *)d_f, (void *)d_s, (void *)d_q }) if (p) (void)hipFree(p); };
-    auto alloc_fail = [&]() { cleanup(); return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed"); };
-    if (hipMalloc((void **)&d_x, n * sizeof(float)) != hipSuccess) return alloc_fail();
-    if (hipMalloc((void **)&d_f, F * sizeof(float)) != hipSuccess) return alloc_fail();
-    if (hipMalloc((void **)&d_s, C * sizeof(float)) != hipSuccess) return alloc_fail();
-    if (hipMalloc((void **)&d_q, F) != hipSuccess) return alloc_fail();
-    EI_IMPULSE_ERROR e = EI_IMPULSE_OK;
-    if (hipMemcpy(d_x, win.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
-    if (!e) e = mfcc_fused_device(h, d_x, 1, 1, d_f, h->is_float ? nullptr : d_q, nullptr);
-    if (!e && hipDeviceSynchronize() != hipSuccess) e = fail(KWS_ERROR_HIP, "MFCC kernel failed");
-    if (e) { cleanup(); return e; }
-    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) { cleanup(); return EI_IMPULSE_CANCELED; }   // ei_run_classifier.h:689-691
+    std::vector<float> scores(C);
+    if (hipMemcpyAsync(w.d_x, w.h_x, n * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+    if (!e) e = mfcc_fused_device(h, w.d_x, 1, 1, w.d_f, h->is_float ? nullptr : w.d_q, w.st);
+    if (!e && debug && hipMemcpyAsync(w.h_f, w.d_f, F * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+    if (!e && hipStreamSynchronize(w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "MFCC kernel failed");
+    if (e) return e;
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;   // ei_run_classifier.h:689-691
     const int dsp_ms = (int)(ei_read_timer_ms() - t0);
     result_timing(h, result)->dsp = dsp_ms;
     if (debug) {
-        if (hipMemcpy(feats.data(), d_f, F * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) {
-            ei_printf("Features (%d ms.): ", dsp_ms);
-            for (size_t ix = 0; ix < F; ix++) { ei_printf_float(feats[ix]); ei_printf(" "); }
-            ei_printf("\n");
-        }
+        ei_printf("Features (%d ms.): ", dsp_ms);
+        for (size_t ix = 0; ix < F; ix++) { ei_printf_float(w.h_f[ix]); ei_printf(" "); }
+        ei_printf("\n");
         ei_printf("Running neural network...\n");
     }
     uint64_t t1 = ei_read_timer_ms();
-    e = h->is_float ? nn_f32_device(h, d_f, 1, d_s, nullptr, nullptr) : kws_nn_batch_device(h, d_q, 1, d_s, nullptr, nullptr, nullptr, nullptr);
-    if (!e && hipMemcpy(scores.data(), d_s, C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
-    cleanup();
+    e = h->is_float ? nn_f32_device(h, w.d_f, 1, w.d_s, nullptr, w.st) : kws_nn_batch_device(h, w.d_q, 1, w.d_s, nullptr, nullptr, nullptr, w.st);
+    if (!e && (hipMemcpyAsync(w.h_s, w.d_s, C * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+               hipStreamSynchronize(w.st) != hipSuccess)) e = fail(KWS_ERROR_HIP, "d2h copy failed");
     if (e) return e;
+    memcpy(scores.data(), w.h_s, C * sizeof(float));
     fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t1));
     if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
     return EI_IMPULSE_OK;
@@ -1462,31 +1502,31 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
         return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples yields %d frames", n_claimed, nf);
     }
     const size_t needed = (size_t)(nf - 1) * stride + frame_len;                // last sample any frame reads
-    std::vector<float> slice(std::max(n_claimed, needed) + 16, 0.0f);
+    const size_t n_x = std::max(n_claimed, needed) + 16;
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
+    EI_IMPULSE_ERROR e = ensure_ws(h, n_x);
+    if (e) return e;
+    kws_handle::Ws &w = h->ws;
+    memset(w.h_x, 0, n_x * sizeof(float));
     {
-        int r = signal->get_data(0, needed, slice.data());
+        int r = signal->get_data(0, needed, w.h_x);
         if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
     }
-    float *d_x = nullptr, *d_m = nullptr, *d_w = nullptr, *d_s = nullptr;
-    auto cleanup = [&]() { for (void *p : { (void *)d_x, (void *)d_m, (void *)d_w, (void *)d_s }) if (p) (void)hipFree(p); };
-    auto alloc_fail = [&]() { cleanup(); return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed"); };
-    if (hipMalloc((void **)&d_x, slice.size() * sizeof(float)) != hipSuccess) return alloc_fail();
-    if (hipMalloc((void **)&d_m, F * sizeof(float)) != hipSuccess) return alloc_fail();
-    if (hipMalloc((void **)&d_w, sizeof(float)) != hipSuccess) return alloc_fail();
-    if (hipMalloc((void **)&d_s, C * sizeof(float)) != hipSuccess) return alloc_fail();
-    EI_IMPULSE_ERROR e = EI_IMPULSE_OK;
-    if (hipMemcpy(d_x, slice.data(), slice.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_w, &eos, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+    w.h_s[0] = eos;                                                              // staged through pinned memory
+    if (hipMemcpyAsync(w.d_x, w.h_x, n_x * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess ||
+        hipMemcpyAsync(w.d_w, w.h_s, sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
     if (!e) {
         KwsDspPlan P = h->dsp;                // same tables, this slice's framing
         P.n_samples = (int)n_claimed;
         P.n_frames = nf;
-        e = spectral_device(h, P, d_x, 1, 1, d_m, d_w, nullptr);
+        e = spectral_device(h, P, w.d_x, 1, 1, w.d_f, w.d_w, w.st);
     }
-    if (!e && hipMemcpy(h->cont_features.data() + h->slice_offset, d_m, feature_size * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    if (!e && (hipMemcpyAsync(w.h_f, w.d_f, feature_size * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+               hipStreamSynchronize(w.st) != hipSuccess))
         e = fail(KWS_ERROR_HIP, "d2h copy failed");
-    if (e) { cleanup(); return e; }
-    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) { cleanup(); return EI_IMPULSE_CANCELED; }
+    if (e) return e;
+    memcpy(h->cont_features.data() + h->slice_offset, w.h_f, feature_size * sizeof(float));
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
 
     // ---- rolling buffer bookkeeping (ei_run_classifier.h:229-239) ------------------------------------------------
     if (!h->feature_buffer_full) {
@@ -1509,26 +1549,27 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
         // calc_cepstral_mean_and_var_normalization on a COPY of the buffer, then run_inference
         std::vector<float> scores(C);
         uint64_t t1 = 0;
-        if (hipMemcpy(d_m, h->cont_features.data(), F * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+        memcpy(w.h_f, h->cont_features.data(), F * sizeof(float));
+        if (hipMemcpyAsync(w.d_f, w.h_f, F * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
         if (!e) {
             std::lock_guard<std::mutex> lk(h->mu);
             e = ensure_scratch(h, 1);
             t1 = ei_read_timer_ms();
-            if (!e) e = cmvn_nn_device(h, d_m, 1, nullptr, nullptr, d_s, nullptr, nullptr, nullptr, nullptr);
+            if (!e) e = cmvn_nn_device(h, w.d_f, 1, nullptr, nullptr, w.d_s, nullptr, nullptr, nullptr, w.st);
         }
-        if (!e && hipMemcpy(scores.data(), d_s, C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
-        if (e) { cleanup(); return e; }
+        if (!e && (hipMemcpyAsync(w.h_s, w.d_s, C * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+                   hipStreamSynchronize(w.st) != hipSuccess)) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+        if (e) return e;
+        memcpy(scores.data(), w.h_s, C * sizeof(float));
         timing->dsp += (int)(t1 - dsp_start_ms);
         fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t1));
         ei_impulse_result_classification_t *cls = (ei_impulse_result_classification_t *)result;
         for (size_t ix = 0; ix < C; ix++) cls[ix].value = run_moving_average_filter(&h->maf[ix], cls[ix].value);
         // shift the feature buffer for new data (ei_run_classifier.h:277-279)
         for (size_t i = 0; i < F - feature_size; i++) h->cont_features[i] = h->cont_features[i + feature_size];
-        cleanup();
         if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
         return EI_IMPULSE_OK;
     }
-    cleanup();
     return EI_IMPULSE_OK;
 }
 

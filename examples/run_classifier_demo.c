@@ -4,14 +4,16 @@
  *
  *   cc -std=c11 -Iinclude examples/run_classifier_demo.c -Lei-keyword-spotting_amd -lkws_mi355x \
  *      -Wl,-rpath,$PWD/ei-keyword-spotting_amd -o run_classifier_demo
- *   KWS_MODEL=models/l476_no_yes.kwsm ./run_classifier_demo [seed]
+ *   KWS_MODEL=models/l476_no_yes.kwsm ./run_classifier_demo [seed [latency-iterations]]
  *
  * It classifies one synthetic 1 s clip in one-shot mode and then streams 2 s of audio through
  * run_classifier_continuous() in 250 ms slices, printing what the reference demo prints.
  */
+#define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "kws/ei_compat.h"
 #include "kws/kws_synth.h"
@@ -31,9 +33,17 @@ static int get_audio_signal_data(size_t offset, size_t length, float *out_ptr)
     return 0;
 }
 
+static double now_us(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
 int main(int argc, char **argv)
 {
     uint32_t seed = argc > 1 ? (uint32_t)atoi(argv[1]) : 1;
+    int latency_iters = argc > 2 ? atoi(argv[2]) : 0;
     kws_synth_fill(seed, 0, 3, RAW_SAMPLE_COUNT, audio);
 
     signal_t signal;
@@ -48,6 +58,15 @@ int main(int argc, char **argv)
     for (size_t ix = 0; ix < EI_CLASSIFIER_LABEL_COUNT; ix++)
         printf("    %s: %.5f\n", result.classification[ix].label, result.classification[ix].value);
 
+    if (latency_iters > 0) {          /* wall time of one drop-in call: callback gather + H2D + kernels + D2H */
+        double t0 = now_us();
+        for (int it = 0; it < latency_iters; it++) {
+            r = run_classifier(&signal, &result, false);
+            if (r != EI_IMPULSE_OK) { printf("ERROR: Failed to run classifier (%d)\n", r); return 1; }
+        }
+        printf("latency: run_classifier %.1f us per call (%d calls)\n", (now_us() - t0) / latency_iters, latency_iters);
+    }
+
     run_classifier_init();
     for (int slice = 0; slice < 8; slice++) {
         window = audio + RAW_SAMPLE_COUNT + (size_t)slice * SLICE_SIZE; window_len = SLICE_SIZE;
@@ -61,6 +80,16 @@ int main(int argc, char **argv)
         for (size_t ix = 0; ix < EI_CLASSIFIER_LABEL_COUNT; ix++)
             printf("  %s %.5f", result.classification[ix].label, result.classification[ix].value);
         printf("\n");
+    }
+    if (latency_iters > 0) {
+        double t0 = now_us();
+        for (int it = 0; it < latency_iters; it++) {
+            window = audio + RAW_SAMPLE_COUNT + (size_t)(it & 3) * SLICE_SIZE; window_len = SLICE_SIZE;
+            signal.total_length = SLICE_SIZE;
+            r = run_classifier_continuous(&signal, &result, false);
+            if (r != EI_IMPULSE_OK) { printf("ERROR: Failed to run classifier (%d)\n", r); return 1; }
+        }
+        printf("latency: run_classifier_continuous %.1f us per 250 ms slice (%d calls)\n", (now_us() - t0) / latency_iters, latency_iters);
     }
     return 0;
 }
