@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "ei_read_timer_us", "ei_printf", "ei_printf_float",
     "kws_create", "kws_create_from_file", "kws_destroy", "kws_last_error", "kws_label_count", "kws_label",
     "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes", "kws_model_is_float",
-    "kws_nn_f32_batch_device", "kws_nn_kernel_name", "kws_set_default_model",
+    "kws_nn_f32_batch_device", "kws_nn_kernel_name", "kws_mfe_batch_device", "kws_filter_count", "kws_set_default_model",
     "kws_default_model", "kws_run_classifier_batch_device", "kws_run_classifier_batch",
     "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
@@ -73,7 +73,7 @@ def lib():
         L.kws_create_from_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
         L.kws_destroy.argtypes = [vp]
         for f in ("kws_label_count", "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes",
-                  "kws_model_is_float"):
+                  "kws_model_is_float", "kws_filter_count"):
             getattr(L, f).argtypes = [vp]
         L.kws_label.restype = C.c_char_p
         L.kws_nn_kernel_name.restype = C.c_char_p
@@ -90,6 +90,7 @@ def lib():
         L.kws_nn_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
         L.kws_nn_batch.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.kws_nn_f32_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.kws_mfe_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
         L.kws_streams_create.argtypes = [vp, sz, C.POINTER(vp)]
         L.kws_streams_destroy.argtypes = [vp]
@@ -159,6 +160,7 @@ class Model:
         self.n_features = self.L.kws_feature_count(h)
         self.clip_samples = self.L.kws_clip_samples(h)
         self.n_frames = self.L.kws_frame_count(h)
+        self.n_filters = self.L.kws_filter_count(h)
         self.pooled_tap_bytes = self.L.kws_pooled_tap_bytes(h)
         self.is_float = bool(self.L.kws_model_is_float(h))
         self.nn_kernel = self.L.kws_nn_kernel_name(h).decode()
@@ -200,6 +202,9 @@ class Model:
 
     def extract_mfcc_batch_device(self, pcm_ptr, B, features_ptr, q_ptr=None, stream=None):
         _check(self.L.kws_extract_mfcc_batch_device(self.h, pcm_ptr, B, features_ptr, q_ptr, stream))
+
+    def mfe_batch_device(self, pcm_ptr, B, mel_ptr, energy_ptr=None, stream=None):
+        _check(self.L.kws_mfe_batch_device(self.h, pcm_ptr, B, mel_ptr, energy_ptr, stream))
 
     def mfcc_batch_device(self, pcm_ptr, B, mfcc_ptr, stream=None):
         _check(self.L.kws_mfcc_batch_device(self.h, pcm_ptr, B, mfcc_ptr, stream))

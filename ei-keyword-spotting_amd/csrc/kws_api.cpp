@@ -27,6 +27,7 @@ int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, 
                         int out_stride, int grid_cap, hipStream_t stream);
 int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream);
 int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream);
+int kws_launch_mfe(const KwsDspPlan &P, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap, hipStream_t stream);
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                           float in_scale, int in_zp, int grid_cap, hipStream_t stream);
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
@@ -938,6 +939,7 @@ const char *kws_label(const kws_handle *h, int i) { return h->model.labels[i].c_
 int kws_feature_count(const kws_handle *h) { return (int)h->model.nn_input_frame_size; }
 int kws_clip_samples(const kws_handle *h) { return (int)h->model.raw_sample_count; }
 int kws_frame_count(const kws_handle *h) { return h->dsp.n_frames; }
+int kws_filter_count(const kws_handle *h) { return h->dsp.n_filters; }
 int kws_pooled_tap_bytes(const kws_handle *h) { return h->pooled_tap_bytes; }
 int kws_model_is_float(const kws_handle *h) { return h->is_float ? 1 : 0; }
 const char *kws_nn_kernel_name(const kws_handle *h)
@@ -1023,6 +1025,17 @@ EI_IMPULSE_ERROR kws_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t
     if (!h || !pcm || !mfcc) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     return spectral_device(h, h->dsp, pcm, 0, B, mfcc, nullptr, (hipStream_t)stream);
+}
+
+EI_IMPULSE_ERROR kws_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *mel, float *energy, void *stream)
+{
+    if (!h || !pcm || !mel) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = kws_launch_mfe(h->dsp, pcm, (int)B, mel, energy, grid_cap_mfcc(h), (hipStream_t)stream);
+    if (rc) return fail(KWS_ERROR_HIP, "MFE kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
 }
 
 EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfcc, size_t B, float *scores, float *features,

@@ -436,6 +436,8 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 e += pl[(KWS_NBINS - 1) * CHF];
                 if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
                 sm.energy[f_base + lane] = e;
+                if constexpr (!WITH_CMVN)
+                    if (P.mfe_energy) P.mfe_energy[(size_t)clip * nfr + f_base + lane] = e;
             }
             PH(3);
             // ---- mel: sparse ascending-bin gather == dot_by_row (numpy.hpp:183-211), zero_handling, log ------
@@ -449,6 +451,8 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                         acc += prod;
                     }
                     if (acc == 0.0f) acc = FLT_EPSILON;                                // functions.hpp:63-69
+                    if constexpr (!WITH_CMVN)
+                        if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + t] = acc;
                     sm.mel[(f_base + fr) * MELS + t] = fast_log(acc);
                 }
             } else {
@@ -460,6 +464,8 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                         acc += prod;
                     }
                     if (acc == 0.0f) acc = FLT_EPSILON;
+                    if constexpr (!WITH_CMVN)
+                        if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + j] = acc;
                     sm.mel[(f_base + fr) * MELS + j] = fast_log(acc);
                 }
             }
@@ -467,6 +473,8 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
             PH(4);
         }
 
+        if constexpr (!WITH_CMVN)
+            if (P.mfe_mel) { WAVE_SYNC(); continue; }                                   // MFE block: no log / DCT output
         // ---- DCT-II via NF-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
         // the cepstra of a frame replace its log-mel row in place (row stride MELS)
 #pragma unroll
@@ -1458,6 +1466,17 @@ int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, 
     if (out_stride == 0) out_stride = P.n_frames * P.n_cepstral;
     return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream)
                         : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream);
+}
+
+// speechpy::feature::mfe (feature.hpp:193-318) for n_clips windows: mel energies + frame energies
+int kws_launch_mfe(const KwsDspPlan &P0, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap,
+                   hipStream_t stream)
+{
+    KwsDspPlan P = P0;
+    P.mfe_mel = mel_out;
+    P.mfe_energy = energy_out;
+    return launch_mfcc_t<false, false, false>(P, pcm, n_clips, nullptr, nullptr, 0.f, 0, nullptr, P.n_frames * P.n_cepstral, grid_cap,
+                                              nullptr, stream);
 }
 
 // ---- continuous mode, many streams: per-class 2-tap moving average (ei_run_classifier.h:134-145) and the feature-buffer

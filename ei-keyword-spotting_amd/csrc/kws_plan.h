@@ -32,6 +32,9 @@ struct KwsDspPlan {
     const float *dct_cos;    // [n_filters/2+1] cosf((float)(i*pi/(2N)))    fast-dct-fft.cpp:71-74
     const float *dct_sin;
     const int *pad_map;      // [n_frames+2*pad] numpy::pad_1d_symmetric row map   numpy.hpp:479-541
+    // per launch, WITH_CMVN = false only: when set the kernel stops after speechpy::feature::mfe (feature.hpp:193-318)
+    // and writes the mel energies [window][frame][filter] and frame energies [window][frame] (both after zero handling)
+    float *mfe_mel, *mfe_energy;
 };
 
 // One "conv block" of the Edge Impulse 1-D CNN family:

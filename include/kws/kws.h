@@ -36,6 +36,7 @@ const char *kws_label(const kws_handle *h, int i);       /* ei_classifier_infere
 int kws_feature_count(const kws_handle *h);              /* EI_CLASSIFIER_NN_INPUT_FRAME_SIZE */
 int kws_clip_samples(const kws_handle *h);               /* EI_CLASSIFIER_RAW_SAMPLE_COUNT */
 int kws_frame_count(const kws_handle *h);                /* MFCC rows (49) */
+int kws_filter_count(const kws_handle *h);               /* mel filters of the DSP block (32) */
 int kws_pooled_tap_bytes(const kws_handle *h);           /* bytes/clip of the pooled-activation tap */
 const char *kws_nn_kernel_name(const kws_handle *h);    /* which network kernel serves this model (diagnostics) */
 int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI_CLASSIFIER_TFLITE_INPUT_QUANTIZED == 0) */
@@ -64,6 +65,10 @@ EI_IMPULSE_ERROR kws_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t
  * matrices; features / q_in optional outputs as above */
 EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfcc, size_t B, float *scores,
                                                  float *features, int8_t *q_in, void *stream);
+/* speechpy::feature::mfe for B clips (dsp/speechpy/feature.hpp:193-318; the MFE block's front end):
+ * mel [B][frames][filters] filterbank energies and energy [B][frames] frame energies (may be NULL), both after
+ * zero handling, before any log. */
+EI_IMPULSE_ERROR kws_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *mel, float *energy, void *stream);
 /* extract_mfcc_features for B clips (classifier/ei_run_dsp.h:256-308) */
 EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features,
                                                int8_t *q_in, void *stream);

@@ -593,3 +593,26 @@ def test_graph_goldens_from_reference_op_registrations(name, pkg, oracle, tmp_pa
         else:
             assert np.abs(s - so).max() <= F32_SCORE_TOL, name
         gm.close()
+
+
+def test_mfe_front_end(pkg, gpu476, gpu432, l476, l432, oracle):
+    """speechpy::feature::mfe (SURVEY 8(f) rank 3): mel filterbank energies + frame energies, against the golden taps of
+    the reference (deep_l476.npz: mel / energy of the deep clips) and the oracle on more clips / the other filterbank."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, "deep_l476.npz"))
+    sp = special_clips()
+    ids = g["ids"]
+    clips = np.stack([oracle.synth(int(s_), int(i), 1)[0] if s_ >= 0 else (sp["step"], sp["impulses"])[int(i)] for s_, i in ids])
+    for gm, om, check_golden in ((gpu476, l476, True), (gpu432, l432, False)):
+        B = len(clips)
+        pcm = torch.from_numpy(clips).to("cuda:0")
+        mel = torch.empty((B, gm.n_frames, gm.n_filters), dtype=torch.float32, device="cuda:0")
+        en = torch.empty((B, gm.n_frames), dtype=torch.float32, device="cuda:0")
+        gm.mfe_batch_device(pcm.data_ptr(), B, mel.data_ptr(), en.data_ptr())
+        torch.cuda.synchronize()
+        mel, en = mel.cpu().numpy(), en.cpu().numpy()
+        for k in range(B):
+            mo, eo = oracle.mfe(clips[k], om.cfg)
+            assert (bits(mel[k]) == bits(mo)).all() and (bits(en[k]) == bits(eo)).all(), k
+            if check_golden:
+                assert (bits(mel[k]) == bits(g["c%d_mel" % k])).all() and (bits(en[k]) == bits(g["c%d_energy" % k])).all(), k
