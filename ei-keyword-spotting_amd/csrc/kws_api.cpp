@@ -180,6 +180,14 @@ bool parse_model(const void *blob, size_t nbytes, Model &m)
         for (uint32_t k = 0; k < nq; k++) t.zero.push_back(r.i32());
         t.qdim = r.i32();
         t.nbytes = r.u32();
+        // self-consistency: known element type, positive dims, nbytes == element count x element size, int8 tensors
+        // carry their quantisation, a per-channel scale list matches the quantised dimension
+        if (r.bad || (t.type != TYPE_F32 && t.type != TYPE_I32 && t.type != TYPE_I8)) return false;
+        uint64_t count = 1;
+        for (int d : t.dims) { if (d <= 0 || d > (1 << 24)) return false; count *= (uint64_t)d; if (count > (1u << 28)) return false; }
+        if ((uint64_t)t.nbytes != count * (t.type == TYPE_I8 ? 1u : 4u)) return false;
+        if (t.type == TYPE_I8 && nq == 0) return false;
+        if (nq > 1 && (t.qdim < 0 || t.qdim >= (int)t.dims.size() || (uint32_t)t.dims[t.qdim] != nq)) return false;
         if (t.is_const) {
             const uint8_t *b = r.bytes(t.nbytes);
             if (!b) return false;
@@ -568,6 +576,8 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
             f_w > 16 || out_c > 64 || x.dims.size() != 4 || (size_t)w.nbytes != (size_t)out_c * f_w * (dw ? 1 : in_c))
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu is not a stride-1 1xK (depthwise) convolution over time", i);
         if (cur_w && (cur_w != in_w || cur_c != in_c)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "shape mismatch into conv %zu", i);
+        if (bias && (bias->type != TYPE_I32 || (int)bias->nbytes != out_c * 4)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu bias", i);
+        if (w.type != TYPE_I8 || x.type != TYPE_I8 || y.type != TYPE_I8) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu tensor types", i);
         const int out_w = h_out_size(padding, in_w, f_w, 1, 1);
         const int pad_left = h_pad_amount(1, 1, in_w, f_w, out_w);
         if (out_w != y.dim4(2) || y.dim4(3) != out_c) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv %zu output shape", i);
@@ -698,7 +708,9 @@ static EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         const Tensor *bias = (fc.in.size() > 2 && fc.in[2] >= 0) ? &m.t[fc.in[2]] : nullptr;
         N.fc_in = w.dims.back(); N.fc_out = w.dims[0];
         const KwsConvBlock &lb = N.blk[N.n_blocks - 1];
-        if (N.fc_in != lb.pool_w * lb.out_c || N.fc_in > 64 || N.fc_out > 48 || N.fc_out != N.n_labels || !w.is_const)
+        if (N.fc_in != lb.pool_w * lb.out_c || N.fc_in > 64 || N.fc_out > 48 || N.fc_out != N.n_labels || !w.is_const ||
+            w.type != TYPE_I8 || (int)w.nbytes != N.fc_in * N.fc_out || y.type != TYPE_I8 ||
+            (bias && (!bias->is_const || bias->type != TYPE_I32 || (int)bias->nbytes != N.fc_out * 4)))
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "FULLY_CONNECTED shape %dx%d outside the kernel's limits", N.fc_out, N.fc_in);
         N.fc_in_off = -x.zero[0]; N.fc_w_off = -w.zero[0]; N.fc_out_zp = y.zero[0];
         const double in_prod = (double)(x.scale[0] * w.scale[0]);     // kernel_util_lite.cc:160-172 (float product)
@@ -888,14 +900,17 @@ EI_IMPULSE_ERROR kws_create(const void *blob, size_t nbytes, int device, kws_han
 {
     if (!blob || !out) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(KWS_ERROR_HIP, "no HIP device available (libkws_mi355x has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(KWS_ERROR_HIP, "device %d out of range (%d devices)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
     kws_handle *h = new kws_handle();
     h->device = device;
+    // the blob is checked first (it may come from anywhere): a malformed one is KWS_ERROR_BAD_ARGUMENT on any machine
     if (!parse_model(blob, nbytes, h->model)) { delete h; return fail(KWS_ERROR_BAD_ARGUMENT, "not a valid .kwsm model blob"); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        delete h;
+        return fail(KWS_ERROR_HIP, "no HIP device available (libkws_mi355x has no CPU fallback)");
+    }
+    if (device < 0 || device >= ndev) { delete h; return fail(KWS_ERROR_HIP, "device %d out of range (%d devices)", device, ndev); }
+    if (hipSetDevice(device) != hipSuccess) { delete h; return fail(KWS_ERROR_HIP, "hipSetDevice(%d) failed", device); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
     EI_IMPULSE_ERROR e = build_dsp_plan(h);

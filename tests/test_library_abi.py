@@ -62,3 +62,28 @@ def test_moving_average_filter(pkg):
     L = pkg.lib()
     outs = [L.run_moving_average_filter(ctypes.byref(m), v) for v in (1.0, 0.5, 0.0, 0.25)]
     assert outs == [0.5, 0.75, 0.25, 0.125]
+
+
+def test_malformed_model_blobs_are_rejected(pkg):
+    """The blob parser runs before any device is touched: truncations, bad magic / version, out-of-range tensor indices
+    and absurd counts are KWS_ERROR_BAD_ARGUMENT (-20) everywhere -- never a crash."""
+    good = open(pkg.DEFAULT_MODEL, "rb").read()
+    import struct
+    bad = [b"", b"KWS", b"KWSM", b"XXXX" + good[4:], good[:4] + struct.pack("<I", 2) + good[8:]]
+    bad += [good[:n] for n in (8, 40, 100, 200, len(good) // 2, len(good) - 1)]
+    for off in (8, 12, 16, 20, 24):                       # n_tensors, n_nodes, n_labels, input / output tensor index
+        bad.append(good[:off] + struct.pack("<I", 0x7fffffff) + good[off + 4:])
+    rng = __import__("numpy").random.default_rng(0)
+    for _ in range(200):                                  # random single-word corruptions of the header / tables
+        off = int(rng.integers(8, 400)) & ~3
+        bad.append(good[:off] + struct.pack("<I", int(rng.integers(0, 2 ** 32))) + good[off + 4:])
+    import torch
+    n_bad_arg = 0
+    for b in bad:
+        try:
+            m = pkg.Model(blob=b)
+            m.close()                                      # a corruption may still be a loadable model (GPU box)
+        except pkg.KwsError as e:
+            assert e.code in (-20, -19, -18), e            # bad blob / no device (CPU box) / unsupported model
+            n_bad_arg += e.code == -20
+    assert n_bad_arg >= 16
