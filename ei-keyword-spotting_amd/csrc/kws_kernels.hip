@@ -657,6 +657,9 @@ __device__ __forceinline__ int one_over_one_plus_x(int a)     // fixedpoint.h:84
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KWS_NN_WAVES = 4;
 constexpr int KWS_POOL_MAX = 8;
+// rows of a block's padded int8 input image in the generic kernel: un-pooled blocks are walked KWS_POOL_MAX time steps at
+// a time, so reads reach up to ceil(out_w / 8) * 8 + taps - 1
+__host__ __device__ inline int nn_rows(const KwsConvBlock &k) { return max(k.in_w, (k.out_w + KWS_POOL_MAX - 1) & ~(KWS_POOL_MAX - 1)) + k.taps; }
 
 struct NnTaps {            // optional debug outputs for the parity tests (all int8, per clip)
     int8_t *pooled;        // concatenation of every block's pooled output [pool_w][out_c]
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
         for (int i = threadIdx.x * 4; i < lbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.add_lut + i);
         s_lut[b] = (const int8_t *)sp;
         sp += lbytes;
-        const int ab = (k.in_w + k.taps) * k.in_cpad;
+        const int ab = nn_rows(k) * k.in_cpad;
         act_bytes = max(act_bytes, ab);
     }
     act_bytes = (act_bytes + 15) & ~15;
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
         // ---- stage the int8 input as [pad_left + t][in_cpad], padding = zero point ((x + offset) == 0) -------
         {
             const KwsConvBlock &k = N.blk[0];
-            const int rows = k.in_w + k.taps;
+            const int rows = nn_rows(k);
             const int zp4 = (int)((unsigned)(k.in_zp & 0xff) * 0x01010101u);
             for (int i = lane * 4; i < rows * k.in_cpad; i += 64 * 4) *(int *)(actA + i) = zp4;
             WAVE_SYNC();
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
         for (int b = 0; b < N.n_blocks; ++b) {
             const KwsConvBlock &k = N.blk[b];
             const bool last = (b + 1 == N.n_blocks);
-            const int nrows = last ? 0 : (N.blk[b + 1].in_w + N.blk[b + 1].taps);
+            const int nrows = last ? 0 : nn_rows(N.blk[b + 1]);
             const int ncp = last ? k.out_c : N.blk[b + 1].in_cpad;
             const int npl = last ? 0 : N.blk[b + 1].pad_left;
             if (!last) {
@@ -774,15 +777,25 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
                 WAVE_SYNC();
             }
             const int n_out = k.pool_w * k.out_c;
-            const int c4n = k.in_cpad >> 2;
-            for (int idx = lane; idx < n_out; idx += 64) {
-                const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
-                const int t0 = pw * k.pool_stride;
-                int acc[KWS_POOL_MAX];
+            // requantise + folded ADD/ReLU of one pooled accumulator, store (integer_ops/conv.h:111-116, add.h)
+            auto finish = [&](int m, int pw, int oc) {
+                m += k.bias_eff[oc];
+                int r = mbqm(m, k.mult[oc], k.shift[oc]) + k.out_zp;
+                r = min(max(r, k.act_min), k.act_max);
+                const int8_t o = k.has_lut ? s_lut[b][oc * 256 + (r + 128)] : (int8_t)r;
+                const int idx = pw * k.out_c + oc;
+                if (last) ((int8_t *)vec)[idx] = o;
+                else nxt[(npl + pw) * ncp + oc] = o;
+                if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
+            };
+            if (k.depthwise) {                           // integer_ops/depthwise_conv.h:64-103: one input channel per output
+                const int tp4 = (k.taps + 3) & ~3;
+                for (int idx = lane; idx < n_out; idx += 64) {
+                    const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                    const int t0 = pw * k.pool_stride;
+                    int acc[KWS_POOL_MAX];
 #pragma unroll
-                for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i] = 0;
-                if (k.depthwise) {                       // integer_ops/depthwise_conv.h:64-103: one input channel per output
-                    const int tp4 = (k.taps + 3) & ~3;
+                    for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i] = 0;
                     const int8_t *wrow = s_w[b] + oc * tp4;
                     const int8_t *xcol = cur + t0 * k.in_cpad + oc / k.depth_mult;
                     for (int tap = 0; tap < k.taps; ++tap) {
@@ -791,32 +804,69 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
                         for (int i = 0; i < KWS_POOL_MAX; ++i)
                             if (i < k.pool) acc[i] += wv * (int)xcol[(i + tap) * k.in_cpad];
                     }
-                } else {
-                    const int *wrow = (const int *)(s_w[b] + (size_t)oc * k.taps * k.in_cpad);
+                    int m = (int)0x80000000;
+#pragma unroll
+                    for (int i = 0; i < KWS_POOL_MAX; ++i)
+                        if (i < k.pool && t0 + i < k.out_w) m = max(m, acc[i]);
+                    finish(m, pw, oc);
+                }
+            } else {
+                // a lane owns one pooling window of OB = 2 (or 1) output channels: every 16-byte activation read feeds
+                // 4 * OB dot products, every 16-byte weight read `pool` of them
+                // (an un-pooled block is walked in groups of KWS_POOL_MAX time steps, each stored on its own)
+                const bool pooled = k.pool > 1;
+                const int tb = pooled ? k.pool : KWS_POOL_MAX, tstride = pooled ? k.pool_stride : KWS_POOL_MAX;
+                const int n_tb = pooled ? k.pool_w : (k.out_w + KWS_POOL_MAX - 1) / KWS_POOL_MAX;
+                const int ob = (n_tb * k.out_c > 64 && (k.out_c & 1) == 0) ? 2 : 1;
+                const int n_ocb = k.out_c / ob;
+                const int c16n = k.in_cpad >> 4;
+                for (int item = lane; item < n_tb * n_ocb; item += 64) {
+                    const int pw = item / n_ocb, oc0 = (item - pw * n_ocb) * ob;
+                    const int t0 = pw * tstride;
+                    int acc[KWS_POOL_MAX][2];
+#pragma unroll
+                    for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i][0] = acc[i][1] = 0;
+                    const int8_t *w0 = s_w[b] + (size_t)oc0 * k.taps * k.in_cpad;
+                    const int8_t *w1 = w0 + (ob == 2 ? k.taps * k.in_cpad : 0);
                     for (int tap = 0; tap < k.taps; ++tap) {
-                        for (int c4 = 0; c4 < c4n; ++c4) {
-                            const int wv = wrow[tap * c4n + c4];
+                        const int8_t *xrow = cur + (t0 + tap) * k.in_cpad;
+                        for (int c16 = 0; c16 < c16n; ++c16) {
+                            const int4 wa = *(const int4 *)(w0 + tap * k.in_cpad + 16 * c16);
+                            const int4 wb = *(const int4 *)(w1 + tap * k.in_cpad + 16 * c16);
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i) {
-                                if (i < k.pool) {
-                                    const int xv = *(const int *)(cur + (t0 + i + tap) * k.in_cpad + 4 * c4);
-                                    acc[i] = __builtin_amdgcn_sdot4(wv, xv, acc[i], false);
+                                if (i < tb) {
+                                    const int4 xv = *(const int4 *)(xrow + i * k.in_cpad + 16 * c16);
+                                    int a = acc[i][0], c = acc[i][1];
+                                    a = __builtin_amdgcn_sdot4(wa.x, xv.x, a, false);
+                                    a = __builtin_amdgcn_sdot4(wa.y, xv.y, a, false);
+                                    a = __builtin_amdgcn_sdot4(wa.z, xv.z, a, false);
+                                    a = __builtin_amdgcn_sdot4(wa.w, xv.w, a, false);
+                                    if (ob == 2) {
+                                        c = __builtin_amdgcn_sdot4(wb.x, xv.x, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb.y, xv.y, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb.z, xv.z, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb.w, xv.w, c, false);
+                                    }
+                                    acc[i][0] = a; acc[i][1] = c;
                                 }
                             }
                         }
                     }
-                }
-                int m = (int)0x80000000;
+                    for (int o = 0; o < ob; ++o) {
+                        if (pooled) {
+                            int m = (int)0x80000000;
 #pragma unroll
-                for (int i = 0; i < KWS_POOL_MAX; ++i)
-                    if (i < k.pool && t0 + i < k.out_w) m = max(m, acc[i]);
-                m += k.bias_eff[oc];
-                int r = mbqm(m, k.mult[oc], k.shift[oc]) + k.out_zp;          // integer_ops/conv.h:111-116
-                r = min(max(r, k.act_min), k.act_max);
-                const int8_t o = k.has_lut ? s_lut[b][oc * 256 + (r + 128)] : (int8_t)r;   // ADD(bias)+ReLU, integer_ops/add.h
-                if (last) ((int8_t *)vec)[idx] = o;
-                else nxt[(npl + pw) * ncp + oc] = o;
-                if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
+                            for (int i = 0; i < KWS_POOL_MAX; ++i)
+                                if (i < tb && t0 + i < k.out_w) m = max(m, acc[i][o]);
+                            finish(m, pw, oc0 + o);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < KWS_POOL_MAX; ++i)
+                                if (t0 + i < k.out_w) finish(acc[i][o], t0 + i, oc0 + o);
+                        }
+                    }
+                }
             }
             pooled_off += n_out;
             WAVE_SYNC();
@@ -1553,7 +1603,7 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N)
         const KwsConvBlock &k = N.blk[b];
         s += ((size_t)k.w_bytes + 15) & ~(size_t)15;
         s += k.has_lut ? (size_t)k.out_c * 256 : 0;
-        const int ab = (k.in_w + k.taps) * k.in_cpad;
+        const int ab = nn_rows(k) * k.in_cpad;
         act = ab > act ? ab : act;
     }
     act = (act + 15) & ~15;
