@@ -480,4 +480,57 @@ double eiref_time_run_classifier(const int16_t *pcm, size_t n_clips, size_t len,
     return (double)(t1 - t0) * 1e-6;
 }
 
+/* CPU baseline for a graph the reference does not ship (BASELINE configs 2, 3, 5): per clip, the reference's
+ * extract_mfcc_features() with the blob's DSP settings, (float graphs) the feature copy of ei_run_classifier.h:447-452 or
+ * (int8 graphs) its quantisation loop :436-444, then the graph through the reference's op registrations -- set up and torn
+ * down per clip as run_inference does with trained_model_init / trained_model_reset (:341-345, :486-488). */
+double eiref_time_graph_classifier(const uint8_t *blob, size_t nbytes, const int16_t *pcm, size_t n_clips, size_t len, int iters,
+                                   float *checksum) {
+    if (nbytes < 8 + 4 * (5 + 3 + 11) || memcmp(blob, "KWSM", 4) != 0) return -1.0;
+    const uint8_t *q = blob + 8;
+    uint32_t hdr[8]; memcpy(hdr, q, sizeof(hdr)); q += sizeof(hdr);              /* nt nn nl t_in t_out raw freq nfeat */
+    int32_t d[8]; memcpy(d, q, sizeof(d)); q += sizeof(d);                        /* axes ncep nfilt fft win low high shift */
+    float f[3]; memcpy(f, q, sizeof(f));                                          /* frame_length frame_stride pre_cof */
+    const uint32_t t_in = hdr[3], t_out = hdr[4], nfeat = hdr[7], nl = hdr[2];
+    if (nl == 0 || nl > 64) return -1.0;
+    /* input tensor type / quantisation: walk to tensor t_in (labels first) */
+    graphrun::Rd r{ blob + 8 + 4 * (8 + 8 + 3), blob + nbytes, false };
+    for (uint32_t i = 0; i < nl; i++) { uint32_t n = r.u32(); r.bytes(n); }
+    uint32_t in_type = 0; float in_scale = 1.f; int in_zp = 0; float out_scale = 1.f; int out_zp = 0;
+    for (uint32_t i = 0; i <= (t_in > t_out ? t_in : t_out); i++) {
+        uint32_t type = r.u32(), nd = r.u32();
+        for (uint32_t k = 0; k < nd; k++) r.i32();
+        uint32_t is_const = r.u32(), nq = r.u32();
+        float sc0 = 1.f; int zp0 = 0;
+        for (uint32_t k = 0; k < nq; k++) { float v = r.f32(); if (k == 0) sc0 = v; }
+        for (uint32_t k = 0; k < nq; k++) { int v = r.i32(); if (k == 0) zp0 = v; }
+        r.i32(); uint32_t nb = r.u32();
+        if (is_const) r.bytes(nb);
+        if (i == t_in) { in_type = type; in_scale = sc0; in_zp = zp0; }
+        if (i == t_out) { out_scale = sc0; out_zp = zp0; }
+    }
+    if (r.bad) return -1.0;
+    std::vector<float> feat(nfeat), scores(nl);
+    std::vector<int8_t> qin(nfeat), qout(nl);
+    float acc = 0.f;
+    uint64_t t0 = ei_read_timer_us();
+    for (int it = 0; it < iters; it++)
+        for (size_t c = 0; c < n_clips; c++) {
+            if (eiref_extract_mfcc(pcm + c * len, len, d[1], f[0], f[1], d[2], d[3], d[4], d[5], d[6], f[2], d[7], feat.data(), nfeat) != 0) return -2.0;
+            int rc;
+            if (in_type == 1) {
+                rc = eiref_graph_run(blob, nbytes, feat.data(), nfeat * 4, scores.data(), nl * 4, nullptr);
+            } else {
+                for (uint32_t ix = 0; ix < nfeat; ix++) qin[ix] = static_cast<int8_t>(round(feat[ix] / in_scale) + in_zp);
+                rc = eiref_graph_run(blob, nbytes, qin.data(), nfeat, qout.data(), nl, nullptr);
+                for (uint32_t ix = 0; ix < nl; ix++) scores[ix] = (float)(qout[ix] - out_zp) * out_scale;
+            }
+            if (rc != 0) return -3.0;
+            acc += scores[0];
+        }
+    uint64_t t1 = ei_read_timer_us();
+    if (checksum) *checksum = acc;
+    return (double)(t1 - t0) * 1e-6;
+}
+
 } /* extern "C" */

@@ -317,6 +317,8 @@ class Reference:
         L.eiref_time_run_classifier.restype = C.c_double
         L.eiref_time_run_classifier.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.eiref_graph_run.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.eiref_time_graph_classifier.restype = C.c_double
+        L.eiref_time_graph_classifier.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         self.n_labels = L.eiref_label_count()
         self.labels = [L.eiref_label(i).decode() for i in range(self.n_labels)]
         self.n_features = L.eiref_feature_count()
@@ -335,6 +337,14 @@ class Reference:
         assert rc == 0, rc
         offs = np.cumsum([0] + [t["nbytes"] for t in tens])
         return out, [taps[offs[i]:offs[i + 1]].view(np_t[t["type"]]) for i, t in enumerate(tens)]
+
+    def time_graph(self, blob, pcm, iters=1):
+        """seconds for iters passes of extract_mfcc_features + the blob's graph (reference op code) over pcm [n][len]"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        chk = C.c_float()
+        t = self.L.eiref_time_graph_classifier(blob, len(blob), _ptr(pcm), pcm.shape[0], pcm.shape[1], iters, C.byref(chk))
+        assert t >= 0, t
+        return t
 
     def run_classifier(self, pcm):
         pcm = np.ascontiguousarray(pcm, np.int16)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --output-format csv).
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <batch> <out.json>
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <batch> <out.json> [model file name]
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): the counters report KiB; on gfx950 FETCH_SIZE counts half
 of the bytes of 16-byte-per-lane coalesced streaming reads, so it is doubled.  WRITE_SIZE is checked against
@@ -26,10 +26,11 @@ def per_kernel(path, counter):
 
 def main():
     fetch, write, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    model = sys.argv[5] if len(sys.argv) > 5 else "cfg2_mfcc40_f32.kwsm"
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     res = {"command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
-                      "--no-cpu-baseline  (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
-           "batch": batch, "unit": "bytes per launch",
+                      "--no-cpu-baseline --no-also  (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
+           "batch": batch, "model": model, "unit": "bytes per launch",
            "correction": "counter values are KiB; FETCH_SIZE doubled (gfx950, 16-byte/lane coalesced streaming reads); "
                          "WRITE_SIZE checked on kws_synth_kernel (batch*32000 B written)",
            "kernels": {}}
