@@ -66,6 +66,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError("%s is missing: run __graft_entry__.build() (hipcc, gfx950) first" % LIB_PATH)
+        # One HIP runtime per process: when PyTorch is going to be used in this process (bench.py, tests) its bundled
+        # libamdhip64 / libhsa-runtime64 must be the copies that get loaded, BEFORE this library pulls in /opt/rocm's --
+        # otherwise the runtime that comes second finds no device.  (A plain C application links /opt/rocm's only.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
         L.kws_last_error.restype = C.c_char_p

@@ -1196,6 +1196,9 @@ EI_IMPULSE_ERROR kws_nn_batch(kws_handle *h, const int8_t *q_in, size_t B, float
 EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, void *stream)
 {
     if (!out) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    int ndev = 0, dev = 0;      // no handle here: make sure the runtime is up before the first launch of the process
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipGetDevice(&dev) != hipSuccess)
+        return fail(KWS_ERROR_HIP, "no HIP device available (libkws_mi355x has no CPU fallback)");
     int rc = kws_launch_synth(seed, first_clip, n_clips, clip_len, out, (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "synth kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;

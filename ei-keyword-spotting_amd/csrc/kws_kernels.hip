@@ -1426,6 +1426,7 @@ void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k)
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int grid_cap,
                       hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
@@ -1478,6 +1479,7 @@ template <bool F32IN, bool WITH_CMVN, bool PROF>
 static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, float *out, int8_t *q_out, float in_scale, int in_zp,
                          const float *wrap, int out_stride, int grid_cap, long long *prof, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
     if (P.n_filters == 40)                                     // mel taps walked from the CSR table: NZ unused
@@ -1498,6 +1500,7 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                           float in_scale, int in_zp, int grid_cap, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     return pcm_is_float ? launch_mfcc_t<true, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream)
                         : launch_mfcc_t<false, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream);
 }
@@ -1505,6 +1508,7 @@ int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
                                int in_zp, int grid_cap, long long *prof_out, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     return launch_mfcc_t<false, true, true>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, prof_out, stream);
 }
 
@@ -1513,6 +1517,7 @@ int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
                         int out_stride, int grid_cap, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (out_stride == 0) out_stride = P.n_frames * P.n_cepstral;
     return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream)
                         : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream);
@@ -1522,6 +1527,7 @@ int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, 
 int kws_launch_mfe(const KwsDspPlan &P0, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap,
                    hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     KwsDspPlan P = P0;
     P.mfe_mel = mel_out;
     P.mfe_energy = energy_out;
@@ -1556,6 +1562,7 @@ __global__ void kws_shift_kernel(const float *__restrict__ src, float *__restric
 
 int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n <= 0) return 0;
     hipLaunchKernelGGL(kws_maf_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, stream, scores, running_sum,
                        maf_buf, n, buf_idx, taps);
@@ -1564,6 +1571,7 @@ int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int
 
 int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_streams <= 0) return 0;
     size_t blocks = ((size_t)n_streams * F + 255) / 256;
     hipLaunchKernelGGL(kws_shift_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, dst, n_streams, F, shift);
@@ -1580,6 +1588,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
                        int *ran_nn, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     *ran_nn = 0;
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
@@ -1613,6 +1622,7 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N)
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
@@ -1632,6 +1642,7 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
 
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n == 0) return 0;
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -1641,6 +1652,7 @@ int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp
 
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream)
 {
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips == 0) return 0;
     dim3 grid((clip_len + 255) / 256, n_clips < 65535u ? n_clips : 65535u);
     hipLaunchKernelGGL(kws_synth_kernel, grid, dim3(256), 0, stream, seed, first_clip, n_clips, clip_len, out);
