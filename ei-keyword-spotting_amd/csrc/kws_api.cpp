@@ -35,9 +35,9 @@ int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips
 int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
                        int *ran_nn, hipStream_t stream);
-int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int grid_cap,
+int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int n_cu,
                       hipStream_t stream);
-size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N);
+size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);
 void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream);
@@ -887,7 +887,7 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
     if (i >= m.n.size() || m.n[i].op != OP_SOFTMAX || m.n[i].in[0] != cur || m.n[i].out[0] != (int)m.t_out || i + 1 != m.n.size())
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "expected a final SOFTMAX");
     N.beta = m.n[i].beta;
-    if (kws_nn_f32_smem_bytes(N) > 150 * 1024) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "float model too large for the kernel's LDS budget");
+    if (kws_nn_f32_smem_bytes(N, 4) > 150 * 1024) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "float model too large for the kernel's LDS budget");
     return EI_IMPULSE_OK;
 }
 
@@ -1003,7 +1003,7 @@ static EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is
 static EI_IMPULSE_ERROR nn_f32_device(kws_handle *h, const float *features, size_t B, float *scores, float *tap_logits, hipStream_t s)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
-    int rc = kws_launch_nn_f32(h->nnf, features, (int)B, scores, tap_logits, grid_cap_nn(h), s);
+    int rc = kws_launch_nn_f32(h->nnf, features, (int)B, scores, tap_logits, h->n_cu, s);
     if (rc) return fail(KWS_ERROR_HIP, "float NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
 }
@@ -1074,6 +1074,10 @@ EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm
     if (e) return e;
     return mfcc_fused_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
 }
+
+// development aid (not in the public headers): per-phase shader-clock totals of wave 0 of the float network kernel
+extern long long *kws_dev_f32_prof;
+void kws_dev_set_f32_prof(long long *dev_buf) { kws_dev_f32_prof = dev_buf; }
 
 // development/test aid (not in the public headers): force the generic dot4 NN kernel
 void kws_dev_force_scalar_nn(int on) { kws_force_scalar_nn = on; }

@@ -1202,12 +1202,15 @@ __host__ __device__ inline int nnf_rows(const KwsConvBlockF32 &k)          // ro
 }
 __host__ __device__ inline int nnf_ocp(const KwsConvBlockF32 &k) { return (k.out_c + 3) & ~3; }
 
+// where a block's (pooled) output goes: the next block's zero-padded input image, or the FULLY_CONNECTED input vector
+struct NnfDst { float *p; int row0, stride; };
+
 template <int TB, int OB>
 __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *__restrict__ x, const float *__restrict__ wt,
-                                         float *__restrict__ y, int lane)
+                                         float *__restrict__ y, const NnfDst &dst, int lane)
 {
     const int J = k.taps * k.in_c, ocp = nnf_ocp(k);
-    const int n_ob = (k.out_c + OB - 1) / OB, n_tb = (k.out_w + TB - 1) / TB;
+    const int n_ob = (k.out_c + OB - 1) / OB, n_tb = k.fused_pool ? k.pool_w : (k.out_w + TB - 1) / TB;
     for (int item = lane; item < n_tb * n_ob; item += 64) {
         const int tb = item / n_ob, ob = item - tb * n_ob;
         const int t0 = tb * TB, oc0 = ob * OB;
@@ -1218,17 +1221,58 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
             for (int o = 0; o < OB; ++o) acc[i][o] = 0.0f;
         const float *xp = x + t0 * k.in_c;          // rows are contiguous: x[(t+tap)*in_c + c] == x[t*in_c + (tap*in_c + c)]
         const float *wp = wt + oc0;
-        for (int j = 0; j < J; ++j) {
-            float w[OB];
+        // software pipeline: the TB activations and the OB-wide weight vector of step j+1 are in flight while step j's
+        // TB*OB multiply-adds issue (LDS latency would otherwise be exposed once per step at 2 waves per SIMD)
+        float wn[OB], xn[TB];
+        auto load_w = [&](int j, float (&w)[OB]) {
+            if constexpr (OB == 4) { const float4 v = *(const float4 *)(wp + j * ocp); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else if constexpr (OB == 2) { const float2 v = *(const float2 *)(wp + j * ocp); w[0] = v.x; w[1] = v.y; }
+            else w[0] = wp[j * ocp];
+        };
+        if constexpr (TB == 1) {
+            // one time step per lane (small blocks): a chain step is a single multiply-add, so the loop is bound by the LDS
+            // round trip unless many steps' operands are requested at once -- 8 steps per batch
+            constexpr int U = 8;
+            for (int j0 = 0; j0 < J; j0 += U) {
+                float wu[U][OB], xu[U];
 #pragma unroll
-            for (int o = 0; o < OB; ++o) w[o] = wp[j * ocp + o];
+                for (int u = 0; u < U; ++u) {
+                    const int jj = min(j0 + u, J - 1);
+                    load_w(jj, wu[u]);
+                    xu[u] = xp[jj];
+                }
 #pragma unroll
-            for (int i = 0; i < TB; ++i) {
-                const float xv = xp[i * k.in_c + j];
+                for (int u = 0; u < U; ++u) {
+                    if (j0 + u < J) {
 #pragma unroll
-                for (int o = 0; o < OB; ++o) {
-                    const float prod = xv * w[o];
-                    acc[i][o] += prod;
+                        for (int o = 0; o < OB; ++o) {
+                            const float prod = xu[u] * wu[u][o];
+                            acc[0][o] += prod;
+                        }
+                    }
+                }
+            }
+        } else {
+            load_w(0, wn);
+#pragma unroll
+            for (int i = 0; i < TB; ++i) xn[i] = xp[i * k.in_c];
+            for (int j = 0; j < J; ++j) {
+                float w[OB], xv[TB];
+#pragma unroll
+                for (int o = 0; o < OB; ++o) w[o] = wn[o];
+#pragma unroll
+                for (int i = 0; i < TB; ++i) xv[i] = xn[i];
+                const int jn = min(j + 1, J - 1);
+                load_w(jn, wn);
+#pragma unroll
+                for (int i = 0; i < TB; ++i) xn[i] = xp[i * k.in_c + jn];
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+#pragma unroll
+                    for (int o = 0; o < OB; ++o) {
+                        const float prod = xv[i] * w[o];
+                        acc[i][o] += prod;
+                    }
                 }
             }
         }
@@ -1237,13 +1281,16 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
             const int oc = oc0 + o;
             if (oc >= k.out_c) break;
             const float bv = k.bias[oc], av = k.addc[oc];
+            float mx = -FLT_MAX;
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
                 if (t0 + i >= k.out_w) break;
                 float v = act_clamp(acc[i][o] + bv, k.conv_min, k.conv_max);
                 if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
-                y[(t0 + i) * k.out_c + oc] = v;
+                if (k.fused_pool) mx = mx < v ? v : mx;                 // MAX_POOL_2D: std::max(max, v), window order
+                else y[(t0 + i) * k.out_c + oc] = v;
             }
+            if (k.fused_pool) dst.p[(dst.row0 + tb) * dst.stride + oc] = act_clamp(mx, k.pool_min, k.pool_max);
         }
     }
 }
@@ -1282,23 +1329,44 @@ __device__ __forceinline__ void nnf_dwconv(const KwsConvBlockF32 &k, const float
 }
 
 template <int TB>
-__device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const float *x, const float *wt, float *y, int lane)
+__device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const float *x, const float *wt, float *y, const NnfDst &dst, int lane)
 {
     if (k.depthwise) nnf_dwconv<TB>(k, x, wt, y, lane);
-    else if (k.ob == 4) nnf_conv<TB, 4>(k, x, wt, y, lane);
-    else if (k.ob == 2) nnf_conv<TB, 2>(k, x, wt, y, lane);
-    else nnf_conv<TB, 1>(k, x, wt, y, lane);
+    else if (k.ob == 4) nnf_conv<TB, 4>(k, x, wt, y, dst, lane);
+    else if (k.ob == 2) nnf_conv<TB, 2>(k, x, wt, y, dst, lane);
+    else nnf_conv<TB, 1>(k, x, wt, y, dst, lane);
 }
 
-__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(KwsNnPlanF32 N, const float *__restrict__ features,
-                                                                             int n_clips, float *__restrict__ scores,
-                                                                             float *__restrict__ tap_logits)
+// LDS layout shared by host and device: weights of every block, then per wave the ping-pong input images A (even blocks) and
+// B (odd blocks), the un-pooled conv output Y (only when some block cannot pool in registers) and 128 floats for FC/softmax
+struct NnfLayout { int w_floats, a_floats, b_floats, y_floats; };
+__host__ __device__ inline NnfLayout nnf_layout(const KwsNnPlanF32 &N)
+{
+    NnfLayout L = { 0, 0, 0, 0 };
+    for (int b = 0; b < N.n_blocks; ++b) {
+        const KwsConvBlockF32 &k = N.blk[b];
+        L.w_floats += (k.depthwise ? k.taps : k.taps * k.in_c) * nnf_ocp(k);
+        const int img = nnf_rows(k) * k.in_c;
+        if (b & 1) L.b_floats = img > L.b_floats ? img : L.b_floats;
+        else L.a_floats = img > L.a_floats ? img : L.a_floats;
+        if (!k.fused_pool) { const int yf = k.out_w * k.out_c; L.y_floats = yf > L.y_floats ? yf : L.y_floats; }
+    }
+    L.a_floats = (L.a_floats + 3) & ~3; L.b_floats = (L.b_floats + 3) & ~3; L.y_floats = (L.y_floats + 3) & ~3;
+    return L;
+}
+
+__global__ __launch_bounds__(1024) void kws_nn_f32_kernel(KwsNnPlanF32 N, const float *__restrict__ features,
+                                                          int n_clips, float *__restrict__ scores,
+                                                          float *__restrict__ tap_logits, long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    // development aid: shader-clock totals per phase of wave 0 of workgroup 0 (input, each block, head)
+    const bool profiling = prof != nullptr && blockIdx.x == 0 && wave == 0;
+    long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;
+    auto mark = [&](int i) { if (profiling) { const long long now = clock64(); ph[i] += now - tlast; tlast = now; } };
     float *sp = (float *)smem_raw;
     const float *s_w[KWS_MAX_BLOCKS];
-    int x_floats = 0, y_floats = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlockF32 &k = N.blk[b];
         const int J = k.depthwise ? k.taps : k.taps * k.in_c, ocp = nnf_ocp(k);
@@ -1308,66 +1376,73 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(Kws
         }
         s_w[b] = sp;
         sp += J * ocp;
-        x_floats = max(x_floats, nnf_rows(k) * k.in_c);
-        y_floats = max(y_floats, k.out_w * k.out_c);
     }
-    x_floats = (x_floats + 3) & ~3;
-    y_floats = (y_floats + 3) & ~3;
-    float *X = sp + wave * (x_floats + y_floats + 128);
-    float *Y = X + x_floats;
-    float *vec = Y + y_floats;
+    const NnfLayout L = nnf_layout(N);
+    float *A = sp + wave * (L.a_floats + L.b_floats + L.y_floats + 128);
+    float *B = A + L.a_floats;
+    float *Y = B + L.b_floats;
+    float *vec = Y + L.y_floats;
     __syncthreads();
 
-    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+    for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
         {
             const KwsConvBlockF32 &k = N.blk[0];
             const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
             const float *src = features + (size_t)clip * N.n_features;
-            for (int i = lane; i < tot; i += 64) X[i] = (i >= lo && i < hi) ? src[i - lo] : 0.0f;
-            WAVE_SYNC();
-        }
-        for (int b = 0; b < N.n_blocks; ++b) {
-            const KwsConvBlockF32 &k = N.blk[b];
-            switch (k.tb) {
-            case 8: nnf_conv_ob<8>(k, X, s_w[b], Y, lane); break;
-            case 7: nnf_conv_ob<7>(k, X, s_w[b], Y, lane); break;
-            case 4: nnf_conv_ob<4>(k, X, s_w[b], Y, lane); break;
-            case 2: nnf_conv_ob<2>(k, X, s_w[b], Y, lane); break;
-            default: nnf_conv_ob<1>(k, X, s_w[b], Y, lane); break;
+            // 8 loads per lane in flight (one at a time this stage is a chain of global-memory round trips)
+            for (int i0 = lane; i0 < tot; i0 += 64 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 64 * u;
+                    v[u] = (i >= lo && i < hi) ? src[i - lo] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 64 * u;
+                    if (i < tot) A[i] = v[u];
+                }
             }
             WAVE_SYNC();
-            // MAX_POOL_2D over time (pooling.h:189-237) into the next block's zero-padded input, or the FC input vector
+        }
+        mark(0);
+        for (int b = 0; b < N.n_blocks; ++b) {
+            const KwsConvBlockF32 &k = N.blk[b];
             const bool last = (b + 1 == N.n_blocks);
+            const float *cur = (b & 1) ? B : A;
+            NnfDst dst;
             const int n_out = k.pool_w * k.out_c;
-            if (!last) {
+            if (last) { dst.p = vec; dst.row0 = 0; dst.stride = k.out_c; }
+            else {
                 const KwsConvBlockF32 &nk = N.blk[b + 1];
-                const int lo = nk.pad_left * nk.in_c, tot = nnf_rows(nk) * nk.in_c;
-                for (int i = lane; i < tot; i += 64) {
-                    const int idx = i - lo;
-                    float mx = 0.0f;
-                    if (idx >= 0 && idx < n_out) {
-                        const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
-                        mx = -FLT_MAX;
-                        for (int q = 0; q < k.pool; ++q) {
-                            const float v = Y[(pw * k.pool_stride + q) * k.out_c + oc];
-                            mx = mx < v ? v : mx;                      // std::max(max, v)
-                        }
-                        mx = act_clamp(mx, k.pool_min, k.pool_max);
-                    }
-                    X[i] = mx;
-                }
-            } else {
+                dst.p = (b & 1) ? A : B; dst.row0 = nk.pad_left; dst.stride = nk.in_c;
+                // the zero padding rows of the next block's input image (its real rows are written below)
+                const int lo = nk.pad_left * nk.in_c, hi = lo + n_out, tot = nnf_rows(nk) * nk.in_c;
+                for (int i = lane; i < tot; i += 64)
+                    if (i < lo || i >= hi) dst.p[i] = 0.0f;
+            }
+            switch (k.tb) {
+            case 8: nnf_conv_ob<8>(k, cur, s_w[b], Y, dst, lane); break;
+            case 7: nnf_conv_ob<7>(k, cur, s_w[b], Y, dst, lane); break;
+            case 4: nnf_conv_ob<4>(k, cur, s_w[b], Y, dst, lane); break;
+            case 2: nnf_conv_ob<2>(k, cur, s_w[b], Y, dst, lane); break;
+            default: nnf_conv_ob<1>(k, cur, s_w[b], Y, dst, lane); break;
+            }
+            WAVE_SYNC();
+            if (!k.fused_pool) {
+                // MAX_POOL_2D over time (pooling.h:189-237) from the staged conv output
                 for (int idx = lane; idx < n_out; idx += 64) {
                     const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
                     float mx = -FLT_MAX;
                     for (int q = 0; q < k.pool; ++q) {
                         const float v = Y[(pw * k.pool_stride + q) * k.out_c + oc];
-                        mx = mx < v ? v : mx;
+                        mx = mx < v ? v : mx;                          // std::max(max, v)
                     }
-                    vec[idx] = act_clamp(mx, k.pool_min, k.pool_max);
+                    dst.p[(dst.row0 + pw) * dst.stride + oc] = act_clamp(mx, k.pool_min, k.pool_max);
                 }
+                WAVE_SYNC();
             }
-            WAVE_SYNC();
+            mark(1 + b);
         }
         // FULLY_CONNECTED (fully_connected.h:26-60) + SOFTMAX (softmax.h:31-63)
         float *lg = vec + 64;
@@ -1390,53 +1465,73 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_f32_kernel(Kws
             scores[(size_t)clip * N.fc_out + lane] = expf((lg[lane] - mx) * N.beta) / sum;
         }
         WAVE_SYNC();
+        mark(1 + KWS_MAX_BLOCKS);
     }
+    if (profiling && lane == 0)
+        for (int i = 0; i < KWS_MAX_BLOCKS + 2; ++i) prof[i] = ph[i];
 }
 
-size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N)
+size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves)
 {
-    size_t fl = 0;
-    int xf = 0, yf = 0;
-    for (int b = 0; b < N.n_blocks; ++b) {
-        const KwsConvBlockF32 &k = N.blk[b];
-        fl += (size_t)(k.depthwise ? k.taps : k.taps * k.in_c) * nnf_ocp(k);
-        xf = std::max(xf, nnf_rows(k) * k.in_c);
-        yf = std::max(yf, k.out_w * k.out_c);
-    }
-    xf = (xf + 3) & ~3;
-    yf = (yf + 3) & ~3;
-    return (fl + (size_t)KWS_NN_WAVES * (xf + yf + 128)) * sizeof(float);
+    const NnfLayout L = nnf_layout(N);
+    return ((size_t)L.w_floats + (size_t)n_waves * (L.a_floats + L.b_floats + L.y_floats + 128)) * sizeof(float);
 }
 
 // (TB, OB) of a conv block: fewest lane passes x chain work, LDS reads as the tie breaker
 void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k)
 {
     static const int tbs[] = { 1, 2, 4, 7, 8 }, obs[] = { 1, 2, 4 };
-    float best = 1e30f;
-    for (int tb : tbs)
-        for (int ob : obs) {
-            if (k->depthwise && ob != 1) continue;
-            const int items = ((k->out_w + tb - 1) / tb) * ((k->out_c + ob - 1) / ob);
-            const int passes = (items + 63) / 64;
-            const float cost = (float)passes * (2.0f * tb * ob + 1.0f * (tb + 1));
-            if (cost < best) { best = cost; k->tb = tb; k->ob = ob; }
-        }
+    // a lane that owns exactly one pooling window can max-pool in registers (no staging buffer, fewer LDS bytes per wave);
+    // taken when that blocking costs no more than the best free one
+    const bool can_fuse = !k->depthwise && k->pool > 1 && k->pool == k->pool_stride &&
+                          (k->pool == 2 || k->pool == 4 || k->pool == 7 || k->pool == 8);
+    float best[2] = { 1e30f, 1e30f };
+    int btb[2] = { 1, 1 }, bob[2] = { 1, 1 };
+    for (int fused = 0; fused < 2; ++fused)
+        for (int tb : tbs)
+            for (int ob : obs) {
+                if (k->depthwise && ob != 1) continue;
+                if (fused && (!can_fuse || tb != k->pool)) continue;
+                const int n_tb = fused ? k->pool_w : (k->out_w + tb - 1) / tb;
+                const int items = n_tb * ((k->out_c + ob - 1) / ob);
+                const int passes = (items + 63) / 64;
+                const float cost = (float)passes * (2.0f * tb * ob + 1.0f * (tb + 1));
+                if (cost < best[fused]) { best[fused] = cost; btb[fused] = tb; bob[fused] = ob; }
+            }
+    k->fused_pool = (can_fuse && best[1] <= best[0]) ? 1 : 0;
+    k->tb = btb[k->fused_pool];
+    k->ob = bob[k->fused_pool];
 }
 
-int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int grid_cap,
+long long *kws_dev_f32_prof = nullptr;      // development aid: device buffer of KWS_MAX_BLOCKS + 2 phase counters, or NULL
+
+// waves per workgroup: as many as fit the CU's 160 KB of LDS (they share one copy of the weights), at most 16
+int kws_nn_f32_waves(const KwsNnPlanF32 &N)
+{
+    for (int w = 16; w > 4; w -= 4)
+        if (kws_nn_f32_smem_bytes(N, w) <= 158 * 1024) return w;
+    return 4;
+}
+
+int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int n_cu,
                       hipStream_t stream)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
-    int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
-    if (grid > grid_cap) grid = grid_cap;
-    const size_t smem = kws_nn_f32_smem_bytes(N);
-    if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
+    int n_waves = kws_nn_f32_waves(N);
+    int grid_mult = 2;
+    if (const char *e = getenv("KWS_DEV_F32_WAVES")) n_waves = atoi(e);          // development knobs (tuning experiments)
+    if (const char *e = getenv("KWS_DEV_F32_GRIDMULT")) grid_mult = atoi(e);
+    const size_t smem = kws_nn_f32_smem_bytes(N, n_waves);
+    const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / smem);
+    int grid = (n_clips + n_waves - 1) / n_waves;
+    if (grid > n_cu * per_cu * grid_mult) grid = n_cu * per_cu * grid_mult;
+    if (smem > 64 * 1024) {                    // opt in to more than the default 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute((const void *)kws_nn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kws_nn_f32_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), smem, stream, N, features, n_clips, scores,
-                       tap_logits);
+    hipLaunchKernelGGL(kws_nn_f32_kernel, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, N, features, n_clips, scores,
+                       tap_logits, kws_dev_f32_prof);
     return (int)hipGetLastError();
 }
 

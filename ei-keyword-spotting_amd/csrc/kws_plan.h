@@ -84,6 +84,7 @@ struct KwsConvBlockF32 {
     int has_add;
     int depthwise, depth_mult;     // DEPTHWISE_CONV_2D (filter [1][1][taps][out_c]); else CONV_2D (filter [out_c][1][taps][in_c])
     int tb, ob;                    // register blocking of the conv: time steps x output channels per lane
+    int fused_pool;                // tb == pool == pool_stride: the lane max-pools its own window, no staging of the conv output
     float conv_min, conv_max;      // fused activation range of the convolution
     float add_min, add_max;        // fused activation range of the ADD (ReLU: [0, max])
     float pool_min, pool_max;

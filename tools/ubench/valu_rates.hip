@@ -35,6 +35,8 @@ template <int OP> void run(const char *name, int waves_per_simd) {
     hipFree(out); hipFree(cyc);
 }
 int main() {
+    // VALU issue rate against occupancy: a lone wave issues one VALU instruction per ~5.3 cycles; how far does the SIMD scale?
+    for (int w : {1, 2, 3, 4, 6, 8}) { run<3>("v_add_f32", w); run<6>("v_pk_add_f32", w); run<2>("v_fma_f64", w); run<0>("v_cvt_f64_f32", w); }
     for (int w : {1, 2}) {
         run<0>("v_cvt_f64_f32", w); run<1>("v_cvt_f32_f64", w); run<2>("v_fma_f64", w); run<3>("v_add_f32", w);
         run<4>("v_sqrt_f64", w); run<5>("v_sqrt_f32", w); run<6>("v_pk_add_f32", w); run<7>("v_mul/add_f64", w);
