@@ -254,7 +254,7 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
 __device__ __forceinline__ int zi(int c) { return c + 8 * (c >> 5); }
 constexpr int KWS_ZF = 2 * (KWS_NC + 8 * (KWS_NC / 32));   // floats per frame buffer
 template <int CHP, int NF>   // frame PAIRS per chunk, mel filters
-struct MfccSmem {
+struct alignas(16) MfccSmem {
     static constexpr int CHF = 2 * CHP;
     static constexpr int MELS = NF + 1;  // padded (odd) row stride of the log-mel / cepstra buffer
     float z[2][KWS_ZF];                  // per half-wave: pre-emphasised frame, then the in-place complex FFT
@@ -524,11 +524,40 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
         float *fout = features + (size_t)clip * (nfr * ncep);
         const int cgrp = lane >> 4, cl = lane & 15;
         const int r0 = cgrp * KWS_CR;
+        // Row offsets of the walk, per row group: off[g][p] = map[min(g*CR + p, prow-1)] * MELS (the FFT buffers are dead by
+        // now and hold the table).  With the offsets laid out in walk order a lane fetches four of them with one 16-byte
+        // read, a batch ahead, so a term costs ONE dependent LDS read (prefetched too) instead of map -> value.
+        int *offt = (int *)&sm.z[0][0];
+        const int offn = ((win + KWS_CR - 1 + 3) & ~3) + 8;
+        for (int i = lane; i < 4 * offn; i += KWS_WAVE) {
+            const int g = i / offn, pp = i - g * offn;
+            offt[i] = sm.u.map[min(g * KWS_CR + pp, prow - 1)] * MELS;
+        }
+        WAVE_SYNC();
+        const int *myoff = offt + cgrp * offn;
         for (int cb = 0; cb < ncep; cb += 16) {
             const int c = cb + cl;
             const bool act = (c < ncep) && (r0 < nfr);
             const int cc = min(c, ncep - 1);
-            auto val = [&](int p) { return sm.mel[sm.u.map[min(r0 + p, prow - 1)] * MELS + cc]; };
+            const float *col = sm.mel + cc;
+            auto val = [&](int p) { return col[myoff[p]]; };
+            // body(x) for the padded rows p = CR-1 .. win-1 (every row's window is open), in order
+            auto main_walk = [&](auto &&body) {
+                int p = KWS_CR - 1;
+                static_assert(((KWS_CR - 1) & 3) == 0, "16-byte aligned offset batches");
+                int4 a = *(const int4 *)(myoff + p);
+                float xq[4] = { col[a.x], col[a.y], col[a.z], col[a.w] };
+                a = *(const int4 *)(myoff + p + 4);
+                for (; p + 4 <= win; p += 4) {
+                    const float x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3];
+                    xq[0] = col[a.x]; xq[1] = col[a.y]; xq[2] = col[a.z]; xq[3] = col[a.w];    // next batch in flight
+                    a = *(const int4 *)(myoff + p + 8);
+                    body(x0); body(x1); body(x2); body(x3);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (p + u < win) body(xq[u]);
+            };
             float sum[KWS_CR], mean[KWS_CR], sd[KWS_CR];
 #pragma unroll
             for (int r = 0; r < KWS_CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
@@ -538,15 +567,10 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
 #pragma unroll
                 for (int r = 0; r <= p; ++r) sum[r] += x;
             }
-            {
-                float xn = val(KWS_CR - 1);
-                for (int p = KWS_CR - 1; p < win; ++p) {         // every row's window is open
-                    const float x = xn;
-                    xn = val(p + 1);                             // next term is in flight while this one is added
+            main_walk([&](float x) {
 #pragma unroll
-                    for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
-                }
-            }
+                for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
+            });
 #pragma unroll
             for (int q = 0; q < KWS_CR - 1; ++q) {               // ramp-down: rows 0..q have finished
                 const float x = val(win + q);
@@ -566,15 +590,10 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
 #pragma unroll
                 for (int r = 0; r <= p; ++r) sq_acc(x, r);
             }
-            {
-                float xn = val(KWS_CR - 1);
-                for (int p = KWS_CR - 1; p < win; ++p) {
-                    const float x = xn;
-                    xn = val(p + 1);
+            main_walk([&](float x) {
 #pragma unroll
-                    for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
-                }
-            }
+                for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
+            });
 #pragma unroll
             for (int q = 0; q < KWS_CR - 1; ++q) {
                 const float x = val(win + q);
@@ -1563,6 +1582,7 @@ __global__ void kws_synth_kernel(uint32_t seed, uint32_t first_clip, uint32_t n_
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
 int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
+int kws_mfcc_max_win(void) { return 4 * (2 * KWS_ZF / 16) - 8 - 3 - (KWS_CR - 1); }   // the CMVN offset table lives in the FFT buffers
 int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
 int kws_mfcc_cmvn_rows(void) { return KWS_CR; }
 int kws_mfcc_max_frames(int n_filters) { return kws_mel_rows(n_filters); }
