@@ -510,7 +510,7 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     }
     fstart[N] = (int)fbin.size();
     P.max_nz = max_nz;
-    if (c.num_filters == 32 && max_nz > kws_mfcc_max_nz())
+    if (max_nz > kws_mfcc_max_nz())
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "mel filter with %d taps (kernel keeps at most %d in registers)", max_nz, kws_mfcc_max_nz());
     std::vector<int> pmap;
     h_pad_map(nfr, P.pad, pmap);

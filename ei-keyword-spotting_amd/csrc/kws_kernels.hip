@@ -299,8 +299,10 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
     // taps in registers; other filter counts walk the CSR table
     int fbin[NZ];
     float fwt[NZ];
-    if constexpr (NF == 32) {
-        const int b0 = P.filt_start[t], b1e = P.filt_start[t + 1];
+    {
+        // NF == 32: filter lane & 31 (two frames per pass of the mel stage); other counts: filter `lane` (lanes >= NF idle)
+        const int fj = NF == 32 ? t : min(lane, NF - 1);
+        const int b0 = P.filt_start[fj], b1e = P.filt_start[fj + 1];
 #pragma unroll
         for (int n = 0; n < NZ; ++n) {
             const bool on = b0 + n < b1e;
@@ -456,17 +458,21 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                     sm.mel[(f_base + fr) * MELS + t] = fast_log(acc);
                 }
             } else {
-                for (int idx = lane; idx < nfc * NF; idx += KWS_WAVE) {
-                    const int fr = idx / NF, j = idx - fr * NF;
-                    float acc = 0.0f;
-                    for (int n = P.filt_start[j]; n < P.filt_start[j + 1]; ++n) {
-                        float prod = sm.u.p[P.filt_bin[n] * CHF + fr] * P.filt_w[n];
-                        acc += prod;
+                // one frame per pass, lane = filter (taps in registers as above; walking the CSR table from memory
+                // instead cost a third of the kernel)
+                if (lane < NF) {
+                    for (int fr = 0; fr < nfc; ++fr) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int n = 0; n < NZ; ++n) {
+                            float prod = sm.u.p[fbin[n] + fr] * fwt[n];
+                            acc += prod;
+                        }
+                        if (acc == 0.0f) acc = FLT_EPSILON;
+                        if constexpr (!WITH_CMVN)
+                            if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + lane] = acc;
+                        sm.mel[(f_base + fr) * MELS + lane] = fast_log(acc);
                     }
-                    if (acc == 0.0f) acc = FLT_EPSILON;
-                    if constexpr (!WITH_CMVN)
-                        if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + j] = acc;
-                    sm.mel[(f_base + fr) * MELS + j] = fast_log(acc);
                 }
             }
             WAVE_SYNC();
@@ -1597,9 +1603,9 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    if (P.n_filters == 40)                                     // mel taps walked from the CSR table: NZ unused
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 1, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
-                           n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    if (P.n_filters == 40 && P.max_nz <= KWS_MAXNZ)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
     else if (P.n_filters != 32)
         return (int)hipErrorInvalidValue;
     else if (P.max_nz <= 4)

@@ -5,11 +5,12 @@ sys.path.insert(0, ROOT)
 import torch
 from __graft_entry__ import load_package
 pkg = load_package()
-m = pkg.Model(pkg.DEFAULT_MODEL)
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+path = sys.argv[1] if len(sys.argv) > 1 else pkg.DEFAULT_MODEL
+m = pkg.Model(path)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda")
 pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
-f = torch.empty((B, 637), dtype=torch.float32, device="cuda")
+f = torch.empty((B, m.n_features), dtype=torch.float32, device="cuda")
 prof = torch.zeros(16, dtype=torch.int64, device="cuda")
 L = pkg.lib()
 L.kws_dev_mfcc_phase_profile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t] + [ctypes.c_void_p] * 3
@@ -21,6 +22,6 @@ p = prof.cpu().numpy()[:10]
 names = ["load+preemph", "fft", "split+power", "energy", "mel+log", "dct", "cmvn pad", "cmvn", "-", "-"]
 tot = p.sum()
 nclips = (B + 3071) // 3072 if B > 3072 else 1
-print("rc", rc, "clips by wg0 ~", nclips, "total cycles", tot, "per clip", tot / max(1, nclips))
+print(os.path.basename(path), "rc", rc, "clips by wg0 ~", nclips, "total cycles", tot, "per clip", tot / max(1, nclips))
 for n, v in zip(names, p):
     print("%-14s %12d  %5.1f%%" % (n, v, 100.0 * v / tot))
