@@ -1603,7 +1603,10 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    if (P.n_filters == 40 && P.max_nz <= KWS_MAXNZ)
+    if (P.n_filters == 40 && P.max_nz <= 8)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else if (P.n_filters == 40 && P.max_nz <= KWS_MAXNZ)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
                            pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
     else if (P.n_filters != 32)
