@@ -47,7 +47,8 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N);
 extern int kws_force_scalar_nn;
 int kws_nn_uses_mfma(const KwsNnPlan &N);
 int kws_mfcc_max_prow(void);
-int kws_mfcc_max_win(void);
+int kws_mfcc_max_win(int n_cepstral);
+int kws_mfcc_max_frames_for(int n_filters, int n_cepstral);
 int kws_mfcc_max_nz(void);
 int kws_mfcc_cmvn_rows(void);
 int kws_mfcc_max_frames(int n_filters);
@@ -478,7 +479,7 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
                     c.fft_length, c.num_filters);
     if (frame_len < c.fft_length || c.pre_shift != 1 || (c.win_size & 1) == 0 || nfr < 1 || nfr > kws_mfcc_max_frames(c.num_filters) ||
         c.num_cepstral < 1 || c.num_cepstral > c.num_filters || (stride * 2) % 16 != 0 || (P.n_samples * 2) % 16 != 0 ||
-        (nfr - 1) * stride + c.fft_length > P.n_samples || nfr + 2 * P.pad > kws_mfcc_max_prow() || c.win_size > kws_mfcc_max_win() || c.win_size < kws_mfcc_cmvn_rows() ||
+        (nfr - 1) * stride + c.fft_length > P.n_samples || nfr + 2 * P.pad > kws_mfcc_max_prow() || c.win_size > kws_mfcc_max_win(c.num_cepstral) || nfr > kws_mfcc_max_frames_for(c.num_filters, c.num_cepstral) || c.win_size < ((c.num_filters == 40 && c.num_cepstral > 16) ? 17 : 13) ||
         nfr > 4 * kws_mfcc_cmvn_rows() ||
         (size_t)nfr * c.num_cepstral != m.nn_input_frame_size)
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC framing outside the kernel's limits (frames %d, frame_len %d, stride %d, "

@@ -238,6 +238,118 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+//  cmvnw (processing.hpp:326-389) over the cepstra in LDS (row stride MELS) + optional outputs.
+//  A lane owns one column and CR consecutive rows r0..r0+CR-1 (CG lanes = CG columns per row group, 64/CG row groups;
+//  <13,16> for up to 16 cepstra, <17,20> for up to 40 in two passes).  Row r's window is padded rows r..r+win-1, so the
+//  CR windows overlap: ONE walk over padded rows r0..r0+win+CR-2 feeds all CR running sums, each of which still receives
+//  its win terms in the reference's ascending order (fp32 sum; fp64 square-accumulate rounded to fp32 after every term,
+//  numpy.hpp:818-824).  CR independent chains per lane hide the fp64 latency.
+//  Row offsets of the walk, per row group: off[g][p] = map[min(g*CR + p, prow-1)] * MELS, laid out in walk order so that a
+//  lane fetches four of them with one 16-byte read a batch ahead: a term costs ONE dependent LDS read (prefetched too).
+// ---------------------------------------------------------------------------------------------------------
+template <int CR, int CG, int MELS>
+__device__ __forceinline__ void cmvn_columns(const float *__restrict__ mel, const int *__restrict__ map, int *__restrict__ offt, int lane,
+                                             int nfr, int ncep, int prow, int win, float *__restrict__ fout, int8_t *__restrict__ qclip,
+                                             float in_scale, int in_zp)
+{
+    constexpr int NG = KWS_WAVE / CG;                              // row groups
+    static_assert(((CR - 1) & 3) == 0, "16-byte aligned offset batches");
+    const float fwin = (float)win;
+    const int cgrp = min(lane / CG, NG - 1), cl = lane - (lane / CG) * CG;
+    const bool lane_on = lane < NG * CG;
+    const int r0 = cgrp * CR;
+    const int offn = ((win + CR - 1 + 3) & ~3) + 8;
+    for (int i = lane; i < NG * offn; i += KWS_WAVE) {
+        const int g = i / offn, pp = i - g * offn;
+        offt[i] = map[min(g * CR + pp, prow - 1)] * MELS;
+    }
+    WAVE_SYNC();
+    const int *myoff = offt + cgrp * offn;
+    for (int cb = 0; cb < ncep; cb += CG) {
+        const int c = cb + cl;
+        const bool act = lane_on && (c < ncep) && (r0 < nfr);
+        const int cc = min(c, ncep - 1);
+        const float *col = mel + cc;
+        auto val = [&](int p) { return col[myoff[p]]; };
+        // body(x) for the padded rows p = CR-1 .. win-1 (every row's window is open), in order
+        auto main_walk = [&](auto &&body) {
+            int p = CR - 1;
+            int4 a = *(const int4 *)(myoff + p);
+            float xq[4] = { col[a.x], col[a.y], col[a.z], col[a.w] };
+            a = *(const int4 *)(myoff + p + 4);
+            for (; p + 4 <= win; p += 4) {
+                const float x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3];
+                xq[0] = col[a.x]; xq[1] = col[a.y]; xq[2] = col[a.z]; xq[3] = col[a.w];    // next batch in flight
+                a = *(const int4 *)(myoff + p + 8);
+                body(x0); body(x1); body(x2); body(x3);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (p + u < win) body(xq[u]);
+        };
+        float sum[CR], mean[CR], sd[CR];
+#pragma unroll
+        for (int r = 0; r < CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
+#pragma unroll
+        for (int p = 0; p < CR - 1; ++p) {               // ramp-up: rows 0..p have started
+            const float x = val(p);
+#pragma unroll
+            for (int r = 0; r <= p; ++r) sum[r] += x;
+        }
+        main_walk([&](float x) {
+#pragma unroll
+            for (int r = 0; r < CR; ++r) sum[r] += x;
+        });
+#pragma unroll
+        for (int q = 0; q < CR - 1; ++q) {               // ramp-down: rows 0..q have finished
+            const float x = val(win + q);
+#pragma unroll
+            for (int r = q + 1; r < CR; ++r) sum[r] += x;
+        }
+#pragma unroll
+        for (int r = 0; r < CR; ++r) mean[r] = sum[r] / fwin;
+        auto sq_acc = [&](float x, int r) {
+            const float d = x - mean[r];
+            const double dd = (double)d;
+            sd[r] = (float)__fma_rn(dd, dd, (double)sd[r]);   // std += pow(d, 2)
+        };
+#pragma unroll
+        for (int p = 0; p < CR - 1; ++p) {
+            const float x = val(p);
+#pragma unroll
+            for (int r = 0; r <= p; ++r) sq_acc(x, r);
+        }
+        main_walk([&](float x) {
+#pragma unroll
+            for (int r = 0; r < CR; ++r) sq_acc(x, r);
+        });
+#pragma unroll
+        for (int q = 0; q < CR - 1; ++q) {
+            const float x = val(win + q);
+#pragma unroll
+            for (int r = q + 1; r < CR; ++r) sq_acc(x, r);
+        }
+#pragma unroll
+        for (int r = 0; r < CR; ++r) {
+            const int row = r0 + r;
+            if (act && row < nfr) {
+                const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
+                const int idx = row * ncep + c;
+                const float xv = mel[row * MELS + c];
+                const float o = (xv - mean[r]) / (dev + FLT_EPSILON);
+                if (fout) fout[idx] = o;                      // optional output (extract_mfcc_features' matrix)
+                if (qclip) {
+                    // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
+                    float qv = roundf(o / in_scale) + (float)in_zp;
+                    int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
+                    qclip[idx] = (int8_t)(iv & 0xff);
+                }
+            }
+        }
+    }
+}
+
 // PROF: development aid -- per-phase shader-clock totals of block 0 are written to prof_out (tools/gpu_phase_profile.py)
 #define KWS_NPHASE 10
 #define PH(i) do { if (PROF) { long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
@@ -271,7 +383,7 @@ struct alignas(16) MfccSmem {
 };
 static_assert(sizeof(MfccSmem<9, 32>) <= 20 * 1024 && sizeof(MfccSmem<9, 40>) <= 20 * 1024, "8 waves per CU need <= 20 KB LDS each");
 
-template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF = 32, bool PROF = false>
+template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF = 32, bool PROF = false, bool WIDE = false>
 __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
                                                             float *__restrict__ features, int8_t *__restrict__ q_out,
                                                             float in_scale, int in_zp, const float *__restrict__ wrap, int out_stride,
@@ -520,109 +632,15 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
         PH(5);
         if constexpr (!WITH_CMVN) continue;
 
-        // ---- cmvnw (processing.hpp:326-389) -------------------------------------------------------------------
-        // A lane owns column c and KWS_CR consecutive rows r0..r0+CR-1.  Row r's window is padded rows r..r+win-1, so
-        // the CR windows overlap: one walk over padded rows r0..r0+win+CR-2 feeds all CR running sums, each of which
-        // still receives its win terms in the reference's ascending order (fp32 sum; fp64 square-accumulate rounded
-        // to fp32 after every term, numpy.hpp:818-824).  13 independent chains per lane hide the fp64 latency.
-        const int win = P.win_size;
-        const float fwin = (float)win;
-        float *fout = features + (size_t)clip * (nfr * ncep);
-        const int cgrp = lane >> 4, cl = lane & 15;
-        const int r0 = cgrp * KWS_CR;
-        // Row offsets of the walk, per row group: off[g][p] = map[min(g*CR + p, prow-1)] * MELS (the FFT buffers are dead by
-        // now and hold the table).  With the offsets laid out in walk order a lane fetches four of them with one 16-byte
-        // read, a batch ahead, so a term costs ONE dependent LDS read (prefetched too) instead of map -> value.
-        int *offt = (int *)&sm.z[0][0];
-        const int offn = ((win + KWS_CR - 1 + 3) & ~3) + 8;
-        for (int i = lane; i < 4 * offn; i += KWS_WAVE) {
-            const int g = i / offn, pp = i - g * offn;
-            offt[i] = sm.u.map[min(g * KWS_CR + pp, prow - 1)] * MELS;
-        }
-        WAVE_SYNC();
-        const int *myoff = offt + cgrp * offn;
-        for (int cb = 0; cb < ncep; cb += 16) {
-            const int c = cb + cl;
-            const bool act = (c < ncep) && (r0 < nfr);
-            const int cc = min(c, ncep - 1);
-            const float *col = sm.mel + cc;
-            auto val = [&](int p) { return col[myoff[p]]; };
-            // body(x) for the padded rows p = CR-1 .. win-1 (every row's window is open), in order
-            auto main_walk = [&](auto &&body) {
-                int p = KWS_CR - 1;
-                static_assert(((KWS_CR - 1) & 3) == 0, "16-byte aligned offset batches");
-                int4 a = *(const int4 *)(myoff + p);
-                float xq[4] = { col[a.x], col[a.y], col[a.z], col[a.w] };
-                a = *(const int4 *)(myoff + p + 4);
-                for (; p + 4 <= win; p += 4) {
-                    const float x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3];
-                    xq[0] = col[a.x]; xq[1] = col[a.y]; xq[2] = col[a.z]; xq[3] = col[a.w];    // next batch in flight
-                    a = *(const int4 *)(myoff + p + 8);
-                    body(x0); body(x1); body(x2); body(x3);
-                }
-#pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    if (p + u < win) body(xq[u]);
-            };
-            float sum[KWS_CR], mean[KWS_CR], sd[KWS_CR];
-#pragma unroll
-            for (int r = 0; r < KWS_CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
-#pragma unroll
-            for (int p = 0; p < KWS_CR - 1; ++p) {               // ramp-up: rows 0..p have started
-                const float x = val(p);
-#pragma unroll
-                for (int r = 0; r <= p; ++r) sum[r] += x;
-            }
-            main_walk([&](float x) {
-#pragma unroll
-                for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
-            });
-#pragma unroll
-            for (int q = 0; q < KWS_CR - 1; ++q) {               // ramp-down: rows 0..q have finished
-                const float x = val(win + q);
-#pragma unroll
-                for (int r = q + 1; r < KWS_CR; ++r) sum[r] += x;
-            }
-#pragma unroll
-            for (int r = 0; r < KWS_CR; ++r) mean[r] = sum[r] / fwin;
-            auto sq_acc = [&](float x, int r) {
-                const float d = x - mean[r];
-                const double dd = (double)d;
-                sd[r] = (float)__fma_rn(dd, dd, (double)sd[r]);   // std += pow(d, 2)
-            };
-#pragma unroll
-            for (int p = 0; p < KWS_CR - 1; ++p) {
-                const float x = val(p);
-#pragma unroll
-                for (int r = 0; r <= p; ++r) sq_acc(x, r);
-            }
-            main_walk([&](float x) {
-#pragma unroll
-                for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
-            });
-#pragma unroll
-            for (int q = 0; q < KWS_CR - 1; ++q) {
-                const float x = val(win + q);
-#pragma unroll
-                for (int r = q + 1; r < KWS_CR; ++r) sq_acc(x, r);
-            }
-#pragma unroll
-            for (int r = 0; r < KWS_CR; ++r) {
-                const int row = r0 + r;
-                if (act && row < nfr) {
-                    const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
-                    const int idx = row * ncep + c;
-                    const float xv = sm.mel[row * MELS + c];
-                    const float o = (xv - mean[r]) / (dev + FLT_EPSILON);
-                    if (features) fout[idx] = o;           // optional output (extract_mfcc_features' matrix)
-                    if (q_out) {
-                        // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
-                        float qv = roundf(o / in_scale) + (float)in_zp;
-                        int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
-                        q_out[(size_t)clip * (nfr * ncep) + idx] = (int8_t)(iv & 0xff);
-                    }
-                }
-            }
+        // ---- cmvnw (processing.hpp:326-389) + input quantisation ---------------------------------------------
+        {
+            float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
+            int8_t *qclip = q_out ? q_out + (size_t)clip * (nfr * ncep) : nullptr;
+            int *offt = (int *)&sm.z[0][0];                       // the FFT buffers are dead by now
+            // WIDE (more than 16 cepstra, chosen at launch): 20 columns x 3 row groups of 17 rows per pass instead of
+            // 16 x 4 x 13 -- 40 cepstra take 2 passes instead of 3.  One layout per instantiation keeps the registers.
+            if constexpr (WIDE) cmvn_columns<17, 20, MELS>(sm.mel, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, fout, qclip, in_scale, in_zp);
+            else cmvn_columns<13, 16, MELS>(sm.mel, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, fout, qclip, in_scale, in_zp);
         }
         WAVE_SYNC();
         PH(7);
@@ -1588,7 +1606,9 @@ __global__ void kws_synth_kernel(uint32_t seed, uint32_t first_clip, uint32_t n_
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
 int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
-int kws_mfcc_max_win(void) { return 4 * (2 * KWS_ZF / 16) - 8 - 3 - (KWS_CR - 1); }   // the CMVN offset table lives in the FFT buffers
+// the CMVN offset table (row groups x walk length) lives in the FFT buffers: 4 x (win + 12 + 3 + 8) or 3 x (win + 16 + 3 + 8) ints
+int kws_mfcc_max_win(int n_cepstral) { (void)n_cepstral; return 2 * KWS_ZF / 4 - 23; }                 // the narrower of the two layouts
+int kws_mfcc_max_frames_for(int n_filters, int n_cepstral) { const int rows = kws_mel_rows(n_filters); return (n_filters == 40 && n_cepstral > 16) ? (rows < 51 ? rows : 51) : (rows < 52 ? rows : 52); }
 int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
 int kws_mfcc_cmvn_rows(void) { return KWS_CR; }
 int kws_mfcc_max_frames(int n_filters) { return kws_mel_rows(n_filters); }
@@ -1603,7 +1623,10 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    if (P.n_filters == 40 && P.max_nz <= 8)
+    if (P.n_filters == 40 && P.max_nz <= 8 && WITH_CMVN && P.n_cepstral > 16)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else if (P.n_filters == 40 && P.max_nz <= 8)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
                            pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
     else if (P.n_filters == 40 && P.max_nz <= KWS_MAXNZ)
