@@ -616,3 +616,37 @@ def test_mfe_front_end(pkg, gpu476, gpu432, l476, l432, oracle):
             assert (bits(mel[k]) == bits(mo)).all() and (bits(en[k]) == bits(eo)).all(), k
             if check_golden:
                 assert (bits(mel[k]) == bits(g["c%d_mel" % k])).all() and (bits(en[k]) == bits(g["c%d_energy" % k])).all(), k
+
+
+def test_full_size_properties_headline_workload(pkg, oracle):
+    """bench.py's headline workload (BASELINE configs[1]: 65 536 clips, 49x40 MFCC + 2-Conv fp32) at full size:
+    (a) permuting the batch permutes scores AND features bit for bit, (b) duplicated clips give identical rows,
+    (c) a strided sample of rows equals the oracle -- features bit for bit, scores within 1e-6, (d) rows are softmaxes."""
+    import torch
+    from kws_testlib import OracleModel
+    path = os.path.join(MODELS, "cfg2_mfcc40_f32.kwsm")
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    B, F, C = 65536, gm.n_features, gm.n_labels
+    pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
+    pcm[1::4096] = pcm[0::4096]
+    scores = torch.empty((B, C), dtype=torch.float32, device="cuda:0")
+    feats = torch.empty((B, F), dtype=torch.float32, device="cuda:0")
+    gm.run_classifier_batch_device(pcm.data_ptr(), B, scores.data_ptr(), feats.data_ptr())
+    torch.cuda.synchronize()
+    s = scores.cpu().numpy()
+    assert (s[1::4096] == s[0::4096]).all()                                           # (b)
+    perm = torch.randperm(B, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(2))
+    pcm2 = pcm[perm].contiguous()
+    scores2, feats2 = torch.empty_like(scores), torch.empty_like(feats)
+    gm.run_classifier_batch_device(pcm2.data_ptr(), B, scores2.data_ptr(), feats2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(scores2, scores[perm]) and torch.equal(feats2.view(torch.int32), feats[perm].view(torch.int32))   # (a)
+    idx = np.arange(11, B, 1999)
+    host = pcm[torch.from_numpy(idx).cuda()].cpu().numpy()
+    so, fo, _ = om.run_batch(host, want_features=True)
+    assert (bits(feats[torch.from_numpy(idx).cuda()].cpu().numpy()) == bits(fo)).all()   # (c)
+    assert np.abs(s[idx] - so).max() <= F32_SCORE_TOL
+    assert (s >= 0).all() and (np.abs(s.sum(1) - 1.0) <= 1e-5).all()                   # (d)
+    gm.close()
