@@ -543,11 +543,25 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                     sm.u.p[lane] = bin_power(dc, P.inv_fft);
                     sm.u.p[KWS_NC * CHF + lane] = bin_power(ny, P.inv_fft);
                 }
+                // 129 ordered adds; the operands arrive 16 at a time, one batch ahead of the adds (the chain would otherwise
+                // wait for an LDS round trip per batch with only two waves per SIMD to cover it)
                 float e = 0.0f;
                 const float *pl = sm.u.p + lane;
-#pragma unroll 16
-                for (int k = 0; k < KWS_NBINS - 1; ++k) e += pl[k * CHF];
-                e += pl[(KWS_NBINS - 1) * CHF];
+                static_assert((KWS_NBINS - 1) % 16 == 0, "batches of 16 bins");
+                float cur[16], nxt[16];
+                const float last = pl[(KWS_NBINS - 1) * CHF];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) cur[u] = pl[u * CHF];
+                for (int k0 = 0; k0 < KWS_NBINS - 1; k0 += 16) {
+                    const int kn = min(k0 + 16, KWS_NBINS - 1 - 16);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) nxt[u] = pl[(kn + u) * CHF];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) e += cur[u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
+                }
+                e += last;
                 if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
                 sm.energy[f_base + lane] = e;
                 if constexpr (!WITH_CMVN)
