@@ -1262,7 +1262,7 @@ __host__ __device__ inline int nnf_ocp(const KwsConvBlockF32 &k) { return (k.out
 // where a block's (pooled) output goes: the next block's zero-padded input image, or the FULLY_CONNECTED input vector
 struct NnfDst { float *p; int row0, stride; };
 
-template <int TB, int OB>
+template <int TB, int OB, bool VEC4>
 __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *__restrict__ x, const float *__restrict__ wt,
                                          float *__restrict__ y, const NnfDst &dst, int lane)
 {
@@ -1305,6 +1305,42 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
                         for (int o = 0; o < OB; ++o) {
                             const float prod = xu[u] * wu[u][o];
                             acc[0][o] += prod;
+                        }
+                    }
+                }
+            }
+        } else if (VEC4 && (k.in_c & 3) == 0) {
+            // channel counts that are multiples of 4 (rows 16-byte aligned): FOUR chain steps per batch -- one 16-byte read
+            // per time row brings the activations of 4 consecutive steps, the batch after next is in flight meanwhile
+            // (TB + 4 LDS instructions per 4 steps instead of 4 * (TB + 1)); needs the 256-register build of the kernel
+            float4 xq[TB];
+            float wq[4][OB];
+            auto load_batch = [&](int j) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load_w(j + u, wq[u]);
+#pragma unroll
+                for (int i = 0; i < TB; ++i) xq[i] = *(const float4 *)(xp + i * k.in_c + j);
+            };
+            load_batch(0);
+            for (int j = 0; j < J; j += 4) {
+                float4 xv[TB];
+                float w[4][OB];
+#pragma unroll
+                for (int i = 0; i < TB; ++i) xv[i] = xq[i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int o = 0; o < OB; ++o) w[u][o] = wq[u][o];
+                load_batch(min(j + 4, J - 4));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                      // chain order: steps j, j+1, j+2, j+3
+#pragma unroll
+                    for (int i = 0; i < TB; ++i) {
+                        const float xs_ = u == 0 ? xv[i].x : u == 1 ? xv[i].y : u == 2 ? xv[i].z : xv[i].w;
+#pragma unroll
+                        for (int o = 0; o < OB; ++o) {
+                            const float prod = xs_ * w[u][o];
+                            acc[i][o] += prod;
                         }
                     }
                 }
@@ -1385,13 +1421,13 @@ __device__ __forceinline__ void nnf_dwconv(const KwsConvBlockF32 &k, const float
     }
 }
 
-template <int TB>
+template <int TB, bool VEC4>
 __device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const float *x, const float *wt, float *y, const NnfDst &dst, int lane)
 {
     if (k.depthwise) nnf_dwconv<TB>(k, x, wt, y, lane);
-    else if (k.ob == 4) nnf_conv<TB, 4>(k, x, wt, y, dst, lane);
-    else if (k.ob == 2) nnf_conv<TB, 2>(k, x, wt, y, dst, lane);
-    else nnf_conv<TB, 1>(k, x, wt, y, dst, lane);
+    else if (k.ob == 4) nnf_conv<TB, 4, VEC4>(k, x, wt, y, dst, lane);
+    else if (k.ob == 2) nnf_conv<TB, 2, VEC4>(k, x, wt, y, dst, lane);
+    else nnf_conv<TB, 1, VEC4>(k, x, wt, y, dst, lane);
 }
 
 // LDS layout shared by host and device: weights of every block, then per wave the ping-pong input images A (even blocks) and
@@ -1412,7 +1448,8 @@ __host__ __device__ inline NnfLayout nnf_layout(const KwsNnPlanF32 &N)
     return L;
 }
 
-__global__ __launch_bounds__(1024) void kws_nn_f32_kernel(KwsNnPlanF32 N, const float *__restrict__ features,
+template <int MAXT>     // threads per workgroup the build allows: 1024 (<= 128 VGPRs) or 512 (<= 256 VGPRs, vectorised conv steps)
+__global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(KwsNnPlanF32 N, const float *__restrict__ features,
                                                           int n_clips, float *__restrict__ scores,
                                                           float *__restrict__ tap_logits, long long *__restrict__ prof)
 {
@@ -1479,11 +1516,11 @@ __global__ __launch_bounds__(1024) void kws_nn_f32_kernel(KwsNnPlanF32 N, const 
                     if (i < lo || i >= hi) dst.p[i] = 0.0f;
             }
             switch (k.tb) {
-            case 8: nnf_conv_ob<8>(k, cur, s_w[b], Y, dst, lane); break;
-            case 7: nnf_conv_ob<7>(k, cur, s_w[b], Y, dst, lane); break;
-            case 4: nnf_conv_ob<4>(k, cur, s_w[b], Y, dst, lane); break;
-            case 2: nnf_conv_ob<2>(k, cur, s_w[b], Y, dst, lane); break;
-            default: nnf_conv_ob<1>(k, cur, s_w[b], Y, dst, lane); break;
+            case 8: nnf_conv_ob<8, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
+            case 7: nnf_conv_ob<7, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
+            case 4: nnf_conv_ob<4, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
+            case 2: nnf_conv_ob<2, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
+            default: nnf_conv_ob<1, false>(k, cur, s_w[b], Y, dst, lane); break;
             }
             WAVE_SYNC();
             if (!k.fused_pool) {
@@ -1583,12 +1620,17 @@ int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips,
     const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / smem);
     int grid = (n_clips + n_waves - 1) / n_waves;
     if (grid > n_cu * per_cu * grid_mult) grid = n_cu * per_cu * grid_mult;
+    const void *fn = n_waves <= 8 ? (const void *)kws_nn_f32_kernel<512> : (const void *)kws_nn_f32_kernel<1024>;
     if (smem > 64 * 1024) {                    // opt in to more than the default 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute((const void *)kws_nn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kws_nn_f32_kernel, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, N, features, n_clips, scores,
-                       tap_logits, kws_dev_f32_prof);
+    if (n_waves <= 8)
+        hipLaunchKernelGGL(kws_nn_f32_kernel<512>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, N, features, n_clips, scores,
+                           tap_logits, kws_dev_f32_prof);
+    else
+        hipLaunchKernelGGL(kws_nn_f32_kernel<1024>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, N, features, n_clips, scores,
+                           tap_logits, kws_dev_f32_prof);
     return (int)hipGetLastError();
 }
 
