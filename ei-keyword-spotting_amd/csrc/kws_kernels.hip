@@ -1290,14 +1290,26 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
             // one time step per lane (small blocks): a chain step is a single multiply-add, so the loop is bound by the LDS
             // round trip unless many steps' operands are requested at once -- 8 steps per batch
             constexpr int U = 8;
-            for (int j0 = 0; j0 < J; j0 += U) {
-                float wu[U][OB], xu[U];
+            float wn_[U][OB], xn_[U];
+            auto load_batch1 = [&](int j0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int jj = min(j0 + u, J - 1);
-                    load_w(jj, wu[u]);
-                    xu[u] = xp[jj];
+                    load_w(jj, wn_[u]);
+                    xn_[u] = xp[jj];
                 }
+            };
+            if constexpr (VEC4) load_batch1(0);                     // 256-register build: batches double-buffered
+            for (int j0 = 0; j0 < J; j0 += U) {
+                float wu[U][OB], xu[U];
+                if constexpr (!VEC4) load_batch1(j0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xu[u] = xn_[u];
+#pragma unroll
+                    for (int o = 0; o < OB; ++o) wu[u][o] = wn_[u][o];
+                }
+                if constexpr (VEC4) load_batch1(min(j0 + U, J - 1));   // the next batch is in flight during this one's chain
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (j0 + u < J) {
@@ -1483,18 +1495,38 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(KwsNnPlanF32 N, const 
             const KwsConvBlockF32 &k = N.blk[0];
             const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
             const float *src = features + (size_t)clip * N.n_features;
-            // 8 loads per lane in flight (one at a time this stage is a chain of global-memory round trips)
-            for (int i0 = lane; i0 < tot; i0 += 64 * 8) {
-                float v[8];
+            if (((lo | hi | N.n_features) & 3) == 0) {
+                // 16-byte copies (the feature vector of a clip and its place in the image are both 16-byte aligned)
+                const float4 *src4 = (const float4 *)src;
+                float4 *A4 = (float4 *)A;
+                const int lo4 = lo >> 2, hi4 = hi >> 2, tot4 = (tot + 3) >> 2;
+                for (int i0 = lane; i0 < tot4; i0 += 64 * 4) {
+                    float4 v[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + 64 * u;
-                    v[u] = (i >= lo && i < hi) ? src[i - lo] : 0.0f;
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 64 * u;
+                        v[u] = (i >= lo4 && i < hi4) ? src4[i - lo4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 64 * u;
+                        if (i < tot4) A4[i] = v[u];
+                    }
                 }
+            } else {
+                // 8 loads per lane in flight (one at a time this stage is a chain of global-memory round trips)
+                for (int i0 = lane; i0 < tot; i0 += 64 * 8) {
+                    float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + 64 * u;
-                    if (i < tot) A[i] = v[u];
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + 64 * u;
+                        v[u] = (i >= lo && i < hi) ? src[i - lo] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + 64 * u;
+                        if (i < tot) A[i] = v[u];
+                    }
                 }
             }
             WAVE_SYNC();
@@ -1520,7 +1552,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(KwsNnPlanF32 N, const 
             case 7: nnf_conv_ob<7, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
             case 4: nnf_conv_ob<4, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
             case 2: nnf_conv_ob<2, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
-            default: nnf_conv_ob<1, false>(k, cur, s_w[b], Y, dst, lane); break;
+            default: nnf_conv_ob<1, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
             }
             WAVE_SYNC();
             if (!k.fused_pool) {
