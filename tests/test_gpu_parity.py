@@ -650,3 +650,40 @@ def test_full_size_properties_headline_workload(pkg, oracle):
     assert np.abs(s[idx] - so).max() <= F32_SCORE_TOL
     assert (s >= 0).all() and (np.abs(s.sum(1) - 1.0) <= 1e-5).all()                   # (d)
     gm.close()
+
+
+def test_streams_with_float_and_40band_models(pkg, oracle):
+    """Continuous mode for many streams with a float32 model and with the 49x40 headline graph: every stream follows the
+    restated run_classifier_continuous() slice by slice (scores within 1e-6: float softmax)."""
+    import torch
+    from kws_testlib import OracleContinuous, OracleModel
+    for name in ("l476_no_yes_f32.kwsm", "cfg2_mfcc40_f32.kwsm", "cfg2_mfcc40_int8.kwsm"):
+        path = os.path.join(MODELS, name)
+        gm = pkg.Model(path, device=0)
+        om = OracleModel(oracle, path)
+        S = 9
+        audio = oracle.synth(14, 0, S * 2).reshape(S, 2 * 16000)
+        sb = pkg.StreamBatch(gm, S)
+        ocs = [OracleContinuous(om) for _ in range(S)]
+        for oc in ocs:
+            oc.init()
+        scores = torch.empty((S, gm.n_labels), dtype=torch.float32, device="cuda")
+        n_prod = 0
+        for k in range(8):
+            sl = np.ascontiguousarray(audio[:, k * 4000:(k + 1) * 4000])
+            d = torch.from_numpy(sl).cuda()
+            produced = sb.step_device(d.data_ptr(), 4000, scores.data_ptr())
+            torch.cuda.synchronize()
+            got = scores.cpu().numpy()
+            for s in range(S):
+                rc, p, want = ocs[s].step(sl[s])
+                assert rc == 0 and p == produced, (name, k, s)
+                if p:
+                    n_prod += 1
+                    if gm.is_float:
+                        assert np.abs(got[s] - want).max() <= F32_SCORE_TOL, (name, k, s)
+                    else:
+                        assert (bits(got[s]) == bits(want)).all(), (name, k, s)
+        assert n_prod > 0
+        sb.close()
+        gm.close()
