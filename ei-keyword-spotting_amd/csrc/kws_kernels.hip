@@ -117,10 +117,9 @@ constexpr int KWS_NC = 128;        // complex FFT size
 constexpr int KWS_NBINS = 129;
 // mel filter counts the kernel is instantiated for: 32 (both shipped impulses) and 40 (BASELINE's 49x40 configs)
 constexpr int KWS_NF_MAX = 40;
-constexpr int KWS_MAXF = 52;       // frames per clip supported by the lane=frame stages (4 CMVN row groups x KWS_CR)
+constexpr int KWS_MAXF = 52;       // frames per clip supported by the lane=frame stages (4 CMVN row groups x 13 rows)
 constexpr int KWS_MAXNZ = 12;      // longest mel filter kept in registers
 constexpr int KWS_MAXPROW = 192;   // rows of the symmetric-padded CMVN matrix (n_frames + win_size - 1)
-constexpr int KWS_CR = 13;         // CMVN: consecutive rows owned by one lane
 // rows of the log-mel / cepstra buffer: LDS per wave must stay <= 20 KB (8 waves per CU)
 __host__ __device__ constexpr int kws_mel_rows(int nf) { return nf <= 32 ? 52 : 50; }
 
@@ -239,6 +238,14 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// static_cast<int8_t>(round(f / scale) + zero_point) of run_inference (ei_run_classifier.h:436-444): no clamp, x86 wrap semantics
+__device__ __forceinline__ int8_t quantize_feature(float o, float in_scale, int in_zp)
+{
+    const float qv = roundf(o / in_scale) + (float)in_zp;
+    const int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
+    return (int8_t)(iv & 0xff);
+}
+
 //  cmvnw (processing.hpp:326-389) over the cepstra in LDS (row stride MELS) + optional outputs.
 //  A lane owns one column and CR consecutive rows r0..r0+CR-1 (CG lanes = CG columns per row group, 64/CG row groups;
 //  <13,16> for up to 16 cepstra, <17,20> for up to 40 in two passes).  Row r's window is padded rows r..r+win-1, so the
@@ -248,10 +255,10 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
 //  Row offsets of the walk, per row group: off[g][p] = map[min(g*CR + p, prow-1)] * MELS, laid out in walk order so that a
 //  lane fetches four of them with one 16-byte read a batch ahead: a term costs ONE dependent LDS read (prefetched too).
 // ---------------------------------------------------------------------------------------------------------
-template <int CR, int CG, int MELS>
-__device__ __forceinline__ void cmvn_columns(const float *__restrict__ mel, const int *__restrict__ map, int *__restrict__ offt, int lane,
-                                             int nfr, int ncep, int prow, int win, float *__restrict__ fout, int8_t *__restrict__ qclip,
-                                             float in_scale, int in_zp)
+//  emit(row, c, o): called once per normalised element o = (x - mean) / (std + eps).
+template <int CR, int CG, typename Emit>
+__device__ __forceinline__ void cmvn_columns(const float *__restrict__ mel, const int MELS, const int *__restrict__ map, int *__restrict__ offt,
+                                             int lane, int nfr, int ncep, int prow, int win, Emit emit)
 {
     constexpr int NG = KWS_WAVE / CG;                              // row groups
     static_assert(((CR - 1) & 3) == 0, "16-byte aligned offset batches");
@@ -335,16 +342,8 @@ __device__ __forceinline__ void cmvn_columns(const float *__restrict__ mel, cons
             const int row = r0 + r;
             if (act && row < nfr) {
                 const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
-                const int idx = row * ncep + c;
                 const float xv = mel[row * MELS + c];
-                const float o = (xv - mean[r]) / (dev + FLT_EPSILON);
-                if (fout) fout[idx] = o;                      // optional output (extract_mfcc_features' matrix)
-                if (qclip) {
-                    // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
-                    float qv = roundf(o / in_scale) + (float)in_zp;
-                    int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
-                    qclip[idx] = (int8_t)(iv & 0xff);
-                }
+                emit(row, c, (xv - mean[r]) / (dev + FLT_EPSILON));
             }
         }
     }
@@ -653,8 +652,13 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
             int *offt = (int *)&sm.z[0][0];                       // the FFT buffers are dead by now
             // WIDE (more than 16 cepstra, chosen at launch): 20 columns x 3 row groups of 17 rows per pass instead of
             // 16 x 4 x 13 -- 40 cepstra take 2 passes instead of 3.  One layout per instantiation keeps the registers.
-            if constexpr (WIDE) cmvn_columns<17, 20, MELS>(sm.mel, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, fout, qclip, in_scale, in_zp);
-            else cmvn_columns<13, 16, MELS>(sm.mel, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, fout, qclip, in_scale, in_zp);
+            auto emit = [&](int row, int c, float o) {
+                const int idx = row * ncep + c;
+                if (fout) fout[idx] = o;                      // optional output (extract_mfcc_features' matrix)
+                if (qclip) qclip[idx] = quantize_feature(o, in_scale, in_zp);
+            };
+            if constexpr (WIDE) cmvn_columns<17, 20>(sm.mel, MELS, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, emit);
+            else cmvn_columns<13, 16>(sm.mel, MELS, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, emit);
         }
         WAVE_SYNC();
         PH(7);
@@ -1097,10 +1101,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
 // ---------------------------------------------------------------------------------------------------------
 //  Kernel 2': cmvnw (processing.hpp:326-389) + input quantisation (ei_run_classifier.h:436-444) [+ the network when
 //  FUSE and the graph fits the matrix-core path].  One wave per window, 4 waves per workgroup.
-//  CMVN: a lane owns column c and KWS_CR consecutive rows r0..r0+CR-1.  Row r's window is padded rows r..r+win-1, so the
-//  CR windows overlap: one walk over padded rows r0..r0+win+CR-2 feeds all CR running sums, each of which still
-//  receives its win terms in the reference's ascending order (fp32 sum; fp64 square-accumulate rounded to fp32 after
-//  every term, numpy.hpp:818-824).  13 independent chains per lane hide the fp64 latency.
+//  CMVN: cmvn_columns<13, 16> (shared with kws_mfcc_kernel).
 // ---------------------------------------------------------------------------------------------------------
 template <bool FUSE>
 __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel(KwsDspPlan P, KwsNnPlan N, const float *__restrict__ mfcc,
@@ -1110,6 +1111,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
 {
     __shared__ int s_map[KWS_MAXPROW];                                    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541)
     __shared__ float s_mfcc[KWS_NN_WAVES][KWS_MAXF * KWS_NF_MAX];       // cepstra before CMVN, [frame][coef] (coef <= filters)
+    __shared__ __attribute__((aligned(16))) int s_off[KWS_NN_WAVES][2 * KWS_ZF];   // cmvn_columns' row-offset table (same bound as in kws_mfcc_kernel)
     __shared__ __attribute__((aligned(16))) int8_t s_lut1[FUSE ? 32 * 256 : 16];
     __shared__ __attribute__((aligned(16))) int8_t s_lut2[FUSE ? 16 * 256 : 16];
     __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][FUSE ? KWS_A1_ROWS * 16 : 16];
@@ -1131,9 +1133,6 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
     __syncthreads();
     float *mf = s_mfcc[wave];
     const int win = P.win_size;
-    const float fwin = (float)win;
-    const int cgrp = lane >> 4, cl = lane & 15;
-    const int r0 = cgrp * KWS_CR;
     const float in_scale = N.in_scale;
     const int in_zp = N.in_zp;
 
@@ -1141,80 +1140,13 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
         const float *src = mfcc + (size_t)clip * nfeat;
         for (int i = lane; i < nfeat; i += 64) mf[i] = src[i];
         WAVE_SYNC();
-        for (int cb = 0; cb < ncep; cb += 16) {
-            const int c = cb + cl;
-            const bool act = (c < ncep) && (r0 < nfr);
-            const int cc = min(c, ncep - 1);
-            auto val = [&](int p) { return mf[s_map[min(r0 + p, prow - 1)] * ncep + cc]; };
-            float sum[KWS_CR], mean[KWS_CR], sd[KWS_CR];
-#pragma unroll
-            for (int r = 0; r < KWS_CR; ++r) { sum[r] = 0.0f; sd[r] = 0.0f; }
-#pragma unroll
-            for (int p = 0; p < KWS_CR - 1; ++p) {               // ramp-up: rows 0..p have started
-                const float x = val(p);
-#pragma unroll
-                for (int r = 0; r <= p; ++r) sum[r] += x;
-            }
-            {
-                float xn = val(KWS_CR - 1);
-                for (int p = KWS_CR - 1; p < win; ++p) {         // every row's window is open
-                    const float x = xn;
-                    xn = val(p + 1);                             // next term is in flight while this one is added
-#pragma unroll
-                    for (int r = 0; r < KWS_CR; ++r) sum[r] += x;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < KWS_CR - 1; ++q) {               // ramp-down: rows 0..q have finished
-                const float x = val(win + q);
-#pragma unroll
-                for (int r = q + 1; r < KWS_CR; ++r) sum[r] += x;
-            }
-#pragma unroll
-            for (int r = 0; r < KWS_CR; ++r) mean[r] = sum[r] / fwin;
-            auto sq_acc = [&](float x, int r) {
-                const float d = x - mean[r];
-                const double dd = (double)d;
-                sd[r] = (float)__fma_rn(dd, dd, (double)sd[r]);   // std += pow(d, 2)
-            };
-#pragma unroll
-            for (int p = 0; p < KWS_CR - 1; ++p) {
-                const float x = val(p);
-#pragma unroll
-                for (int r = 0; r <= p; ++r) sq_acc(x, r);
-            }
-            {
-                float xn = val(KWS_CR - 1);
-                for (int p = KWS_CR - 1; p < win; ++p) {
-                    const float x = xn;
-                    xn = val(p + 1);
-#pragma unroll
-                    for (int r = 0; r < KWS_CR; ++r) sq_acc(x, r);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < KWS_CR - 1; ++q) {
-                const float x = val(win + q);
-#pragma unroll
-                for (int r = q + 1; r < KWS_CR; ++r) sq_acc(x, r);
-            }
-#pragma unroll
-            for (int r = 0; r < KWS_CR; ++r) {
-                const int row = r0 + r;
-                if (act && row < nfr) {
-                    const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
-                    const int idx = row * ncep + c;
-                    const float o = (mf[idx] - mean[r]) / (dev + FLT_EPSILON);
-                    if (features) features[(size_t)clip * nfeat + idx] = o;
-                    // static_cast<int8_t>(round(f / scale) + zero_point): no clamp, x86 wrap semantics
-                    float qv = roundf(o / in_scale) + (float)in_zp;
-                    int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
-                    const int8_t qb = (int8_t)(iv & 0xff);
-                    if (q_out) q_out[(size_t)clip * nfeat + idx] = qb;
-                    if constexpr (FUSE) act1[(row + N.blk[0].pad_left) * 16 + c] = qb;
-                }
-            }
-        }
+        cmvn_columns<13, 16>(mf, ncep, s_map, s_off[wave], lane, nfr, ncep, prow, win, [&](int row, int c, float o) {
+            const int idx = row * ncep + c;
+            if (features) features[(size_t)clip * nfeat + idx] = o;
+            const int8_t qb = quantize_feature(o, in_scale, in_zp);
+            if (q_out) q_out[(size_t)clip * nfeat + idx] = qb;
+            if constexpr (FUSE) act1[(row + N.blk[0].pad_left) * 16 + c] = qb;
+        });
         WAVE_SYNC();
         if constexpr (FUSE) nn_mfma_clip(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
     }
@@ -1698,7 +1630,7 @@ int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
 int kws_mfcc_max_win(int n_cepstral) { (void)n_cepstral; return 2 * KWS_ZF / 4 - 23; }                 // the narrower of the two layouts
 int kws_mfcc_max_frames_for(int n_filters, int n_cepstral) { const int rows = kws_mel_rows(n_filters); return (n_filters == 40 && n_cepstral > 16) ? (rows < 51 ? rows : 51) : (rows < 52 ? rows : 52); }
 int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
-int kws_mfcc_cmvn_rows(void) { return KWS_CR; }
+int kws_mfcc_cmvn_rows(void) { return 13; }
 int kws_mfcc_max_frames(int n_filters) { return kws_mel_rows(n_filters); }
 int kws_mfcc_fft_length(void) { return KWS_FFT; }
 
