@@ -5,8 +5,8 @@ Headline workload = BASELINE.json configs[1] as worded: batch 65 536 synthetic 1
 2-Conv CNN, fp32, 1x MI355X.  The reference ships no such model, so the graph is generated with
 seeded weights (tools/synth_model.py + tools/dequantize_model.py -> models/cfg2_mfcc40_f32.kwsm); the DSP block is the
 reference's own code path for that configuration (bit-exact, tests/golden/mfcc40_l476.npz).  At N = 1 the same run also
-times the model the reference DOES ship (49x13 MFCC, int8: BASELINE configs[3]) and its fp32 twin; they are reported under
-"also" in the same JSON line.
+times the model the reference DOES ship (49x13 MFCC, int8), its fp32 twin and the int8 form of the headline graph (the two
+readings of BASELINE configs[3]); they are reported under "also" in the same JSON line.
 
 One "step" = one pass of the hot path over one batch of B synthetic 1 s @ 16 kHz int16 clips per GPU, the clips
 already resident in HBM (generated on the device by kws_synth_clips_device).  N > 1: one process per GPU
@@ -28,12 +28,12 @@ HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MI
 
 SHIPPED_MODEL = os.path.join(ROOT, "models", "l476_no_yes.kwsm")            # BASELINE configs[3]: what the reference ships
 DEFAULT_MODEL = os.path.join(ROOT, "models", "cfg2_mfcc40_f32.kwsm")       # BASELINE configs[1] as worded
-ALSO_MODELS = [SHIPPED_MODEL, os.path.join(ROOT, "models", "l476_no_yes_f32.kwsm")]
+ALSO_MODELS = [SHIPPED_MODEL, os.path.join(ROOT, "models", "l476_no_yes_f32.kwsm"), os.path.join(ROOT, "models", "cfg2_mfcc40_int8.kwsm")]
 WORKLOADS = {
     "cfg2_mfcc40_f32.kwsm": "BASELINE configs[1]: 40-band MFCC (49x40: 40 mel, 40 cepstra, fft 256, CMVN 101) + 2-Conv CNN, fp32; "
                             "graph with seeded synthetic weights (the reference ships no such model)",
-    "cfg2_mfcc40_int8.kwsm": "int8 form of BASELINE configs[1] (49x40 MFCC + 2-Conv CNN), seeded synthetic weights",
-    "l476_no_yes.kwsm": "BASELINE configs[3]: the impulse the reference ships, 4-class no/noise/unknown/yes (MFCC 49x13: 32 mel, "
+    "cfg2_mfcc40_int8.kwsm": "BASELINE configs[3] read as the configs[1] graph quantised: 49x40 MFCC + int8 2-Conv CNN, seeded synthetic weights",
+    "l476_no_yes.kwsm": "BASELINE configs[3] read as the reference's own int8 model: the impulse the reference ships, 4-class no/noise/unknown/yes (MFCC 49x13: 32 mel, "
                         "fft 256, CMVN 101; int8 2-Conv CNN)",
     "l476_no_yes_f32.kwsm": "de-quantised fp32 twin of the shipped impulse (MFCC 49x13 + fp32 2-Conv CNN)",
     "cfg5_dscnn_mfcc40_int8.kwsm": "BASELINE configs[4] shape: 49x40 MFCC + 7-block depthwise-separable CNN, 12 labels, int8, synthetic weights",
