@@ -1576,10 +1576,7 @@ int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips,
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
-    int n_waves = kws_nn_f32_waves(N);
-    int grid_mult = 2;
-    if (const char *e = getenv("KWS_DEV_F32_WAVES")) n_waves = atoi(e);          // development knobs (tuning experiments)
-    if (const char *e = getenv("KWS_DEV_F32_GRIDMULT")) grid_mult = atoi(e);
+    const int n_waves = kws_nn_f32_waves(N), grid_mult = 2;
     const size_t smem = kws_nn_f32_smem_bytes(N, n_waves);
     const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / smem);
     int grid = (n_clips + n_waves - 1) / n_waves;
