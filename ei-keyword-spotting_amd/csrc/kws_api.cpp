@@ -35,8 +35,8 @@ int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips
 int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
                        int *ran_nn, hipStream_t stream);
-int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int n_cu,
-                      hipStream_t stream);
+int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
+                      float *tap_logits, int n_cu, hipStream_t stream);
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);
 void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
@@ -407,6 +407,7 @@ struct kws_handle {
     KwsNnPlan nn{};
     bool is_float = false;        // float32 model: nnf is the plan, nn only carries a neutral input quantisation
     KwsNnPlanF32 nnf{};
+    const KwsNnPlanF32 *d_nnf = nullptr;   // the same plan in device memory (the float kernel reads it from there)
     int pooled_tap_bytes = 0;
     std::vector<void *> dev_allocs;
     // scratch for the combined entry points (grown on demand)
@@ -890,6 +891,13 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "expected a final SOFTMAX");
     N.beta = m.n[i].beta;
     if (kws_nn_f32_smem_bytes(N, 4) > 150 * 1024) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "float model too large for the kernel's LDS budget");
+    {
+        void *d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(KwsNnPlanF32)));
+        h->dev_allocs.push_back(d);
+        HIP_TRY(hipMemcpy(d, &N, sizeof(KwsNnPlanF32), hipMemcpyHostToDevice));
+        h->d_nnf = (const KwsNnPlanF32 *)d;
+    }
     return EI_IMPULSE_OK;
 }
 
@@ -1005,7 +1013,7 @@ static EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is
 static EI_IMPULSE_ERROR nn_f32_device(kws_handle *h, const float *features, size_t B, float *scores, float *tap_logits, hipStream_t s)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
-    int rc = kws_launch_nn_f32(h->nnf, features, (int)B, scores, tap_logits, h->n_cu, s);
+    int rc = kws_launch_nn_f32(h->nnf, h->d_nnf, features, (int)B, scores, tap_logits, h->n_cu, s);
     if (rc) return fail(KWS_ERROR_HIP, "float NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
 }

@@ -1184,12 +1184,17 @@ __device__ __forceinline__ float act_clamp(float x, float lo, float hi)   // Act
     return hi < a ? hi : a;
 }
 
-__host__ __device__ inline int nnf_rows(const KwsConvBlockF32 &k)          // rows of the zero-padded input image
+// how a block's outputs leave the conv: pooled in registers (fused_pool), written straight to the next image (no pooling
+// node), or staged in Y for a separate pooling pass
+__host__ __device__ __forceinline__ bool nnf_direct(const KwsConvBlockF32 &k) { return k.pool == 1; }
+__host__ __device__ __forceinline__ bool nnf_staged(const KwsConvBlockF32 &k) { return !k.fused_pool && !nnf_direct(k); }
+__host__ __device__ __forceinline__ int nnf_ntb(const KwsConvBlockF32 &k) { return k.fused_pool ? k.pool_w : (k.out_w + k.tb - 1) / k.tb; }
+__host__ __device__ __forceinline__ int nnf_rows(const KwsConvBlockF32 &k)          // rows of the zero-padded input image
 {
-    const int a = k.in_w + k.taps, b = k.out_w + 7 + k.taps;     // ceil(out_w / TB) * TB <= out_w + 7 for every TB <= 8
+    const int a = k.pad_left + k.in_w, b = nnf_ntb(k) * k.tb + k.taps - 1;    // rows the blocked walk touches (k.tb is final)
     return a > b ? a : b;
 }
-__host__ __device__ inline int nnf_ocp(const KwsConvBlockF32 &k) { return (k.out_c + 3) & ~3; }
+__host__ __device__ __forceinline__ int nnf_ocp(const KwsConvBlockF32 &k) { return (k.out_c + 3) & ~3; }
 
 // where a block's (pooled) output goes: the next block's zero-padded input image, or the FULLY_CONNECTED input vector
 struct NnfDst { float *p; int row0, stride; };
@@ -1199,7 +1204,8 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
                                          float *__restrict__ y, const NnfDst &dst, int lane)
 {
     const int J = k.taps * k.in_c, ocp = nnf_ocp(k);
-    const int n_ob = (k.out_c + OB - 1) / OB, n_tb = k.fused_pool ? k.pool_w : (k.out_w + TB - 1) / TB;
+    const int n_ob = (k.out_c + OB - 1) / OB, n_tb = nnf_ntb(k);
+    const bool direct = nnf_direct(k);
     for (int item = lane; item < n_tb * n_ob; item += 64) {
         const int tb = item / n_ob, ob = item - tb * n_ob;
         const int t0 = tb * TB, oc0 = ob * OB;
@@ -1316,16 +1322,18 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
 #pragma unroll
         for (int o = 0; o < OB; ++o) {
             const int oc = oc0 + o;
-            if (oc >= k.out_c) break;
+            if (oc >= k.out_c) continue;
             const float bv = k.bias[oc], av = k.addc[oc];
             float mx = -FLT_MAX;
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
-                if (t0 + i >= k.out_w) break;
-                float v = act_clamp(acc[i][o] + bv, k.conv_min, k.conv_max);
-                if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
-                if (k.fused_pool) mx = mx < v ? v : mx;                 // MAX_POOL_2D: std::max(max, v), window order
-                else y[(t0 + i) * k.out_c + oc] = v;
+                if (t0 + i < k.out_w) {
+                    float v = act_clamp(acc[i][o] + bv, k.conv_min, k.conv_max);
+                    if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
+                    if (k.fused_pool) mx = mx < v ? v : mx;             // MAX_POOL_2D: std::max(max, v), window order
+                    else if (direct) dst.p[(dst.row0 + t0 + i) * dst.stride + oc] = v;
+                    else y[(t0 + i) * k.out_c + oc] = v;
+                }
             }
             if (k.fused_pool) dst.p[(dst.row0 + tb) * dst.stride + oc] = act_clamp(mx, k.pool_min, k.pool_max);
         }
@@ -1336,9 +1344,10 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
 // channel oc / depth_mult only.  A lane owns TB consecutive time steps of one output channel.
 template <int TB>
 __device__ __forceinline__ void nnf_dwconv(const KwsConvBlockF32 &k, const float *__restrict__ x, const float *__restrict__ wt,
-                                           float *__restrict__ y, int lane)
+                                           float *__restrict__ y, const NnfDst &dst, int lane)
 {
-    const int ocp = nnf_ocp(k), n_tb = (k.out_w + TB - 1) / TB;
+    const int ocp = nnf_ocp(k), n_tb = nnf_ntb(k);
+    const bool direct = nnf_direct(k);
     for (int item = lane; item < n_tb * k.out_c; item += 64) {
         const int tb = item / k.out_c, oc = item - tb * k.out_c;
         const int t0 = tb * TB;
@@ -1355,20 +1364,25 @@ __device__ __forceinline__ void nnf_dwconv(const KwsConvBlockF32 &k, const float
             }
         }
         const float bv = k.bias[oc], av = k.addc[oc];
+        float mx = -FLT_MAX;
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
-            if (t0 + i >= k.out_w) break;
-            float v = act_clamp(acc[i] + bv, k.conv_min, k.conv_max);
-            if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
-            y[(t0 + i) * k.out_c + oc] = v;
+            if (t0 + i < k.out_w) {
+                float v = act_clamp(acc[i] + bv, k.conv_min, k.conv_max);
+                if (k.has_add) v = act_clamp(v + av, k.add_min, k.add_max);
+                if (k.fused_pool) mx = mx < v ? v : mx;
+                else if (direct) dst.p[(dst.row0 + t0 + i) * dst.stride + oc] = v;
+                else y[(t0 + i) * k.out_c + oc] = v;
+            }
         }
+        if (k.fused_pool) dst.p[(dst.row0 + tb) * dst.stride + oc] = act_clamp(mx, k.pool_min, k.pool_max);
     }
 }
 
 template <int TB, bool VEC4>
 __device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const float *x, const float *wt, float *y, const NnfDst &dst, int lane)
 {
-    if (k.depthwise) nnf_dwconv<TB>(k, x, wt, y, lane);
+    if (k.depthwise) nnf_dwconv<TB>(k, x, wt, y, dst, lane);
     else if (k.ob == 4) nnf_conv<TB, 4, VEC4>(k, x, wt, y, dst, lane);
     else if (k.ob == 2) nnf_conv<TB, 2, VEC4>(k, x, wt, y, dst, lane);
     else nnf_conv<TB, 1, VEC4>(k, x, wt, y, dst, lane);
@@ -1377,7 +1391,7 @@ __device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const floa
 // LDS layout shared by host and device: weights of every block, then per wave the ping-pong input images A (even blocks) and
 // B (odd blocks), the un-pooled conv output Y (only when some block cannot pool in registers) and 128 floats for FC/softmax
 struct NnfLayout { int w_floats, a_floats, b_floats, y_floats; };
-__host__ __device__ inline NnfLayout nnf_layout(const KwsNnPlanF32 &N)
+__host__ __device__ __forceinline__ NnfLayout nnf_layout(const KwsNnPlanF32 &N)
 {
     NnfLayout L = { 0, 0, 0, 0 };
     for (int b = 0; b < N.n_blocks; ++b) {
@@ -1386,17 +1400,20 @@ __host__ __device__ inline NnfLayout nnf_layout(const KwsNnPlanF32 &N)
         const int img = nnf_rows(k) * k.in_c;
         if (b & 1) L.b_floats = img > L.b_floats ? img : L.b_floats;
         else L.a_floats = img > L.a_floats ? img : L.a_floats;
-        if (!k.fused_pool) { const int yf = k.out_w * k.out_c; L.y_floats = yf > L.y_floats ? yf : L.y_floats; }
+        if (nnf_staged(k)) { const int yf = k.out_w * k.out_c; L.y_floats = yf > L.y_floats ? yf : L.y_floats; }
     }
     L.a_floats = (L.a_floats + 3) & ~3; L.b_floats = (L.b_floats + 3) & ~3; L.y_floats = (L.y_floats + 3) & ~3;
     return L;
 }
 
 template <int MAXT>     // threads per workgroup the build allows: 1024 (<= 128 VGPRs) or 512 (<= 256 VGPRs, vectorised conv steps)
-__global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(KwsNnPlanF32 N, const float *__restrict__ features,
+__global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__restrict__ Np, const float *__restrict__ features,
                                                           int n_clips, float *__restrict__ scores,
                                                           float *__restrict__ tap_logits, long long *__restrict__ prof)
 {
+    // the plan is read from memory (scalar loads, any block index); by value in the kernel arguments the compiler copies it to
+    // scratch as soon as a block is indexed dynamically
+    const KwsNnPlanF32 &N = *Np;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     // development aid: shader-clock totals per phase of wave 0 of workgroup 0 (input, each block, head)
@@ -1487,7 +1504,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(KwsNnPlanF32 N, const 
             default: nnf_conv_ob<1, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
             }
             WAVE_SYNC();
-            if (!k.fused_pool) {
+            if (nnf_staged(k)) {
                 // MAX_POOL_2D over time (pooling.h:189-237) from the staged conv output
                 for (int idx = lane; idx < n_out; idx += 64) {
                     const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
@@ -1541,7 +1558,7 @@ void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k)
     static const int tbs[] = { 1, 2, 4, 7, 8 }, obs[] = { 1, 2, 4 };
     // a lane that owns exactly one pooling window can max-pool in registers (no staging buffer, fewer LDS bytes per wave);
     // taken when that blocking costs no more than the best free one
-    const bool can_fuse = !k->depthwise && k->pool > 1 && k->pool == k->pool_stride &&
+    const bool can_fuse = k->pool > 1 && k->pool == k->pool_stride &&
                           (k->pool == 2 || k->pool == 4 || k->pool == 7 || k->pool == 8);
     float best[2] = { 1e30f, 1e30f };
     int btb[2] = { 1, 1 }, bob[2] = { 1, 1 };
@@ -1566,13 +1583,17 @@ long long *kws_dev_f32_prof = nullptr;      // development aid: device buffer of
 // waves per workgroup: as many as fit the CU's 160 KB of LDS (they share one copy of the weights), at most 16
 int kws_nn_f32_waves(const KwsNnPlanF32 &N)
 {
-    for (int w = 16; w > 4; w -= 4)
+    // a conv block with a channel count that is a multiple of 4 wants the 256-register build (16-byte activation reads),
+    // which serves at most 8 waves per workgroup
+    bool vec4 = false;
+    for (int b = 0; b < N.n_blocks; ++b) vec4 |= !N.blk[b].depthwise && N.blk[b].tb > 1 && (N.blk[b].in_c & 3) == 0;
+    for (int w = vec4 ? 8 : 16; w > 4; --w)
         if (kws_nn_f32_smem_bytes(N, w) <= 158 * 1024) return w;
     return 4;
 }
 
-int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips, float *scores, float *tap_logits, int n_cu,
-                      hipStream_t stream)
+int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
+                      float *tap_logits, int n_cu, hipStream_t stream)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
@@ -1587,11 +1608,11 @@ int kws_launch_nn_f32(const KwsNnPlanF32 &N, const float *features, int n_clips,
         if (e != hipSuccess) return (int)e;
     }
     if (n_waves <= 8)
-        hipLaunchKernelGGL(kws_nn_f32_kernel<512>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, N, features, n_clips, scores,
-                           tap_logits, kws_dev_f32_prof);
+        hipLaunchKernelGGL(kws_nn_f32_kernel<512>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, d_plan, features, n_clips,
+                           scores, tap_logits, kws_dev_f32_prof);
     else
-        hipLaunchKernelGGL(kws_nn_f32_kernel<1024>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, N, features, n_clips, scores,
-                           tap_logits, kws_dev_f32_prof);
+        hipLaunchKernelGGL(kws_nn_f32_kernel<1024>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, d_plan, features, n_clips,
+                           scores, tap_logits, kws_dev_f32_prof);
     return (int)hipGetLastError();
 }
 
