@@ -953,24 +953,29 @@ constexpr int KWS_A2_ROWS = 24;    // >= 15 + 8 + 1 rows of 32 B
 constexpr int KWS_MFMA_POOL = 7;
 
 // per-wave constants of the matrix-core path, fixed for the whole launch
+template <int CP>               // bytes (= padded channels) per activation row of block 1: 16, or 64 for up to 64 input channels
 struct NnMfmaCtx {
-    v4i wb1[4], wb2[4];          // weight fragments
+    static constexpr int KS1 = CP == 16 ? 4 : 16;      // k-steps of 32 for block 1: 2 taps per step, or 2 steps per tap
+    v4i wb1[KS1], wb2[4];        // weight fragments
     int b1, m1, sh1, b2, m2, sh2;
     bool oc1_ok, oc2_ok;
 };
 
-// Weight fragments: k-slot (h, j) of k-step s is tap 2s+h, channel j (block 1); the 16-byte group G = 4s+g of k-step s
-// is tap G>>1, channel half G&1 (block 2).  A and B use the same slot->k map, so the instruction's internal ordering of
-// k is irrelevant.
-__device__ __forceinline__ void nn_mfma_init(NnMfmaCtx &c, const KwsNnPlan &N, int lane)
+// Weight fragments.  Block 1, CP = 16: k-slot (h, j) of k-step s is tap 2s+h, channel j; CP = 64: k-step s is tap s>>1,
+// channels 32*(s&1) + 16*h + j (channels beyond the model's padded count are zero weights).  Block 2: the 16-byte group
+// G = 4s+g of k-step s is tap G>>1, channel half G&1.  A and B use the same slot->k map, so the instruction's internal
+// ordering of k is irrelevant.
+template <int CP>
+__device__ __forceinline__ void nn_mfma_init(NnMfmaCtx<CP> &c, const KwsNnPlan &N, int lane)
 {
     const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
     const int oc = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int tap = 2 * s + h;
+    for (int s = 0; s < NnMfmaCtx<CP>::KS1; ++s) {
+        const int tap = CP == 16 ? 2 * s + h : s >> 1;
+        const int ch = CP == 16 ? 0 : 32 * (s & 1) + 16 * h;
         v4i w = { 0, 0, 0, 0 };
-        if (oc < k1.out_c && tap < k1.taps) w = *(const v4i *)(k1.w + ((size_t)oc * k1.taps + tap) * 16);
+        if (oc < k1.out_c && tap < k1.taps && ch < k1.in_cpad) w = *(const v4i *)(k1.w + ((size_t)oc * k1.taps + tap) * k1.in_cpad + ch);
         c.wb1[s] = w;
     }
     const int oc2 = lane & 15, g = lane >> 4;
@@ -988,26 +993,30 @@ __device__ __forceinline__ void nn_mfma_init(NnMfmaCtx &c, const KwsNnPlan &N, i
 }
 
 // padding rows/columns of the activation buffers hold the input zero point ((x + input_offset) == 0) for the whole launch
+template <int CP>
 __device__ __forceinline__ void nn_mfma_fill_padding(const KwsNnPlan &N, int8_t *act1, int8_t *act2, int lane)
 {
     const int z1 = (int)((unsigned)(N.blk[0].in_zp & 0xff) * 0x01010101u), z2 = (int)((unsigned)(N.blk[1].in_zp & 0xff) * 0x01010101u);
-    for (int i = lane; i < KWS_A1_ROWS * 4; i += 64) ((int *)act1)[i] = z1;
+    for (int i = lane; i < KWS_A1_ROWS * (CP / 4); i += 64) ((int *)act1)[i] = z1;
     for (int i = lane; i < KWS_A2_ROWS * 8; i += 64) ((int *)act2)[i] = z2;
 }
 
 // One clip through both conv blocks, FC and softmax; act1 already holds the int8 input rows.
-__device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx &c, const KwsNnPlan &N, const int8_t *act1, int8_t *act2, int *vec,
+template <int CP>
+__device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx<CP> &c, const KwsNnPlan &N, const int8_t *act1, int8_t *act2, int *vec,
                                              const int8_t *s_lut1, const int8_t *s_lut2, int lane, int clip,
                                              float *__restrict__ scores, const NnTaps &taps)
 {
     const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
     const int oc1 = lane & 31, hh = lane >> 5, oc2 = lane & 15, g4 = lane >> 4;
-    // ---- conv 1: two 32-row tiles x four k-steps -------------------------------------------------------------
+    // ---- conv 1: two 32-row tiles x KS1 k-steps ---------------------------------------------------------------
     v16i acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const v4i a0 = *(const v4i *)(act1 + (oc1 + 2 * s + hh) * 16);            // row = time (lane&31) + tap
-        const v4i a1 = *(const v4i *)(act1 + (32 + oc1 + 2 * s + hh) * 16);
+    for (int s = 0; s < NnMfmaCtx<CP>::KS1; ++s) {
+        const int tap = CP == 16 ? 2 * s + hh : s >> 1;
+        const int ch = CP == 16 ? 0 : 32 * (s & 1) + 16 * hh;
+        const v4i a0 = *(const v4i *)(act1 + (oc1 + tap) * CP + ch);              // row = time (lane&31) + tap
+        const v4i a1 = *(const v4i *)(act1 + (32 + oc1 + tap) * CP + ch);
         acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, c.wb1[s], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, c.wb1[s], acc1, 0, 0, 0);
     }
@@ -1068,12 +1077,13 @@ __device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx &c, const KwsNnPlan
     nn_head(N, vec, lane, clip, scores, taps);
 }
 
+template <int CP>
 __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                               float *__restrict__ scores, NnTaps taps)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_lut1[32 * 256];
     __shared__ __attribute__((aligned(16))) int8_t s_lut2[16 * 256];
-    __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][KWS_A1_ROWS * 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][KWS_A1_ROWS * CP];
     __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][KWS_A2_ROWS * 32];
     __shared__ int s_vec[KWS_NN_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1081,20 +1091,20 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
     for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
     for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
     int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
-    nn_mfma_fill_padding(N, act1, act2, lane);
-    NnMfmaCtx ctx;
-    nn_mfma_init(ctx, N, lane);
+    nn_mfma_fill_padding<CP>(N, act1, act2, lane);
+    NnMfmaCtx<CP> ctx;
+    nn_mfma_init<CP>(ctx, N, lane);
     __syncthreads();
     const int F = N.n_features;
     for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
-        // ---- int8 input tensor [time][in_c] -> LDS rows of 16 B at row (time + pad_left) ------------------------
+        // ---- int8 input tensor [time][in_c] -> LDS rows of CP bytes at row (time + pad_left) --------------------
         const int8_t *src = q_in + (size_t)clip * F;
         for (int i = lane; i < F; i += 64) {
             const int tt = i / k1.in_c, c = i - tt * k1.in_c;
-            act1[(tt + k1.pad_left) * 16 + c] = src[i];
+            act1[(tt + k1.pad_left) * CP + c] = src[i];
         }
         WAVE_SYNC();
-        nn_mfma_clip(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
+        nn_mfma_clip<CP>(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
     }
 }
 
@@ -1121,14 +1131,14 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
     const int nfr = P.n_frames, ncep = P.n_cepstral, nfeat = nfr * ncep;
     const int prow = nfr + 2 * P.pad;
     for (int i = threadIdx.x; i < prow; i += blockDim.x) s_map[i] = P.pad_map[i];
-    NnMfmaCtx ctx;
+    NnMfmaCtx<16> ctx;
     int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
     if constexpr (FUSE) {
         const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
         for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
         for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
-        nn_mfma_fill_padding(N, act1, act2, lane);
-        nn_mfma_init(ctx, N, lane);
+        nn_mfma_fill_padding<16>(N, act1, act2, lane);
+        nn_mfma_init<16>(ctx, N, lane);
     }
     __syncthreads();
     float *mf = s_mfcc[wave];
@@ -1148,7 +1158,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
             if constexpr (FUSE) act1[(row + N.blk[0].pad_left) * 16 + c] = qb;
         });
         WAVE_SYNC();
-        if constexpr (FUSE) nn_mfma_clip(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
+        if constexpr (FUSE) nn_mfma_clip<16>(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
     }
 }
 
@@ -1158,7 +1168,7 @@ static bool nn_fits_mfma(const KwsNnPlan &N)
     if (N.n_blocks != 2) return false;
     const KwsConvBlock &a = N.blk[0], &b = N.blk[1];
     if (a.depthwise || b.depthwise) return false;
-    return a.in_cpad == 16 && a.taps <= 8 && a.out_c <= 32 && a.in_w <= 64 && a.pool == KWS_MFMA_POOL && a.pool_stride == KWS_MFMA_POOL &&
+    return (a.in_cpad == 16 || a.in_cpad <= 64) && a.taps <= 8 && a.out_c <= 32 && a.in_w <= 64 && a.pool == KWS_MFMA_POOL && a.pool_stride == KWS_MFMA_POOL &&
            a.pool_w <= KWS_MFMA_POOL && b.in_cpad == 32 && b.taps <= 8 && b.out_c <= 16 && b.in_w <= 16 && b.pool_w == 1 &&
            b.pool >= b.out_w && N.fc_in == b.out_c;
 }
@@ -1779,7 +1789,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
     NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
-    if (scores && nn_fits_mfma(N) && !kws_force_scalar_nn) {
+    if (scores && nn_fits_mfma(N) && N.blk[0].in_cpad == 16 && !kws_force_scalar_nn) {      // (64-byte rows: separate network launch)
         hipLaunchKernelGGL((kws_cmvn_nn_kernel<true>), dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, P, N, mfcc, n_clips,
                            features, q_out, scores, taps);
         *ran_nn = 1;
@@ -1813,7 +1823,10 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
     if (grid > grid_cap) grid = grid_cap;
     NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
     if (nn_fits_mfma(N) && !kws_force_scalar_nn) {
-        hipLaunchKernelGGL(kws_nn_mfma_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
+        if (N.blk[0].in_cpad == 16)
+            hipLaunchKernelGGL(kws_nn_mfma_kernel<16>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
+        else
+            hipLaunchKernelGGL(kws_nn_mfma_kernel<64>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
         return (int)hipGetLastError();
     }
     const size_t smem = kws_nn_smem_bytes(N);
