@@ -3,7 +3,7 @@
 //
 // Everything that the reference recomputes per clip on the CPU but that does not depend on the audio is computed
 // HERE once per model, with the reference's own formulas and precisions (each builder cites its source), and
-// uploaded to HBM; the per-clip arithmetic runs in kws_kernels.hip.  There is no CPU fallback: if no HIP device or
+// uploaded to HBM; the per-clip arithmetic runs in kws_mfcc.hip / kws_nn_int8.hip / kws_nn_f32.hip.  There is no CPU fallback: if no HIP device or
 // code object is available every entry point fails with KWS_ERROR_HIP.
 #include <hip/hip_runtime.h>
 
@@ -22,7 +22,7 @@
 #include "../../include/kws/kws.h"
 #include "kws_plan.h"
 
-// launchers in kws_kernels.hip
+// launchers in kws_mfcc.hip, kws_nn_int8.hip, kws_nn_f32.hip, kws_misc.hip
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
                         int out_stride, int grid_cap, hipStream_t stream);
 int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream);
@@ -473,7 +473,7 @@ static EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     P.dct_s0 = sqrtf(1.0f / (float)(4 * N));
     P.dct_s1 = sqrtf(1.0f / (float)(2 * N));
 
-    // what the gfx950 kernels implement (kws_kernels.hip: KWS_FFT, KWS_NF, KWS_MAXF ...)
+    // what the gfx950 kernels implement (kws_device.h: KWS_FFT, KWS_NF_MAX, KWS_MAXF ...)
     if (c.axes != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC block with %d axes", c.axes);
     if (c.fft_length != 256 || (c.num_filters != 32 && c.num_filters != 40))
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC kernel is built for fft_length 256 and 32 or 40 filters (got %d / %d)",

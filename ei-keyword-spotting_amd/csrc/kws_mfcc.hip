@@ -1,0 +1,515 @@
+// kws_mfcc.hip -- kws_mfcc_kernel: one wavefront owns one 1 s / 16 kHz clip.  Replaces the reference's
+// extract_mfcc_features() (SDK/classifier/ei_run_dsp.h:256-308): coalesced 16-byte int16 loads, pre-emphasis in registers,
+// the 256-point real FFT staged in LDS, power spectrum, sparse mel gather, fast log, DCT, windowed CMVN and the int8
+// quantisation of ei_run_classifier.h:436-444.  See kws_device.h for the bit-exactness contract.
+#include "kws_device.h"
+
+// one frame pair's worth of samples for this lane: 8 samples + the sample before them
+template <bool F32IN> struct RawSamples;
+template <> struct RawSamples<false> { int4 v; short prev; };
+template <> struct RawSamples<true> { float4 v0, v1; float prev; };
+
+template <bool F32IN>
+__device__ __forceinline__ RawSamples<F32IN> fetch_samples(const void *clip_base, int s0, int n_samples)
+{
+    // x[n-1] for the first of the 8 samples; at n = 0 the reference uses the LAST sample of the window
+    // (processing.hpp:68, 104-106); the caller may override that value (continuous mode), see wrap below
+    const int ip = (s0 == 0) ? (n_samples - 1) : (s0 - 1);
+    RawSamples<F32IN> r;
+    if constexpr (F32IN) {
+        const float *xf = (const float *)clip_base;
+        r.v0 = *(const float4 *)(xf + s0);
+        r.v1 = *(const float4 *)(xf + s0 + 4);
+        r.prev = xf[ip];
+    } else {
+        const int16_t *x = (const int16_t *)clip_base;
+        r.v = *(const int4 *)(x + s0);
+        r.prev = x[ip];
+    }
+    return r;
+}
+
+// kf_bfly5 with m = 1 (kiss_fft.cpp:131-192): every product and sum in the reference's order
+__device__ __forceinline__ void bfly5(cf &F0, cf &F1, cf &F2, cf &F3, cf &F4, cf t1, cf t2, cf t3, cf t4, cf ya, cf yb)
+{
+    const cf s0 = F0;
+    const cf s1 = cmul(F1, t1), s2 = cmul(F2, t2), s3 = cmul(F3, t3), s4 = cmul(F4, t4);
+    const cf s7 = cadd(s1, s4), s10 = csub(s1, s4), s8 = cadd(s2, s3), s9 = csub(s2, s3);
+    float tt, a, b;
+    tt = s7.r + s8.r; F0.r = F0.r + tt;
+    tt = s7.i + s8.i; F0.i = F0.i + tt;
+    cf s5, s6, s11, s12;
+    a = s7.r * ya.r; b = s8.r * yb.r; s5.r = (s0.r + a) + b;
+    a = s7.i * ya.r; b = s8.i * yb.r; s5.i = (s0.i + a) + b;
+    a = s10.i * ya.i; b = s9.i * yb.i; s6.r = a + b;
+    a = s10.r * ya.i; b = s9.r * yb.i; s6.i = (-a) - b;
+    F1 = csub(s5, s6);
+    F4 = cadd(s5, s6);
+    a = s7.r * yb.r; b = s8.r * ya.r; s11.r = (s0.r + a) + b;
+    a = s7.i * yb.r; b = s8.i * ya.r; s11.i = (s0.i + a) + b;
+    a = s10.i * yb.i; b = s9.i * ya.i; s12.r = (-a) + b;
+    a = s10.r * yb.i; b = s9.r * ya.i; s12.i = a - b;
+    F2 = cadd(s11, s12);
+    F3 = csub(s11, s12);
+}
+
+// numpy::dct2 of one frame (numpy.hpp:378-401 -> dct::transform, fast-dct-fft.cpp:37-80 -> kiss_fftr(NF)): v holds the NF
+// log-mel energies; R receives the NF/2+1 spectrum points the transform reads.  The complex FFT of NF/2 points is
+// kf_work's recursion unrolled: NF = 32 -> 16 = 4 x 4 (kf_bfly4, kf_bfly4); NF = 40 -> 20 = 4 x 5 (kf_bfly5 leaves of
+// stride 4, then kf_bfly4 with m = 5).
+template <int NF, typename Emit>
+__device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspPlan &P, Emit emit)   // emit(i, R[i]), i = 0..NF/2
+{
+    constexpr int NC = NF / 2;
+    // even/odd reorder (in[i] = v[2i], in[NF-1-i] = v[2i+1]) read as NC complex points
+    auto rin = [&](int i) { return (i < NC) ? v[2 * i] : v[2 * (NF - 1 - i) + 1]; };
+    cf F[NC];
+    if constexpr (NF == 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = q + 4 * j;                           // complex input index of leaf q
+                F[4 * q + j].r = rin(2 * n);
+                F[4 * q + j].i = rin(2 * n + 1);
+            }
+        const cf d0 = to_cf(P.dct_tw[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfly4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3], d0, d0, d0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+    } else {
+        static_assert(NF == 40, "DCT sizes: 32, 40");
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = q + 4 * j;
+                F[5 * q + j].r = rin(2 * n);
+                F[5 * q + j].i = rin(2 * n + 1);
+            }
+        const cf d0 = to_cf(P.dct_tw[0]), ya = to_cf(P.dct_tw[4]), yb = to_cf(P.dct_tw[8]);   // tw[fstride*m], tw[2*fstride*m]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfly5(F[5 * q], F[5 * q + 1], F[5 * q + 2], F[5 * q + 3], F[5 * q + 4], d0, d0, d0, d0, ya, yb);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            bfly4(F[k], F[k + 5], F[k + 10], F[k + 15], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+    }
+    // kiss_fftr split (kiss_fftr.cpp:84-119); every spectrum point is handed on as soon as it exists
+    cf r0, rn;
+    r0.r = F[0].r + F[0].i; r0.i = 0.0f;
+    rn.r = F[0].r - F[0].i; rn.i = 0.0f;
+    emit(0, r0);
+    emit(NC, rn);
+#pragma unroll
+    for (int k = 1; k <= NC / 2; ++k) {
+        cf fpk = F[k], fpnk;
+        fpnk.r = F[NC - k].r; fpnk.i = -F[NC - k].i;
+        cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+        cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
+        cf lo, hi;
+        lo.r = (f1k.r + twv.r) * 0.5f;
+        lo.i = (f1k.i + twv.i) * 0.5f;
+        hi.r = (f1k.r - twv.r) * 0.5f;
+        hi.i = (twv.i - f1k.i) * 0.5f;
+        if (k != NC - k) emit(k, lo);                              // k == ncfft/2: overwritten by the "ncfft-k" store
+        emit(NC - k, hi);
+    }
+}
+
+// PROF: development aid -- per-phase shader-clock totals of block 0 are written to prof_out (tools/gpu_phase_profile.py)
+#define KWS_NPHASE 10
+#define PH(i) do { if (PROF) { long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 1: MFCC.  WITH_CMVN = true is the batch hot path: extract_mfcc_features = mfcc + cmvnw + input
+//  quantisation in ONE launch, the cepstra never leave LDS.  WITH_CMVN = false stops after speechpy::feature::mfcc
+//  (feature.hpp:370-439) and writes the cepstra BEFORE cmvnw to HBM (stage API, continuous mode: there cmvnw runs
+//  over a rolling window, in kws_cmvn_nn_kernel).
+//  F32IN: samples arrive as float (the SDK's signal_t callback), else int16 PCM.  NZ: mel taps kept in registers.
+//  wrap (optional, one float per window): the value the reference's pre-emphasis uses as x[-1]; NULL = x[N-1].
+// ---------------------------------------------------------------------------------------------------------
+template <int CHP, int NF>   // frame PAIRS per chunk, mel filters
+struct alignas(16) MfccSmem {
+    static constexpr int CHF = 2 * CHP;
+    static constexpr int MELS = NF + 1;  // padded (odd) row stride of the log-mel / cepstra buffer
+    float z[2][KWS_ZF];                  // per half-wave: pre-emphasised frame, then the in-place complex FFT
+    // power spectrum [bin][frame in chunk]; after the last chunk of a clip the same storage holds the
+    // pad_1d_symmetric row map for cmvnw
+    union {
+        float p[KWS_NBINS * CHF];
+        int map[KWS_MAXPROW];
+    } u;
+    // log-mel energies [frame][filter]; the DCT overwrites each row in place with that frame's cepstra
+    float mel[kws_mel_rows(NF) * MELS];
+    float energy[kws_mel_rows(NF)];
+    float dcny[2 * CHF];                 // tmp[0] of each frame of the chunk (DC / Nyquist source)
+};
+static_assert(sizeof(MfccSmem<9, 32>) <= 20 * 1024 && sizeof(MfccSmem<9, 40>) <= 20 * 1024, "8 waves per CU need <= 20 KB LDS each");
+
+template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF = 32, bool PROF = false, bool WIDE = false>
+__global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
+                                                            float *__restrict__ features, int8_t *__restrict__ q_out,
+                                                            float in_scale, int in_zp, const float *__restrict__ wrap, int out_stride,
+                                                            long long *prof_out = nullptr)
+{
+    constexpr int CHF = 2 * CHP;
+    constexpr int MELS = NF + 1, NCEPT = NF / 2 + 1;     // DCT only produces outputs 0..NF/2 (fast-dct-fft.cpp:71)
+    __shared__ MfccSmem<CHP, NF> sm;
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, t = lane & 31;
+
+    // ---- per-lane constants, fixed for the whole launch --------------------------------------------------
+    const int k01 = t & 1, g01 = t >> 1;
+    const int n0 = (g01 >> 2) + 4 * (g01 & 3);            // digit-reversed input base of this lane's radix-4 group
+    const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
+    const int K2 = t & 7, G2 = t >> 3;
+    const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
+    const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
+    const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
+    const int nfr = P.n_frames, ncep = P.n_cepstral;
+    const int n_pairs = (nfr + 1) >> 1;
+    const int prow = nfr + 2 * P.pad;
+    float *zb = sm.z[half];
+    // NF == 32: this lane's mel filter (filter index = lane & 31 in every pass of the mel stage) keeps its ascending-bin
+    // taps in registers; other filter counts walk the CSR table
+    int fbin[NZ];
+    float fwt[NZ];
+    {
+        // NF == 32: filter lane & 31 (two frames per pass of the mel stage); other counts: filter `lane` (lanes >= NF idle)
+        const int fj = NF == 32 ? t : min(lane, NF - 1);
+        const int b0 = P.filt_start[fj], b1e = P.filt_start[fj + 1];
+#pragma unroll
+        for (int n = 0; n < NZ; ++n) {
+            const bool on = b0 + n < b1e;
+            fbin[n] = on ? P.filt_bin[b0 + n] * CHF : 0;
+            fwt[n] = on ? P.filt_w[b0 + n] : 0.0f;
+        }
+    }
+    int mapreg[KWS_MAXPROW / KWS_WAVE];    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541), KWS_WAVE entries apart
+#pragma unroll
+    for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) mapreg[i] = (lane + i * KWS_WAVE < prow) ? P.pad_map[lane + i * KWS_WAVE] : 0;
+    long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
+
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+        const void *xbase = F32IN ? (const void *)((const float *)pcm_v + (size_t)clip * P.n_samples)
+                                  : (const void *)((const int16_t *)pcm_v + (size_t)clip * P.n_samples);
+        // software prefetch, two frame pairs deep: the samples of pair p+2 are requested before pair p is transformed
+        RawSamples<F32IN> nxt = fetch_samples<F32IN>(xbase, min(half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+        RawSamples<F32IN> nxt2 = fetch_samples<F32IN>(xbase, min(2 + half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+        const bool has_wrap = wrap != nullptr;
+        const float wrapv = has_wrap ? wrap[clip] : 0.0f;
+
+        for (int pair0 = 0; pair0 < n_pairs; pair0 += CHP) {
+            const int pair1 = min(pair0 + CHP, n_pairs);
+            for (int pr = pair0; pr < pair1; ++pr) {
+                // ---- 8 samples/lane (16 B, coalesced: 32 lanes = the 256 samples of a frame that rfft keeps) -----
+                const int f = 2 * pr + half;
+                const RawSamples<F32IN> cur = nxt;
+                nxt = nxt2;
+                if (pr + 2 < n_pairs)
+                    nxt2 = fetch_samples<F32IN>(xbase, min(f + 4, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+                const bool first_sample = has_wrap && (min(f, nfr - 1) * P.frame_stride + 8 * t == 0);
+                float y[8];
+                if constexpr (F32IN) {
+                    const float v[8] = { cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w };
+                    float prev = first_sample ? wrapv : cur.prev;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float pl = P.pre_cof * prev;                                   // cof * prev, then subtract
+                        y[j] = v[j] - pl;
+                        prev = v[j];
+                    }
+                } else {
+                    float prev = first_sample ? wrapv : (float)cur.prev * (1.0f / 32768.0f);
+                    const int w[4] = { cur.v.x, cur.v.y, cur.v.z, cur.v.w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);   // numpy::int16_to_float
+                        float hi = (float)(short)(w[j] >> 16) * (1.0f / 32768.0f);
+                        float pl = P.pre_cof * prev;
+                        y[2 * j] = lo - pl;
+                        float ph_ = P.pre_cof * lo;
+                        y[2 * j + 1] = hi - ph_;
+                        prev = hi;
+                    }
+                }
+                *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);        // complex slots 4t..4t+3
+                *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                WAVE_SYNC();
+                PH(0);
+
+                // ---- kf_bfly2 (m=1) fused with kf_bfly4 (m=2): kiss_fft.cpp:232-296 levels 4 and 3 ---------
+                cf u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cf a = ld_cf(zb, n0 + 16 * i), b = ld_cf(zb, n0 + 16 * i + 64);
+                    u[i] = k01 ? csub(a, b) : cadd(a, b);       // b * tw[0], tw[0] = (1, -0)
+                }
+                bfly4(u[0], u[1], u[2], u[3], a1, a2, a3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, 8 * g01 + k01 + 2 * i, u[i]);
+                WAVE_SYNC();
+                // ---- kf_bfly4 m=8, fstride=4 ----------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
+                bfly4(u[0], u[1], u[2], u[3], b1, b2, b3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, u[i]);
+                WAVE_SYNC();
+                // ---- kf_bfly4 m=32, fstride=1 ---------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, t + 32 * i);
+                bfly4(u[0], u[1], u[2], u[3], c1, c2, c3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
+                WAVE_SYNC();
+
+                PH(1);
+                // ---- kiss_fftr split (kiss_fftr.cpp:84-119) + power spectrum -------------------------------
+                const int fr = f - 2 * pair0;                 // frame slot in the chunk
+                float *pcol = sm.u.p + fr;
+                const bool live = f < nfr;
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;            // 1..64
+                    const cf stw = rep ? st2 : st1;
+                    cf fpk = ld_cf(zb, k), fq = ld_cf(zb, KWS_NC - k);
+                    cf fpnk; fpnk.r = fq.r; fpnk.i = -fq.i;
+                    cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    cf twv = cmul(f2k, stw);
+                    cf lo, hi;
+                    lo.r = (f1k.r + twv.r) * 0.5f;             // HALF_OF
+                    lo.i = (f1k.i + twv.i) * 0.5f;
+                    hi.r = (f1k.r - twv.r) * 0.5f;
+                    hi.i = (twv.i - f1k.i) * 0.5f;
+                    if (live) {
+                        if (k != KWS_NC / 2) pcol[k * CHF] = bin_power(lo, P.inv_fft);   // k == 64: overwritten by the
+                        pcol[(KWS_NC - k) * CHF] = bin_power(hi, P.inv_fft);            // "ncfft-k" store
+                    }
+                }
+                // DC / Nyquist bins (kiss_fftr.cpp:84-96) need tmp[0] only: parked per frame, evaluated once per chunk
+                // with one frame per lane instead of one lane per wave here
+                if (t == 0 && live) *(float2 *)(sm.dcny + 2 * fr) = *(const float2 *)zb;
+                WAVE_SYNC();
+                PH(2);
+            }
+
+            // ---- per chunk: frame energy (sequential fp32 sum, numpy.hpp:88-94) -------------------------------
+            const int f_base = 2 * pair0;
+            const int nfc = min(2 * pair1, nfr) - f_base;
+            if (lane < nfc) {
+                {
+                    const float2 d = *(const float2 *)(sm.dcny + 2 * lane);
+                    cf dc, ny;
+                    dc.r = d.x + d.y; dc.i = 0.0f;
+                    ny.r = d.x - d.y; ny.i = 0.0f;
+                    sm.u.p[lane] = bin_power(dc, P.inv_fft);
+                    sm.u.p[KWS_NC * CHF + lane] = bin_power(ny, P.inv_fft);
+                }
+                // 129 ordered adds; the operands arrive 16 at a time, one batch ahead of the adds (the chain would otherwise
+                // wait for an LDS round trip per batch with only two waves per SIMD to cover it)
+                float e = 0.0f;
+                const float *pl = sm.u.p + lane;
+                static_assert((KWS_NBINS - 1) % 16 == 0, "batches of 16 bins");
+                float cur[16], nxt[16];
+                const float last = pl[(KWS_NBINS - 1) * CHF];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) cur[u] = pl[u * CHF];
+                for (int k0 = 0; k0 < KWS_NBINS - 1; k0 += 16) {
+                    const int kn = min(k0 + 16, KWS_NBINS - 1 - 16);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) nxt[u] = pl[(kn + u) * CHF];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) e += cur[u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
+                }
+                e += last;
+                if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
+                sm.energy[f_base + lane] = e;
+                if constexpr (!WITH_CMVN)
+                    if (P.mfe_energy) P.mfe_energy[(size_t)clip * nfr + f_base + lane] = e;
+            }
+            PH(3);
+            // ---- mel: sparse ascending-bin gather == dot_by_row (numpy.hpp:183-211), zero_handling, log ------
+            if constexpr (NF == 32) {
+                for (int idx = lane; idx < nfc * NF; idx += KWS_WAVE) {
+                    const int fr = idx >> 5;                                          // filter j == lane & 31 == t
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int n = 0; n < NZ; ++n) {         // taps beyond a filter's end have weight 0: power >= 0 is
+                        float prod = sm.u.p[fbin[n] + fr] * fwt[n];   // finite, so they add an exact +0
+                        acc += prod;
+                    }
+                    if (acc == 0.0f) acc = FLT_EPSILON;                                // functions.hpp:63-69
+                    if constexpr (!WITH_CMVN)
+                        if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + t] = acc;
+                    sm.mel[(f_base + fr) * MELS + t] = fast_log(acc);
+                }
+            } else {
+                // one frame per pass, lane = filter (taps in registers as above; walking the CSR table from memory
+                // instead cost a third of the kernel)
+                if (lane < NF) {
+                    for (int fr = 0; fr < nfc; ++fr) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int n = 0; n < NZ; ++n) {
+                            float prod = sm.u.p[fbin[n] + fr] * fwt[n];
+                            acc += prod;
+                        }
+                        if (acc == 0.0f) acc = FLT_EPSILON;
+                        if constexpr (!WITH_CMVN)
+                            if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + lane] = acc;
+                        sm.mel[(f_base + fr) * MELS + lane] = fast_log(acc);
+                    }
+                }
+            }
+            WAVE_SYNC();
+            PH(4);
+        }
+
+        if constexpr (!WITH_CMVN)
+            if (P.mfe_mel) { WAVE_SYNC(); continue; }                                   // MFE block: no log / DCT output
+        // ---- DCT-II via NF-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
+        // the cepstra of a frame replace its log-mel row in place (row stride MELS)
+#pragma unroll
+        for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) sm.u.map[lane + i * KWS_WAVE] = mapreg[i];
+        if (lane < nfr) {
+            float v[NF];
+            float *mrow = sm.mel + lane * MELS;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) v[i] = mrow[i];
+            float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + lane * ncep;
+            auto put = [&](int i, cf R) {
+                if (i < ncep) {
+                    float a = R.r * P.dct_cos[i];
+                    float b = R.i * P.dct_sin[i];
+                    float d = (a + b) * 2.0f;
+                    d = d * (i == 0 ? P.dct_s0 : P.dct_s1);
+                    orow[i] = d;
+                }
+            };
+            // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
+            if constexpr (NF == 32) {            // 17 spectrum points fit the register budget: scale + store after the split
+                cf R[NCEPT];
+                dct_spectrum<NF>(v, P, [&](int i, cf r) { R[i] = r; });
+#pragma unroll
+                for (int i = 0; i < NCEPT; ++i) put(i, R[i]);
+#pragma unroll
+                for (int i = NCEPT; i < NF; ++i)
+                    if (i < ncep) orow[i] = (v[i] * 2.0f) * P.dct_s1;
+            } else {                              // 40 filters: hand every point on as soon as it exists (no spills);
+                // in place: element i >= NCEPT is read, then written, by this lane only
+                for (int i = NCEPT; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * P.dct_s1;
+                dct_spectrum<NF>(v, P, put);
+            }
+            orow[0] = fast_log(sm.energy[lane]);                                       // feature.hpp:425-429
+        }
+        WAVE_SYNC();
+        PH(5);
+        if constexpr (!WITH_CMVN) continue;
+
+        // ---- cmvnw (processing.hpp:326-389) + input quantisation ---------------------------------------------
+        {
+            float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
+            int8_t *qclip = q_out ? q_out + (size_t)clip * (nfr * ncep) : nullptr;
+            int *offt = (int *)&sm.z[0][0];                       // the FFT buffers are dead by now
+            // WIDE (more than 16 cepstra, chosen at launch): 20 columns x 3 row groups of 17 rows per pass instead of
+            // 16 x 4 x 13 -- 40 cepstra take 2 passes instead of 3.  One layout per instantiation keeps the registers.
+            auto emit = [&](int row, int c, float o) {
+                const int idx = row * ncep + c;
+                if (fout) fout[idx] = o;                      // optional output (extract_mfcc_features' matrix)
+                if (qclip) qclip[idx] = quantize_feature(o, in_scale, in_zp);
+            };
+            if constexpr (WIDE) cmvn_columns<17, 20>(sm.mel, MELS, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, emit);
+            else cmvn_columns<13, 16>(sm.mel, MELS, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, emit);
+        }
+        WAVE_SYNC();
+        PH(7);
+    }
+    if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
+        for (int i = 0; i < KWS_NPHASE; ++i) prof_out[i] = ph[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  launchers (called from kws_api.cpp)
+// ---------------------------------------------------------------------------------------------------------
+int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
+// the CMVN offset table (row groups x walk length) lives in the FFT buffers: 4 x (win + 12 + 3 + 8) or 3 x (win + 16 + 3 + 8) ints
+int kws_mfcc_max_win(int n_cepstral) { (void)n_cepstral; return 2 * KWS_ZF / 4 - 23; }                 // the narrower of the two layouts
+int kws_mfcc_max_frames_for(int n_filters, int n_cepstral) { const int rows = kws_mel_rows(n_filters); return (n_filters == 40 && n_cepstral > 16) ? (rows < 51 ? rows : 51) : (rows < 52 ? rows : 52); }
+int kws_mfcc_max_nz(void) { return KWS_MAXNZ; }
+int kws_mfcc_cmvn_rows(void) { return 13; }
+int kws_mfcc_max_frames(int n_filters) { return kws_mel_rows(n_filters); }
+int kws_mfcc_fft_length(void) { return KWS_FFT; }
+
+constexpr int KWS_CHP = 9;
+
+template <bool F32IN, bool WITH_CMVN, bool PROF>
+static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, float *out, int8_t *q_out, float in_scale, int in_zp,
+                         const float *wrap, int out_stride, int grid_cap, long long *prof, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    if (n_clips <= 0) return 0;
+    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
+    if (P.n_filters == 40 && P.max_nz <= 8 && WITH_CMVN && P.n_cepstral > 16)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else if (P.n_filters == 40 && P.max_nz <= 8)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else if (P.n_filters == 40 && P.max_nz <= KWS_MAXNZ)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else if (P.n_filters != 32)
+        return (int)hipErrorInvalidValue;
+    else if (P.max_nz <= 4)
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 4, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
+                           n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    else
+        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+    return (int)hipGetLastError();
+}
+
+// extract_mfcc_features (+ quantisation) for n_clips windows in one launch
+int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
+                          float in_scale, int in_zp, int grid_cap, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    return pcm_is_float ? launch_mfcc_t<true, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream)
+                        : launch_mfcc_t<false, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream);
+}
+
+int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
+                               int in_zp, int grid_cap, long long *prof_out, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    return launch_mfcc_t<false, true, true>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, prof_out, stream);
+}
+
+// speechpy::feature::mfcc for n_clips windows -> mfcc_out[n_clips][n_frames*n_cepstral] (cepstra before cmvnw)
+// out_stride: floats between consecutive windows' outputs (0 = packed, n_frames*n_cepstral)
+int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
+                        int out_stride, int grid_cap, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    if (out_stride == 0) out_stride = P.n_frames * P.n_cepstral;
+    return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream)
+                        : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream);
+}
+
+// speechpy::feature::mfe (feature.hpp:193-318) for n_clips windows: mel energies + frame energies
+int kws_launch_mfe(const KwsDspPlan &P0, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap,
+                   hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    KwsDspPlan P = P0;
+    P.mfe_mel = mel_out;
+    P.mfe_energy = energy_out;
+    return launch_mfcc_t<false, false, false>(P, pcm, n_clips, nullptr, nullptr, 0.f, 0, nullptr, P.n_frames * P.n_cepstral, grid_cap,
+                                              nullptr, stream);
+}
+

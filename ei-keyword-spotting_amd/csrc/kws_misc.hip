@@ -1,0 +1,93 @@
+// kws_misc.hip -- small kernels: feature quantisation, the synthetic clip generator, the per-stream moving average and
+// feature-buffer shift of continuous mode.
+#include "kws_device.h"
+#include "../../include/kws/kws_synth.h"
+
+// ---------------------------------------------------------------------------------------------------------
+//  float features -> int8 input tensor (the quantise loop of run_inference, ei_run_classifier.h:436-444)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void kws_quantize_kernel(const float *__restrict__ f, int8_t *__restrict__ q, size_t n, float scale, int zp)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float qv = roundf(f[i] / scale) + (float)zp;
+        int iv = (qv >= -2147483648.0f && qv < 2147483648.0f) ? (int)qv : (int)0x80000000;
+        q[i] = (int8_t)(iv & 0xff);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  synthetic clips, generated in HBM (include/kws/kws_synth.h; bit-identical to the host generator)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void kws_synth_kernel(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out)
+{
+    for (uint32_t c = blockIdx.y; c < n_clips; c += gridDim.y) {
+        const kws_synth_params p = kws_synth_clip_params(seed, first_clip + c);
+        for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < clip_len; n += gridDim.x * blockDim.x)
+            out[(size_t)c * clip_len + n] = kws_synth_sample(&p, n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  launchers (called from kws_api.cpp)
+// ---------------------------------------------------------------------------------------------------------
+// ---- continuous mode, many streams: per-class 2-tap moving average (ei_run_classifier.h:134-145) and the feature-buffer
+//      shift (ei_run_classifier.h:277-279) for S streams advancing in lock step
+__global__ void kws_maf_kernel(float *__restrict__ scores, float *__restrict__ running_sum, float *__restrict__ maf_buf, int n,
+                               int buf_idx, int taps)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float rs = running_sum[i];
+        const float v = scores[i];
+        rs -= maf_buf[(size_t)i * taps + buf_idx];
+        rs += v;
+        maf_buf[(size_t)i * taps + buf_idx] = v;
+        running_sum[i] = rs;
+        scores[i] = rs / (float)taps;
+    }
+}
+
+__global__ void kws_shift_kernel(const float *__restrict__ src, float *__restrict__ dst, int n_streams, int F, int shift)
+{
+    const size_t total = (size_t)n_streams * F;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % F);
+        dst[i] = (k < F - shift) ? src[i + shift] : src[i];     // the tail keeps its old values, as in the reference
+    }
+}
+
+int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(kws_maf_kernel, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, stream, scores, running_sum,
+                       maf_buf, n, buf_idx, taps);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    if (n_streams <= 0) return 0;
+    size_t blocks = ((size_t)n_streams * F + 255) / 256;
+    hipLaunchKernelGGL(kws_shift_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, dst, n_streams, F, shift);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(kws_quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f, q, n, scale, zp);
+    return (int)hipGetLastError();
+}
+
+int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    if (n_clips == 0) return 0;
+    dim3 grid((clip_len + 255) / 256, n_clips < 65535u ? n_clips : 65535u);
+    hipLaunchKernelGGL(kws_synth_kernel, grid, dim3(256), 0, stream, seed, first_clip, n_clips, clip_len, out);
+    return (int)hipGetLastError();
+}

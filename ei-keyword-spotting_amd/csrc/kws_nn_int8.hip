@@ -1,0 +1,579 @@
+// kws_nn_int8.hip -- the int8 network: kws_nn_kernel (generic, v_dot4), kws_nn_mfma_kernel (matrix cores) and
+// kws_cmvn_nn_kernel (cmvnw + quantise [+ network] for the stage API / continuous mode).  Replaces the EON-compiled
+// TFLite-Micro graph (MODEL/tflite-model/trained_model_compiled.cpp:312-328).
+#include "kws_device.h"
+
+// ---------------------------------------------------------------------------------------------------------
+//  gemmlowp / TFLite fixed-point helpers (fixedpoint.h:329-368, TFL/kernels/internal/common.h:138-162)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int srdhm(int a, int b)
+{
+    const bool overflow = (a == b) && (a == (int)0x80000000);
+    const long long ab = (long long)a * (long long)b;
+    const int nudge = ab >= 0 ? (1 << 30) : (1 - (1 << 30));
+    const int hi = (int)((ab + nudge) / (1ll << 31));          // truncating division
+    return overflow ? 0x7fffffff : hi;
+}
+__device__ __forceinline__ int rdivpot(int x, int e)
+{
+    const int mask = (int)((1ll << e) - 1);
+    const int rem = x & mask;
+    const int thr = (mask >> 1) + (x < 0 ? 1 : 0);
+    return (x >> e) + (rem > thr ? 1 : 0);
+}
+__device__ __forceinline__ int mbqm(int x, int mult, int shift)
+{
+    const int ls = shift > 0 ? shift : 0, rs = shift > 0 ? 0 : -shift;
+    return rdivpot(srdhm((int)((unsigned)x << ls), mult), rs);
+}
+__device__ __forceinline__ int sat_shl(int x, int e)
+{
+    const int thr = (int)((1u << (31 - e)) - 1);
+    if (x > thr) return 0x7fffffff;
+    if (x < -thr) return (int)0x80000000;
+    return x << e;
+}
+__device__ __forceinline__ int one_over_one_plus_x(int a)     // fixedpoint.h:842-862
+{
+    const long long sum = (long long)a + 0x7fffffffll;
+    const int half_den = (int)((sum + (sum >= 0 ? 1 : -1)) / 2);
+    int x = (int)(1515870810u + (unsigned)srdhm(half_den, -1010580540));
+    for (int i = 0; i < 3; ++i) {
+        const int hdx = srdhm(half_den, x);
+        const int one_minus = (int)((1u << 29) - (unsigned)hdx);
+        x = (int)((unsigned)x + (unsigned)sat_shl(srdhm(x, one_minus), 2));
+    }
+    return sat_shl(x, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 2: the int8 CNN.  4 waves per workgroup share the weights and the ADD look-up tables in LDS; each wave
+//  owns one clip.  conv accumulators are exact int32 (v_dot4_i32_i8); because requantisation, the folded
+//  ADD+ReLU table and the clamps are all monotonically non-decreasing, max-pooling is applied to the raw
+//  accumulators first (max commutes with a non-decreasing map), then ONE requantisation per pooled output.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KWS_NN_WAVES = 4;
+constexpr int KWS_POOL_MAX = 8;
+// rows of a block's padded int8 input image in the generic kernel: un-pooled blocks are walked KWS_POOL_MAX time steps at
+// a time, so reads reach up to ceil(out_w / 8) * 8 + taps - 1
+__host__ __device__ inline int nn_rows(const KwsConvBlock &k) { return max(k.in_w, (k.out_w + KWS_POOL_MAX - 1) & ~(KWS_POOL_MAX - 1)) + k.taps; }
+
+struct NnTaps {            // optional debug outputs for the parity tests (all int8, per clip)
+    int8_t *pooled;        // concatenation of every block's pooled output [pool_w][out_c]
+    int pooled_stride;
+    int8_t *fc;            // [fc_out]
+    int8_t *out_q;         // [n_labels]
+};
+
+// FULLY_CONNECTED (integer_ops/fully_connected.h:23-63) + SOFTMAX int8->int8 (reference/softmax.h:66-144) for one clip.
+// vec: per-wave LDS scratch; bytes [0,64) hold the last pooled vector (int8), ints [16, 16+fc_out) receive the logits.
+__device__ __forceinline__ void nn_head(const KwsNnPlan &N, int *vec, int lane, int clip, float *__restrict__ scores,
+                                        const NnTaps &taps)
+{
+    // ---- FULLY_CONNECTED (integer_ops/fully_connected.h:23-63): input = last pooled vector ------------------
+    const int8_t *xin = (const int8_t *)vec;
+    int logit = 0;
+    if (lane < N.fc_out) {
+        int acc = 0;
+        for (int d = 0; d < N.fc_in; ++d)
+            acc += ((int)N.fc_w[lane * N.fc_in + d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
+        acc += N.fc_bias[lane];
+        acc = mbqm(acc, N.fc_mult, N.fc_shift) + N.fc_out_zp;
+        logit = min(max(acc, N.fc_act_min), N.fc_act_max);
+    }
+    WAVE_SYNC();
+    int *lg = vec + 16;     // logits as int32, after the (<=64 byte) pooled vector
+    if (lane < N.fc_out) {
+        lg[lane] = logit;
+        if (taps.fc) taps.fc[(size_t)clip * N.fc_out + lane] = (int8_t)logit;
+    }
+    WAVE_SYNC();
+    // ---- SOFTMAX int8 -> int8 (reference/softmax.h:66-144), every lane < n_labels redundantly ---------------
+    if (lane < N.fc_out) {
+        int mx = -128;
+        for (int c = 0; c < N.fc_out; ++c) mx = max(mx, lg[c]);
+        int sum = 0;
+        for (int c = 0; c < N.fc_out; ++c) {
+            const int d = mx - lg[c];
+            if (N.sm_valid[d]) sum = (int)((unsigned)sum + (unsigned)rdivpot(N.sm_exp[d], 12));
+        }
+        const int hp1 = sum ? __clz(sum) : 32;                                  // GetReciprocal, common.h:530-546
+        const int nbits = 12 - hp1;
+        const int ssm1 = (int)(((unsigned)sum << hp1) - (1u << 31));
+        const int scale = one_over_one_plus_x(ssm1);
+        const int d = mx - logit;
+        int o = -128;
+        if (N.sm_valid[d]) {
+            const int unsat = rdivpot(srdhm(scale, N.sm_exp[d]), nbits + 31 - 8);
+            o = min(max(unsat - 128, -128), 127);
+        }
+        if (taps.out_q) taps.out_q[(size_t)clip * N.fc_out + lane] = (int8_t)o;
+        scores[(size_t)clip * N.fc_out + lane] = (float)(o - N.out_zp) * N.out_scale;   // ei_run_classifier.h:470
+    }
+    WAVE_SYNC();
+}
+
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+                                                                         float *__restrict__ scores, NnTaps taps)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- shared: weights + ADD tables of every block ---------------------------------------------------------
+    unsigned char *sp = smem_raw;
+    const int8_t *s_w[KWS_MAX_BLOCKS];
+    const int8_t *s_lut[KWS_MAX_BLOCKS];
+    int act_bytes = 0;
+    for (int b = 0; b < N.n_blocks; ++b) {
+        const KwsConvBlock &k = N.blk[b];
+        const int wbytes = k.w_bytes;
+        for (int i = threadIdx.x * 4; i < wbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.w + i);
+        s_w[b] = (const int8_t *)sp;
+        sp += (wbytes + 15) & ~15;
+        const int lbytes = k.has_lut ? k.out_c * 256 : 0;
+        for (int i = threadIdx.x * 4; i < lbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.add_lut + i);
+        s_lut[b] = (const int8_t *)sp;
+        sp += lbytes;
+        const int ab = nn_rows(k) * k.in_cpad;
+        act_bytes = max(act_bytes, ab);
+    }
+    act_bytes = (act_bytes + 15) & ~15;
+    // per wave: two activation buffers (ping-pong) + a small vector for FC/softmax
+    int8_t *actA = (int8_t *)(sp + wave * (2 * act_bytes + 64 * 4));
+    int8_t *actB = actA + act_bytes;
+    int *vec = (int *)(actB + act_bytes);
+    __syncthreads();
+
+    const int F = N.n_features;
+    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+        // ---- stage the int8 input as [pad_left + t][in_cpad], padding = zero point ((x + offset) == 0) -------
+        {
+            const KwsConvBlock &k = N.blk[0];
+            const int rows = nn_rows(k);
+            const int zp4 = (int)((unsigned)(k.in_zp & 0xff) * 0x01010101u);
+            for (int i = lane * 4; i < rows * k.in_cpad; i += 64 * 4) *(int *)(actA + i) = zp4;
+            WAVE_SYNC();
+            const int8_t *src = q_in + (size_t)clip * F;
+            for (int i = lane; i < k.in_w * k.in_c; i += 64) {
+                const int tt = i / k.in_c, c = i - tt * k.in_c;
+                actA[(tt + k.pad_left) * k.in_cpad + c] = src[i];
+            }
+            WAVE_SYNC();
+        }
+        int8_t *cur = actA, *nxt = actB;
+        int pooled_off = 0;
+        for (int b = 0; b < N.n_blocks; ++b) {
+            const KwsConvBlock &k = N.blk[b];
+            const bool last = (b + 1 == N.n_blocks);
+            const int nrows = last ? 0 : nn_rows(N.blk[b + 1]);
+            const int ncp = last ? k.out_c : N.blk[b + 1].in_cpad;
+            const int npl = last ? 0 : N.blk[b + 1].pad_left;
+            if (!last) {
+                const int zp4 = (int)((unsigned)(N.blk[b + 1].in_zp & 0xff) * 0x01010101u);
+                for (int i = lane * 4; i < nrows * ncp; i += 64 * 4) *(int *)(nxt + i) = zp4;
+                WAVE_SYNC();
+            }
+            const int n_out = k.pool_w * k.out_c;
+            // requantise + folded ADD/ReLU of one pooled accumulator, store (integer_ops/conv.h:111-116, add.h)
+            auto finish = [&](int m, int pw, int oc) {
+                m += k.bias_eff[oc];
+                int r = mbqm(m, k.mult[oc], k.shift[oc]) + k.out_zp;
+                r = min(max(r, k.act_min), k.act_max);
+                const int8_t o = k.has_lut ? s_lut[b][oc * 256 + (r + 128)] : (int8_t)r;
+                const int idx = pw * k.out_c + oc;
+                if (last) ((int8_t *)vec)[idx] = o;
+                else nxt[(npl + pw) * ncp + oc] = o;
+                if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
+            };
+            if (k.depthwise) {                           // integer_ops/depthwise_conv.h:64-103: one input channel per output
+                const int tp4 = (k.taps + 3) & ~3;
+                for (int idx = lane; idx < n_out; idx += 64) {
+                    const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                    const int t0 = pw * k.pool_stride;
+                    int acc[KWS_POOL_MAX];
+#pragma unroll
+                    for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i] = 0;
+                    const int8_t *wrow = s_w[b] + oc * tp4;
+                    const int8_t *xcol = cur + t0 * k.in_cpad + oc / k.depth_mult;
+                    for (int tap = 0; tap < k.taps; ++tap) {
+                        const int wv = wrow[tap];
+#pragma unroll
+                        for (int i = 0; i < KWS_POOL_MAX; ++i)
+                            if (i < k.pool) acc[i] += wv * (int)xcol[(i + tap) * k.in_cpad];
+                    }
+                    int m = (int)0x80000000;
+#pragma unroll
+                    for (int i = 0; i < KWS_POOL_MAX; ++i)
+                        if (i < k.pool && t0 + i < k.out_w) m = max(m, acc[i]);
+                    finish(m, pw, oc);
+                }
+            } else {
+                // a lane owns one pooling window of OB = 2 (or 1) output channels: every 16-byte activation read feeds
+                // 4 * OB dot products, every 16-byte weight read `pool` of them
+                // (an un-pooled block is walked in groups of KWS_POOL_MAX time steps, each stored on its own)
+                const bool pooled = k.pool > 1;
+                const int tb = pooled ? k.pool : KWS_POOL_MAX, tstride = pooled ? k.pool_stride : KWS_POOL_MAX;
+                const int n_tb = pooled ? k.pool_w : (k.out_w + KWS_POOL_MAX - 1) / KWS_POOL_MAX;
+                const int ob = (n_tb * k.out_c > 64 && (k.out_c & 1) == 0) ? 2 : 1;
+                const int n_ocb = k.out_c / ob;
+                const int c16n = k.in_cpad >> 4;
+                for (int item = lane; item < n_tb * n_ocb; item += 64) {
+                    const int pw = item / n_ocb, oc0 = (item - pw * n_ocb) * ob;
+                    const int t0 = pw * tstride;
+                    int acc[KWS_POOL_MAX][2];
+#pragma unroll
+                    for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i][0] = acc[i][1] = 0;
+                    const int8_t *w0 = s_w[b] + (size_t)oc0 * k.taps * k.in_cpad;
+                    const int8_t *w1 = w0 + (ob == 2 ? k.taps * k.in_cpad : 0);
+                    for (int tap = 0; tap < k.taps; ++tap) {
+                        const int8_t *xrow = cur + (t0 + tap) * k.in_cpad;
+                        for (int c16 = 0; c16 < c16n; ++c16) {
+                            const int4 wa = *(const int4 *)(w0 + tap * k.in_cpad + 16 * c16);
+                            const int4 wb = *(const int4 *)(w1 + tap * k.in_cpad + 16 * c16);
+#pragma unroll
+                            for (int i = 0; i < KWS_POOL_MAX; ++i) {
+                                if (i < tb) {
+                                    const int4 xv = *(const int4 *)(xrow + i * k.in_cpad + 16 * c16);
+                                    int a = acc[i][0], c = acc[i][1];
+                                    a = __builtin_amdgcn_sdot4(wa.x, xv.x, a, false);
+                                    a = __builtin_amdgcn_sdot4(wa.y, xv.y, a, false);
+                                    a = __builtin_amdgcn_sdot4(wa.z, xv.z, a, false);
+                                    a = __builtin_amdgcn_sdot4(wa.w, xv.w, a, false);
+                                    if (ob == 2) {
+                                        c = __builtin_amdgcn_sdot4(wb.x, xv.x, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb.y, xv.y, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb.z, xv.z, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb.w, xv.w, c, false);
+                                    }
+                                    acc[i][0] = a; acc[i][1] = c;
+                                }
+                            }
+                        }
+                    }
+                    for (int o = 0; o < ob; ++o) {
+                        if (pooled) {
+                            int m = (int)0x80000000;
+#pragma unroll
+                            for (int i = 0; i < KWS_POOL_MAX; ++i)
+                                if (i < tb && t0 + i < k.out_w) m = max(m, acc[i][o]);
+                            finish(m, pw, oc0 + o);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < KWS_POOL_MAX; ++i)
+                                if (t0 + i < k.out_w) finish(acc[i][o], t0 + i, oc0 + o);
+                        }
+                    }
+                }
+            }
+            pooled_off += n_out;
+            WAVE_SYNC();
+            int8_t *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        nn_head(N, vec, lane, clip, scores, taps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 2, matrix-core path for the shipped graph shape (two conv blocks: time<=64 x 16ch x <=8 taps -> <=32 ch,
+//  pool 7/7; then time<=16 x 32ch x <=8 taps -> <=16 ch, global pool).  The 1xK convolutions are genuine
+//  contractions: per clip  [time x (taps*16)] x [(taps*16) x out_c]  on v_mfma_i32_32x32x32_i8 (8 per clip) and
+//  [time x (taps*32)] x [(taps*32) x out_c] on v_mfma_i32_16x16x64_i8 (4 per clip).  int32 accumulation is exact, so
+//  the result is bit-identical to the reference's scalar loops whatever the summation order.  One wave per clip;
+//  weight fragments stay in registers for the whole launch; activations are read from LDS as aligned 16-byte rows.
+// ---------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int KWS_A1_ROWS = 72;    // >= 63 + 8 + 1 rows of 16 B: activations of block 1, row = time + tap
+constexpr int KWS_A2_ROWS = 24;    // >= 15 + 8 + 1 rows of 32 B
+constexpr int KWS_MFMA_POOL = 7;
+
+// per-wave constants of the matrix-core path, fixed for the whole launch
+template <int CP>               // bytes (= padded channels) per activation row of block 1: 16, or 64 for up to 64 input channels
+struct NnMfmaCtx {
+    static constexpr int KS1 = CP == 16 ? 4 : 16;      // k-steps of 32 for block 1: 2 taps per step, or 2 steps per tap
+    v4i wb1[KS1], wb2[4];        // weight fragments
+    int b1, m1, sh1, b2, m2, sh2;
+    bool oc1_ok, oc2_ok;
+};
+
+// Weight fragments.  Block 1, CP = 16: k-slot (h, j) of k-step s is tap 2s+h, channel j; CP = 64: k-step s is tap s>>1,
+// channels 32*(s&1) + 16*h + j (channels beyond the model's padded count are zero weights).  Block 2: the 16-byte group
+// G = 4s+g of k-step s is tap G>>1, channel half G&1.  A and B use the same slot->k map, so the instruction's internal
+// ordering of k is irrelevant.
+template <int CP>
+__device__ __forceinline__ void nn_mfma_init(NnMfmaCtx<CP> &c, const KwsNnPlan &N, int lane)
+{
+    const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+    const int oc = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < NnMfmaCtx<CP>::KS1; ++s) {
+        const int tap = CP == 16 ? 2 * s + h : s >> 1;
+        const int ch = CP == 16 ? 0 : 32 * (s & 1) + 16 * h;
+        v4i w = { 0, 0, 0, 0 };
+        if (oc < k1.out_c && tap < k1.taps && ch < k1.in_cpad) w = *(const v4i *)(k1.w + ((size_t)oc * k1.taps + tap) * k1.in_cpad + ch);
+        c.wb1[s] = w;
+    }
+    const int oc2 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int G = 4 * s + g, tap = G >> 1, ch = G & 1;
+        v4i w = { 0, 0, 0, 0 };
+        if (oc2 < k2.out_c && tap < k2.taps) w = *(const v4i *)(k2.w + ((size_t)oc2 * k2.taps + tap) * 32 + ch * 16);
+        c.wb2[s] = w;
+    }
+    c.oc1_ok = oc < k1.out_c;
+    c.b1 = c.oc1_ok ? k1.bias_eff[oc] : 0; c.m1 = c.oc1_ok ? k1.mult[oc] : 0; c.sh1 = c.oc1_ok ? k1.shift[oc] : 0;
+    c.oc2_ok = oc2 < k2.out_c;
+    c.b2 = c.oc2_ok ? k2.bias_eff[oc2] : 0; c.m2 = c.oc2_ok ? k2.mult[oc2] : 0; c.sh2 = c.oc2_ok ? k2.shift[oc2] : 0;
+}
+
+// padding rows/columns of the activation buffers hold the input zero point ((x + input_offset) == 0) for the whole launch
+template <int CP>
+__device__ __forceinline__ void nn_mfma_fill_padding(const KwsNnPlan &N, int8_t *act1, int8_t *act2, int lane)
+{
+    const int z1 = (int)((unsigned)(N.blk[0].in_zp & 0xff) * 0x01010101u), z2 = (int)((unsigned)(N.blk[1].in_zp & 0xff) * 0x01010101u);
+    for (int i = lane; i < KWS_A1_ROWS * (CP / 4); i += 64) ((int *)act1)[i] = z1;
+    for (int i = lane; i < KWS_A2_ROWS * 8; i += 64) ((int *)act2)[i] = z2;
+}
+
+// One clip through both conv blocks, FC and softmax; act1 already holds the int8 input rows.
+template <int CP>
+__device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx<CP> &c, const KwsNnPlan &N, const int8_t *act1, int8_t *act2, int *vec,
+                                             const int8_t *s_lut1, const int8_t *s_lut2, int lane, int clip,
+                                             float *__restrict__ scores, const NnTaps &taps)
+{
+    const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+    const int oc1 = lane & 31, hh = lane >> 5, oc2 = lane & 15, g4 = lane >> 4;
+    // ---- conv 1: two 32-row tiles x KS1 k-steps ---------------------------------------------------------------
+    v16i acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
+#pragma unroll
+    for (int s = 0; s < NnMfmaCtx<CP>::KS1; ++s) {
+        const int tap = CP == 16 ? 2 * s + hh : s >> 1;
+        const int ch = CP == 16 ? 0 : 32 * (s & 1) + 16 * hh;
+        const v4i a0 = *(const v4i *)(act1 + (oc1 + tap) * CP + ch);              // row = time (lane&31) + tap
+        const v4i a1 = *(const v4i *)(act1 + (32 + oc1 + tap) * CP + ch);
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, c.wb1[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, c.wb1[s], acc1, 0, 0, 0);
+    }
+    // ---- max-pool 7/7 on the raw accumulators (monotone requantisation, see the scalar kernel) --------------
+    // accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+    int pm[KWS_MFMA_POOL];
+#pragma unroll
+    for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = (int)0x80000000;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = mt ? acc1[r] : acc0[r];
+            const int t0 = 32 * mt + (r & 3) + 8 * (r >> 2), t1 = t0 + 4;       // time if lane>>5 is 0 / 1
+            if (t0 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t0 / KWS_MFMA_POOL] = max(pm[t0 / KWS_MFMA_POOL], hh == 0 ? v : (int)0x80000000);
+            if (t1 / KWS_MFMA_POOL < KWS_MFMA_POOL) pm[t1 / KWS_MFMA_POOL] = max(pm[t1 / KWS_MFMA_POOL], hh == 1 ? v : (int)0x80000000);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KWS_MFMA_POOL; ++i) pm[i] = max(pm[i], __shfl_xor(pm[i], 32));
+    // requantise + ADD/ReLU table: half-wave 0 takes pooled rows 0..3, half-wave 1 rows 4..6
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pw = i + 4 * hh;
+        const int m = (hh == 0) ? pm[i] : pm[(i + 4 < KWS_MFMA_POOL) ? i + 4 : 0];
+        if (c.oc1_ok && pw < k1.pool_w) {
+            int rq = mbqm(m + c.b1, c.m1, c.sh1) + k1.out_zp;
+            rq = min(max(rq, k1.act_min), k1.act_max);
+            const int8_t o = s_lut1[oc1 * 256 + (rq + 128)];
+            act2[(pw + k2.pad_left) * 32 + oc1] = o;
+            if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pw * k1.out_c + oc1] = o;
+        }
+    }
+    WAVE_SYNC();
+    // ---- conv 2: one 16-row tile x four k-steps of 64 ----------------------------------------------------------
+    v4i c2 = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int G = 4 * s + g4;
+        const v4i a = *(const v4i *)(act2 + (oc2 + (G >> 1)) * 32 + (G & 1) * 16);  // row = time (lane&15) + tap
+        c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c.wb2[s], c2, 0, 0, 0);
+    }
+    // accumulator register r of a 16x16 tile holds row 4*(lane>>4) + r, column lane&15; global max-pool over time
+    int pm2 = (int)0x80000000;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * g4 + r < k2.out_w) pm2 = max(pm2, c2[r]);
+    pm2 = max(pm2, __shfl_xor(pm2, 16));
+    pm2 = max(pm2, __shfl_xor(pm2, 32));
+    if (lane < 16 && c.oc2_ok) {
+        int rq = mbqm(pm2 + c.b2, c.m2, c.sh2) + k2.out_zp;
+        rq = min(max(rq, k2.act_min), k2.act_max);
+        const int8_t o = s_lut2[oc2 * 256 + (rq + 128)];
+        ((int8_t *)vec)[oc2] = o;
+        if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + k1.pool_w * k1.out_c + oc2] = o;
+    }
+    WAVE_SYNC();
+    nn_head(N, vec, lane, clip, scores, taps);
+}
+
+template <int CP>
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+                                                                              float *__restrict__ scores, NnTaps taps)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_lut1[32 * 256];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut2[16 * 256];
+    __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][KWS_A1_ROWS * CP];
+    __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][KWS_A2_ROWS * 32];
+    __shared__ int s_vec[KWS_NN_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+    for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
+    for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
+    int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
+    nn_mfma_fill_padding<CP>(N, act1, act2, lane);
+    NnMfmaCtx<CP> ctx;
+    nn_mfma_init<CP>(ctx, N, lane);
+    __syncthreads();
+    const int F = N.n_features;
+    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+        // ---- int8 input tensor [time][in_c] -> LDS rows of CP bytes at row (time + pad_left) --------------------
+        const int8_t *src = q_in + (size_t)clip * F;
+        for (int i = lane; i < F; i += 64) {
+            const int tt = i / k1.in_c, c = i - tt * k1.in_c;
+            act1[(tt + k1.pad_left) * CP + c] = src[i];
+        }
+        WAVE_SYNC();
+        nn_mfma_clip<CP>(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  Kernel 2': cmvnw (processing.hpp:326-389) + input quantisation (ei_run_classifier.h:436-444) [+ the network when
+//  FUSE and the graph fits the matrix-core path].  One wave per window, 4 waves per workgroup.
+//  CMVN: cmvn_columns<13, 16> (shared with kws_mfcc_kernel).
+// ---------------------------------------------------------------------------------------------------------
+template <bool FUSE>
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel(KwsDspPlan P, KwsNnPlan N, const float *__restrict__ mfcc,
+                                                                              int n_clips, float *__restrict__ features,
+                                                                              int8_t *__restrict__ q_out, float *__restrict__ scores,
+                                                                              NnTaps taps)
+{
+    __shared__ int s_map[KWS_MAXPROW];                                    // numpy::pad_1d_symmetric row map (numpy.hpp:479-541)
+    __shared__ float s_mfcc[KWS_NN_WAVES][KWS_MAXF * KWS_NF_MAX];       // cepstra before CMVN, [frame][coef] (coef <= filters)
+    __shared__ __attribute__((aligned(16))) int s_off[KWS_NN_WAVES][2 * KWS_ZF];   // cmvn_columns' row-offset table (same bound as in kws_mfcc_kernel)
+    __shared__ __attribute__((aligned(16))) int8_t s_lut1[FUSE ? 32 * 256 : 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut2[FUSE ? 16 * 256 : 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][FUSE ? KWS_A1_ROWS * 16 : 16];
+    __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][FUSE ? KWS_A2_ROWS * 32 : 16];
+    __shared__ int s_vec[KWS_NN_WAVES][FUSE ? 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nfr = P.n_frames, ncep = P.n_cepstral, nfeat = nfr * ncep;
+    const int prow = nfr + 2 * P.pad;
+    for (int i = threadIdx.x; i < prow; i += blockDim.x) s_map[i] = P.pad_map[i];
+    NnMfmaCtx<16> ctx;
+    int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
+    if constexpr (FUSE) {
+        const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+        for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
+        for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
+        nn_mfma_fill_padding<16>(N, act1, act2, lane);
+        nn_mfma_init<16>(ctx, N, lane);
+    }
+    __syncthreads();
+    float *mf = s_mfcc[wave];
+    const int win = P.win_size;
+    const float in_scale = N.in_scale;
+    const int in_zp = N.in_zp;
+
+    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+        const float *src = mfcc + (size_t)clip * nfeat;
+        for (int i = lane; i < nfeat; i += 64) mf[i] = src[i];
+        WAVE_SYNC();
+        cmvn_columns<13, 16>(mf, ncep, s_map, s_off[wave], lane, nfr, ncep, prow, win, [&](int row, int c, float o) {
+            const int idx = row * ncep + c;
+            if (features) features[(size_t)clip * nfeat + idx] = o;
+            const int8_t qb = quantize_feature(o, in_scale, in_zp);
+            if (q_out) q_out[(size_t)clip * nfeat + idx] = qb;
+            if constexpr (FUSE) act1[(row + N.blk[0].pad_left) * 16 + c] = qb;
+        });
+        WAVE_SYNC();
+        if constexpr (FUSE) nn_mfma_clip<16>(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
+    }
+}
+
+// the matrix-core kernel covers this graph shape; anything else runs on kws_nn_kernel
+static bool nn_fits_mfma(const KwsNnPlan &N)
+{
+    if (N.n_blocks != 2) return false;
+    const KwsConvBlock &a = N.blk[0], &b = N.blk[1];
+    if (a.depthwise || b.depthwise) return false;
+    return (a.in_cpad == 16 || a.in_cpad <= 64) && a.taps <= 8 && a.out_c <= 32 && a.in_w <= 64 && a.pool == KWS_MFMA_POOL && a.pool_stride == KWS_MFMA_POOL &&
+           a.pool_w <= KWS_MFMA_POOL && b.in_cpad == 32 && b.taps <= 8 && b.out_c <= 16 && b.in_w <= 16 && b.pool_w == 1 &&
+           b.pool >= b.out_w && N.fc_in == b.out_c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  launchers (called from kws_api.cpp)
+// ---------------------------------------------------------------------------------------------------------
+static bool nn_fits_mfma(const KwsNnPlan &N);
+int kws_force_scalar_nn = 0;   // tests: run the generic (dot4) kernel even when the matrix-core kernel applies
+int kws_nn_uses_mfma(const KwsNnPlan &N) { return nn_fits_mfma(N) && !kws_force_scalar_nn; }
+
+// cmvnw + quantise (+ the network when it fits the matrix-core path and scores != NULL).  Returns 1 in *ran_nn if the
+// network ran inside this launch.
+int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
+                       float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
+                       int *ran_nn, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    *ran_nn = 0;
+    if (n_clips <= 0) return 0;
+    int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
+    if (grid > grid_cap) grid = grid_cap;
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
+    if (scores && nn_fits_mfma(N) && N.blk[0].in_cpad == 16 && !kws_force_scalar_nn) {      // (64-byte rows: separate network launch)
+        hipLaunchKernelGGL((kws_cmvn_nn_kernel<true>), dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, P, N, mfcc, n_clips,
+                           features, q_out, scores, taps);
+        *ran_nn = 1;
+    } else {
+        hipLaunchKernelGGL((kws_cmvn_nn_kernel<false>), dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, P, N, mfcc, n_clips,
+                           features, q_out, scores, taps);
+    }
+    return (int)hipGetLastError();
+}
+size_t kws_nn_smem_bytes(const KwsNnPlan &N)
+{
+    size_t s = 0;
+    int act = 0;
+    for (int b = 0; b < N.n_blocks; ++b) {
+        const KwsConvBlock &k = N.blk[b];
+        s += ((size_t)k.w_bytes + 15) & ~(size_t)15;
+        s += k.has_lut ? (size_t)k.out_c * 256 : 0;
+        const int ab = nn_rows(k) * k.in_cpad;
+        act = ab > act ? ab : act;
+    }
+    act = (act + 15) & ~15;
+    return s + (size_t)KWS_NN_WAVES * (2 * act + 64 * 4);
+}
+
+int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
+                  int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream)
+{
+    (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
+    if (n_clips <= 0) return 0;
+    int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
+    if (grid > grid_cap) grid = grid_cap;
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
+    if (nn_fits_mfma(N) && !kws_force_scalar_nn) {
+        if (N.blk[0].in_cpad == 16)
+            hipLaunchKernelGGL(kws_nn_mfma_kernel<16>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
+        else
+            hipLaunchKernelGGL(kws_nn_mfma_kernel<64>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
+        return (int)hipGetLastError();
+    }
+    const size_t smem = kws_nn_smem_bytes(N);
+    if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute((const void *)kws_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), smem, stream, N, q_in, n_clips, scores, taps);
+    return (int)hipGetLastError();
+}
+
