@@ -1,0 +1,182 @@
+// kws_internal.h -- shared by the host translation units of libkws_mi355x.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kws/kws.h"
+#include "kws_plan.h"
+
+// launchers in kws_mfcc.hip, kws_nn_int8.hip, kws_nn_f32.hip, kws_misc.hip
+int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
+                        int out_stride, int grid_cap, hipStream_t stream);
+int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream);
+int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream);
+int kws_launch_mfe(const KwsDspPlan &P, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap, hipStream_t stream);
+int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
+                          float in_scale, int in_zp, int grid_cap, hipStream_t stream);
+int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
+                               int in_zp, int grid_cap, long long *prof_out, hipStream_t stream);
+int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
+                       float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
+                       int *ran_nn, hipStream_t stream);
+int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
+                      float *tap_logits, int n_cu, hipStream_t stream);
+size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);
+void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k);
+int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
+                  int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream);
+int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
+int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
+size_t kws_nn_smem_bytes(const KwsNnPlan &N);
+extern int kws_force_scalar_nn;
+int kws_nn_uses_mfma(const KwsNnPlan &N);
+int kws_mfcc_max_prow(void);
+int kws_mfcc_max_win(int n_cepstral);
+int kws_mfcc_max_frames_for(int n_filters, int n_cepstral);
+int kws_mfcc_max_nz(void);
+int kws_mfcc_cmvn_rows(void);
+int kws_mfcc_max_frames(int n_filters);
+
+
+// ---- errors: the last failure of the calling thread (message via kws_last_error()) ---------------------------------------
+EI_IMPULSE_ERROR kws_fail(EI_IMPULSE_ERROR code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+EI_IMPULSE_ERROR kws_last_error_code(void);
+#define fail kws_fail
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(KWS_ERROR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- model blob (layout: tools/eon_import.py) -----------------------------------------------------------------------------
+
+enum { OP_RESHAPE = 0, OP_CONV_2D, OP_ADD, OP_MAX_POOL_2D, OP_FULLY_CONNECTED, OP_SOFTMAX, OP_DEPTHWISE_CONV_2D };
+enum { TYPE_F32 = 1, TYPE_I32 = 2, TYPE_I8 = 9 };
+
+struct Tensor {
+    uint32_t type = 0;
+    std::vector<int> dims;
+    bool is_const = false;
+    std::vector<float> scale;
+    std::vector<int32_t> zero;
+    int qdim = 0;
+    uint32_t nbytes = 0;
+    std::vector<uint8_t> data;
+    int dim4(int i) const { int pad = 4 - (int)dims.size(); return i < pad ? 1 : dims[i - pad]; }
+};
+struct Node {
+    uint32_t op = 0;
+    std::vector<int> in, out;
+    int p[8] = { 0 };
+    float beta = 0;
+};
+struct DspCfg {
+    int axes, num_cepstral, num_filters, fft_length, win_size, low_frequency, high_frequency, pre_shift;
+    float frame_length, frame_stride, pre_cof;
+};
+struct Model {
+    std::vector<Tensor> t;
+    std::vector<Node> n;
+    std::vector<std::string> labels;
+    uint32_t t_in = 0, t_out = 0, raw_sample_count = 0, frequency = 0, nn_input_frame_size = 0;
+    DspCfg dsp;
+};
+
+// kws_model.cpp: blob parser and the host arithmetic the table builders need (same formulas as the reference's setup code)
+bool parse_model(const void *blob, size_t nbytes, Model &m);
+float h_fast_log(float a);
+float h_freq_to_mel(float f);
+float h_mel_to_freq(float mel);
+void h_linspace(float start, float stop, uint32_t number, float *out);
+std::vector<float> h_filterbank(int num_filter, int coefficients, uint32_t fs, uint32_t low, uint32_t high);
+void h_twiddles(int nfft, std::vector<float2> &tw);
+void h_super_twiddles(int ncfft, std::vector<float2> &st);
+void h_pad_map(int rows, int pad, std::vector<int> &map);
+int32_t h_srdhm(int32_t a, int32_t b);
+int32_t h_rdivpot(int32_t x, int e);
+void h_quantize_multiplier(double m, int32_t *q, int *shift);
+int32_t h_wadd(int32_t a, int32_t b);
+int32_t h_wsub(int32_t a, int32_t b);
+int32_t h_sat_shl(int32_t x, int e);
+int32_t h_exp_interval(int32_t a);
+int32_t h_exp_neg_q5_26(int32_t a);
+void h_act_range(int activation, float scale, int32_t zp, int32_t *amin, int32_t *amax);
+int h_out_size(int padding, int image, int filter, int stride, int dil);
+int h_pad_amount(int stride, int dil, int in_size, int filter, int out);
+
+// ------------------------------------------------------------------------------------------------------------
+//  handle
+// ------------------------------------------------------------------------------------------------------------
+struct kws_handle {
+    Model model;
+    int device = 0;
+    int n_cu = 256;
+    KwsDspPlan dsp{};
+    KwsNnPlan nn{};
+    bool is_float = false;        // float32 model: nnf is the plan, nn only carries a neutral input quantisation
+    KwsNnPlanF32 nnf{};
+    const KwsNnPlanF32 *d_nnf = nullptr;   // the same plan in device memory (the float kernel reads it from there)
+    int pooled_tap_bytes = 0;
+    std::vector<void *> dev_allocs;
+    // scratch for the combined entry points (grown on demand)
+    float *s_mfcc = nullptr;      // cepstra before CMVN, [B][n_features]
+    int8_t *s_q = nullptr;
+    size_t s_cap = 0;
+    std::mutex mu;
+    // single-clip workspace of the SDK entry points: allocated once, pinned host staging, own stream
+    struct Ws {
+        float *h_x = nullptr, *d_x = nullptr;     // samples / slice (host pinned, device)
+        size_t cap_x = 0;
+        float *d_f = nullptr, *d_s = nullptr, *d_w = nullptr;   // features (or cepstra), scores, wrap sample
+        int8_t *d_q = nullptr;
+        float *h_s = nullptr, *h_f = nullptr;     // pinned: scores, features
+        hipStream_t st = nullptr;
+    } ws;
+    std::mutex sdk_mu;            // the SDK entry points are serialised (the reference is non-reentrant)
+    // continuous-mode state (ei_run_classifier.h:115-121, 187)
+    std::vector<float> cont_features;
+    size_t slice_offset = 0;
+    bool feature_buffer_full = false;
+    bool cont_first_run = false;
+    std::vector<ei_impulse_maf> maf;
+
+    template <typename T> EI_IMPULSE_ERROR upload(const std::vector<T> &v, const T **out)
+    {
+        void *d = nullptr;
+        size_t nb = std::max<size_t>(v.size() * sizeof(T), 16);
+        HIP_TRY(hipMalloc(&d, nb));
+        dev_allocs.push_back(d);
+        if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        *out = (const T *)d;
+        return EI_IMPULSE_OK;
+    }
+};
+
+// kws_plan.cpp: execution plans (tables computed once per model, uploaded to HBM)
+EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h);
+EI_IMPULSE_ERROR build_nn_plan(kws_handle *h);
+
+// kws_api.cpp: stage launchers shared with the stream / SDK entry points (kws_sdk.cpp); internal, not exported
+#define KWS_INTERNAL __attribute__((visibility("hidden")))
+extern "C" {
+KWS_INTERNAL EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B);
+KWS_INTERNAL int grid_cap_mfcc(const kws_handle *h);
+KWS_INTERNAL int grid_cap_nn(const kws_handle *h);
+KWS_INTERNAL EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
+                                 const float *wrap, hipStream_t s, int out_stride = 0);
+KWS_INTERNAL EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s);
+KWS_INTERNAL EI_IMPULSE_ERROR nn_f32_device(kws_handle *h, const float *features, size_t B, float *scores, float *tap_logits, hipStream_t s);
+KWS_INTERNAL EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, float *features, int8_t *q, float *scores,
+                                int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out, hipStream_t s);
+}

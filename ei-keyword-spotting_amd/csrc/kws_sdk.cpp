@@ -1,0 +1,402 @@
+// kws_sdk.cpp -- continuous mode for many streams (kws_streams_*) and the SDK-compatible single-clip entry points of
+// include/kws/ei_compat.h (run_classifier, run_classifier_continuous, run_inference, ...).
+#include "kws_internal.h"
+
+#pragma GCC visibility push(default)     // the library is built with -fvisibility=hidden: only the C ABI is exported
+extern "C" {
+// ------------------------------------------------------------------------------------------------------------
+//  continuous mode for S streams in lock step ("many concurrent streams, per-stream state in HBM")
+// ------------------------------------------------------------------------------------------------------------
+struct kws_stream_batch {
+    kws_handle *h = nullptr;
+    size_t S = 0;
+    float *feat[2] = { nullptr, nullptr };   // rolling cepstra buffers [S][F] (ping-pong for the shift)
+    int cur = 0;
+    float *running_sum = nullptr, *maf_buf = nullptr;   // [S][C], [S][C][taps]
+    float *zeros = nullptr;                   // [S] end-of-signal samples when the caller gives none
+    size_t slice_offset = 0;
+    bool full = false, first_run = false;     // first_run: like the reference's function-static, never reset
+    uint32_t buf_idx = 0;
+};
+static const int kMafTaps = EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW >> 1;
+
+void kws_streams_destroy(kws_stream_batch *sb)
+{
+    if (!sb) return;
+    for (void *p : { (void *)sb->feat[0], (void *)sb->feat[1], (void *)sb->running_sum, (void *)sb->maf_buf, (void *)sb->zeros })
+        if (p) (void)hipFree(p);
+    delete sb;
+}
+
+EI_IMPULSE_ERROR kws_streams_init(kws_stream_batch *sb)          // run_classifier_init for every stream
+{
+    if (!sb) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(sb->h->device));
+    const size_t C = sb->h->model.labels.size();
+    sb->slice_offset = 0;
+    sb->full = false;
+    sb->buf_idx = 0;
+    HIP_TRY(hipMemset(sb->running_sum, 0, sb->S * C * sizeof(float)));
+    HIP_TRY(hipMemset(sb->maf_buf, 0, sb->S * C * kMafTaps * sizeof(float)));
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_streams_create(kws_handle *h, size_t S, kws_stream_batch **out)
+{
+    if (!h || !out || S == 0 || S > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "bad argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(h->device));
+    kws_stream_batch *sb = new kws_stream_batch();
+    sb->h = h; sb->S = S;
+    const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
+    bool ok = hipMalloc((void **)&sb->feat[0], S * F * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->feat[1], S * F * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->running_sum, S * C * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->maf_buf, S * C * kMafTaps * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&sb->zeros, S * sizeof(float)) == hipSuccess;
+    if (ok) ok = hipMemset(sb->feat[0], 0, S * F * sizeof(float)) == hipSuccess && hipMemset(sb->feat[1], 0, S * F * sizeof(float)) == hipSuccess &&
+                 hipMemset(sb->zeros, 0, S * sizeof(float)) == hipSuccess;
+    if (!ok) { kws_streams_destroy(sb); return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed"); }
+    EI_IMPULSE_ERROR e = kws_streams_init(sb);
+    if (e) { kws_streams_destroy(sb); return e; }
+    *out = sb;
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *slices, size_t slice_samples, const float *end_of_signal,
+                                         float *scores, int *produced, void *stream)
+{
+    if (!sb || !slices || !scores || !produced) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    kws_handle *h = sb->h;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const Model &m = h->model;
+    const size_t F = m.nn_input_frame_size, C = m.labels.size(), S = sb->S;
+    *produced = 0;
+    // extract_mfcc_per_slice_features: every step but the first claims one more frame length (ei_run_dsp.h:319-325)
+    size_t n_claimed = slice_samples;
+    const bool grown = sb->first_run;
+    if (grown) n_claimed += (size_t)(m.dsp.frame_length * (float)m.frequency);
+    sb->first_run = true;
+    const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
+    const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
+    const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)m.dsp.num_cepstral;
+    if (nf < 1 || nf > kws_mfcc_max_frames(h->dsp.n_filters) || feature_size > F || sb->slice_offset + feature_size > F ||
+        (size_t)(nf - 1) * stride + h->dsp.fft_len > slice_samples || (slice_samples * 2) % 16 != 0)
+        return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples (claimed %zu) yields %d frames", slice_samples, n_claimed, nf);
+    KwsDspPlan P = h->dsp;
+    P.n_samples = (int)slice_samples;      // memory stride between the streams' slices
+    P.n_frames = nf;
+    // x[-1] of the slice: the reference takes the sample at total_length-1, which lies beyond the slice once it has grown
+    const float *wrap = grown ? (end_of_signal ? end_of_signal : sb->zeros) : nullptr;
+    float *feat = sb->feat[sb->cur];
+    EI_IMPULSE_ERROR e = spectral_device(h, P, slices, 0, S, feat + sb->slice_offset, wrap, st, (int)F);
+    if (e) return e;
+    if (!sb->full) {
+        sb->slice_offset += feature_size;
+        if (sb->slice_offset > (F - feature_size)) { sb->full = true; sb->slice_offset -= feature_size; }
+    }
+    if (!sb->full) return EI_IMPULSE_OK;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        e = ensure_scratch(h, S);
+        if (!e) e = cmvn_nn_device(h, feat, S, nullptr, nullptr, scores, nullptr, nullptr, nullptr, st);
+    }
+    if (e) return e;
+    int rc = kws_launch_maf(scores, sb->running_sum, sb->maf_buf, (int)(S * C), (int)sb->buf_idx, kMafTaps, st);
+    if (rc) return fail(KWS_ERROR_HIP, "moving-average kernel launch failed");
+    if (++sb->buf_idx >= (uint32_t)kMafTaps) sb->buf_idx = 0;
+    rc = kws_launch_shift(feat, sb->feat[sb->cur ^ 1], (int)S, (int)F, (int)feature_size, st);
+    if (rc) return fail(KWS_ERROR_HIP, "shift kernel launch failed");
+    sb->cur ^= 1;
+    *produced = 1;
+    return EI_IMPULSE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+//  SDK-compatible single-clip entry points
+// ------------------------------------------------------------------------------------------------------------
+// workspace for one window / slice of n_x float samples
+static EI_IMPULSE_ERROR ensure_ws(kws_handle *h, size_t n_x)
+{
+    kws_handle::Ws &w = h->ws;
+    const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
+    auto oom = [&]() { return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed"); };
+    if (!w.st) {
+        if (hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking) != hipSuccess) return fail(KWS_ERROR_HIP, "stream creation failed");
+        if (hipMalloc((void **)&w.d_f, F * sizeof(float)) != hipSuccess || hipMalloc((void **)&w.d_s, C * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&w.d_w, 16) != hipSuccess || hipMalloc((void **)&w.d_q, F + 16) != hipSuccess ||
+            hipHostMalloc((void **)&w.h_s, C * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&w.h_f, F * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return oom();
+    }
+    if (n_x > w.cap_x) {
+        if (w.d_x) (void)hipFree(w.d_x);
+        if (w.h_x) (void)hipHostFree(w.h_x);
+        w.d_x = nullptr; w.h_x = nullptr; w.cap_x = 0;
+        if (hipMalloc((void **)&w.d_x, n_x * sizeof(float)) != hipSuccess ||
+            hipHostMalloc((void **)&w.h_x, n_x * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return oom();
+        w.cap_x = n_x;
+    }
+    return EI_IMPULSE_OK;
+}
+
+static kws_handle *g_default = nullptr;
+static bool g_default_owned = false;
+static std::mutex g_default_mu;
+
+EI_IMPULSE_ERROR kws_set_default_model(kws_handle *h)
+{
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g_default && g_default_owned && g_default != h) kws_destroy(g_default);
+    g_default = h;
+    g_default_owned = false;
+    return EI_IMPULSE_OK;
+}
+
+kws_handle *kws_default_model(void)
+{
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        const char *path = getenv("KWS_MODEL");
+        if (!path) { fail(KWS_ERROR_NO_MODEL, "no model: call kws_set_default_model() or set KWS_MODEL"); return nullptr; }
+        const char *dev = getenv("KWS_DEVICE");
+        kws_handle *h = nullptr;
+        if (kws_create_from_file(path, dev ? atoi(dev) : 0, &h) != EI_IMPULSE_OK) return nullptr;
+        g_default = h;
+        g_default_owned = true;
+    }
+    return g_default;
+}
+
+// The label count of the loaded model decides where `anomaly` and `timing` sit behind the classification array
+// (classifier/ei_classifier_types.h:41-45): the caller's ei_impulse_result_t must be compiled for that model.
+static void fill_result(const kws_handle *h, ei_impulse_result_t *result, const float *scores, bool debug, int ms)
+{
+    const int C = (int)h->model.labels.size();
+    ei_impulse_result_classification_t *cls = (ei_impulse_result_classification_t *)result;
+    ei_impulse_result_timing_t *timing = (ei_impulse_result_timing_t *)((char *)result + (size_t)C * sizeof(*cls) + sizeof(float));
+    timing->classification = ms;
+    if (debug) ei_printf("Predictions (time: %d ms.):\n", ms);
+    for (int ix = 0; ix < C; ix++) {
+        if (debug) { ei_printf("%s:\t", h->model.labels[ix].c_str()); ei_printf_float(scores[ix]); ei_printf("\n"); }
+        cls[ix].label = h->model.labels[ix].c_str();
+        cls[ix].value = scores[ix];
+    }
+}
+static ei_impulse_result_timing_t *result_timing(const kws_handle *h, ei_impulse_result_t *result)
+{
+    const size_t C = h->model.labels.size();
+    return (ei_impulse_result_timing_t *)((char *)result + C * sizeof(ei_impulse_result_classification_t) + sizeof(float));
+}
+
+EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result, bool debug)
+{
+    kws_handle *h = kws_default_model();
+    if (!h) return kws_last_error_code() != EI_IMPULSE_OK ? kws_last_error_code() : KWS_ERROR_NO_MODEL;   // why the default model is missing
+    if (!fmatrix || !fmatrix->buffer || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
+    if ((size_t)fmatrix->rows * fmatrix->cols != F) return fail(EI_IMPULSE_ERROR_SHAPES_DONT_MATCH, "feature matrix is %ux%u, model needs %zu", fmatrix->rows, fmatrix->cols, F);
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
+    uint64_t t0 = ei_read_timer_ms();
+    std::vector<float> scores(C);
+    EI_IMPULSE_ERROR e = ensure_ws(h, 1);
+    if (e) return e;
+    kws_handle::Ws &w = h->ws;
+    memcpy(w.h_f, fmatrix->buffer, F * sizeof(float));
+    if (hipMemcpyAsync(w.d_f, w.h_f, F * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+    if (!e) e = kws_run_inference_batch_device(h, w.d_f, 1, w.d_s, w.st);
+    if (!e && (hipMemcpyAsync(w.h_s, w.d_s, C * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+               hipStreamSynchronize(w.st) != hipSuccess)) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+    if (e) return e;
+    memcpy(scores.data(), w.h_s, C * sizeof(float));
+    fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t0));
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;     // ei_run_classifier.h:489-491
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, bool debug)
+{
+    kws_handle *h = kws_default_model();
+    if (!h) return kws_last_error_code() != EI_IMPULSE_OK ? kws_last_error_code() : KWS_ERROR_NO_MODEL;   // why the default model is missing
+    if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    const size_t n = h->model.raw_sample_count, F = h->model.nn_input_frame_size, C = h->model.labels.size();
+    // The reference sizes its frame count from signal->total_length (ei_run_dsp.h:277-286); a length that yields another
+    // feature count than the model's is EIDSP_MATRIX_SIZE_MISMATCH there (-> EI_IMPULSE_DSP_ERROR).
+    if (signal->total_length != n) { ei_printf("ERR: Failed to run DSP process (%d)\n", -1002); return fail(EI_IMPULSE_DSP_ERROR, "signal length %zu, model window %zu", signal->total_length, n); }
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
+    uint64_t t0 = ei_read_timer_ms();
+    EI_IMPULSE_ERROR e = ensure_ws(h, n);
+    if (e) return e;
+    kws_handle::Ws &w = h->ws;
+    // gather the window through the caller's callback (float samples, as the SDK hands them to the DSP block) straight
+    // into pinned memory
+    const size_t chunk = 4000;
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t len = std::min(chunk, n - off);
+        int r = signal->get_data(off, len, w.h_x + off);
+        if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
+    }
+    std::vector<float> scores(C);
+    if (hipMemcpyAsync(w.d_x, w.h_x, n * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+    if (!e) e = mfcc_fused_device(h, w.d_x, 1, 1, w.d_f, h->is_float ? nullptr : w.d_q, w.st);
+    if (!e && debug && hipMemcpyAsync(w.h_f, w.d_f, F * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+    if (!e && hipStreamSynchronize(w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "MFCC kernel failed");
+    if (e) return e;
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;   // ei_run_classifier.h:689-691
+    const int dsp_ms = (int)(ei_read_timer_ms() - t0);
+    result_timing(h, result)->dsp = dsp_ms;
+    if (debug) {
+        ei_printf("Features (%d ms.): ", dsp_ms);
+        for (size_t ix = 0; ix < F; ix++) { ei_printf_float(w.h_f[ix]); ei_printf(" "); }
+        ei_printf("\n");
+        ei_printf("Running neural network...\n");
+    }
+    uint64_t t1 = ei_read_timer_ms();
+    e = h->is_float ? nn_f32_device(h, w.d_f, 1, w.d_s, nullptr, w.st) : kws_nn_batch_device(h, w.d_q, 1, w.d_s, nullptr, nullptr, nullptr, w.st);
+    if (!e && (hipMemcpyAsync(w.h_s, w.d_s, C * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+               hipStreamSynchronize(w.st) != hipSuccess)) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+    if (e) return e;
+    memcpy(scores.data(), w.h_s, C * sizeof(float));
+    fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t1));
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+    return EI_IMPULSE_OK;
+}
+
+// ei_run_classifier.h:134-145
+float run_moving_average_filter(ei_impulse_maf *maf, float classification)
+{
+    maf->running_sum -= maf->maf_buffer[maf->buf_idx];
+    maf->running_sum += classification;
+    maf->maf_buffer[maf->buf_idx] = classification;
+    if (++maf->buf_idx >= (EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW >> 1)) maf->buf_idx = 0;
+    return maf->running_sum / (float)(EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW >> 1);
+}
+
+// ei_run_classifier.h:164-172
+void run_classifier_init(void)
+{
+    kws_handle *h = kws_default_model();
+    if (!h) return;
+    h->slice_offset = 0;
+    h->feature_buffer_full = false;
+    h->cont_first_run = false;
+    h->cont_features.assign(h->model.nn_input_frame_size, 0.0f);
+    for (auto &m : h->maf) { m.buf_idx = 0; m.running_sum = 0; for (float &v : m.maf_buffer) v = 0.f; }
+}
+
+// ei_run_classifier.h:184-282 + ei_run_dsp.h:310-366 -- continuous (sliced) mode.  One call = one slice of audio:
+// cepstra of the slice (speechpy::feature::mfcc, no CMVN) are appended to a rolling feature buffer; once it is full every
+// call normalises a copy of the whole buffer (cmvnw), runs the network and a 2-tap moving average per class.
+// The slice's MFCC and the window's cmvnw + network run on the GPU (kws_mfcc_kernel<WITH_CMVN=false>,
+// kws_cmvn_nn_kernel); the rolling buffer and the filters are host state of the default model handle.
+//
+// Reference quirks that are kept: a function-static `first_run` (ei_run_dsp.h:313) that NOTHING resets makes every call
+// but the process's first grow signal->total_length by one frame length IN THE CALLER'S STRUCT and take one more frame;
+// the pre-emphasis constructor then asks get_data for the sample at total_length-1 (beyond the slice) and ignores the
+// callback's return value (buffer pre-zeroed).
+static bool g_cont_first_run = false;
+
+EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t *result, bool debug)
+{
+    kws_handle *h = kws_default_model();
+    if (!h) return kws_last_error_code() != EI_IMPULSE_OK ? kws_last_error_code() : KWS_ERROR_NO_MODEL;   // why the default model is missing
+    if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    const Model &m = h->model;
+    const size_t F = m.nn_input_frame_size, C = m.labels.size();
+    const int ncep = m.dsp.num_cepstral;
+    if (h->cont_features.size() != F) h->cont_features.assign(F, 0.0f);         // static_features_matrix (calloc'd)
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t dsp_start_ms = ei_read_timer_ms();
+
+    // ---- extract_mfcc_per_slice_features ----------------------------------------------------------------------
+    if (g_cont_first_run) signal->total_length += (size_t)(m.dsp.frame_length * (float)m.frequency);
+    g_cont_first_run = true;
+    const size_t n_claimed = signal->total_length;
+    float eos = 0.0f;                                                           // _end_of_signal_buffer (calloc)
+    if (n_claimed >= 1) (void)signal->get_data(n_claimed - (size_t)m.dsp.pre_shift, (size_t)m.dsp.pre_shift, &eos);
+    const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
+    const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
+    const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)ncep;
+    if (nf < 1 || feature_size > F || h->slice_offset + feature_size > F || nf > kws_mfcc_max_frames(h->dsp.n_filters)) {
+        ei_printf("ERR: MFCC failed (%d)\n", -1002);                           // EIDSP_MATRIX_SIZE_MISMATCH
+        ei_printf("ERR: Failed to run DSP process (%d)\n", -1002);
+        return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples yields %d frames", n_claimed, nf);
+    }
+    const size_t needed = (size_t)(nf - 1) * stride + frame_len;                // last sample any frame reads
+    const size_t n_x = std::max(n_claimed, needed) + 16;
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
+    EI_IMPULSE_ERROR e = ensure_ws(h, n_x);
+    if (e) return e;
+    kws_handle::Ws &w = h->ws;
+    memset(w.h_x, 0, n_x * sizeof(float));
+    {
+        int r = signal->get_data(0, needed, w.h_x);
+        if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
+    }
+    w.h_s[0] = eos;                                                              // staged through pinned memory
+    if (hipMemcpyAsync(w.d_x, w.h_x, n_x * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess ||
+        hipMemcpyAsync(w.d_w, w.h_s, sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+    if (!e) {
+        KwsDspPlan P = h->dsp;                // same tables, this slice's framing
+        P.n_samples = (int)n_claimed;
+        P.n_frames = nf;
+        e = spectral_device(h, P, w.d_x, 1, 1, w.d_f, w.d_w, w.st);
+    }
+    if (!e && (hipMemcpyAsync(w.h_f, w.d_f, feature_size * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+               hipStreamSynchronize(w.st) != hipSuccess))
+        e = fail(KWS_ERROR_HIP, "d2h copy failed");
+    if (e) return e;
+    memcpy(h->cont_features.data() + h->slice_offset, w.h_f, feature_size * sizeof(float));
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+
+    // ---- rolling buffer bookkeeping (ei_run_classifier.h:229-239) ------------------------------------------------
+    if (!h->feature_buffer_full) {
+        h->slice_offset += feature_size;
+        if (h->slice_offset > (F - feature_size)) {
+            h->feature_buffer_full = true;
+            h->slice_offset -= feature_size;
+        }
+    }
+    ei_impulse_result_timing_t *timing = result_timing(h, result);
+    timing->dsp = (int)(ei_read_timer_ms() - dsp_start_ms);
+    if (debug) {
+        ei_printf("\r\nFeatures (%d ms.): ", timing->dsp);
+        for (size_t ix = 0; ix < F; ix++) { ei_printf_float(h->cont_features[ix]); ei_printf(" "); }
+        ei_printf("\n");
+        ei_printf("Running neural network...\n");
+    }
+    if (h->feature_buffer_full) {
+        dsp_start_ms = ei_read_timer_ms();
+        // calc_cepstral_mean_and_var_normalization on a COPY of the buffer, then run_inference
+        std::vector<float> scores(C);
+        uint64_t t1 = 0;
+        memcpy(w.h_f, h->cont_features.data(), F * sizeof(float));
+        if (hipMemcpyAsync(w.d_f, w.h_f, F * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
+        if (!e) {
+            std::lock_guard<std::mutex> lk(h->mu);
+            e = ensure_scratch(h, 1);
+            t1 = ei_read_timer_ms();
+            if (!e) e = cmvn_nn_device(h, w.d_f, 1, nullptr, nullptr, w.d_s, nullptr, nullptr, nullptr, w.st);
+        }
+        if (!e && (hipMemcpyAsync(w.h_s, w.d_s, C * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess ||
+                   hipStreamSynchronize(w.st) != hipSuccess)) e = fail(KWS_ERROR_HIP, "d2h copy failed");
+        if (e) return e;
+        memcpy(scores.data(), w.h_s, C * sizeof(float));
+        timing->dsp += (int)(t1 - dsp_start_ms);
+        fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t1));
+        ei_impulse_result_classification_t *cls = (ei_impulse_result_classification_t *)result;
+        for (size_t ix = 0; ix < C; ix++) cls[ix].value = run_moving_average_filter(&h->maf[ix], cls[ix].value);
+        // shift the feature buffer for new data (ei_run_classifier.h:277-279)
+        for (size_t i = 0; i < F - feature_size; i++) h->cont_features[i] = h->cont_features[i + feature_size];
+        if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+        return EI_IMPULSE_OK;
+    }
+    return EI_IMPULSE_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop
