@@ -188,6 +188,8 @@ EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm
 // development aid (not in the public headers): per-phase shader-clock totals of wave 0 of the float network kernel
 extern long long *kws_dev_f32_prof;
 void kws_dev_set_f32_prof(long long *dev_buf) { kws_dev_f32_prof = dev_buf; }
+extern long long *kws_dev_nn_prof;
+void kws_dev_set_nn_prof(long long *dev_buf) { kws_dev_nn_prof = dev_buf; }
 
 // development/test aid (not in the public headers): force the generic dot4 NN kernel
 void kws_dev_force_scalar_nn(int on) { kws_force_scalar_nn = on; }

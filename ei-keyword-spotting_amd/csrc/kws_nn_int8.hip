@@ -63,6 +63,7 @@ struct NnTaps {            // optional debug outputs for the parity tests (all i
     int pooled_stride;
     int8_t *fc;            // [fc_out]
     int8_t *out_q;         // [n_labels]
+    long long *prof;       // development aid: shader-clock totals per phase of wave 0 of workgroup 0 (generic kernel), or NULL
 };
 
 // FULLY_CONNECTED (integer_ops/fully_connected.h:23-63) + SOFTMAX int8->int8 (reference/softmax.h:66-144) for one clip.
@@ -145,6 +146,9 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
     __syncthreads();
 
     const int F = N.n_features;
+    const bool profiling = taps.prof != nullptr && blockIdx.x == 0 && wave == 0;
+    long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;
+    auto mark = [&](int i) { if (profiling) { const long long now = clock64(); ph[i] += now - tlast; tlast = now; } };
     for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
         // ---- stage the int8 input as [pad_left + t][in_cpad], padding = zero point ((x + offset) == 0) -------
         {
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
             }
             WAVE_SYNC();
         }
+        mark(0);
         int8_t *cur = actA, *nxt = actB;
         int pooled_off = 0;
         for (int b = 0; b < N.n_blocks; ++b) {
@@ -175,9 +180,11 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
             }
             const int n_out = k.pool_w * k.out_c;
             // requantise + folded ADD/ReLU of one pooled accumulator, store (integer_ops/conv.h:111-116, add.h)
-            auto finish = [&](int m, int pw, int oc) {
-                m += k.bias_eff[oc];
-                int r = mbqm(m, k.mult[oc], k.shift[oc]) + k.out_zp;
+            struct Rq { int bias, mult, shift; };                // per-channel requantisation constants, fetched once per item
+            auto rq_of = [&](int oc) { Rq q = { k.bias_eff[oc], k.mult[oc], k.shift[oc] }; return q; };
+            auto finish = [&](int m, int pw, int oc, const Rq &q) {
+                m += q.bias;
+                int r = mbqm(m, q.mult, q.shift) + k.out_zp;
                 r = min(max(r, k.act_min), k.act_max);
                 const int8_t o = k.has_lut ? s_lut[b][oc * 256 + (r + 128)] : (int8_t)r;
                 const int idx = pw * k.out_c + oc;
@@ -185,7 +192,64 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
                 else nxt[(npl + pw) * ncp + oc] = o;
                 if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
             };
-            if (k.depthwise) {                           // integer_ops/depthwise_conv.h:64-103: one input channel per output
+            if (k.depthwise && k.depth_mult == 1 && (k.out_c & 3) == 0 && k.taps <= 8) {
+                // integer_ops/depthwise_conv.h:64-103, one input channel per output.  A lane owns 4 consecutive channels of
+                // one pooling window (or of 8 time steps when the block is not pooled): the tb + taps - 1 activation rows
+                // it needs are read ONCE as 32-bit words (4 channels each), the 4 x taps weights as 8 words, everything
+                // else is register arithmetic -- one pass over the block instead of one LDS round trip per multiply
+                const bool pooled = k.pool > 1;
+                const int tb = pooled ? k.pool : KWS_POOL_MAX, tstride = pooled ? k.pool_stride : KWS_POOL_MAX;
+                const int n_tb = pooled ? k.pool_w : (k.out_w + KWS_POOL_MAX - 1) / KWS_POOL_MAX;
+                const int n_cg = k.out_c >> 2, tp4 = (k.taps + 3) & ~3, nrow = tb + k.taps - 1;
+                for (int item = lane; item < n_tb * n_cg; item += 64) {
+                    const int pw = item / n_cg, oc0 = (item - pw * n_cg) * 4;
+                    const int t0 = pw * tstride;
+                    int xw[KWS_POOL_MAX + 7], ww[4][2];
+#pragma unroll
+                    for (int r = 0; r < KWS_POOL_MAX + 7; ++r)
+                        xw[r] = r < nrow ? *(const int *)(cur + (t0 + r) * k.in_cpad + oc0) : 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int *wr = (const int *)(s_w[b] + (oc0 + c) * tp4);
+                        ww[c][0] = wr[0];
+                        ww[c][1] = tp4 > 4 ? wr[1] : 0;
+                    }
+                    int acc[KWS_POOL_MAX][4];
+#pragma unroll
+                    for (int i = 0; i < KWS_POOL_MAX; ++i)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[i][c] = 0;
+#pragma unroll
+                    for (int tap = 0; tap < 8; ++tap) {
+                        if (tap < k.taps) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int wv = (ww[c][tap >> 2] << (24 - 8 * (tap & 3))) >> 24;      // sign-extended byte
+#pragma unroll
+                                for (int i = 0; i < KWS_POOL_MAX; ++i)
+                                    if (i < tb) acc[i][c] += wv * ((xw[i + tap] << (24 - 8 * c)) >> 24);
+                            }
+                        }
+                    }
+                    Rq rq[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rq[c] = rq_of(oc0 + c);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (pooled) {
+                            int m = (int)0x80000000;
+#pragma unroll
+                            for (int i = 0; i < KWS_POOL_MAX; ++i)
+                                if (i < tb && t0 + i < k.out_w) m = max(m, acc[i][c]);
+                            finish(m, pw, oc0 + c, rq[c]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < KWS_POOL_MAX; ++i)
+                                if (t0 + i < k.out_w) finish(acc[i][c], t0 + i, oc0 + c, rq[c]);
+                        }
+                    }
+                }
+            } else if (k.depthwise) {                    // any depth multiplier / channel count: one output per lane and pass
                 const int tp4 = (k.taps + 3) & ~3;
                 for (int idx = lane; idx < n_out; idx += 64) {
                     const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
@@ -205,7 +269,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
 #pragma unroll
                     for (int i = 0; i < KWS_POOL_MAX; ++i)
                         if (i < k.pool && t0 + i < k.out_w) m = max(m, acc[i]);
-                    finish(m, pw, oc);
+                    finish(m, pw, oc, rq_of(oc));
                 }
             } else {
                 // a lane owns one pooling window of OB = 2 (or 1) output channels: every 16-byte activation read feeds
@@ -251,26 +315,31 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
                         }
                     }
                     for (int o = 0; o < ob; ++o) {
+                        const Rq rq = rq_of(oc0 + o);
                         if (pooled) {
                             int m = (int)0x80000000;
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i)
                                 if (i < tb && t0 + i < k.out_w) m = max(m, acc[i][o]);
-                            finish(m, pw, oc0 + o);
+                            finish(m, pw, oc0 + o, rq);
                         } else {
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i)
-                                if (t0 + i < k.out_w) finish(acc[i][o], t0 + i, oc0 + o);
+                                if (t0 + i < k.out_w) finish(acc[i][o], t0 + i, oc0 + o, rq);
                         }
                     }
                 }
             }
             pooled_off += n_out;
             WAVE_SYNC();
+            mark(1 + b);
             int8_t *tmp = cur; cur = nxt; nxt = tmp;
         }
         nn_head(N, vec, lane, clip, scores, taps);
+        mark(1 + KWS_MAX_BLOCKS);
     }
+    if (profiling && lane == 0)
+        for (int i = 0; i < KWS_MAX_BLOCKS + 2; ++i) taps.prof[i] = ph[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -513,6 +582,7 @@ static bool nn_fits_mfma(const KwsNnPlan &N)
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
 static bool nn_fits_mfma(const KwsNnPlan &N);
+long long *kws_dev_nn_prof = nullptr;   // development aid (tools/gpu_nn_phase_profile.py)
 int kws_force_scalar_nn = 0;   // tests: run the generic (dot4) kernel even when the matrix-core kernel applies
 int kws_nn_uses_mfma(const KwsNnPlan &N) { return nn_fits_mfma(N) && !kws_force_scalar_nn; }
 
@@ -527,7 +597,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
-    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q, kws_dev_nn_prof };
     if (scores && nn_fits_mfma(N) && N.blk[0].in_cpad == 16 && !kws_force_scalar_nn) {      // (64-byte rows: separate network launch)
         hipLaunchKernelGGL((kws_cmvn_nn_kernel<true>), dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, P, N, mfcc, n_clips,
                            features, q_out, scores, taps);
@@ -560,7 +630,7 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
-    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q };
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q, kws_dev_nn_prof };
     if (nn_fits_mfma(N) && !kws_force_scalar_nn) {
         if (N.blk[0].in_cpad == 16)
             hipLaunchKernelGGL(kws_nn_mfma_kernel<16>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
