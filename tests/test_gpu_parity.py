@@ -687,3 +687,24 @@ def test_streams_with_float_and_40band_models(pkg, oracle):
         assert n_prod > 0
         sb.close()
         gm.close()
+
+
+def test_soak_headline_model_2048_clips(pkg, oracle):
+    """A longer randomised comparison for the 49x40 fp32 graph bench.py times: 4.0 M feature words bit for bit, every
+    score within 1e-6 of the restated reference float kernels, logits bit for bit."""
+    from kws_testlib import OracleModel
+    path = os.path.join(MODELS, "cfg2_mfcc40_f32.kwsm")
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    n = 2048
+    clips = oracle.synth(777, 4242, n)
+    s, f, _ = gm.run_classifier_batch(clips, want_features=True)
+    so, fo, _ = om.run_batch(clips, want_features=True)
+    assert int((bits(f) != bits(fo)).sum()) == 0
+    assert np.abs(s - so).max() <= F32_SCORE_TOL
+    _, lg = _f32_logits(pkg, gm, f)
+    n_t = len(om.tensor_bytes)
+    for i in range(0, n, 97):
+        _, taps = om.nn_invoke_f32(fo[i], taps=True)
+        assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), i
+    gm.close()
