@@ -110,7 +110,7 @@ def cpu_baseline(seconds=8.0, model_path=DEFAULT_MODEL):
     wall = time.time() - t0
     return {"value": round(sum(rates), 1), "unit": "clips/s", "cores": len(rates), "kind": kind,
             "per_core": round(sum(rates) / max(1, len(rates)), 1), "single_process": round(single, 1),
-            "model": os.path.basename(model_path),
+            "kwsm_file": os.path.basename(model_path),
             "sample": "%d concurrent processes, each looping the reference's MFCC + network over %d seed-0 synthetic clips "
                       "for %.0f s (%.1f s wall incl. start-up)" % (len(rates), n_clips, seconds, wall)}
 
@@ -236,7 +236,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+f64 (MFCC) / %s (CNN)" % ("f32" if is_float else "i8"), "data": "synthetic",
-            "config": {"workload": workload(r["model"]), "clips_per_gpu": B, "global_batch": world * B, "model": r["model"],
+            "config": {"workload": workload(r["model"]), "clips_per_gpu": B, "global_batch": world * B, "kwsm_file": r["model"],
                        "parity": parity(is_float), "collective": "all_gather(scores) over RCCL" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "kws_mfcc_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -246,7 +246,7 @@ def main():
             "checksum": r["checksum"],
         }
         if also:
-            out["also"] = [{"model": x["model"], "workload": workload(x["model"]), "value": round(B * a.steps / x["dt"], 1),
+            out["also"] = [{"kwsm_file": x["model"], "workload": workload(x["model"]), "value": round(B * a.steps / x["dt"], 1),
                             "unit": "clips/s", "ms_per_step": round(x["dt"] / a.steps * 1e3, 4),
                             "dtype": "f32+f64 (MFCC) / %s (CNN)" % ("f32" if x["is_float"] else "i8"), "parity": parity(x["is_float"]),
                             "kernel_ms": {"kws_mfcc_kernel": round(x["ms_mfcc"], 4), x["nn_kernel"]: round(x["ms_nn"], 4)},
