@@ -10,13 +10,14 @@
 //  expf is the device's.  Zero-padded activation rows stand in for the reference's skipped out-of-image taps: they add
 //  an exact 0 (x*0 = +-0, and total + (+-0) == total for every total the chain can hold, +0 included).
 //
-//  The 148 k multiply-adds per clip are order-constrained only WITHIN one output's chain, so a lane runs TB x OB chains
-//  (TB consecutive time steps x OB consecutive output channels) side by side: per chain step it reads TB activations and
-//  one OB-wide weight vector from LDS for TB*OB independent mul+add pairs (packed v_pk_mul_f32 / v_pk_add_f32).  The plan
-//  picks (TB, OB) per conv block so that the work items fill the 64 lanes (conv1 49x30: 7x4 -> 56 lanes, 91 steps;
-//  conv2 7x10: 1x2 -> 35 lanes, 210 steps).
-//  LDS: weights transposed to [tap*in_c + c][out_c padded to 4] once per workgroup; per wave X (block input, rows
-//  zero-padded), Y (conv+bias+ADD output before pooling) and a small vector for the FULLY_CONNECTED input / logits.
+//  The multiply-adds of a clip are order-constrained only WITHIN one output's chain, so a lane runs TB x OB chains (TB
+//  consecutive time steps x OB consecutive output channels) side by side: per chain step it reads TB activations and one
+//  OB-wide weight vector from LDS for TB*OB independent mul+add pairs.  The plan picks (TB, OB) per conv block so that the
+//  work items fill the 64 lanes (shipped shape: conv1 49x30 -> 7x4, 56 lanes; conv2 7x10 -> 1x2, 35 lanes); a lane that
+//  owns exactly one pooling window max-pools in registers, an un-pooled block writes straight into the next image.
+//  LDS: per workgroup the weights of every block transposed to [tap*in_c + c][out_c padded to 4]; per wave the ping-pong
+//  input images A / B (zero-padded rows), Y only for blocks whose pooling cannot happen in registers, and 128 floats for
+//  the FULLY_CONNECTED input / logits.  The plan is read from device memory (nnf_layout() is shared with the host).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_clamp(float x, float lo, float hi)   // ActivationFunctionWithMinMax
 {
