@@ -352,17 +352,36 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 // one frame per pass, lane = filter (taps in registers as above; walking the CSR table from memory
                 // instead cost a third of the kernel)
                 if (lane < NF) {
-                    for (int fr = 0; fr < nfc; ++fr) {
-                        float acc = 0.0f;
+                    // three frames per trip: their 3 x NZ operands are requested together (one frame at a time the loop is
+                    // a chain of LDS round trips with only two waves per SIMD to cover them)
+                    for (int fr0 = 0; fr0 < nfc; fr0 += 3) {
+                        float acc[3] = { 0.0f, 0.0f, 0.0f };
+                        float xv[3][NZ];
 #pragma unroll
-                        for (int n = 0; n < NZ; ++n) {
-                            float prod = sm.u.p[fbin[n] + fr] * fwt[n];
-                            acc += prod;
+                        for (int u = 0; u < 3; ++u) {
+                            const int fr = min(fr0 + u, nfc - 1);
+#pragma unroll
+                            for (int n = 0; n < NZ; ++n) xv[u][n] = sm.u.p[fbin[n] + fr];
                         }
-                        if (acc == 0.0f) acc = FLT_EPSILON;
-                        if constexpr (!WITH_CMVN)
-                            if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + lane] = acc;
-                        sm.mel[(f_base + fr) * MELS + lane] = fast_log(acc);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+                            for (int n = 0; n < NZ; ++n) {
+                                float prod = xv[u][n] * fwt[n];
+                                acc[u] += prod;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const int fr = fr0 + u;
+                            if (fr < nfc) {
+                                float a = acc[u];
+                                if (a == 0.0f) a = FLT_EPSILON;
+                                if constexpr (!WITH_CMVN)
+                                    if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + lane] = a;
+                                sm.mel[(f_base + fr) * MELS + lane] = fast_log(a);
+                            }
+                        }
                     }
                 }
             }
