@@ -262,7 +262,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
     long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;
     auto mark = [&](int i) { if (profiling) { const long long now = clock64(); ph[i] += now - tlast; tlast = now; } };
     float *sp = (float *)smem_raw;
-    const float *s_w[KWS_MAX_BLOCKS];
+    int s_w_off[KWS_MAX_BLOCKS];     // float offsets into the LDS block: pointers kept in an array lose their address space (flat loads)
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlockF32 &k = N.blk[b];
         const int J = k.depthwise ? k.taps : k.taps * k.in_c, ocp = nnf_ocp(k);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
             const int j = i / ocp, oc = i - j * ocp;
             sp[i] = oc < k.out_c ? (k.depthwise ? k.w[j * k.out_c + oc] : k.w[oc * J + j]) : 0.0f;
         }
-        s_w[b] = sp;
+        s_w_off[b] = (int)(sp - (float *)smem_raw);
         sp += J * ocp;
     }
     const NnfLayout L = nnf_layout(N);
@@ -338,11 +338,11 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
                     if (i < lo || i >= hi) dst.p[i] = 0.0f;
             }
             switch (k.tb) {
-            case 8: nnf_conv_ob<8, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
-            case 7: nnf_conv_ob<7, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
-            case 4: nnf_conv_ob<4, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
-            case 2: nnf_conv_ob<2, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
-            default: nnf_conv_ob<1, (MAXT <= 512)>(k, cur, s_w[b], Y, dst, lane); break;
+            case 8: nnf_conv_ob<8, (MAXT <= 512)>(k, cur, (const float *)smem_raw + s_w_off[b], Y, dst, lane); break;
+            case 7: nnf_conv_ob<7, (MAXT <= 512)>(k, cur, (const float *)smem_raw + s_w_off[b], Y, dst, lane); break;
+            case 4: nnf_conv_ob<4, (MAXT <= 512)>(k, cur, (const float *)smem_raw + s_w_off[b], Y, dst, lane); break;
+            case 2: nnf_conv_ob<2, (MAXT <= 512)>(k, cur, (const float *)smem_raw + s_w_off[b], Y, dst, lane); break;
+            default: nnf_conv_ob<1, (MAXT <= 512)>(k, cur, (const float *)smem_raw + s_w_off[b], Y, dst, lane); break;
             }
             WAVE_SYNC();
             if (nnf_staged(k)) {
@@ -438,7 +438,7 @@ int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const f
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
-    const int n_waves = kws_nn_f32_waves(N), grid_mult = 2;
+    const int n_waves = kws_nn_f32_waves(N), grid_mult = 1;
     const size_t smem = kws_nn_f32_smem_bytes(N, n_waves);
     const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / smem);
     int grid = (n_clips + n_waves - 1) / n_waves;
