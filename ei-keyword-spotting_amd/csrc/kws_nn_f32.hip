@@ -36,6 +36,13 @@ __host__ __device__ __forceinline__ int nnf_rows(const KwsConvBlockF32 &k)      
     return a > b ? a : b;
 }
 __host__ __device__ __forceinline__ int nnf_ocp(const KwsConvBlockF32 &k) { return (k.out_c + 3) & ~3; }
+// LDS position of weight (step j, output channel oc) of a conv block: [j][oc] (a lane reads OB consecutive channels of one
+// step) for register-blocked blocks; [oc block][j][OB] for one-time-step blocks, whose lanes stream their own weights
+__device__ __forceinline__ int nnf_w_index(const KwsConvBlockF32 &k, int J, int j, int oc)
+{
+    if (k.depthwise || k.tb != 1) return j * nnf_ocp(k) + oc;
+    return ((oc / k.ob) * J + j) * k.ob + (oc % k.ob);
+}
 
 // where a block's (pooled) output goes: the next block's zero-padded input image, or the FULLY_CONNECTED input vector
 struct NnfDst { float *p; int row0, stride; };
@@ -66,40 +73,47 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
             else w[0] = wp[j * ocp];
         };
         if constexpr (TB == 1) {
-            // one time step per lane (small blocks): a chain step is a single multiply-add, so the loop is bound by the LDS
-            // round trip unless many steps' operands are requested at once -- 8 steps per batch
-            constexpr int U = 8;
-            float wn_[U][OB], xn_[U];
-            auto load_batch1 = [&](int j0) {
+            // one time step per lane (small blocks): a chain step is a single multiply-add per output channel, so issue
+            // slots decide.  The weights of such a block sit in LDS as [oc block][step][OB] (nnf_w_index), i.e. a lane's
+            // weight stream is contiguous: 8 steps' operands are 16 * OB / 4 + 4 reads at immediate offsets from two running
+            // pointers, full batches run without clamps or predicates, the J % 8 last steps one by one.  (No double
+            // buffering: the rotating copies cost more issue slots than the exposed round trip, which the SIMD's other
+            // wave -- usually inside a register-blocked block -- fills.)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            constexpr int U = 8, NV = (OB + 1) / 2;
+            const float *wq = wt + (size_t)ob * J * OB;
+            const int Jm = J & ~(U - 1);
+            f2v a2[NV];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int jj = min(j0 + u, J - 1);
-                    load_w(jj, wn_[u]);
-                    xn_[u] = xp[jj];
-                }
-            };
-            if constexpr (VEC4) load_batch1(0);                     // 256-register build: batches double-buffered
-            for (int j0 = 0; j0 < J; j0 += U) {
-                float wu[U][OB], xu[U];
-                if constexpr (!VEC4) load_batch1(j0);
+            for (int v = 0; v < NV; ++v) a2[v] = (f2v){ 0.0f, 0.0f };
+            auto step1 = [&](const float *wj, float xs_) {        // products and sums rounded separately (-ffp-contract=off)
+                if constexpr (OB == 1) { const float prod = xs_ * wj[0]; a2[0].x += prod; }
+                else {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    xu[u] = xn_[u];
-#pragma unroll
-                    for (int o = 0; o < OB; ++o) wu[u][o] = wn_[u][o];
-                }
-                if constexpr (VEC4) load_batch1(min(j0 + U, J - 1));   // the next batch is in flight during this one's chain
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (j0 + u < J) {
-#pragma unroll
-                        for (int o = 0; o < OB; ++o) {
-                            const float prod = xu[u] * wu[u][o];
-                            acc[0][o] += prod;
-                        }
+                    for (int v = 0; v < NV; ++v) {
+                        const f2v wv = { wj[2 * v], wj[2 * v + 1] };
+                        const f2v prod = wv * xs_;
+                        a2[v] += prod;
                     }
                 }
+            };
+            for (int j0 = 0; j0 < Jm; j0 += U) {
+                float w[U * OB], xs_[U];
+#pragma unroll
+                for (int i = 0; i < U * OB; ++i) w[i] = wq[j0 * OB + i];
+#pragma unroll
+                for (int u = 0; u < U; ++u) xs_[u] = xp[j0 + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u) step1(w + u * OB, xs_[u]);
             }
+            for (int j = Jm; j < J; ++j) {
+                float w[OB];
+#pragma unroll
+                for (int o = 0; o < OB; ++o) w[o] = wq[j * OB + o];
+                step1(w, xp[j]);
+            }
+#pragma unroll
+            for (int o = 0; o < OB; ++o) acc[0][o] = (o & 1) ? a2[o >> 1].y : a2[o >> 1].x;
         } else if (VEC4 && (k.in_c & 3) == 0) {
             // channel counts that are multiples of 4 (rows 16-byte aligned): FOUR chain steps per batch -- one 16-byte read
             // per time row brings the activations of 4 consecutive steps, the batch after next is in flight meanwhile
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
         const int J = k.depthwise ? k.taps : k.taps * k.in_c, ocp = nnf_ocp(k);
         for (int i = threadIdx.x; i < J * ocp; i += blockDim.x) {      // [oc][j] -> [j][oc], zero in the padding channels
             const int j = i / ocp, oc = i - j * ocp;
-            sp[i] = oc < k.out_c ? (k.depthwise ? k.w[j * k.out_c + oc] : k.w[oc * J + j]) : 0.0f;
+            sp[nnf_w_index(k, J, j, oc)] = oc < k.out_c ? (k.depthwise ? k.w[j * k.out_c + oc] : k.w[oc * J + j]) : 0.0f;
         }
         s_w_off[b] = (int)(sp - (float *)smem_raw);
         sp += J * ocp;
