@@ -337,7 +337,9 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
         }
         mark(0);
         for (int b = 0; b < N.n_blocks; ++b) {
-            const KwsConvBlockF32 &k = N.blk[b];
+            // a COPY of the block's parameters (scalar registers): through the reference every epilogue step reloads its clamp
+            // bounds and strides from memory, because the LDS stores in between might alias the plan
+            const KwsConvBlockF32 k = N.blk[b];
             const bool last = (b + 1 == N.n_blocks);
             const float *cur = (b & 1) ? B : A;
             NnfDst dst;
@@ -375,24 +377,42 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
             mark(1 + b);
         }
         // FULLY_CONNECTED (fully_connected.h:26-60) + SOFTMAX (softmax.h:31-63)
-        float *lg = vec + 64;
-        if (lane < N.fc_out) {
+        float *lg = vec + 64, *ex = vec;          // ex overwrites the FC input once every lane is done with it
+        const int fc_in = N.fc_in, fc_out = N.fc_out;
+        const float beta = N.beta;
+        if (lane < fc_out) {
+            const float *fw = N.fc_w + lane * fc_in;
             float total = 0.0f;
-            for (int d = 0; d < N.fc_in; ++d) {
-                const float prod = vec[d] * N.fc_w[lane * N.fc_in + d];
+            int d = 0;
+            for (; d + 4 <= fc_in; d += 4) {                  // four weights in flight per round trip; the chain stays in order
+                const float w0 = fw[d], w1 = fw[d + 1], w2 = fw[d + 2], w3 = fw[d + 3];
+                const float x0 = vec[d], x1 = vec[d + 1], x2 = vec[d + 2], x3 = vec[d + 3];
+                const float p0 = x0 * w0, p1 = x1 * w1, p2 = x2 * w2, p3 = x3 * w3;
+                total += p0; total += p1; total += p2; total += p3;
+            }
+            for (; d < fc_in; ++d) {
+                const float prod = vec[d] * fw[d];
                 total += prod;
             }
             const float lgt = act_clamp(total + N.fc_bias[lane], N.fc_min, N.fc_max);
             lg[lane] = lgt;
-            if (tap_logits) tap_logits[(size_t)clip * N.fc_out + lane] = lgt;
+            if (tap_logits) tap_logits[(size_t)clip * fc_out + lane] = lgt;
         }
         WAVE_SYNC();
-        if (lane < N.fc_out) {
+        // softmax.h:31-63: max, then sum += exp((x - max) * beta) in class order, then exp(...) / sum.  Each lane evaluates
+        // its own class's exponential once; the sum adds the same values in the same order
+        float e_own = 0.0f;
+        if (lane < fc_out) {
             float mx = -FLT_MAX;
-            for (int c = 0; c < N.fc_out; ++c) mx = mx < lg[c] ? lg[c] : mx;
+            for (int c = 0; c < fc_out; ++c) mx = mx < lg[c] ? lg[c] : mx;
+            e_own = expf((lg[lane] - mx) * beta);
+            ex[lane] = e_own;
+        }
+        WAVE_SYNC();
+        if (lane < fc_out) {
             float sum = 0.0f;
-            for (int c = 0; c < N.fc_out; ++c) sum += expf((lg[c] - mx) * N.beta);
-            scores[(size_t)clip * N.fc_out + lane] = expf((lg[lane] - mx) * N.beta) / sum;
+            for (int c = 0; c < fc_out; ++c) sum += ex[c];
+            scores[(size_t)clip * fc_out + lane] = e_own / sum;
         }
         WAVE_SYNC();
         mark(1 + KWS_MAX_BLOCKS);
