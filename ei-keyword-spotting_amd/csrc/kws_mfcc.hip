@@ -3,6 +3,7 @@
 // the 256-point real FFT staged in LDS, power spectrum, sparse mel gather, fast log, DCT, windowed CMVN and the int8
 // quantisation of ei_run_classifier.h:436-444.  See kws_device.h for the bit-exactness contract.
 #include "kws_device.h"
+#include "kws_dct_tables.h"
 
 // one frame pair's worth of samples for this lane: 8 samples + the sample before them
 template <bool F32IN> struct RawSamples;
@@ -58,9 +59,14 @@ __device__ __forceinline__ void bfly5(cf &F0, cf &F1, cf &F2, cf &F3, cf &F4, cf
 // kf_work's recursion unrolled: NF = 32 -> 16 = 4 x 4 (kf_bfly4, kf_bfly4); NF = 40 -> 20 = 4 x 5 (kf_bfly5 leaves of
 // stride 4, then kf_bfly4 with m = 5).
 template <int NF, typename Emit>
-__device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspPlan &P, Emit emit)   // emit(i, R[i]), i = 0..NF/2
+__device__ __forceinline__ void dct_spectrum(const float (&v)[NF], Emit emit)   // emit(i, R[i]), i = 0..NF/2
 {
     constexpr int NC = NF / 2;
+    // twiddles as literals (kws_dct_tables.h): every index below is a compile-time constant once the loops are unrolled.
+    // From the plan's tables they are scalar loads whose registers get spilled and reloaded around every output.
+    typedef KwsDctTab<NF> T;
+    auto tw = [](int i) { cf c; c.r = T::tw_r[i]; c.i = T::tw_i[i]; return c; };
+    auto stw = [](int i) { cf c; c.r = T::stw_r[i]; c.i = T::stw_i[i]; return c; };
     // even/odd reorder (in[i] = v[2i], in[NF-1-i] = v[2i+1]) read as NC complex points
     auto rin = [&](int i) { return (i < NC) ? v[2 * i] : v[2 * (NF - 1 - i) + 1]; };
     cf F[NC];
@@ -73,12 +79,12 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
                 F[4 * q + j].r = rin(2 * n);
                 F[4 * q + j].i = rin(2 * n + 1);
             }
-        const cf d0 = to_cf(P.dct_tw[0]);
+        const cf d0 = tw(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) bfly4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3], d0, d0, d0);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+            bfly4(F[k], F[k + 4], F[k + 8], F[k + 12], tw(k), tw(2 * k), tw(3 * k));
     } else {
         static_assert(NF == 40, "DCT sizes: 32, 40");
 #pragma unroll
@@ -89,12 +95,12 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
                 F[5 * q + j].r = rin(2 * n);
                 F[5 * q + j].i = rin(2 * n + 1);
             }
-        const cf d0 = to_cf(P.dct_tw[0]), ya = to_cf(P.dct_tw[4]), yb = to_cf(P.dct_tw[8]);   // tw[fstride*m], tw[2*fstride*m]
+        const cf d0 = tw(0), ya = tw(4), yb = tw(8);   // tw[fstride*m], tw[2*fstride*m]
 #pragma unroll
         for (int q = 0; q < 4; ++q) bfly5(F[5 * q], F[5 * q + 1], F[5 * q + 2], F[5 * q + 3], F[5 * q + 4], d0, d0, d0, d0, ya, yb);
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            bfly4(F[k], F[k + 5], F[k + 10], F[k + 15], to_cf(P.dct_tw[k]), to_cf(P.dct_tw[2 * k]), to_cf(P.dct_tw[3 * k]));
+            bfly4(F[k], F[k + 5], F[k + 10], F[k + 15], tw(k), tw(2 * k), tw(3 * k));
     }
     // kiss_fftr split (kiss_fftr.cpp:84-119); every spectrum point is handed on as soon as it exists
     cf r0, rn;
@@ -107,7 +113,7 @@ __device__ __forceinline__ void dct_spectrum(const float (&v)[NF], const KwsDspP
         cf fpk = F[k], fpnk;
         fpnk.r = F[NC - k].r; fpnk.i = -F[NC - k].i;
         cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
-        cf twv = cmul(f2k, to_cf(P.dct_stw[k - 1]));
+        cf twv = cmul(f2k, stw(k - 1));
         cf lo, hi;
         lo.r = (f1k.r + twv.r) * 0.5f;
         lo.i = (f1k.i + twv.i) * 0.5f;
@@ -401,28 +407,31 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
 #pragma unroll
             for (int i = 0; i < NF; ++i) v[i] = mrow[i];
             float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + lane * ncep;
+            typedef KwsDctTab<NF> T;
             auto put = [&](int i, cf R) {
-                if (i < ncep) {
-                    float a = R.r * P.dct_cos[i];
-                    float b = R.i * P.dct_sin[i];
+                // in place (WITH_CMVN) every output is stored: columns >= ncep of the row are never read again and the
+                // row is MELS > NCEPT wide; the packed HBM rows of the stage API only take the first ncep
+                if (WITH_CMVN || i < ncep) {
+                    float a = R.r * T::cs[i];
+                    float b = R.i * T::sn[i];
                     float d = (a + b) * 2.0f;
-                    d = d * (i == 0 ? P.dct_s0 : P.dct_s1);
+                    d = d * (i == 0 ? T::s0 : T::s1);
                     orow[i] = d;
                 }
             };
             // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
             if constexpr (NF == 32) {            // 17 spectrum points fit the register budget: scale + store after the split
                 cf R[NCEPT];
-                dct_spectrum<NF>(v, P, [&](int i, cf r) { R[i] = r; });
+                dct_spectrum<NF>(v, [&](int i, cf r) { R[i] = r; });
 #pragma unroll
                 for (int i = 0; i < NCEPT; ++i) put(i, R[i]);
 #pragma unroll
                 for (int i = NCEPT; i < NF; ++i)
-                    if (i < ncep) orow[i] = (v[i] * 2.0f) * P.dct_s1;
+                    if (i < ncep) orow[i] = (v[i] * 2.0f) * T::s1;
             } else {                              // 40 filters: hand every point on as soon as it exists (no spills);
                 // in place: element i >= NCEPT is read, then written, by this lane only
-                for (int i = NCEPT; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * P.dct_s1;
-                dct_spectrum<NF>(v, P, put);
+                for (int i = NCEPT; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * T::s1;
+                dct_spectrum<NF>(v, put);
             }
             orow[0] = fast_log(sm.energy[lane]);                                       // feature.hpp:425-429
         }

@@ -2,6 +2,21 @@
 // audio is computed HERE once per model, with the reference's own formulas and precisions (each builder cites its source),
 // and uploaded to HBM.
 #include "kws_internal.h"
+#include "kws_dct_tables.h"
+#include <cstring>
+
+template <int NF>
+static bool dct_tables_match(const std::vector<float2> &tw, const std::vector<float2> &stw, const std::vector<float> &cs,
+                             const std::vector<float> &sn, float s0, float s1)
+{
+    typedef KwsDctTab<NF> T;
+    auto same = [](float a, float b) { return std::memcmp(&a, &b, sizeof(float)) == 0; };      // bit for bit (signed zeros too)
+    if ((int)tw.size() != NF / 2 || (int)stw.size() != NF / 4 || (int)cs.size() != NF / 2 + 1 || (int)sn.size() != NF / 2 + 1) return false;
+    for (int i = 0; i < NF / 2; ++i) if (!same(tw[i].x, T::tw_r[i]) || !same(tw[i].y, T::tw_i[i])) return false;
+    for (int i = 0; i < NF / 4; ++i) if (!same(stw[i].x, T::stw_r[i]) || !same(stw[i].y, T::stw_i[i])) return false;
+    for (int i = 0; i < NF / 2 + 1; ++i) if (!same(cs[i], T::cs[i]) || !same(sn[i], T::sn[i])) return false;
+    return same(s0, T::s0) && same(s1, T::s1);
+}
 
 EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
 {
@@ -55,6 +70,14 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
         float temp = (float)((double)i * M_PI / (double)(N * 2));
         dcos[i] = cosf(temp);
         dsin[i] = sinf(temp);
+    }
+    // the kernel carries the DCT constants as literals (kws_dct_tables.h, tools/gen_dct_tables.cpp): they must be exactly
+    // what this host computes in the reference's way, or the features would silently differ
+    {
+        bool same;
+        if (N == 32) same = dct_tables_match<32>(dtw, dstw, dcos, dsin, P.dct_s0, P.dct_s1);
+        else same = dct_tables_match<40>(dtw, dstw, dcos, dsin, P.dct_s0, P.dct_s1);
+        if (!same) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "DCT constants of the kernel build differ from this host's (%d filters)", N);
     }
     const uint32_t high = c.high_frequency == 0 ? fs / 2 : (uint32_t)c.high_frequency;   // feature.hpp:203-205
     std::vector<float> fb = h_filterbank(N, P.n_bins, fs, (uint32_t)c.low_frequency, high);
