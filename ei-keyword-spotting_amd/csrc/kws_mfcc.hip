@@ -365,9 +365,12 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                         float xv[3][NZ];
 #pragma unroll
                         for (int u = 0; u < 3; ++u) {
-                            const int fr = min(fr0 + u, nfc - 1);
+                            // no clamp on the frame slot (one address per tap, the frames at immediate offsets): slots
+                            // fr0 + u <= 3 * ((nfc - 1) / 3) + 2 < CHF hold a finite power of an earlier chunk at worst,
+                            // and their sums are dropped below
+                            static_assert(3 * ((2 * CHP - 1) / 3) + 2 < CHF, "frame slots of a trip stay inside a bin's row");
 #pragma unroll
-                            for (int n = 0; n < NZ; ++n) xv[u][n] = sm.u.p[fbin[n] + fr];
+                            for (int n = 0; n < NZ; ++n) xv[u][n] = sm.u.p[fbin[n] + fr0 + u];
                         }
 #pragma unroll
                         for (int u = 0; u < 3; ++u) {
