@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--model", default=DEFAULT_MODEL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads timed at N = 1")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise RCCL and all-gather the scores even with one rank (smoke test of the N > 1 path on a 1-GPU box)")
     ap.add_argument("--cpu-worker", nargs=3, metavar=("KIND", "N_CLIPS", "SECONDS"))
     a = ap.parse_args()
     if a.cpu_worker:
@@ -144,7 +146,16 @@ def main():
     pkg = load_package()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_collective
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints a version banner on stdout when it initialises; this process's stdout carries exactly one JSON line,
+        # so fd 1 points at stderr while the process group exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        if "MASTER_ADDR" not in os.environ:                        # plain `python bench.py --force-collective`
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
     B = a.batch
     n = 16000
@@ -155,7 +166,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -205,13 +216,20 @@ def main():
         model.close()
         return res
 
-    r = measure(a.model, a.steps, a.warmup, world > 1)
+    r = measure(a.model, a.steps, a.warmup, use_dist)
     also = []
     if world == 1 and not a.no_also:
         for mp in ALSO_MODELS:
             if not os.path.samefile(mp, a.model):
                 also.append(measure(mp, a.steps, a.warmup, False))
 
+    if use_dist:
+        dist.destroy_process_group()
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)                             # the banner may still sit in the C library's buffer
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         dt, ms_mfcc, ms_nn, is_float = r["dt"], r["ms_mfcc"], r["ms_nn"], r["is_float"]
         algo_bytes = 16000 * 2 + r["labels"] * 4          # int16 PCM in + C float scores out, per clip
@@ -237,7 +255,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+f64 (MFCC) / %s (CNN)" % ("f32" if is_float else "i8"), "data": "synthetic",
             "config": {"workload": workload(r["model"]), "clips_per_gpu": B, "global_batch": world * B, "kwsm_file": r["model"],
-                       "parity": parity(is_float), "collective": "all_gather(scores) over RCCL" if world > 1 else "none"},
+                       "parity": parity(is_float), "collective": "all_gather(scores) over RCCL" if use_dist else "none"},
             "roofline": {"bound": "hbm", "kernel": "kws_mfcc_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc)",
@@ -255,8 +273,6 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
