@@ -209,6 +209,23 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
 
         for (int pair0 = 0; pair0 < n_pairs; pair0 += CHP) {
             const int pair1 = min(pair0 + CHP, n_pairs);
+            cf pend[4] = {};                                  // split outputs of the previous pair: lo0, hi0, lo1, hi1
+            bool pend_any = false, pend_live = false;
+            float *pend_pcol = sm.u.p;
+            // The power spectrum of the PREVIOUS pair (4 bins per lane, ~35 fp64-heavy instructions each, operands in
+            // registers) is evaluated one bin at a time right after each stage's LDS reads are issued: that arithmetic
+            // needs no memory, so it runs in the shadow of the round trip the butterflies would otherwise wait out.
+            auto power_of_pending = [&](int which) {
+                if (pend_any) {                                                    // uniform: no pair pending at chunk start
+                    const int k = t + 1 + 32 * (which >> 1);
+                    const cf v = pend[which];
+                    const float pw = bin_power(v, P.inv_fft);
+                    if (pend_live) {
+                        if (which & 1) pend_pcol[(KWS_NC - k) * CHF] = pw;          // hi: the "ncfft-k" store
+                        else if (k != KWS_NC / 2) pend_pcol[k * CHF] = pw;          // lo; k == 64 is overwritten by hi
+                    }
+                }
+            };
             for (int pr = pair0; pr < pair1; ++pr) {
                 // ---- 8 samples/lane (16 B, coalesced: 32 lanes = the 256 samples of a frame that rfft keeps) -----
                 const int f = 2 * pr + half;
@@ -248,10 +265,13 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
 
                 // ---- kf_bfly2 (m=1) fused with kf_bfly4 (m=2): kiss_fft.cpp:232-296 levels 4 and 3 ---------
                 cf u[4];
+                {
+                    cf la[4], lb[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    cf a = ld_cf(zb, n0 + 16 * i), b = ld_cf(zb, n0 + 16 * i + 64);
-                    u[i] = k01 ? csub(a, b) : cadd(a, b);       // b * tw[0], tw[0] = (1, -0)
+                    for (int i = 0; i < 4; ++i) { la[i] = ld_cf(zb, n0 + 16 * i); lb[i] = ld_cf(zb, n0 + 16 * i + 64); }
+                    power_of_pending(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[i] = k01 ? csub(la[i], lb[i]) : cadd(la[i], lb[i]);       // b * tw[0], tw[0] = (1, -0)
                 }
                 bfly4(u[0], u[1], u[2], u[3], a1, a2, a3);
 #pragma unroll
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 // ---- kf_bfly4 m=8, fstride=4 ----------------------------------------------------------------
 #pragma unroll
                 for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
+                power_of_pending(1);
                 bfly4(u[0], u[1], u[2], u[3], b1, b2, b3);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, u[i]);
@@ -267,40 +288,52 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 // ---- kf_bfly4 m=32, fstride=1 ---------------------------------------------------------------
 #pragma unroll
                 for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, t + 32 * i);
+                power_of_pending(2);
                 bfly4(u[0], u[1], u[2], u[3], c1, c2, c3);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
                 WAVE_SYNC();
 
                 PH(1);
-                // ---- kiss_fftr split (kiss_fftr.cpp:84-119) + power spectrum -------------------------------
+                // ---- kiss_fftr split (kiss_fftr.cpp:84-119); its power spectrum is left pending for the next pair -----
                 const int fr = f - 2 * pair0;                 // frame slot in the chunk
-                float *pcol = sm.u.p + fr;
                 const bool live = f < nfr;
+                cf fpk[2], fq[2];
 #pragma unroll
                 for (int rep = 0; rep < 2; ++rep) {
                     const int k = t + 1 + 32 * rep;            // 1..64
+                    fpk[rep] = ld_cf(zb, k);
+                    fq[rep] = ld_cf(zb, KWS_NC - k);
+                }
+                power_of_pending(3);
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
                     const cf stw = rep ? st2 : st1;
-                    cf fpk = ld_cf(zb, k), fq = ld_cf(zb, KWS_NC - k);
-                    cf fpnk; fpnk.r = fq.r; fpnk.i = -fq.i;
-                    cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    cf fpnk; fpnk.r = fq[rep].r; fpnk.i = -fq[rep].i;
+                    cf f1k = cadd(fpk[rep], fpnk), f2k = csub(fpk[rep], fpnk);
                     cf twv = cmul(f2k, stw);
                     cf lo, hi;
                     lo.r = (f1k.r + twv.r) * 0.5f;             // HALF_OF
                     lo.i = (f1k.i + twv.i) * 0.5f;
                     hi.r = (f1k.r - twv.r) * 0.5f;
                     hi.i = (twv.i - f1k.i) * 0.5f;
-                    if (live) {
-                        if (k != KWS_NC / 2) pcol[k * CHF] = bin_power(lo, P.inv_fft);   // k == 64: overwritten by the
-                        pcol[(KWS_NC - k) * CHF] = bin_power(hi, P.inv_fft);            // "ncfft-k" store
-                    }
+                    pend[2 * rep] = lo;
+                    pend[2 * rep + 1] = hi;
                 }
+                pend_any = true;
+                pend_live = live;
+                pend_pcol = sm.u.p + fr;
                 // DC / Nyquist bins (kiss_fftr.cpp:84-96) need tmp[0] only: parked per frame, evaluated once per chunk
                 // with one frame per lane instead of one lane per wave here
                 if (t == 0 && live) *(float2 *)(sm.dcny + 2 * fr) = *(const float2 *)zb;
                 WAVE_SYNC();
                 PH(2);
             }
+            // the chunk's last pair
+#pragma unroll
+            for (int w = 0; w < 4; ++w) power_of_pending(w);
+            pend_any = false;
+            WAVE_SYNC();
 
             // ---- per chunk: frame energy (sequential fp32 sum, numpy.hpp:88-94) -------------------------------
             const int f_base = 2 * pair0;
