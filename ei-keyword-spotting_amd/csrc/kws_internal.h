@@ -38,7 +38,7 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
-size_t kws_nn_smem_bytes(const KwsNnPlan &N);
+size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves);
 extern int kws_force_scalar_nn;
 int kws_nn_uses_mfma(const KwsNnPlan &N);
 int kws_mfcc_max_prow(void);

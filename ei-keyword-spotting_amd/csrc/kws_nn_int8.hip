@@ -52,11 +52,19 @@ __device__ __forceinline__ int one_over_one_plus_x(int a)     // fixedpoint.h:84
 //  ADD+ReLU table and the clamps are all monotonically non-decreasing, max-pooling is applied to the raw
 //  accumulators first (max commutes with a non-decreasing map), then ONE requantisation per pooled output.
 // ---------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int KWS_NN_WAVES = 4;
+constexpr int KWS_NN_WAVES_MAX = 8;      // generic kernel: as many waves per workgroup as the LDS allows (they share weights and tables)
 constexpr int KWS_POOL_MAX = 8;
 // rows of a block's padded int8 input image in the generic kernel: un-pooled blocks are walked KWS_POOL_MAX time steps at
 // a time, so reads reach up to ceil(out_w / 8) * 8 + taps - 1
-__host__ __device__ inline int nn_rows(const KwsConvBlock &k) { return max(k.in_w, (k.out_w + KWS_POOL_MAX - 1) & ~(KWS_POOL_MAX - 1)) + k.taps; }
+// (matrix-core blocks read whole 32-row tiles: up to ceil(out_w / 32) * 32 + taps rows, the odd tap of a 2-tap k-step included)
+__host__ __device__ inline int nn_rows(const KwsConvBlock &k)
+{
+    const int walk = k.mfma ? ((k.out_w + 31) & ~31) + 1 : (k.out_w + KWS_POOL_MAX - 1) & ~(KWS_POOL_MAX - 1);
+    return max(k.in_w, walk) + k.taps;
+}
 
 struct NnTaps {            // optional debug outputs for the parity tests (all int8, per clip)
     int8_t *pooled;        // concatenation of every block's pooled output [pool_w][out_c]
@@ -114,11 +122,11 @@ __device__ __forceinline__ void nn_head(const KwsNnPlan &N, int *vec, int lane, 
     WAVE_SYNC();
 }
 
-__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                          float *__restrict__ scores, NnTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
 
     // ---- shared: weights + ADD tables of every block ---------------------------------------------------------
     unsigned char *sp = smem_raw;
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
     const bool profiling = taps.prof != nullptr && blockIdx.x == 0 && wave == 0;
     long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;
     auto mark = [&](int i) { if (profiling) { const long long now = clock64(); ph[i] += now - tlast; tlast = now; } };
-    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+    for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
         // ---- stage the int8 input as [pad_left + t][in_cpad], padding = zero point ((x + offset) == 0) -------
         {
             const KwsConvBlock &k = N.blk[0];
@@ -271,6 +279,37 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
                         if (i < k.pool && t0 + i < k.out_w) m = max(m, acc[i]);
                     finish(m, pw, oc, rq_of(oc));
                 }
+            } else if (k.mfma) {
+                // CONV_2D without pooling on v_mfma_i32_32x32x32_i8: [time x (taps * in_cpad)] x [(taps * in_cpad) x out_c], one or
+                // two 32-row tiles, k-steps of 32 bytes = two taps (16-byte rows), one tap (32) or half a tap (64).  A and B use
+                // the same slot -> (tap, channel) map; int32 accumulation is exact, so the sums equal the reference's scalar loops
+                const int cp = k.in_cpad, n = lane & 31, hh = lane >> 5;
+                const int ks = cp == 16 ? (k.taps + 1) >> 1 : cp == 32 ? k.taps : 2 * k.taps;
+                const bool two = k.out_w > 32;
+                v16i acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
+                const int8_t *wrow = s_w[b] + (size_t)min(n, k.out_c - 1) * k.taps * cp;      // columns >= out_c: never stored
+                for (int s_ = 0; s_ < ks; ++s_) {
+                    const int tap = cp == 16 ? 2 * s_ + hh : cp == 32 ? s_ : s_ >> 1;
+                    const int ch = cp == 16 ? 0 : cp == 32 ? 16 * hh : 32 * (s_ & 1) + 16 * hh;
+                    v4i wv = { 0, 0, 0, 0 };
+                    if (tap < k.taps) wv = *(const v4i *)(wrow + tap * cp + ch);
+                    const v4i a0 = *(const v4i *)(cur + (n + tap) * cp + ch);                  // row = time (lane & 31) + tap
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, wv, acc0, 0, 0, 0);
+                    if (two) {
+                        const v4i a1 = *(const v4i *)(cur + (32 + n + tap) * cp + ch);
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wv, acc1, 0, 0, 0);
+                    }
+                }
+                // accumulator register r of a tile holds row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column lane & 31
+                if (n < k.out_c) {
+                    const Rq rq = rq_of(n);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (row < k.out_w) finish(acc0[r], row, n, rq);
+                        if (two && 32 + row < k.out_w) finish(acc1[r], 32 + row, n, rq);
+                    }
+                }
             } else {
                 // a lane owns one pooling window of OB = 2 (or 1) output channels: every 16-byte activation read feeds
                 // 4 * OB dot products, every 16-byte weight read `pool` of them
@@ -350,8 +389,6 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_kernel(KwsNnPl
 //  the result is bit-identical to the reference's scalar loops whatever the summation order.  One wave per clip;
 //  weight fragments stay in registers for the whole launch; activations are read from LDS as aligned 16-byte rows.
 // ---------------------------------------------------------------------------------------------------------
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int KWS_A1_ROWS = 72;    // >= 63 + 8 + 1 rows of 16 B: activations of block 1, row = time + tap
 constexpr int KWS_A2_ROWS = 24;    // >= 15 + 8 + 1 rows of 32 B
@@ -608,7 +645,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
     }
     return (int)hipGetLastError();
 }
-size_t kws_nn_smem_bytes(const KwsNnPlan &N)
+size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves)
 {
     size_t s = 0;
     int act = 0;
@@ -620,7 +657,7 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N)
         act = ab > act ? ab : act;
     }
     act = (act + 15) & ~15;
-    return s + (size_t)KWS_NN_WAVES * (2 * act + 64 * 4);
+    return s + (size_t)n_waves * (2 * act + 64 * 4);
 }
 
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
@@ -638,12 +675,19 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
             hipLaunchKernelGGL(kws_nn_mfma_kernel<64>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
         return (int)hipGetLastError();
     }
-    const size_t smem = kws_nn_smem_bytes(N);
+    // generic kernel: 8 waves per workgroup when the CU's LDS holds them (2 per SIMD instead of 1 for wide models whose
+    // tables allow a single workgroup per CU), one round of persistent workgroups
+    int nw = KWS_NN_WAVES_MAX;
+    while (nw > KWS_NN_WAVES && kws_nn_smem_bytes(N, nw) > 158 * 1024) --nw;
+    const size_t smem = kws_nn_smem_bytes(N, nw);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / smem, (size_t)(8 / nw)));           // 171 VGPRs: two waves per SIMD
+    grid = (n_clips + nw - 1) / nw;
+    if (grid > (grid_cap / 4) * per_cu) grid = (grid_cap / 4) * per_cu;          // grid_cap = 4 workgroups per CU
     if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
         hipError_t e = hipFuncSetAttribute((const void *)kws_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), smem, stream, N, q_in, n_clips, scores, taps);
+    hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * nw), smem, stream, N, q_in, n_clips, scores, taps);
     return (int)hipGetLastError();
 }
 

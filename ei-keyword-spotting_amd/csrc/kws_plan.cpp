@@ -270,6 +270,19 @@ EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
             i++;
             if (!skip_reshapes()) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "reshape changes quantisation");
         }
+        // un-pooled CONV_2D blocks (e.g. the pointwise halves of a depthwise-separable CNN) run on the matrix cores in the
+        // generic kernel: 16-byte k-groups need activation rows of 16, 32 or 64 bytes
+        k.mfma = (!dw && k.pool == 1 && in_c <= 64 && out_c <= 32 && out_w <= 64 && f_w <= 8) ? 1 : 0;
+        if (k.mfma) {
+            const int cp = in_c <= 16 ? 16 : in_c <= 32 ? 32 : 64;
+            if (cp != k.in_cpad) {
+                std::vector<int8_t> w2((size_t)out_c * f_w * cp, 0);
+                for (int r = 0; r < out_c * f_w; r++) std::memcpy(&w2[(size_t)r * cp], &wp[(size_t)r * k.in_cpad], (size_t)in_c);
+                wp.swap(w2);
+                k.in_cpad = cp;
+                k.w_bytes = (int)wp.size();
+            }
+        }
         EI_IMPULSE_ERROR e;
         if ((e = h->upload(wp, &k.w))) return e;
         if ((e = h->upload(beff, &k.bias_eff))) return e;

@@ -50,6 +50,8 @@ struct KwsConvBlock {
     int out_zp, act_min, act_max;    // conv output zero point and clamp
     int depthwise, depth_mult; // DEPTHWISE_CONV_2D: output channel oc reads input channel oc / depth_mult
     int has_lut;               // an ADD follows the convolution (add_lut is not the identity)
+    int mfma;                  // generic kernel: this block's convolution runs on the matrix cores (CONV_2D, no pooling,
+                               // in_cpad 16 / 32 / 64, out_c <= 32, out_w <= 64)
     int w_bytes;               // bytes of w
     const int8_t *w;           // conv: [out_c][taps][in_cpad], zero padded; depthwise: [out_c][taps padded to 4]
     const int32_t *bias_eff;   // [out_c] bias + input_offset * sum(w)
