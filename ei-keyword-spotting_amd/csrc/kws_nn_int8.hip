@@ -76,7 +76,24 @@ struct NnTaps {            // optional debug outputs for the parity tests (all i
 
 // FULLY_CONNECTED (integer_ops/fully_connected.h:23-63) + SOFTMAX int8->int8 (reference/softmax.h:66-144) for one clip.
 // vec: per-wave LDS scratch; bytes [0,64) hold the last pooled vector (int8), ints [16, 16+fc_out) receive the logits.
-__device__ __forceinline__ void nn_head(const KwsNnPlan &N, int *vec, int lane, int clip, float *__restrict__ scores,
+// The FC weights / bias and the softmax tables are read from LDS copies (NnHeadTab, staged once per workgroup): from global
+// memory every step of these short dependent loops is an L2 round trip.
+constexpr int KWS_HEAD_FCW = 48 * 64;       // build_nn_plan: fc_out <= 48, fc_in <= 64
+constexpr int KWS_HEAD_BYTES = KWS_HEAD_FCW + 48 * 4 + 256 * 4 + 256;
+struct NnHeadTab { const int8_t *fc_w; const int *fc_bias; const int *sm_exp; const uint8_t *sm_valid; };
+__device__ __forceinline__ NnHeadTab nn_head_stage(const KwsNnPlan &N, unsigned char *lds)      // lds: KWS_HEAD_BYTES, 16-byte aligned
+{
+    int8_t *fw = (int8_t *)lds;
+    int *fb = (int *)(lds + KWS_HEAD_FCW), *se = fb + 48;
+    uint8_t *sv = (uint8_t *)(se + 256);
+    for (int i = threadIdx.x; i < N.fc_out * N.fc_in; i += blockDim.x) fw[i] = N.fc_w[i];
+    for (int i = threadIdx.x; i < N.fc_out; i += blockDim.x) fb[i] = N.fc_bias[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) { se[i] = N.sm_exp[i]; sv[i] = N.sm_valid[i]; }
+    NnHeadTab t = { fw, fb, se, sv };
+    return t;                                                                                // caller: __syncthreads()
+}
+
+__device__ __forceinline__ void nn_head(const KwsNnPlan &N, const NnHeadTab &H, int *vec, int lane, int clip, float *__restrict__ scores,
                                         const NnTaps &taps)
 {
     // ---- FULLY_CONNECTED (integer_ops/fully_connected.h:23-63): input = last pooled vector ------------------
@@ -85,8 +102,8 @@ __device__ __forceinline__ void nn_head(const KwsNnPlan &N, int *vec, int lane, 
     if (lane < N.fc_out) {
         int acc = 0;
         for (int d = 0; d < N.fc_in; ++d)
-            acc += ((int)N.fc_w[lane * N.fc_in + d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
-        acc += N.fc_bias[lane];
+            acc += ((int)H.fc_w[lane * N.fc_in + d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
+        acc += H.fc_bias[lane];
         acc = mbqm(acc, N.fc_mult, N.fc_shift) + N.fc_out_zp;
         logit = min(max(acc, N.fc_act_min), N.fc_act_max);
     }
@@ -104,7 +121,7 @@ __device__ __forceinline__ void nn_head(const KwsNnPlan &N, int *vec, int lane, 
         int sum = 0;
         for (int c = 0; c < N.fc_out; ++c) {
             const int d = mx - lg[c];
-            if (N.sm_valid[d]) sum = (int)((unsigned)sum + (unsigned)rdivpot(N.sm_exp[d], 12));
+            if (H.sm_valid[d]) sum = (int)((unsigned)sum + (unsigned)rdivpot(H.sm_exp[d], 12));
         }
         const int hp1 = sum ? __clz(sum) : 32;                                  // GetReciprocal, common.h:530-546
         const int nbits = 12 - hp1;
@@ -112,8 +129,8 @@ __device__ __forceinline__ void nn_head(const KwsNnPlan &N, int *vec, int lane, 
         const int scale = one_over_one_plus_x(ssm1);
         const int d = mx - logit;
         int o = -128;
-        if (N.sm_valid[d]) {
-            const int unsat = rdivpot(srdhm(scale, N.sm_exp[d]), nbits + 31 - 8);
+        if (H.sm_valid[d]) {
+            const int unsat = rdivpot(srdhm(scale, H.sm_exp[d]), nbits + 31 - 8);
             o = min(max(unsat - 128, -128), 127);
         }
         if (taps.out_q) taps.out_q[(size_t)clip * N.fc_out + lane] = (int8_t)o;
@@ -129,7 +146,8 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
 
     // ---- shared: weights + ADD tables of every block ---------------------------------------------------------
-    unsigned char *sp = smem_raw;
+    const NnHeadTab head = nn_head_stage(N, smem_raw);
+    unsigned char *sp = smem_raw + ((KWS_HEAD_BYTES + 15) & ~15);
     const int8_t *s_w[KWS_MAX_BLOCKS];
     const int8_t *s_lut[KWS_MAX_BLOCKS];
     int act_bytes = 0;
@@ -374,7 +392,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
             mark(1 + b);
             int8_t *tmp = cur; cur = nxt; nxt = tmp;
         }
-        nn_head(N, vec, lane, clip, scores, taps);
+        nn_head(N, head, vec, lane, clip, scores, taps);
         mark(1 + KWS_MAX_BLOCKS);
     }
     if (profiling && lane == 0)
@@ -445,7 +463,7 @@ __device__ __forceinline__ void nn_mfma_fill_padding(const KwsNnPlan &N, int8_t 
 
 // One clip through both conv blocks, FC and softmax; act1 already holds the int8 input rows.
 template <int CP>
-__device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx<CP> &c, const KwsNnPlan &N, const int8_t *act1, int8_t *act2, int *vec,
+__device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx<CP> &c, const KwsNnPlan &N, const NnHeadTab &head, const int8_t *act1, int8_t *act2, int *vec,
                                              const int8_t *s_lut1, const int8_t *s_lut2, int lane, int clip,
                                              float *__restrict__ scores, const NnTaps &taps)
 {
@@ -516,7 +534,7 @@ __device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx<CP> &c, const KwsNn
         if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + k1.pool_w * k1.out_c + oc2] = o;
     }
     WAVE_SYNC();
-    nn_head(N, vec, lane, clip, scores, taps);
+    nn_head(N, head, vec, lane, clip, scores, taps);
 }
 
 template <int CP>
@@ -528,8 +546,10 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
     __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][KWS_A1_ROWS * CP];
     __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][KWS_A2_ROWS * 32];
     __shared__ int s_vec[KWS_NN_WAVES][64];
+    __shared__ __attribute__((aligned(16))) unsigned char s_head[KWS_HEAD_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
+    const NnHeadTab head = nn_head_stage(N, s_head);
     for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
     for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
     int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
             act1[(tt + k1.pad_left) * CP + c] = src[i];
         }
         WAVE_SYNC();
-        nn_mfma_clip<CP>(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
+        nn_mfma_clip<CP>(ctx, N, head, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
     }
 }
 
@@ -569,6 +589,8 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
     __shared__ __attribute__((aligned(16))) int8_t s_act1[KWS_NN_WAVES][FUSE ? KWS_A1_ROWS * 16 : 16];
     __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][FUSE ? KWS_A2_ROWS * 32 : 16];
     __shared__ int s_vec[KWS_NN_WAVES][FUSE ? 64 : 1];
+    __shared__ __attribute__((aligned(16))) unsigned char s_head[FUSE ? KWS_HEAD_BYTES : 16];
+    NnHeadTab head = { nullptr, nullptr, nullptr, nullptr };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nfr = P.n_frames, ncep = P.n_cepstral, nfeat = nfr * ncep;
     const int prow = nfr + 2 * P.pad;
@@ -576,6 +598,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
     NnMfmaCtx<16> ctx;
     int8_t *act1 = s_act1[wave], *act2 = s_act2[wave];
     if constexpr (FUSE) {
+        head = nn_head_stage(N, s_head);
         const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
         for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
         for (int i = threadIdx.x * 4; i < k2.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut2 + i) = *(const int *)(k2.add_lut + i);
@@ -600,7 +623,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
             if constexpr (FUSE) act1[(row + N.blk[0].pad_left) * 16 + c] = qb;
         });
         WAVE_SYNC();
-        if constexpr (FUSE) nn_mfma_clip<16>(ctx, N, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
+        if constexpr (FUSE) nn_mfma_clip<16>(ctx, N, head, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
     }
 }
 
@@ -647,7 +670,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
 }
 size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves)
 {
-    size_t s = 0;
+    size_t s = (KWS_HEAD_BYTES + 15) & ~15;
     int act = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlock &k = N.blk[b];
