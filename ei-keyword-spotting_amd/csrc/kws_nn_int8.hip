@@ -172,6 +172,8 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
     __syncthreads();
 
     const int F = N.n_features;
+    // i / in_c for i < n_features <= 4096 as a multiply + shift (exact: i * 1 < 2^20 / in_c for in_c <= 64)
+    const unsigned inv_c = (1u << 20) / (unsigned)N.blk[0].in_c + 1u;
     const bool profiling = taps.prof != nullptr && blockIdx.x == 0 && wave == 0;
     long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;
     auto mark = [&](int i) { if (profiling) { const long long now = clock64(); ph[i] += now - tlast; tlast = now; } };
@@ -181,11 +183,11 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
             const KwsConvBlock &k = N.blk[0];
             const int rows = nn_rows(k);
             const int zp4 = (int)((unsigned)(k.in_zp & 0xff) * 0x01010101u);
-            for (int i = lane * 4; i < rows * k.in_cpad; i += 64 * 4) *(int *)(actA + i) = zp4;
+            for (int i = lane * 16; i < rows * k.in_cpad; i += 64 * 16) *(int4 *)(actA + i) = make_int4(zp4, zp4, zp4, zp4);
             WAVE_SYNC();
             const int8_t *src = q_in + (size_t)clip * F;
             for (int i = lane; i < k.in_w * k.in_c; i += 64) {
-                const int tt = i / k.in_c, c = i - tt * k.in_c;
+                const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k.in_c;       // i / in_c
                 actA[(tt + k.pad_left) * k.in_cpad + c] = src[i];
             }
             WAVE_SYNC();
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
             const int npl = last ? 0 : N.blk[b + 1].pad_left;
             if (!last) {
                 const int zp4 = (int)((unsigned)(N.blk[b + 1].in_zp & 0xff) * 0x01010101u);
-                for (int i = lane * 4; i < nrows * ncp; i += 64 * 4) *(int *)(nxt + i) = zp4;
+                for (int i = lane * 16; i < nrows * ncp; i += 64 * 16) *(int4 *)(nxt + i) = make_int4(zp4, zp4, zp4, zp4);
                 WAVE_SYNC();
             }
             const int n_out = k.pool_w * k.out_c;
@@ -558,11 +560,12 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
     nn_mfma_init<CP>(ctx, N, lane);
     __syncthreads();
     const int F = N.n_features;
+    const unsigned inv_c = (1u << 20) / (unsigned)k1.in_c + 1u;          // i / in_c == (i * inv_c) >> 20 for i < n_features <= 4096
     for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
         // ---- int8 input tensor [time][in_c] -> LDS rows of CP bytes at row (time + pad_left) --------------------
         const int8_t *src = q_in + (size_t)clip * F;
         for (int i = lane; i < F; i += 64) {
-            const int tt = i / k1.in_c, c = i - tt * k1.in_c;
+            const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k1.in_c;       // i / in_c
             act1[(tt + k1.pad_left) * CP + c] = src[i];
         }
         WAVE_SYNC();
