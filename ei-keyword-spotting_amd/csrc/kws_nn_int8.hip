@@ -186,9 +186,16 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
             for (int i = lane * 16; i < rows * k.in_cpad; i += 64 * 16) *(int4 *)(actA + i) = make_int4(zp4, zp4, zp4, zp4);
             WAVE_SYNC();
             const int8_t *src = q_in + (size_t)clip * F;
-            for (int i = lane; i < k.in_w * k.in_c; i += 64) {
-                const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k.in_c;       // i / in_c
-                actA[(tt + k.pad_left) * k.in_cpad + c] = src[i];
+            if ((k.in_c & 3) == 0) {                       // four channels per copy (feature vector and rows 4-byte aligned)
+                for (int i = lane * 4; i < k.in_w * k.in_c; i += 64 * 4) {
+                    const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k.in_c;
+                    *(int *)(actA + (tt + k.pad_left) * k.in_cpad + c) = *(const int *)(src + i);
+                }
+            } else {
+                for (int i = lane; i < k.in_w * k.in_c; i += 64) {
+                    const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k.in_c;       // i / in_c
+                    actA[(tt + k.pad_left) * k.in_cpad + c] = src[i];
+                }
             }
             WAVE_SYNC();
         }
@@ -564,9 +571,16 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
     for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
         // ---- int8 input tensor [time][in_c] -> LDS rows of CP bytes at row (time + pad_left) --------------------
         const int8_t *src = q_in + (size_t)clip * F;
-        for (int i = lane; i < F; i += 64) {
-            const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k1.in_c;       // i / in_c
-            act1[(tt + k1.pad_left) * CP + c] = src[i];
+        if ((k1.in_c & 3) == 0) {                          // four channels per copy (feature vector and rows 4-byte aligned)
+            for (int i = lane * 4; i < F; i += 64 * 4) {
+                const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k1.in_c;
+                *(int *)(act1 + (tt + k1.pad_left) * CP + c) = *(const int *)(src + i);
+            }
+        } else {
+            for (int i = lane; i < F; i += 64) {
+                const int tt = (int)(((unsigned)i * inv_c) >> 20), c = i - tt * k1.in_c;       // i / in_c
+                act1[(tt + k1.pad_left) * CP + c] = src[i];
+            }
         }
         WAVE_SYNC();
         nn_mfma_clip<CP>(ctx, N, head, act1, act2, s_vec[wave], s_lut1, s_lut2, lane, clip, scores, taps);
