@@ -1,0 +1,84 @@
+"""Opt-in deep parity sweep (not collected by pytest; run on the GPU box):  python tests/deep_soak.py [rounds] [clips]
+
+Every clip of `rounds` full batches (default 2 x 65 536) goes through the HIP path AND the CPU restatement of the reference
+(oracle/, one worker process per host core), for the shipped int8 impulse and for the 49x40 fp32 headline graph: MFCC
+features compared bit for bit, int8 input tensors and int8-model scores exactly, float-model scores within 1e-6.
+Writes one summary line per model; exit status 1 on any difference.
+"""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from kws_testlib import MODELS, ROOT, Oracle, OracleModel  # noqa: E402
+
+_W = {}
+
+
+def _worker(args):
+    path, seed, first, n = args
+    if path not in _W:
+        o = _W.setdefault("oracle", Oracle())
+        _W[path] = OracleModel(o, path)
+    om, o = _W[path], _W["oracle"]
+    clips = o.synth(seed, first, n)
+    s, f, q = om.run_batch(clips, want_features=True)
+    return first, s, f, q
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    sys.path.insert(0, ROOT)
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    cores = len(os.sched_getaffinity(0))
+    chunk = 512
+    bad = 0
+    with mp.get_context("spawn").Pool(cores) as pool:
+        for name in ("l476_no_yes.kwsm", "cfg2_mfcc40_f32.kwsm"):
+            path = os.path.join(MODELS, name)
+            gm = pkg.Model(path, device=0)
+            F, C = gm.n_features, gm.n_labels
+            t0 = time.time()
+            n_feat_diff = n_q_diff = n_clips = 0
+            max_score = 0.0
+            for r in range(rounds):
+                seed, base = 1000 + r, 7 * r * B
+                pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+                pkg.synth_clips_device(seed, base, B, 16000, pcm.data_ptr())
+                feats = torch.empty((B, F), dtype=torch.float32, device="cuda:0")
+                scores = torch.empty((B, C), dtype=torch.float32, device="cuda:0")
+                q = None if gm.is_float else torch.empty((B, F), dtype=torch.int8, device="cuda:0")
+                gm.run_classifier_batch_device(pcm.data_ptr(), B, scores.data_ptr(), feats.data_ptr(), None if q is None else q.data_ptr())
+                torch.cuda.synchronize()
+                gf, gs = feats.cpu().numpy(), scores.cpu().numpy()
+                gq = None if q is None else q.cpu().numpy()
+                jobs = [(path, seed, base + i, min(chunk, B - i)) for i in range(0, B, chunk)]
+                for first, s, f, qq in pool.imap_unordered(_worker, jobs):
+                    i = first - base
+                    n = len(s)
+                    n_feat_diff += int((gf[i:i + n].view(np.uint32) != f.view(np.uint32)).sum())
+                    if gq is not None:
+                        n_q_diff += int((gq[i:i + n] != qq).sum())
+                        max_score = max(max_score, float(np.abs(gs[i:i + n] - s).max()))
+                        n_q_diff += int((gs[i:i + n].view(np.uint32) != s.view(np.uint32)).sum())
+                    else:
+                        max_score = max(max_score, float(np.abs(gs[i:i + n] - s).max()))
+                    n_clips += n
+            ok = n_feat_diff == 0 and n_q_diff == 0 and max_score <= (1e-6 if gm.is_float else 0.0)
+            bad += 0 if ok else 1
+            print("%s: %d clips, %d feature words compared: %d differ; int8 tensor/score words differing: %d; max |score - oracle| = %.3g; "
+                  "%s (%.0f s, %d oracle workers)" % (name, n_clips, n_clips * F, n_feat_diff, n_q_diff, max_score,
+                                                      "OK" if ok else "MISMATCH", time.time() - t0, cores), flush=True)
+            gm.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
