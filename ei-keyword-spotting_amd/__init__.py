@@ -188,10 +188,13 @@ class Model:
         B = pcm.shape[0]
         assert pcm.shape[1] == self.clip_samples
         s = np.zeros((B, self.n_labels), np.float32)
+        if not want_features:                                                      # scores only: nothing else crosses PCIe
+            _check(self.L.kws_run_classifier_batch(self.h, _p(pcm), B, _p(s), None, None))
+            return s
         f = np.zeros((B, self.n_features), np.float32)
         q = None if self.is_float else np.zeros((B, self.n_features), np.int8)     # float models have no int8 tensor
         _check(self.L.kws_run_classifier_batch(self.h, _p(pcm), B, _p(s), _p(f), None if q is None else _p(q)))
-        return (s, f, q) if want_features else s
+        return s, f, q
 
     def nn_batch(self, q):
         q = np.ascontiguousarray(q, np.int8).reshape(-1, self.n_features)

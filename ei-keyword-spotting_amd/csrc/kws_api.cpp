@@ -51,6 +51,10 @@ void kws_destroy(kws_handle *h)
     for (void *p : h->dev_allocs) (void)hipFree(p);
     if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
+    for (int k = 0; k < 2; ++k) {
+        for (void *p : { (void *)h->pipe.pcm[k], (void *)h->pipe.s[k], (void *)h->pipe.f[k], (void *)h->pipe.q[k] }) if (p) (void)hipFree(p);
+        if (h->pipe.st[k]) (void)hipStreamDestroy(h->pipe.st[k]);
+    }
     for (void *p : { (void *)h->ws.d_x, (void *)h->ws.d_f, (void *)h->ws.d_s, (void *)h->ws.d_w, (void *)h->ws.d_q })
         if (p) (void)hipFree(p);
     for (void *p : { (void *)h->ws.h_x, (void *)h->ws.h_s, (void *)h->ws.h_f })
@@ -236,26 +240,60 @@ EI_IMPULSE_ERROR kws_run_inference_batch_device(kws_handle *h, const float *feat
     return kws_nn_batch_device(h, h->s_q, B, scores, nullptr, nullptr, nullptr, stream);
 }
 
+// extract_mfcc_features + the network for B windows in HBM.  float models: f must be a [B][n_features] buffer (the network
+// reads it); int8 models: q must be a [B][n_features] buffer, f is optional (the float feature matrix only leaves the chip
+// when somebody asks for it: the cepstra stay in LDS)
+static EI_IMPULSE_ERROR classify_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *f, int8_t *q, hipStream_t s)
+{
+    EI_IMPULSE_ERROR e;
+    if (h->is_float) {
+        e = mfcc_fused_device(h, pcm, 0, B, f, nullptr, s);
+        return e ? e : nn_f32_device(h, f, B, scores, nullptr, s);
+    }
+    e = mfcc_fused_device(h, pcm, 0, B, f, q, s);
+    if (e) return e;
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    int rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
+    if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
+}
+
 EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *features,
                                                  int8_t *q_in, void *stream)
 {
     if (!h || !pcm || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->is_float && q_in) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 input tensor requested from a float32 model");
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
-    if (h->is_float) {                       // features -> HBM (caller's buffer or scratch) -> float network
-        if (q_in) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 input tensor requested from a float32 model");
-        float *f = features ? features : h->s_mfcc;
-        e = mfcc_fused_device(h, pcm, 0, B, f, nullptr, (hipStream_t)stream);
-        return e ? e : nn_f32_device(h, f, B, scores, nullptr, (hipStream_t)stream);
+    return classify_device(h, pcm, B, scores, h->is_float ? (features ? features : h->s_mfcc) : features,
+                           h->is_float ? nullptr : (q_in ? q_in : h->s_q), (hipStream_t)stream);
+}
+
+// Host buffers in, host buffers out.  The batch is cut into chunks that alternate between two streams, each with its own device
+// buffers: while one chunk's kernels run, the next chunk's PCM crosses PCIe (pinned host memory: truly asynchronous; pageable
+// memory: the runtime stages it, the other stream's kernels still overlap).  The device buffers live in the handle.
+static const size_t kHostChunk = 8192;       // clips per chunk: 262 MB of PCM per buffer
+static EI_IMPULSE_ERROR ensure_pipe(kws_handle *h, size_t chunk)
+{
+    kws_handle::HostPipe &p = h->pipe;
+    const size_t n = h->model.raw_sample_count, F = h->model.nn_input_frame_size, C = h->model.labels.size();
+    for (int k = 0; k < 2; ++k)
+        if (!p.st[k] && hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking) != hipSuccess) return fail(KWS_ERROR_HIP, "stream creation failed");
+    if (chunk <= p.cap) return EI_IMPULSE_OK;
+    for (int k = 0; k < 2; ++k) {
+        for (void *q : { (void *)p.pcm[k], (void *)p.s[k], (void *)p.f[k], (void *)p.q[k] }) if (q) (void)hipFree(q);
+        p.pcm[k] = nullptr; p.s[k] = nullptr; p.f[k] = nullptr; p.q[k] = nullptr;
     }
-    // one fused launch for extract_mfcc_features + quantisation (the cepstra stay in LDS), then the network;
-    // the float feature matrix only leaves the chip when the caller asks for it
-    int8_t *q = q_in ? q_in : h->s_q;
-    e = mfcc_fused_device(h, pcm, 0, B, features, q, (hipStream_t)stream);
-    if (e) return e;
-    return kws_nn_batch_device(h, q, B, scores, nullptr, nullptr, nullptr, stream);
+    p.cap = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (hipMalloc((void **)&p.pcm[k], chunk * n * sizeof(int16_t)) != hipSuccess || hipMalloc((void **)&p.s[k], chunk * C * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&p.f[k], chunk * F * sizeof(float)) != hipSuccess || (!h->is_float && hipMalloc((void **)&p.q[k], chunk * F) != hipSuccess))
+            return fail(EI_IMPULSE_ALLOC_FAILED, "device allocation failed");
+    }
+    p.cap = chunk;
+    return EI_IMPULSE_OK;
 }
 
 EI_IMPULSE_ERROR kws_run_classifier_batch(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *features, int8_t *q_in)
@@ -263,27 +301,33 @@ EI_IMPULSE_ERROR kws_run_classifier_batch(kws_handle *h, const int16_t *pcm, siz
     if (!h || !pcm || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     if (B == 0) return EI_IMPULSE_OK;
     HIP_TRY(hipSetDevice(h->device));
+    if (h->is_float && q_in) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 input tensor requested from a float32 model");
     const size_t n = h->model.raw_sample_count, F = h->model.nn_input_frame_size, C = h->model.labels.size();
-    int16_t *d_pcm = nullptr; float *d_s = nullptr, *d_f = nullptr; int8_t *d_q = nullptr;
-    EI_IMPULSE_ERROR e = EI_IMPULSE_OK;
-    auto cleanup = [&]() { if (d_pcm) (void)hipFree(d_pcm); if (d_s) (void)hipFree(d_s); if (d_f) (void)hipFree(d_f); if (d_q) (void)hipFree(d_q); };
-#define TRY_OR_CLEAN(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(KWS_ERROR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
-    TRY_OR_CLEAN(hipMalloc((void **)&d_pcm, B * n * sizeof(int16_t)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_s, B * C * sizeof(float)));
-    TRY_OR_CLEAN(hipMalloc((void **)&d_f, B * F * sizeof(float)));
-    if (h->is_float && q_in) { cleanup(); return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 input tensor requested from a float32 model"); }
-    if (!h->is_float) TRY_OR_CLEAN(hipMalloc((void **)&d_q, B * F));
-    TRY_OR_CLEAN(hipMemcpy(d_pcm, pcm, B * n * sizeof(int16_t), hipMemcpyHostToDevice));
-    e = kws_run_classifier_batch_device(h, d_pcm, B, d_s, d_f, d_q, nullptr);
-    if (e == EI_IMPULSE_OK) {
-        TRY_OR_CLEAN(hipMemcpy(scores, d_s, B * C * sizeof(float), hipMemcpyDeviceToHost));
-        if (features) TRY_OR_CLEAN(hipMemcpy(features, d_f, B * F * sizeof(float), hipMemcpyDeviceToHost));
-        if (q_in) TRY_OR_CLEAN(hipMemcpy(q_in, d_q, B * F, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(h->pipe_mu);
+    const size_t chunk = std::min(B, kHostChunk);
+    EI_IMPULSE_ERROR e = ensure_pipe(h, chunk);
+    if (e) return e;
+    kws_handle::HostPipe &p = h->pipe;
+    hipError_t he = hipSuccess;
+    size_t i = 0;
+    for (size_t off = 0; off < B && !e && he == hipSuccess; off += chunk, ++i) {
+        const int k = (int)(i & 1);
+        const size_t nb = std::min(chunk, B - off);
+        he = hipMemcpyAsync(p.pcm[k], pcm + off * n, nb * n * sizeof(int16_t), hipMemcpyHostToDevice, p.st[k]);
+        if (he != hipSuccess) break;
+        e = classify_device(h, p.pcm[k], nb, p.s[k], (h->is_float || features) ? p.f[k] : nullptr, h->is_float ? nullptr : p.q[k], p.st[k]);
+        if (e) break;
+        he = hipMemcpyAsync(scores + off * C, p.s[k], nb * C * sizeof(float), hipMemcpyDeviceToHost, p.st[k]);
+        if (he == hipSuccess && features) he = hipMemcpyAsync(features + off * F, p.f[k], nb * F * sizeof(float), hipMemcpyDeviceToHost, p.st[k]);
+        if (he == hipSuccess && q_in) he = hipMemcpyAsync(q_in + off * F, p.q[k], nb * F, hipMemcpyDeviceToHost, p.st[k]);
     }
-    cleanup();
-    return e;
+    for (int k = 0; k < 2; ++k) { const hipError_t se = hipStreamSynchronize(p.st[k]); if (he == hipSuccess) he = se; }
+    if (e) return e;
+    if (he != hipSuccess) return fail(KWS_ERROR_HIP, "kws_run_classifier_batch: %s", hipGetErrorString(he));
+    return EI_IMPULSE_OK;
 }
 
+#define TRY_OR_CLEAN(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(KWS_ERROR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
 EI_IMPULSE_ERROR kws_nn_batch(kws_handle *h, const int8_t *q_in, size_t B, float *scores, int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out)
 {
     if (!h || !q_in || !scores) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");

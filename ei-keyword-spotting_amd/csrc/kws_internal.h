@@ -133,6 +133,16 @@ struct kws_handle {
     float *s_mfcc = nullptr;      // cepstra before CMVN, [B][n_features]
     int8_t *s_q = nullptr;
     size_t s_cap = 0;
+    // host-buffer entry point (kws_run_classifier_batch): two streams, each with its own chunk-sized device buffers, so that
+    // the PCIe transfer of one chunk overlaps the kernels of the other; allocated once, grown on demand
+    struct HostPipe {
+        hipStream_t st[2] = { nullptr, nullptr };
+        int16_t *pcm[2] = { nullptr, nullptr };
+        float *s[2] = { nullptr, nullptr }, *f[2] = { nullptr, nullptr };
+        int8_t *q[2] = { nullptr, nullptr };
+        size_t cap = 0;
+    } pipe;
+    std::mutex pipe_mu;
     std::mutex mu;
     // single-clip workspace of the SDK entry points: allocated once, pinned host staging, own stream
     struct Ws {

@@ -708,3 +708,27 @@ def test_soak_headline_model_2048_clips(pkg, oracle):
         _, taps = om.nn_invoke_f32(fo[i], taps=True)
         assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), i
     gm.close()
+
+
+def test_host_buffer_entry_point_is_chunked_and_identical(pkg, oracle):
+    """kws_run_classifier_batch (host buffers) pipelines chunks of 8192 clips over two streams: a batch that spans three
+    chunks (the last one ragged) returns exactly what the device entry point returns, for an int8 and a float32 model."""
+    import torch
+    n = 8192 * 2 + 3616
+    clips = oracle.synth(31, 900000, n)
+    for name in ("l476_no_yes.kwsm", "cfg2_mfcc40_f32.kwsm"):
+        gm = pkg.Model(os.path.join(MODELS, name), device=0)
+        s, f, q = gm.run_classifier_batch(clips, want_features=True)
+        d = torch.from_numpy(clips).to("cuda:0")
+        sd = torch.empty((n, gm.n_labels), dtype=torch.float32, device="cuda:0")
+        fd = torch.empty((n, gm.n_features), dtype=torch.float32, device="cuda:0")
+        qd = None if gm.is_float else torch.empty((n, gm.n_features), dtype=torch.int8, device="cuda:0")
+        gm.run_classifier_batch_device(d.data_ptr(), n, sd.data_ptr(), fd.data_ptr(), None if qd is None else qd.data_ptr())
+        torch.cuda.synchronize()
+        assert (bits(s) == bits(sd.cpu().numpy())).all(), name
+        assert (bits(f) == bits(fd.cpu().numpy())).all(), name
+        if qd is not None:
+            assert (q == qd.cpu().numpy()).all(), name
+        s2 = gm.run_classifier_batch(clips[:5])                    # a later, smaller call reuses the buffers
+        assert (bits(s2) == bits(s[:5])).all(), name
+        gm.close()
