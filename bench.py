@@ -28,7 +28,8 @@ HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MI
 
 SHIPPED_MODEL = os.path.join(ROOT, "models", "l476_no_yes.kwsm")            # BASELINE configs[3]: what the reference ships
 DEFAULT_MODEL = os.path.join(ROOT, "models", "cfg2_mfcc40_f32.kwsm")       # BASELINE configs[1] as worded
-ALSO_MODELS = [SHIPPED_MODEL, os.path.join(ROOT, "models", "l476_no_yes_f32.kwsm"), os.path.join(ROOT, "models", "cfg2_mfcc40_int8.kwsm")]
+ALSO_MODELS = [SHIPPED_MODEL] + [os.path.join(ROOT, "models", n) for n in ("l476_no_yes_f32.kwsm", "cfg2_mfcc40_int8.kwsm",
+                                                                       "cfg5_dscnn_mfcc40_int8.kwsm", "cfg5_dscnn_mfcc40_f32.kwsm")]
 WORKLOADS = {
     "cfg2_mfcc40_f32.kwsm": "BASELINE configs[1]: 40-band MFCC (49x40: 40 mel, 40 cepstra, fft 256, CMVN 101) + 2-Conv CNN, fp32; "
                             "graph with seeded synthetic weights (the reference ships no such model)",
