@@ -294,12 +294,33 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
     float *vec = Y + L.y_floats;
     __syncthreads();
 
+    // next-clip prefetch registers (256-register build only): NNF_PF x 64 float4 cover the first block's padded input image
+    constexpr int NNF_PF = 9;
+    float4 pf[NNF_PF];
+#pragma unroll
+    for (int u = 0; u < NNF_PF; ++u) pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool have_pf = false;
+    const bool pf_ok = [&]() {
+        const KwsConvBlockF32 &k = N.blk[0];
+        const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
+        return ((lo | hi | N.n_features) & 3) == 0 && ((tot + 3) >> 2) <= 64 * NNF_PF && N.n_blocks > 1;
+    }();
     for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
         {
             const KwsConvBlockF32 &k = N.blk[0];
             const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
             const float *src = features + (size_t)clip * N.n_features;
-            if (((lo | hi | N.n_features) & 3) == 0) {
+            if (have_pf) {
+                // the feature vector was requested while the previous clip's tail blocks ran (see below): it only has to be
+                // placed, zero padding rows included
+                float4 *A4 = (float4 *)A;
+                const int lo4 = lo >> 2, hi4 = hi >> 2, tot4 = (tot + 3) >> 2;
+#pragma unroll
+                for (int u = 0; u < NNF_PF; ++u) {
+                    const int i = lane + 64 * u;
+                    if (i < tot4) A4[i] = (i >= lo4 && i < hi4) ? pf[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else if (((lo | hi | N.n_features) & 3) == 0) {
                 // 16-byte copies (the feature vector of a clip and its place in the image are both 16-byte aligned)
                 const float4 *src4 = (const float4 *)src;
                 float4 *A4 = (float4 *)A;
@@ -361,6 +382,22 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
             default: nnf_conv_ob<1, (MAXT <= 512)>(k, cur, (const float *)smem_raw + s_w_off[b], Y, dst, lane); break;
             }
             WAVE_SYNC();
+            if (b == 0 && MAXT <= 512 && pf_ok) {
+                // block 0 (most of the clip's time) is done: request the NEXT clip's feature vector now, so that it arrives
+                // while the short tail blocks, FC and softmax run (phases with little VALU work and nothing to prefetch)
+                const int nclip = clip + gridDim.x * n_waves;
+                have_pf = nclip < n_clips;
+                if (have_pf) {
+                    const KwsConvBlockF32 &k0 = N.blk[0];
+                    const int lo4 = (k0.pad_left * k0.in_c) >> 2, hi4 = lo4 + ((k0.in_w * k0.in_c) >> 2);
+                    const float4 *src4 = (const float4 *)(features + (size_t)nclip * N.n_features);
+#pragma unroll
+                    for (int u = 0; u < NNF_PF; ++u) {
+                        const int i = lane + 64 * u;
+                        if (i >= lo4 && i < hi4) pf[u] = src4[i - lo4];
+                    }
+                }
+            }
             if (nnf_staged(k)) {
                 // MAX_POOL_2D over time (pooling.h:189-237) from the staged conv output
                 for (int idx = lane; idx < n_out; idx += 64) {
