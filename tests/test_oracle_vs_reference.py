@@ -194,3 +194,24 @@ def test_synthetic_graphs_through_reference_op_registrations(name, oracle, refer
                     if a.dtype == np.float32:
                         assert (bits(a) == bits(t)).all(), (name, it)           # everything up to the logits
                 assert np.abs(out - oo).max() <= 1e-7                          # softmax: libm expf on both sides
+
+
+def test_l432_model_through_reference_op_registrations(oracle, reference):
+    """The second shipped impulse (L432, 3 classes).  Its own SDK copy cannot be built here, but its
+    graph and tables can be evaluated by the reference's TFLite-Micro op code all the same: every tensor of
+    models/l432_trick_or_treat.kwsm through init/prepare/invoke of Register_*() == the restatement, bit for bit; its DSP
+    settings through the reference's extract_mfcc_features are the `high_frequency=0` case of the MFCC configurations above."""
+    import os
+    from kws_testlib import MODELS, OracleModel
+    path = os.path.join(MODELS, "l432_trick_or_treat.kwsm")
+    blob = open(path, "rb").read()
+    om = OracleModel(oracle, path)
+    rng = np.random.default_rng(432)
+    for it in range(64):
+        x = rng.integers(-128, 128, om.n_features).astype(np.int8)
+        out, taps = reference.graph_run(blob, x)
+        oo, ot = om.nn_invoke(x, taps=True)
+        assert (out == oo).all(), it
+        for a, t in zip(taps, ot):
+            if a.dtype == np.int8:
+                assert (a == t).all(), it
