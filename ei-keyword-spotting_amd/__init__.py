@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
+    "kws_extract_mfe_batch_device",
     "kws_synth_clips_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
@@ -98,6 +99,7 @@ def lib():
         L.kws_nn_batch.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.kws_nn_f32_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.kws_mfe_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.kws_extract_mfe_batch_device.argtypes = [vp, vp, sz, vp, vp]
         L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
         L.kws_streams_create.argtypes = [vp, sz, C.POINTER(vp)]
         L.kws_streams_destroy.argtypes = [vp]
@@ -215,6 +217,9 @@ class Model:
 
     def mfe_batch_device(self, pcm_ptr, B, mel_ptr, energy_ptr=None, stream=None):
         _check(self.L.kws_mfe_batch_device(self.h, pcm_ptr, B, mel_ptr, energy_ptr, stream))
+
+    def extract_mfe_batch_device(self, pcm_ptr, B, features_ptr, stream=None):
+        _check(self.L.kws_extract_mfe_batch_device(self.h, pcm_ptr, B, features_ptr, stream))
 
     def mfcc_batch_device(self, pcm_ptr, B, mfcc_ptr, stream=None):
         _check(self.L.kws_mfcc_batch_device(self.h, pcm_ptr, B, mfcc_ptr, stream))

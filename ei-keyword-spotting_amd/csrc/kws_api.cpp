@@ -167,6 +167,25 @@ EI_IMPULSE_ERROR kws_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t 
     return EI_IMPULSE_OK;
 }
 
+EI_IMPULSE_ERROR kws_extract_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features, void *stream)
+{
+    if (!h || !pcm || !features) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    // the MFE block hands the raw signal to feature::mfe (ei_run_dsp.h:398-400; extract_mfcc_features wraps it in the
+    // pre-emphasis class first): coefficient 0 makes the kernel's y = x - cof * prev the identity, bit for bit
+    KwsDspPlan P = h->dsp;
+    P.pre_cof = 0.0f;
+    const int rows = P.n_frames, cols = P.n_filters;
+    if (rows > (cols > 16 ? 51 : 52)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%d frames x %d filters outside the MFE normalisation kernel's limits", rows, cols);
+    int rc = kws_launch_mfe(P, pcm, (int)B, features, nullptr, grid_cap_mfcc(h), (hipStream_t)stream);
+    if (rc) return fail(KWS_ERROR_HIP, "MFE kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    rc = kws_launch_mfe_norm(features, (int)B, rows, cols, P.win_size, P.pad_map, rows + 2 * P.pad, grid_cap_nn(h), (hipStream_t)stream);
+    if (rc) return fail(KWS_ERROR_HIP, "MFE normalisation kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
+}
+
 EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfcc, size_t B, float *scores, float *features,
                                                  int8_t *q_in, void *stream)
 {

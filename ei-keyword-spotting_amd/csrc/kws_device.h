@@ -145,7 +145,8 @@ __device__ __forceinline__ int8_t quantize_feature(float o, float in_scale, int 
 //  lane fetches four of them with one 16-byte read a batch ahead: a term costs ONE dependent LDS read (prefetched too).
 // ---------------------------------------------------------------------------------------------------------
 //  emit(row, c, o): called once per normalised element o = (x - mean) / (std + eps).
-template <int CR, int CG, typename Emit>
+//  VARIANCE = false: cmvnw's variance_normalization = false branch (processing.hpp:379-385), o = x - mean, no second walk.
+template <int CR, int CG, typename Emit, bool VARIANCE = true>
 __device__ __forceinline__ void cmvn_columns(const float *__restrict__ mel, const int MELS, const int *__restrict__ map, int *__restrict__ offt,
                                              int lane, int nfr, int ncep, int prow, int win, Emit emit)
 {
@@ -205,34 +206,40 @@ __device__ __forceinline__ void cmvn_columns(const float *__restrict__ mel, cons
         }
 #pragma unroll
         for (int r = 0; r < CR; ++r) mean[r] = sum[r] / fwin;
-        auto sq_acc = [&](float x, int r) {
-            const float d = x - mean[r];
-            const double dd = (double)d;
-            sd[r] = (float)__fma_rn(dd, dd, (double)sd[r]);   // std += pow(d, 2)
-        };
+        if constexpr (VARIANCE) {
+            auto sq_acc = [&](float x, int r) {
+                const float d = x - mean[r];
+                const double dd = (double)d;
+                sd[r] = (float)__fma_rn(dd, dd, (double)sd[r]);   // std += pow(d, 2)
+            };
 #pragma unroll
-        for (int p = 0; p < CR - 1; ++p) {
-            const float x = val(p);
+            for (int p = 0; p < CR - 1; ++p) {
+                const float x = val(p);
 #pragma unroll
-            for (int r = 0; r <= p; ++r) sq_acc(x, r);
-        }
-        main_walk([&](float x) {
+                for (int r = 0; r <= p; ++r) sq_acc(x, r);
+            }
+            main_walk([&](float x) {
 #pragma unroll
-            for (int r = 0; r < CR; ++r) sq_acc(x, r);
-        });
+                for (int r = 0; r < CR; ++r) sq_acc(x, r);
+            });
 #pragma unroll
-        for (int q = 0; q < CR - 1; ++q) {
-            const float x = val(win + q);
+            for (int q = 0; q < CR - 1; ++q) {
+                const float x = val(win + q);
 #pragma unroll
-            for (int r = q + 1; r < CR; ++r) sq_acc(x, r);
+                for (int r = q + 1; r < CR; ++r) sq_acc(x, r);
+            }
         }
 #pragma unroll
         for (int r = 0; r < CR; ++r) {
             const int row = r0 + r;
             if (act && row < nfr) {
-                const float dev = sqrtf(sd[r] / fwin);        // correctly rounded (clang expands v_sqrt_f32 + fix-up)
                 const float xv = mel[row * MELS + c];
-                emit(row, c, (xv - mean[r]) / (dev + FLT_EPSILON));
+                if constexpr (VARIANCE) {
+                    const float dev = sqrtf(sd[r] / fwin);    // correctly rounded (clang expands v_sqrt_f32 + fix-up)
+                    emit(row, c, (xv - mean[r]) / (dev + FLT_EPSILON));
+                } else {
+                    emit(row, c, xv - mean[r]);
+                }
             }
         }
     }

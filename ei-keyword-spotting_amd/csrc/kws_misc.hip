@@ -91,3 +91,66 @@ int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint3
     hipLaunchKernelGGL(kws_synth_kernel, grid, dim3(256), 0, stream, seed, first_clip, n_clips, clip_len, out);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+//  MFE block of the newer SDK copy (L432 .../edge-impulse-sdk): extract_mfe_features (classifier/ei_run_dsp.h:369-418) =
+//  speechpy::feature::mfe -> processing::cmvnw(win_size, variance_normalization = false, scale = true)
+//  (dsp/speechpy/processing.hpp:327-399) -> numpy::normalize (dsp/numpy.hpp:1391-1429).  This kernel is the part after mfe:
+//  one wave per clip, the [frames][filters] matrix in LDS, windowed mean subtraction with cmvn_columns<.., VARIANCE = false>,
+//  then (x - min) * (1 / (max - min)) over the whole matrix, in place in HBM.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KWS_MFE_NORM_WAVES = 4;
+__global__ __launch_bounds__(KWS_WAVE * KWS_MFE_NORM_WAVES) void kws_mfe_norm_kernel(float *__restrict__ feat, int n_clips, int rows, int cols, int win,
+                                                                                   const int *__restrict__ pad_map, int prow)
+{
+    constexpr int MAXR = KWS_MAXF, MAXC = KWS_NF_MAX, MELS = MAXC + 1;
+    __shared__ int s_map[KWS_MAXPROW];
+    __shared__ float s_in[KWS_MFE_NORM_WAVES][MAXR * MELS];
+    __shared__ float s_out[KWS_MFE_NORM_WAVES][MAXR * MAXC];
+    __shared__ __attribute__((aligned(16))) int s_off[KWS_MFE_NORM_WAVES][2 * KWS_ZF];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < prow; i += blockDim.x) s_map[i] = pad_map[i];
+    __syncthreads();
+    float *in = s_in[wave], *out = s_out[wave];
+    const int n = rows * cols;
+    for (int clip = blockIdx.x * KWS_MFE_NORM_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_MFE_NORM_WAVES) {
+        float *g = feat + (size_t)clip * n;
+        for (int i = lane; i < n; i += KWS_WAVE) {
+            const int r = i / cols, c = i - r * cols;
+            in[r * MELS + c] = g[i];
+        }
+        WAVE_SYNC();
+        float mn = FLT_MAX, mx = -FLT_MAX;                      // numpy::min / max (numpy.hpp:842-905): strict comparisons
+        auto emit = [&](int row, int c, float o) {
+            out[row * cols + c] = o;
+            if (o < mn) mn = o;
+            if (o > mx) mx = o;
+        };
+        if (cols > 16) cmvn_columns<17, 20, decltype(emit), false>(in, MELS, s_map, s_off[wave], lane, rows, cols, prow, win, emit);
+        else cmvn_columns<13, 16, decltype(emit), false>(in, MELS, s_map, s_off[wave], lane, rows, cols, prow, win, emit);
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {               // min / max are exact: any reduction order gives the same value
+            const float a = __shfl_xor(mn, sft), b = __shfl_xor(mx, sft);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        WAVE_SYNC();
+        const float row_scale = 1.0f / (mx - mn);               // numpy.hpp:1416
+        for (int i = lane; i < n; i += KWS_WAVE) {
+            float o = out[i] - mn;                              // numpy::subtract, then numpy::scale (skipped for 1.0f)
+            if (row_scale != 1.0f) o = o * row_scale;
+            g[i] = o;
+        }
+        WAVE_SYNC();
+    }
+}
+
+int kws_launch_mfe_norm(float *feat, int n_clips, int rows, int cols, int win, const int *pad_map, int prow, int grid_cap, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_clips <= 0) return 0;
+    int grid = (n_clips + KWS_MFE_NORM_WAVES - 1) / KWS_MFE_NORM_WAVES;
+    if (grid > grid_cap) grid = grid_cap;
+    hipLaunchKernelGGL(kws_mfe_norm_kernel, dim3(grid), dim3(KWS_WAVE * KWS_MFE_NORM_WAVES), 0, stream, feat, n_clips, rows, cols, win, pad_map, prow);
+    return (int)hipGetLastError();
+}

@@ -69,6 +69,11 @@ EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfc
  * mel [B][frames][filters] filterbank energies and energy [B][frames] frame energies (may be NULL), both after
  * zero handling, before any log. */
 EI_IMPULSE_ERROR kws_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *mel, float *energy, void *stream);
+/* extract_mfe_features for B clips -- the MFE DSP block of the newer SDK copy (nucleo-l432 .../edge-impulse-sdk/classifier/
+ * ei_run_dsp.h:369-418): speechpy::feature::mfe on the raw signal (no pre-emphasis), processing::cmvnw(win_size, false, true)
+ * (dsp/speechpy/processing.hpp:327-399) and numpy::normalize (dsp/numpy.hpp:1391-1429).  Frame / filter / window settings are
+ * the model's DSP settings; features [B][frames * filters] float, device. */
+EI_IMPULSE_ERROR kws_extract_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features, void *stream);
 /* extract_mfcc_features for B clips (classifier/ei_run_dsp.h:256-308) */
 EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm, size_t B, float *features,
                                                int8_t *q_in, void *stream);

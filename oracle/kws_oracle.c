@@ -583,6 +583,46 @@ int kwso_extract_mfcc(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, f
 }
 
 /* ====================================================================== */
+/*  MFE block of the L432 SDK copy             (L432 = .../nucleo-l432-keyword-spotting/keyword-spotting-02-v3/edge-impulse-sdk) */
+/*  extract_mfe_features                       L432 classifier/ei_run_dsp.h:369-418 */
+/*     = speechpy::feature::mfe (feature.hpp:193-318, the same text in both SDK copies)                                    */
+/*       -> processing::cmvnw(win_size, variance_normalization = false, scale = true)   L432 dsp/speechpy/processing.hpp:327-399 */
+/*       -> numpy::normalize                   L432 dsp/numpy.hpp:1391-1429                                                 */
+/*  Pinned against oracle/_ref/libei_ref_l432dsp.so (the two L432 headers compiled in place, ref_l432_dsp.cpp).              */
+/* ====================================================================== */
+int kwso_normalize(float *m, size_t n)
+{
+    float mn = FLT_MAX, mx = -FLT_MAX;                       /* numpy::min / max, numpy.hpp:842-905: strict comparisons */
+    for (size_t i = 0; i < n; i++) if (m[i] < mn) mn = m[i];
+    for (size_t i = 0; i < n; i++) if (m[i] > mx) mx = m[i];
+    const float row_scale = 1.0f / (mx - mn);                /* numpy.hpp:1416 */
+    for (size_t i = 0; i < n; i++) m[i] -= mn;               /* numpy::subtract, numpy.hpp:641-646 */
+    if (row_scale != 1.0f)                                   /* numpy::scale returns early for 1.0f, numpy.hpp:548-549 */
+        for (size_t i = 0; i < n; i++) m[i] *= row_scale;
+    return KWSO_OK;
+}
+
+int kwso_cmvnw_scale(float *m, int rows, int cols, int win_size, int variance_normalization, int scale)
+{
+    int rc = kwso_cmvnw(m, rows, cols, win_size, variance_normalization);
+    if (rc) return rc;
+    return scale ? kwso_normalize(m, (size_t)rows * (size_t)cols) : KWSO_OK;
+}
+
+/* features: [frames][num_filters] (num_cepstral of the config is not used) */
+int kwso_extract_mfe(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, float *features)
+{
+    const int frames = kwso_num_frames(n, c);
+    if (frames <= 0) return -1002;
+    float *energies = (float *)malloc(sizeof(float) * (size_t)frames);
+    if (!energies) return KWSO_ERR_OOM;
+    int rc = kwso_mfe(pcm, n, c, features, energies);
+    free(energies);
+    if (rc) return rc;
+    return kwso_cmvnw_scale(features, frames, c->num_filters, c->win_size, 0, 1);
+}
+
+/* ====================================================================== */
 /*  fixed-point helpers                                                    */
 /* ====================================================================== */
 int32_t kwso_srdhm(int32_t a, int32_t b)                 /* gemmlowp fixedpoint.h:329-339 */

@@ -63,6 +63,10 @@ int   kwso_dct2_ortho(float *inout, int n);            /* numpy.hpp:378-401 + dc
 int   kwso_mfcc_nocmvn(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, float *out);
 /* in-place windowed CMVN                                               processing.hpp:326-389 */
 int   kwso_cmvnw(float *m, int rows, int cols, int win_size, int variance_normalization);
+/* MFE block of the L432 SDK copy: cmvnw(..., scale) + numpy::normalize, extract_mfe_features */
+int   kwso_normalize(float *m, size_t n);
+int   kwso_cmvnw_scale(float *m, int rows, int cols, int win_size, int variance_normalization, int scale);
+int   kwso_extract_mfe(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, float *features);
 /* extract_mfcc_features: features[frames*num_cepstral]                 classifier/ei_run_dsp.h:256-308 */
 int   kwso_extract_mfcc(const int16_t *pcm, size_t n, const kwso_mfcc_config *c, float *features);
 

@@ -66,6 +66,9 @@ class Oracle:
         L.kwso_dct2_ortho.argtypes = [C.c_void_p, C.c_int]
         L.kwso_mfcc_nocmvn.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(MfccConfig), C.c_void_p]
         L.kwso_cmvnw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.kwso_cmvnw_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.kwso_extract_mfe.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(MfccConfig), C.c_void_p]
+        L.kwso_normalize.argtypes = [C.c_void_p, C.c_size_t]
         L.kwso_extract_mfcc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(MfccConfig), C.c_void_p]
         L.kwso_srdhm.restype = C.c_int32
         L.kwso_srdhm.argtypes = [C.c_int32, C.c_int32]
@@ -170,6 +173,24 @@ class Oracle:
         rc = self.L.kwso_cmvnw(_ptr(m), m.shape[0], m.shape[1], win_size, int(var_norm))
         assert rc == 0, rc
         return m
+
+    def cmvnw_scale(self, m, win_size, var_norm=False, scale=True):
+        """L432 SDK copy: processing::cmvnw(matrix, win_size, variance_normalization, scale)."""
+        m = np.array(m, np.float32)
+        rc = self.L.kwso_cmvnw_scale(_ptr(m), m.shape[0], m.shape[1], win_size, int(var_norm), int(scale))
+        assert rc == 0, rc
+        return m
+
+    def extract_mfe(self, pcm, cfg):
+        """L432 SDK copy: extract_mfe_features (no pre-emphasis whatever cfg.pre_cof says)."""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        c = MfccConfig.from_buffer_copy(cfg)
+        c.pre_cof = 0.0
+        nf = self.num_frames(pcm.size, c)
+        out = np.zeros(nf * c.num_filters, np.float32)
+        rc = self.L.kwso_extract_mfe(_ptr(pcm), pcm.size, C.byref(c), _ptr(out))
+        assert rc == 0, rc
+        return out
 
     def extract_mfcc(self, pcm, cfg):
         pcm = np.ascontiguousarray(pcm, np.int16)
@@ -283,6 +304,30 @@ class OracleContinuous:
 
 def have_reference():
     return os.path.exists(REF_SO)
+
+
+REF432_SO = os.path.join(ROOT, "oracle", "_ref", "libei_ref_l432dsp.so")
+
+
+class ReferenceL432Dsp:
+    """processing.hpp + numpy.hpp of the L432 SDK copy, compiled in place (oracle/ref_l432_dsp.cpp)."""
+
+    def __init__(self):
+        L = self.L = C.CDLL(REF432_SO)
+        L.eiref432_cmvnw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.eiref432_normalize.argtypes = [C.c_void_p, C.c_int, C.c_int]
+
+    def cmvnw(self, m, win_size, var_norm, scale):
+        m = np.array(m, np.float32)
+        rc = self.L.eiref432_cmvnw(_ptr(m), m.shape[0], m.shape[1], win_size, int(var_norm), int(scale))
+        assert rc == 0, rc
+        return m
+
+    def normalize(self, m):
+        m = np.array(m, np.float32)
+        rc = self.L.eiref432_normalize(_ptr(m), m.shape[0], m.shape[1])
+        assert rc == 0, rc
+        return m
 
 
 class Reference:

@@ -732,3 +732,37 @@ def test_host_buffer_entry_point_is_chunked_and_identical(pkg, oracle):
         s2 = gm.run_classifier_batch(clips[:5])                    # a later, smaller call reuses the buffers
         assert (bits(s2) == bits(s[:5])).all(), name
         gm.close()
+
+
+def test_mfe_block_golden_and_oracle(pkg, oracle, tmp_path):
+    """kws_extract_mfe_batch_device = extract_mfe_features of the L432 SDK copy (feature::mfe on the raw signal, cmvnw(win,
+    false, true), numpy::normalize): the reference's own outputs (tests/golden/mfe_block_l432.npz) and the restatement, bit
+    for bit -- constant clips normalise to 0 * inf = NaN on both sides (NaN payload/sign not compared)."""
+    import torch
+    from kws_testlib import synth_model_blob, L476_CONFIG
+    from test_oracle_golden import MFE_BLOCK_CASES, mfe_block_clips, same_bits_or_both_nan
+    g = np.load(os.path.join(GOLDEN, "mfe_block_l432.npz"))
+    gclips = mfe_block_clips(oracle, g)
+    cfg0 = L476_CONFIG()
+    models = {"f32": dict(seed=1), "f40": dict(seed=11, num_filters=40, ncep=40, low=300, high=0, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3),
+              "f32w51": dict(seed=2, ncep=10, win_size=51, high=4000, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3)}
+    for name, kw in MFE_BLOCK_CASES:
+        gm = pkg.Model(blob=synth_model_blob(**models[name]))
+        cfg = cfg0.copy(**kw)
+        nf = gm.n_filters
+        rows = oracle.num_frames(16000, cfg)
+
+        def run(clips):
+            d = torch.from_numpy(np.ascontiguousarray(clips)).to("cuda:0")
+            out = torch.empty((len(clips), rows * nf), dtype=torch.float32, device="cuda:0")
+            gm.extract_mfe_batch_device(d.data_ptr(), len(clips), out.data_ptr())
+            torch.cuda.synchronize()
+            return out.cpu().numpy()
+        got = run(gclips)
+        for i in range(len(gclips)):
+            assert same_bits_or_both_nan(got[i], g[name][i]), (name, i)            # the reference itself
+        clips = oracle.synth(123, 7, 200)
+        got = run(clips)
+        for i in range(len(clips)):
+            assert same_bits_or_both_nan(got[i], oracle.extract_mfe(clips[i], cfg)), (name, i)
+        gm.close()

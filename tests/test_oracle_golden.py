@@ -183,6 +183,32 @@ def test_mfcc40_golden(oracle):
             assert (bits(oracle.extract_mfcc(x, c)) == bits(g[name][i])).all(), (name, i)
 
 
+MFE_BLOCK_CASES = (("f32", dict()), ("f40", dict(num_filters=40, num_cepstral=40, high_frequency=0)), ("f32w51", dict(win_size=51)))
+
+
+def mfe_block_clips(oracle, g):
+    from kws_testlib import special_clips
+    sp = special_clips()
+    return np.concatenate([oracle.synth(int(g["seed"]), 0, int(g["n"])), np.stack([sp[str(k)] for k in g["special_names"]])])
+
+
+def same_bits_or_both_nan(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+def test_mfe_block_golden(oracle):
+    """extract_mfe_features of the L432 SDK copy (tools/make_golden.py mfe_block: the reference's feature::mfe, then the L432
+    headers' cmvnw(win, false, true) + numpy::normalize); constant clips normalise to 0 * inf = NaN there too."""
+    from kws_testlib import L476_CONFIG
+    g = _load("mfe_block_l432.npz")
+    clips = mfe_block_clips(oracle, g)
+    cfg = L476_CONFIG()
+    for name, kw in MFE_BLOCK_CASES:
+        for i, x in enumerate(clips):
+            assert same_bits_or_both_nan(oracle.extract_mfe(x, cfg.copy(**kw)), g[name][i]), (name, i)
+
+
 def test_synthetic_graph_goldens(oracle, tmp_path):
     """Outputs of the reference's own op registrations for the synthetic graphs (tools/make_golden.py graphs)."""
     from kws_testlib import SYNTH_SPECS, OracleModel, synth_model_blob

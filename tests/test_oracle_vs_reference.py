@@ -215,3 +215,38 @@ def test_l432_model_through_reference_op_registrations(oracle, reference):
         for a, t in zip(taps, ot):
             if a.dtype == np.int8:
                 assert (a == t).all(), it
+
+
+def _same_bits_or_both_nan(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+def test_l432_mfe_block_normalisation_pinned(oracle, reference):
+    """The MFE block of the newer SDK copy: processing::cmvnw(win, variance_normalization, scale) and numpy::normalize from the
+    L432 headers compiled in place (oracle/_ref/libei_ref_l432dsp.so) == the restatement, bit for bit, for every flag
+    combination; and extract_mfe_features' composition (feature::mfe on the raw signal -- the same text in both copies, so the
+    L476 build's -- then cmvnw(win, false, true)) == kwso_extract_mfe, incl. constant clips whose normalisation is 0 * inf."""
+    import os
+    from kws_testlib import REF432_SO, ReferenceL432Dsp, L476_CONFIG, special_clips
+    if not os.path.exists(REF432_SO):
+        pytest.skip("oracle/_ref/libei_ref_l432dsp.so not built (no /root/reference here)")
+    r432 = ReferenceL432Dsp()
+    rng = np.random.default_rng(5)
+    for rows, cols, win in ((49, 32, 101), (49, 40, 101), (12, 13, 5), (7, 3, 51), (49, 40, 13), (1, 4, 3)):
+        m = (rng.standard_normal((rows, cols)) * rng.uniform(0.01, 50)).astype(np.float32)
+        for vn in (False, True):
+            for sc in (False, True):
+                assert _same_bits_or_both_nan(r432.cmvnw(m, win, vn, sc), oracle.cmvnw_scale(m, win, vn, sc)), (rows, cols, win, vn, sc)
+        a = r432.normalize(m)
+        b = m.copy()
+        oracle.L.kwso_normalize(b.ctypes.data_as(__import__("ctypes").c_void_p), b.size)
+        assert _same_bits_or_both_nan(a, b)
+    cfg = L476_CONFIG()
+    clips = list(oracle.synth(9, 0, 6)) + list(special_clips().values())
+    for kw in (dict(), dict(num_filters=40, num_cepstral=40, high_frequency=0), dict(win_size=51), dict(fft_length=512, num_filters=24)):
+        c = cfg.copy(pre_cof=0.0, **kw)
+        for x in clips:
+            mel, _ = reference.mfe(x, c)
+            want = r432.cmvnw(mel, c.win_size, False, True).reshape(-1)
+            assert _same_bits_or_both_nan(want, oracle.extract_mfe(x, cfg.copy(**kw))), kw

@@ -37,6 +37,27 @@ def mfcc40(ref, synth, cfg):
     print("mfcc40_l476.npz", os.path.getsize(os.path.join(GOLDEN, "mfcc40_l476.npz")), "bytes")
 
 
+def mfe_block(ref, synth, cfg):
+    """The MFE block of the L432 SDK copy (extract_mfe_features, ei_run_dsp.h:369-418): feature::mfe on the raw signal -- the
+    L476 build's, the function is the same text in both copies -- then cmvnw(win_size, false, true) + numpy::normalize from
+    the L432 headers compiled in place (oracle/ref_l432_dsp.cpp)."""
+    from kws_testlib import ReferenceL432Dsp
+    r432 = ReferenceL432Dsp()
+    clips = synth.synth(9, 0, 10)
+    sp = special_clips()
+    clips = np.concatenate([clips, np.stack([sp[k] for k in sorted(sp) if k != "zeros"])])   # all-zero clip: max == min -> 0 * inf
+    out = {"seed": np.int32(9), "n": np.int32(10), "special_names": np.array([k for k in sorted(sp) if k != "zeros"])}
+    for name, kw in (("f32", dict()), ("f40", dict(num_filters=40, num_cepstral=40, high_frequency=0)), ("f32w51", dict(win_size=51))):
+        c = cfg.copy(pre_cof=0.0, **kw)
+        rows = []
+        for x in clips:
+            mel, _ = ref.mfe(x, c)
+            rows.append(r432.cmvnw(mel, c.win_size, False, True).reshape(-1))
+        out[name] = np.stack(rows)
+    np.savez_compressed(os.path.join(GOLDEN, "mfe_block_l432.npz"), **out)
+    print("mfe_block_l432.npz", os.path.getsize(os.path.join(GOLDEN, "mfe_block_l432.npz")), "bytes")
+
+
 def graphs(ref):
     """Synthetic graphs (kws_testlib.SYNTH_SPECS; int8 and float32 twins) evaluated by the reference's own TFLite-Micro
     op registrations (eiref_graph_run): inputs are regenerated in the tests from the seed, outputs are stored."""
@@ -69,6 +90,8 @@ def main():
     ref = Reference()
     if "--only-mfcc40" in sys.argv:
         return mfcc40(ref, Oracle(), L476_CONFIG())
+    if "--only-mfe-block" in sys.argv:
+        return mfe_block(ref, Oracle(), L476_CONFIG())
     if "--only-graphs" in sys.argv:
         return graphs(ref)
     synth = Oracle()          # only used for kwso_synth_fill (shared integer generator)
