@@ -178,7 +178,9 @@ EI_IMPULSE_ERROR kws_extract_mfe_batch_device(kws_handle *h, const int16_t *pcm,
     KwsDspPlan P = h->dsp;
     P.pre_cof = 0.0f;
     const int rows = P.n_frames, cols = P.n_filters;
-    if (rows > (cols > 16 ? 51 : 52)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%d frames x %d filters outside the MFE normalisation kernel's limits", rows, cols);
+    // cmvn_columns<17, 20> (more than 16 columns) walks 3 x 17 rows and needs a window of at least 17 rows; <13, 16>: 4 x 13, 13
+    if (rows > (cols > 16 ? 51 : 52) || P.win_size < (cols > 16 ? 17 : 13))
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%d frames x %d filters, window %d outside the MFE normalisation kernel's limits", rows, cols, P.win_size);
     int rc = kws_launch_mfe(P, pcm, (int)B, features, nullptr, grid_cap_mfcc(h), (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "MFE kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     rc = kws_launch_mfe_norm(features, (int)B, rows, cols, P.win_size, P.pad_map, rows + 2 * P.pad, grid_cap_nn(h), (hipStream_t)stream);
