@@ -6,12 +6,15 @@
 // ---------------------------------------------------------------------------------------------------------
 //  gemmlowp / TFLite fixed-point helpers (fixedpoint.h:329-368, TFL/kernels/internal/common.h:138-162)
 // ---------------------------------------------------------------------------------------------------------
+// gemmlowp SaturatingRoundingDoublingHighMul (fixedpoint.h:329-339): nudge = ab >= 0 ? 2^30 : 1 - 2^30, then a TRUNCATING
+// division of ab + nudge by 2^31.  With ab = q * 2^31 + r (0 <= r < 2^31) both signs give q + (r >= 2^30), i.e. the
+// arithmetic shift (ab + 2^30) >> 31: for ab < 0 the numerator ab + 1 - 2^30 is negative with remainder r + 1 - 2^30 (mod
+// 2^31), and truncation adds 1 exactly when that remainder is non-zero after the wrap, which is again r >= 2^30.
 __device__ __forceinline__ int srdhm(int a, int b)
 {
     const bool overflow = (a == b) && (a == (int)0x80000000);
     const long long ab = (long long)a * (long long)b;
-    const int nudge = ab >= 0 ? (1 << 30) : (1 - (1 << 30));
-    const int hi = (int)((ab + nudge) / (1ll << 31));          // truncating division
+    const int hi = (int)((ab + (1ll << 30)) >> 31);
     return overflow ? 0x7fffffff : hi;
 }
 __device__ __forceinline__ int rdivpot(int x, int e)
