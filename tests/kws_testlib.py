@@ -586,6 +586,8 @@ SYNTH_SPECS = {
     # un-pooled CONV_2D blocks of every row width: 13 -> 16-byte rows with an even tap count and two 32-row tiles, 24 -> 32-byte
     # rows but 40 outputs (stays on v_dot4), 40 -> 64-byte rows; then a pooled tail
     "mfma_mix": dict(seed=23, ncep=13, blocks=((24, 4, 1), (40, 2, 1), (32, 3, 1), (8, 3, 7)), n_labels=4),
+    # one 32-row tile with 64-byte rows (40 channels after a pooled block), then an even-tap pooled tail
+    "mfma_mix2": dict(seed=24, ncep=13, blocks=((40, 3, 7), (16, 3, 1), (8, 2, 7)), n_labels=3),
     "dscnn_b": dict(seed=22, ncep=10, blocks=(("dw", 2, 7, 7, 3), ("pw", 12, 1), ("dw", 1, 3, 7, 1)), n_labels=3),
     # BASELINE config 5 as worded: 49x40 MFCC, deeper depthwise-separable CNN, 10 keywords (+ noise/unknown); synthetic weights
     "cfg5_dscnn": dict(seed=50, num_filters=40, ncep=40, low=300, high=0, n_labels=12,
