@@ -244,6 +244,17 @@ def main():
         except Exception:
             pass
 
+        # what actually bounds the kernel: rocprofv3 SQ counters of this same command (profiles/r01h_pmc_util/), headline model only
+        valu = None
+        try:
+            if traffic is not None:
+                u = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_util", "summary.json")))["kernels"]["kws_mfcc_kernel"]
+                valu = {"VALUBusy_pct": round(u["VALUBusy"], 1), "VALUUtilization_pct": round(u["VALUUtilization"], 1),
+                        "valu_instructions_per_clip": round(u["VALU_instructions_per_clip"]),
+                        "source": "profiles/r01h_pmc_util/summary.json (rocprofv3 --pmc, separate passes)"}
+        except Exception:
+            pass
+
         def workload(name):
             return WORKLOADS.get(name, name) + "; %d clips of 1 s @ 16 kHz int16 per GPU resident in HBM" % B
 
@@ -261,7 +272,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc)",
                          "algorithmic_bytes_per_launch": algo_bytes * B, "algorithmic_bytes_per_clip": algo_bytes,
-                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), r["nn_kernel"]: round(ms_nn, 4)}},
+                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), r["nn_kernel"]: round(ms_nn, 4)},
+                         "note": "the kernel is VALU-issue-bound (order-constrained fp32/fp64 arithmetic of the reference), not HBM-bound; see valu",
+                         "valu": valu},
             "checksum": r["checksum"],
         }
         if also:
