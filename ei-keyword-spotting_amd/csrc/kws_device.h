@@ -146,24 +146,27 @@ __device__ __forceinline__ int8_t quantize_feature(float o, float in_scale, int 
 // ---------------------------------------------------------------------------------------------------------
 //  emit(row, c, o): called once per normalised element o = (x - mean) / (std + eps).
 //  VARIANCE = false: cmvnw's variance_normalization = false branch (processing.hpp:379-385), o = x - mean, no second walk.
+//  g0 / cb_begin / cb_end: this wave's share when several waves split one matrix (latency mode): its first row group and
+//  the column range it walks (multiples of CG); one wave doing everything passes 0, 0, ncep.
 template <int CR, int CG, typename Emit, bool VARIANCE = true>
 __device__ __forceinline__ void cmvn_columns(const float *__restrict__ mel, const int MELS, const int *__restrict__ map, int *__restrict__ offt,
-                                             int lane, int nfr, int ncep, int prow, int win, Emit emit)
+                                             int lane, int nfr, int ncep, int prow, int win, Emit emit,
+                                             int g0 = 0, int cb_begin = 0, int cb_end = 0x7fffffff)
 {
     constexpr int NG = KWS_WAVE / CG;                              // row groups
     static_assert(((CR - 1) & 3) == 0, "16-byte aligned offset batches");
     const float fwin = (float)win;
     const int cgrp = min(lane / CG, NG - 1), cl = lane - (lane / CG) * CG;
     const bool lane_on = lane < NG * CG;
-    const int r0 = cgrp * CR;
+    const int r0 = (g0 + cgrp) * CR;
     const int offn = ((win + CR - 1 + 3) & ~3) + 8;
     for (int i = lane; i < NG * offn; i += KWS_WAVE) {
         const int g = i / offn, pp = i - g * offn;
-        offt[i] = map[min(g * CR + pp, prow - 1)] * MELS;
+        offt[i] = map[min((g0 + g) * CR + pp, prow - 1)] * MELS;
     }
     WAVE_SYNC();
     const int *myoff = offt + cgrp * offn;
-    for (int cb = 0; cb < ncep; cb += CG) {
+    for (int cb = cb_begin; cb < min(ncep, cb_end); cb += CG) {
         const int c = cb + cl;
         const bool act = lane_on && (c < ncep) && (r0 < nfr);
         const int cc = min(c, ncep - 1);

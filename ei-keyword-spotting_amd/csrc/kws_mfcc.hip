@@ -154,17 +154,44 @@ struct alignas(16) MfccSmem {
 };
 static_assert(sizeof(MfccSmem<9, 32>) <= 20 * 1024 && sizeof(MfccSmem<9, 40>) <= 20 * 1024, "8 waves per CU need <= 20 KB LDS each");
 
-template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF = 32, bool PROF = false, bool WIDE = false>
-__global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
+// Latency mode (LW > 0 waves per clip, one workgroup per clip, for calls with a handful of windows such as run_classifier()):
+// every wave transforms its own 2 * CHP frames with private FFT / power-spectrum buffers; the log-mel / cepstra matrix, the
+// frame energies and the pad map are shared, and cmvnw's (row group, column block) tasks are dealt out over the waves.
+template <int CHP, int NF, int LW>
+struct alignas(16) MfccSmemLat {
+    static constexpr int CHF = 2 * CHP + 2;           // row stride of the power-spectrum buffer (two spare slots: the 40-filter mel
+                                                      // stage reads frame slots in threes)
+    static constexpr int MELS = NF + 1;
+    float z[LW][2][KWS_ZF];
+    float p[LW][KWS_NBINS * CHF];
+    float dcny[LW][2 * CHF];
+    int map[KWS_MAXPROW];
+    float mel[kws_mel_rows(NF) * MELS];
+    float energy[kws_mel_rows(NF)];
+};
+template <int CHP, int NF, int LW> struct MfccSmemSel { typedef MfccSmemLat<CHP, NF, LW> type; };
+template <int CHP, int NF> struct MfccSmemSel<CHP, NF, 0> { typedef MfccSmem<CHP, NF> type; };
+
+template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF = 32, bool PROF = false, bool WIDE = false, int LW = 0>
+__global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
                                                             float *__restrict__ features, int8_t *__restrict__ q_out,
                                                             float in_scale, int in_zp, const float *__restrict__ wrap, int out_stride,
                                                             long long *prof_out = nullptr)
 {
-    constexpr int CHF = 2 * CHP;
+    constexpr int CHF = 2 * CHP + (LW ? 2 : 0);          // frame slots per power-spectrum row (stride)
     constexpr int MELS = NF + 1, NCEPT = NF / 2 + 1;     // DCT only produces outputs 0..NF/2 (fast-dct-fft.cpp:71)
-    __shared__ MfccSmem<CHP, NF> sm;
-    const int lane = threadIdx.x;
+    __shared__ typename MfccSmemSel<CHP, NF, LW>::type sm;
+    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = LW ? (int)(threadIdx.x >> 6) : 0;
     const int half = lane >> 5, t = lane & 31;
+    // this wave's view of the LDS block (one wave per workgroup unless LW > 0)
+    float *zw, *sm_p, *sm_dcny, *sm_mel, *sm_energy;
+    int *sm_map;
+    if constexpr (LW > 0) {
+        zw = &sm.z[wave][0][0]; sm_p = sm.p[wave]; sm_dcny = sm.dcny[wave]; sm_map = sm.map;
+    } else {
+        zw = &sm.z[0][0]; sm_p = sm.u.p; sm_dcny = sm.dcny; sm_map = sm.u.map;
+    }
+    sm_mel = sm.mel; sm_energy = sm.energy;
 
     // ---- per-lane constants, fixed for the whole launch --------------------------------------------------
     const int k01 = t & 1, g01 = t >> 1;
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
     const int nfr = P.n_frames, ncep = P.n_cepstral;
     const int n_pairs = (nfr + 1) >> 1;
     const int prow = nfr + 2 * P.pad;
-    float *zb = sm.z[half];
+    float *zb = zw + half * KWS_ZF;
     // NF == 32: this lane's mel filter (filter index = lane & 31 in every pass of the mel stage) keeps its ascending-bin
     // taps in registers; other filter counts walk the CSR table
     int fbin[NZ];
@@ -197,21 +224,26 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
 #pragma unroll
     for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) mapreg[i] = (lane + i * KWS_WAVE < prow) ? P.pad_map[lane + i * KWS_WAVE] : 0;
     long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
+    if constexpr (LW > 0) {
+        for (int i = threadIdx.x; i < prow; i += blockDim.x) sm_map[i] = P.pad_map[i];
+        __syncthreads();
+    }
+    const int fp0 = LW ? wave * CHP : 0;                    // first frame pair of this wave
 
     for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
         const void *xbase = F32IN ? (const void *)((const float *)pcm_v + (size_t)clip * P.n_samples)
                                   : (const void *)((const int16_t *)pcm_v + (size_t)clip * P.n_samples);
         // software prefetch, two frame pairs deep: the samples of pair p+2 are requested before pair p is transformed
-        RawSamples<F32IN> nxt = fetch_samples<F32IN>(xbase, min(half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
-        RawSamples<F32IN> nxt2 = fetch_samples<F32IN>(xbase, min(2 + half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+        RawSamples<F32IN> nxt = fetch_samples<F32IN>(xbase, min(2 * fp0 + half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+        RawSamples<F32IN> nxt2 = fetch_samples<F32IN>(xbase, min(2 * fp0 + 2 + half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
         const bool has_wrap = wrap != nullptr;
         const float wrapv = has_wrap ? wrap[clip] : 0.0f;
 
-        for (int pair0 = 0; pair0 < n_pairs; pair0 += CHP) {
+        for (int pair0 = fp0; pair0 < n_pairs; pair0 += (LW ? n_pairs : CHP)) {      // latency mode: this wave's one chunk
             const int pair1 = min(pair0 + CHP, n_pairs);
             cf pend[4] = {};                                  // split outputs of the previous pair: lo0, hi0, lo1, hi1
             bool pend_any = false, pend_live = false;
-            float *pend_pcol = sm.u.p;
+            float *pend_pcol = sm_p;
             // The power spectrum of the PREVIOUS pair (4 bins per lane, ~35 fp64-heavy instructions each, operands in
             // registers) is evaluated one bin at a time right after each stage's LDS reads are issued: that arithmetic
             // needs no memory, so it runs in the shadow of the round trip the butterflies would otherwise wait out.
@@ -322,10 +354,10 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 }
                 pend_any = true;
                 pend_live = live;
-                pend_pcol = sm.u.p + fr;
+                pend_pcol = sm_p + fr;
                 // DC / Nyquist bins (kiss_fftr.cpp:84-96) need tmp[0] only: parked per frame, evaluated once per chunk
                 // with one frame per lane instead of one lane per wave here
-                if (t == 0 && live) *(float2 *)(sm.dcny + 2 * fr) = *(const float2 *)zb;
+                if (t == 0 && live) *(float2 *)(sm_dcny + 2 * fr) = *(const float2 *)zb;
                 WAVE_SYNC();
                 PH(2);
             }
@@ -340,17 +372,17 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
             const int nfc = min(2 * pair1, nfr) - f_base;
             if (lane < nfc) {
                 {
-                    const float2 d = *(const float2 *)(sm.dcny + 2 * lane);
+                    const float2 d = *(const float2 *)(sm_dcny + 2 * lane);
                     cf dc, ny;
                     dc.r = d.x + d.y; dc.i = 0.0f;
                     ny.r = d.x - d.y; ny.i = 0.0f;
-                    sm.u.p[lane] = bin_power(dc, P.inv_fft);
-                    sm.u.p[KWS_NC * CHF + lane] = bin_power(ny, P.inv_fft);
+                    sm_p[lane] = bin_power(dc, P.inv_fft);
+                    sm_p[KWS_NC * CHF + lane] = bin_power(ny, P.inv_fft);
                 }
                 // 129 ordered adds; the operands arrive 16 at a time, one batch ahead of the adds (the chain would otherwise
                 // wait for an LDS round trip per batch with only two waves per SIMD to cover it)
                 float e = 0.0f;
-                const float *pl = sm.u.p + lane;
+                const float *pl = sm_p + lane;
                 static_assert((KWS_NBINS - 1) % 16 == 0, "batches of 16 bins");
                 float cur[16], nxt[16];
                 const float last = pl[(KWS_NBINS - 1) * CHF];
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 }
                 e += last;
                 if (e == 0.0f) e = FLT_EPSILON;                                       // feature.hpp:296-298
-                sm.energy[f_base + lane] = e;
+                sm_energy[f_base + lane] = e;
                 if constexpr (!WITH_CMVN)
                     if (P.mfe_energy) P.mfe_energy[(size_t)clip * nfr + f_base + lane] = e;
             }
@@ -379,13 +411,13 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                     float acc = 0.0f;
 #pragma unroll
                     for (int n = 0; n < NZ; ++n) {         // taps beyond a filter's end have weight 0: power >= 0 is
-                        float prod = sm.u.p[fbin[n] + fr] * fwt[n];   // finite, so they add an exact +0
+                        float prod = sm_p[fbin[n] + fr] * fwt[n];   // finite, so they add an exact +0
                         acc += prod;
                     }
                     if (acc == 0.0f) acc = FLT_EPSILON;                                // functions.hpp:63-69
                     if constexpr (!WITH_CMVN)
                         if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + t] = acc;
-                    sm.mel[(f_base + fr) * MELS + t] = fast_log(acc);
+                    sm_mel[(f_base + fr) * MELS + t] = fast_log(acc);
                 }
             } else {
                 // one frame per pass, lane = filter (taps in registers as above; walking the CSR table from memory
@@ -403,7 +435,7 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                             // and their sums are dropped below
                             static_assert(3 * ((2 * CHP - 1) / 3) + 2 < CHF, "frame slots of a trip stay inside a bin's row");
 #pragma unroll
-                            for (int n = 0; n < NZ; ++n) xv[u][n] = sm.u.p[fbin[n] + fr0 + u];
+                            for (int n = 0; n < NZ; ++n) xv[u][n] = sm_p[fbin[n] + fr0 + u];
                         }
 #pragma unroll
                         for (int u = 0; u < 3; ++u) {
@@ -421,7 +453,7 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                                 if (a == 0.0f) a = FLT_EPSILON;
                                 if constexpr (!WITH_CMVN)
                                     if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + lane] = a;
-                                sm.mel[(f_base + fr) * MELS + lane] = fast_log(a);
+                                sm_mel[(f_base + fr) * MELS + lane] = fast_log(a);
                             }
                         }
                     }
@@ -435,14 +467,17 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
             if (P.mfe_mel) { WAVE_SYNC(); continue; }                                   // MFE block: no log / DCT output
         // ---- DCT-II via NF-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80) ------
         // the cepstra of a frame replace its log-mel row in place (row stride MELS)
+        if constexpr (LW == 0) {
 #pragma unroll
-        for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) sm.u.map[lane + i * KWS_WAVE] = mapreg[i];
-        if (lane < nfr) {
+            for (int i = 0; i < KWS_MAXPROW / KWS_WAVE; ++i) sm_map[lane + i * KWS_WAVE] = mapreg[i];
+        }
+        const int drow = LW ? 2 * fp0 + lane : lane;               // latency mode: the frames this wave produced
+        if (LW ? (lane < 2 * CHP && drow < nfr) : (lane < nfr)) {
             float v[NF];
-            float *mrow = sm.mel + lane * MELS;
+            float *mrow = sm_mel + drow * MELS;
 #pragma unroll
             for (int i = 0; i < NF; ++i) v[i] = mrow[i];
-            float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + lane * ncep;
+            float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + drow * ncep;
             typedef KwsDctTab<NF> T;
             auto put = [&](int i, cf R) {
                 // in place (WITH_CMVN) every output is stored: columns >= ncep of the row are never read again and the
@@ -469,9 +504,10 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 for (int i = NCEPT; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * T::s1;
                 dct_spectrum<NF>(v, put);
             }
-            orow[0] = fast_log(sm.energy[lane]);                                       // feature.hpp:425-429
+            orow[0] = fast_log(sm_energy[drow]);                                       // feature.hpp:425-429
         }
         WAVE_SYNC();
+        if constexpr (LW > 0) __syncthreads();                     // every wave's rows are in place
         PH(5);
         if constexpr (!WITH_CMVN) continue;
 
@@ -479,7 +515,7 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
         {
             float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
             int8_t *qclip = q_out ? q_out + (size_t)clip * (nfr * ncep) : nullptr;
-            int *offt = (int *)&sm.z[0][0];                       // the FFT buffers are dead by now
+            int *offt = (int *)zw;                                // the FFT buffers are dead by now
             // WIDE (more than 16 cepstra, chosen at launch): 20 columns x 3 row groups of 17 rows per pass instead of
             // 16 x 4 x 13 -- 40 cepstra take 2 passes instead of 3.  One layout per instantiation keeps the registers.
             auto emit = [&](int row, int c, float o) {
@@ -487,10 +523,20 @@ __global__ __launch_bounds__(KWS_WAVE, 2) void kws_mfcc_kernel(KwsDspPlan P, con
                 if (fout) fout[idx] = o;                      // optional output (extract_mfcc_features' matrix)
                 if (qclip) qclip[idx] = quantize_feature(o, in_scale, in_zp);
             };
-            if constexpr (WIDE) cmvn_columns<17, 20>(sm.mel, MELS, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, emit);
-            else cmvn_columns<13, 16>(sm.mel, MELS, sm.u.map, offt, lane, nfr, ncep, prow, P.win_size, emit);
+            if constexpr (LW > 0) {
+                // short chains instead of few lanes: 5 rows per lane, 16 columns x 4 row groups per wave and task
+                constexpr int LCR = 5, LCG = 16, LNG = KWS_WAVE / LCG;
+                const int nrg = (nfr + LCR * LNG - 1) / (LCR * LNG), ncb = (ncep + LCG - 1) / LCG;
+                for (int task = wave; task < nrg * ncb; task += LW) {
+                    const int rg = task % nrg, cbk = task / nrg;
+                    cmvn_columns<LCR, LCG>(sm_mel, MELS, sm_map, offt, lane, nfr, ncep, prow, P.win_size, emit, rg * LNG, cbk * LCG, cbk * LCG + LCG);
+                    WAVE_SYNC();
+                }
+            } else if constexpr (WIDE) cmvn_columns<17, 20>(sm_mel, MELS, sm_map, offt, lane, nfr, ncep, prow, P.win_size, emit);
+            else cmvn_columns<13, 16>(sm_mel, MELS, sm_map, offt, lane, nfr, ncep, prow, P.win_size, emit);
         }
         WAVE_SYNC();
+        if constexpr (LW > 0) __syncthreads();                     // the shared matrix is rewritten by the next clip
         PH(7);
     }
     if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
@@ -510,6 +556,8 @@ int kws_mfcc_max_frames(int n_filters) { return kws_mel_rows(n_filters); }
 int kws_mfcc_fft_length(void) { return KWS_FFT; }
 
 constexpr int KWS_CHP = 9;
+// latency mode: 7 waves x 8 frames per window (56 >= KWS_MAXF), taken for float-sample calls of at most 16 windows
+constexpr int KWS_LAT_CHP = 4, KWS_LAT_WAVES = 7, KWS_LAT_MAX_CLIPS = 16;
 
 template <bool F32IN, bool WITH_CMVN, bool PROF>
 static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, float *out, int8_t *q_out, float in_scale, int in_zp,
@@ -518,6 +566,26 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     const int grid = n_clips < grid_cap ? n_clips : grid_cap;
+    if constexpr (F32IN && WITH_CMVN && !PROF) {
+        // a handful of windows (run_classifier(): one): one workgroup of KWS_LAT_WAVES waves per window instead of one wave
+        if (n_clips <= KWS_LAT_MAX_CLIPS && P.n_frames <= 2 * KWS_LAT_CHP * KWS_LAT_WAVES && (P.n_filters == 32 || P.n_filters == 40) &&
+            P.max_nz <= KWS_MAXNZ) {
+            const dim3 blk(KWS_WAVE * KWS_LAT_WAVES);
+            if (P.n_filters == 40 && P.max_nz <= 8)
+                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, 8, 40, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+            else if (P.n_filters == 40)
+                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, KWS_MAXNZ, 40, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+            else if (P.max_nz <= 4)
+                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, 4, 32, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+            else
+                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, KWS_MAXNZ, 32, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+            return (int)hipGetLastError();
+        }
+    }
     if (P.n_filters == 40 && P.max_nz <= 8 && WITH_CMVN && P.n_cepstral > 16)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
                            pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);

@@ -766,3 +766,39 @@ def test_mfe_block_golden_and_oracle(pkg, oracle, tmp_path):
         for i in range(len(clips)):
             assert same_bits_or_both_nan(got[i], oracle.extract_mfe(clips[i], cfg)), (name, i)
         gm.close()
+
+
+def test_run_classifier_latency_mode_matches_batch_path(pkg, gpu476, oracle, tmp_path):
+    """run_classifier() on one window takes the latency-mode MFCC kernel (7 waves per window, cmvnw dealt out in 5-row tasks);
+    its scores must be those of the batch path (one wave per clip) bit for bit -- 32 and 40 filters, 13 / 40 / 30 / 10 cepstra,
+    windows 101 and 51, int8 and float32 graphs, random and edge-case clips."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dequantize_model import dequantize
+    from kws_testlib import synth_model_blob
+    sp = special_clips()
+    clips = np.concatenate([oracle.synth(77, 3, 6), np.stack([sp[k] for k in sorted(sp)])])
+    blobs = [open(os.path.join(MODELS, "l476_no_yes.kwsm"), "rb").read(), open(os.path.join(MODELS, "cfg2_mfcc40_f32.kwsm"), "rb").read(),
+             synth_model_blob(**MFCC40_MODELS["f40c30w51"]), dequantize(synth_model_blob(**MFCC40_MODELS["f40c13"])),
+             synth_model_blob(seed=2, ncep=10, win_size=51, high=0, blocks=((16, 5, 7), (8, 3, 7)), n_labels=3)]
+    try:
+        for bi, blob in enumerate(blobs):
+            gm = pkg.Model(blob=blob)
+            gm.set_default()
+            want = gm.run_classifier_batch(clips)
+            res = pkg.result_struct(gm.n_labels)()
+            for ci, clip in enumerate(clips):
+                buf = clip.astype(np.float32) / np.float32(32768)
+
+                @pkg.GET_DATA_FN
+                def get_data(offset, length, out):
+                    ctypes.memmove(out, buf[offset:offset + length].ctypes.data, 4 * length)
+                    return 0
+                sig = pkg.Signal(get_data=get_data, total_length=16000)
+                assert pkg.lib().run_classifier(ctypes.byref(sig), ctypes.byref(res), False) == 0
+                got = np.float32([res.classification[i].value for i in range(gm.n_labels)])
+                assert (bits(got) == bits(want[ci])).all(), (bi, ci)
+            gpu476.set_default()
+            gm.close()
+    finally:
+        gpu476.set_default()
