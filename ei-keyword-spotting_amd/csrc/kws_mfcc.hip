@@ -2,6 +2,9 @@
 // extract_mfcc_features() (SDK/classifier/ei_run_dsp.h:256-308): coalesced 16-byte int16 loads, pre-emphasis in registers,
 // the 256-point real FFT staged in LDS, power spectrum, sparse mel gather, fast log, DCT, windowed CMVN and the int8
 // quantisation of ei_run_classifier.h:436-444.  See kws_device.h for the bit-exactness contract.
+// Two shapes of the same code: the throughput shape (one wave per clip, persistent grid) and, for calls with a handful of
+// windows, the latency shape (LW waves per clip: frames and cmvnw tasks dealt out over a workgroup).  Built without the SLP
+// vectoriser (see the Makefile); the DCT constants are literals (kws_dct_tables.h).
 #include "kws_device.h"
 #include "kws_dct_tables.h"
 

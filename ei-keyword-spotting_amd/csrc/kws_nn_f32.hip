@@ -18,6 +18,8 @@
 //  LDS: per workgroup the weights of every block transposed to [tap*in_c + c][out_c padded to 4]; per wave the ping-pong
 //  input images A / B (zero-padded rows), Y only for blocks whose pooling cannot happen in registers, and 128 floats for
 //  the FULLY_CONNECTED input / logits.  The plan is read from device memory (nnf_layout() is shared with the host).
+//  LDS locations are carried as offsets from the extern __shared__ base (pointers kept in arrays degrade to flat loads); the
+//  next clip's feature vector is requested after block 0 and placed at the next iteration's top (256-register build).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_clamp(float x, float lo, float hi)   // ActivationFunctionWithMinMax
 {

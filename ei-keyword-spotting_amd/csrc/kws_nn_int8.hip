@@ -1,4 +1,5 @@
-// kws_nn_int8.hip -- the int8 network: kws_nn_kernel (generic, v_dot4), kws_nn_mfma_kernel (matrix cores) and
+// kws_nn_int8.hip -- the int8 network: kws_nn_kernel (generic: any chain of conv blocks; un-pooled CONV_2D on the matrix
+// cores, depthwise in registers, the rest on v_dot4), kws_nn_mfma_kernel (the two-block shape entirely on the matrix cores) and
 // kws_cmvn_nn_kernel (cmvnw + quantise [+ network] for the stage API / continuous mode).  Replaces the EON-compiled
 // TFLite-Micro graph (MODEL/tflite-model/trained_model_compiled.cpp:312-328).
 #include "kws_device.h"
