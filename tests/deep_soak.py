@@ -3,7 +3,8 @@
 Every clip of `rounds` full batches (default 2 x 65 536) goes through the HIP path AND the CPU restatement of the reference
 (oracle/, one worker process per host core), for the shipped int8 impulse and for the 49x40 fp32 headline graph: MFCC
 features compared bit for bit, int8 input tensors and int8-model scores exactly, float-model scores within 1e-6.
-Writes one summary line per model; exit status 1 on any difference.
+Then 3 000 windows per model go through run_classifier() one by one (the latency-mode kernel) and must equal the batch path's
+scores bit for bit.  Writes one summary line per model and check; exit status 1 on any difference.
 """
 import multiprocessing as mp
 import os
@@ -77,6 +78,31 @@ def main():
                   "%s (%.0f s, %d oracle workers)" % (name, n_clips, n_clips * F, n_feat_diff, n_q_diff, max_score,
                                                       "OK" if ok else "MISMATCH", time.time() - t0, cores), flush=True)
             gm.close()
+    # the latency-mode kernel (run_classifier(), one window per call) against the batch path, many windows
+    import ctypes
+    o = Oracle()
+    n_lat = 3000
+    for name in ("l476_no_yes.kwsm", "cfg2_mfcc40_f32.kwsm"):
+        gm = pkg.Model(os.path.join(MODELS, name), device=0)
+        gm.set_default()
+        clips = o.synth(4242, 10 ** 6, n_lat)
+        want = gm.run_classifier_batch(clips)
+        res = pkg.result_struct(gm.n_labels)()
+        diff = 0
+        for ci in range(n_lat):
+            buf = clips[ci].astype(np.float32) / np.float32(32768)
+
+            @pkg.GET_DATA_FN
+            def get_data(offset, length, out):
+                ctypes.memmove(out, buf[offset:offset + length].ctypes.data, 4 * length)
+                return 0
+            sig = pkg.Signal(get_data=get_data, total_length=16000)
+            rc = pkg.lib().run_classifier(ctypes.byref(sig), ctypes.byref(res), False)
+            got = np.float32([res.classification[i].value for i in range(gm.n_labels)])
+            diff += int(rc != 0 or (got.view(np.uint32) != want[ci].view(np.uint32)).any())
+        print("%s: run_classifier() (latency-mode kernel) on %d windows: %d differ from the batch path" % (name, n_lat, diff), flush=True)
+        bad += 1 if diff else 0
+        gm.close()
     sys.exit(1 if bad else 0)
 
 
