@@ -247,10 +247,10 @@ __device__ __forceinline__ void nnf_conv_ob(const KwsConvBlockF32 &k, const floa
 
 // LDS layout shared by host and device: weights of every block, then per wave the ping-pong input images A (even blocks) and
 // B (odd blocks), the un-pooled conv output Y (only when some block cannot pool in registers) and 128 floats for FC/softmax
-struct NnfLayout { int w_floats, a_floats, b_floats, y_floats; };
+struct NnfLayout { int w_floats, a_floats, b_floats, y_floats, fc_floats, vec_floats; };
 __host__ __device__ __forceinline__ NnfLayout nnf_layout(const KwsNnPlanF32 &N)
 {
-    NnfLayout L = { 0, 0, 0, 0 };
+    NnfLayout L = { 0, 0, 0, 0, 0, 0 };
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlockF32 &k = N.blk[b];
         L.w_floats += (k.depthwise ? k.taps : k.taps * k.in_c) * nnf_ocp(k);
@@ -260,6 +260,10 @@ __host__ __device__ __forceinline__ NnfLayout nnf_layout(const KwsNnPlanF32 &N)
         if (nnf_staged(k)) { const int yf = k.out_w * k.out_c; L.y_floats = yf > L.y_floats ? yf : L.y_floats; }
     }
     L.a_floats = (L.a_floats + 3) & ~3; L.b_floats = (L.b_floats + 3) & ~3; L.y_floats = (L.y_floats + 3) & ~3;
+    // FULLY_CONNECTED weights + bias, shared by the workgroup (a global read per chain step would be an L2 round trip each);
+    // per wave: the FC input vector (the last block's pooled output, also reused for the exponentials) + 64 floats of logits
+    L.fc_floats = (N.fc_out * N.fc_in + N.fc_out + 3) & ~3;
+    L.vec_floats = (((N.fc_in > 64 ? N.fc_in : 64) + 3) & ~3) + 64;
     return L;
 }
 
@@ -290,7 +294,11 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
         sp += J * ocp;
     }
     const NnfLayout L = nnf_layout(N);
-    float *A = sp + wave * (L.a_floats + L.b_floats + L.y_floats + 128);
+    const float *s_fcw = sp, *s_fcb = sp + N.fc_out * N.fc_in;
+    for (int i = threadIdx.x; i < N.fc_out * N.fc_in; i += blockDim.x) sp[i] = N.fc_w[i];
+    for (int i = threadIdx.x; i < N.fc_out; i += blockDim.x) sp[N.fc_out * N.fc_in + i] = N.fc_bias[i];
+    sp += L.fc_floats;
+    float *A = sp + wave * (L.a_floats + L.b_floats + L.y_floats + L.vec_floats);
     float *B = A + L.a_floats;
     float *Y = B + L.b_floats;
     float *vec = Y + L.y_floats;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
                 for (int idx = lane; idx < n_out; idx += 64) {
                     const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
                     float mx = -FLT_MAX;
-                    for (int q = 0; q < k.pool; ++q) {
+                    for (int q = 0; q < k.pool && pw * k.pool_stride + q < k.out_w; ++q) {      // the last window may be ragged (SAME)
                         const float v = Y[(pw * k.pool_stride + q) * k.out_c + oc];
                         mx = mx < v ? v : mx;                          // std::max(max, v)
                     }
@@ -416,11 +424,11 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
             mark(1 + b);
         }
         // FULLY_CONNECTED (fully_connected.h:26-60) + SOFTMAX (softmax.h:31-63)
-        float *lg = vec + 64, *ex = vec;          // ex overwrites the FC input once every lane is done with it
+        float *lg = vec + (L.vec_floats - 64), *ex = vec;          // ex overwrites the FC input once every lane is done with it
         const int fc_in = N.fc_in, fc_out = N.fc_out;
         const float beta = N.beta;
         if (lane < fc_out) {
-            const float *fw = N.fc_w + lane * fc_in;
+            const float *fw = s_fcw + lane * fc_in;
             float total = 0.0f;
             int d = 0;
             for (; d + 4 <= fc_in; d += 4) {                  // four weights in flight per round trip; the chain stays in order
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
                 const float prod = vec[d] * fw[d];
                 total += prod;
             }
-            const float lgt = act_clamp(total + N.fc_bias[lane], N.fc_min, N.fc_max);
+            const float lgt = act_clamp(total + s_fcb[lane], N.fc_min, N.fc_max);
             lg[lane] = lgt;
             if (tap_logits) tap_logits[(size_t)clip * fc_out + lane] = lgt;
         }
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves)
 {
     const NnfLayout L = nnf_layout(N);
-    return ((size_t)L.w_floats + (size_t)n_waves * (L.a_floats + L.b_floats + L.y_floats + 128)) * sizeof(float);
+    return ((size_t)L.w_floats + L.fc_floats + (size_t)n_waves * (L.a_floats + L.b_floats + L.y_floats + L.vec_floats)) * sizeof(float);
 }
 
 // (TB, OB) of a conv block: fewest lane passes x chain work, LDS reads as the tie breaker

@@ -79,16 +79,19 @@ struct NnTaps {            // optional debug outputs for the parity tests (all i
 };
 
 // FULLY_CONNECTED (integer_ops/fully_connected.h:23-63) + SOFTMAX int8->int8 (reference/softmax.h:66-144) for one clip.
-// vec: per-wave LDS scratch; bytes [0,64) hold the last pooled vector (int8), ints [16, 16+fc_out) receive the logits.
+// xin: the last block's pooled output (the FC input vector, int8, in LDS); lg: 64 ints of LDS for the logits.
 // The FC weights / bias and the softmax tables are read from LDS copies (NnHeadTab, staged once per workgroup): from global
 // memory every step of these short dependent loops is an L2 round trip.
-constexpr int KWS_HEAD_FCW = 48 * 64;       // build_nn_plan: fc_out <= 48, fc_in <= 64
-constexpr int KWS_HEAD_BYTES = KWS_HEAD_FCW + 48 * 4 + 256 * 4 + 256;
+constexpr int KWS_HEAD_FCW = 48 * 64;       // the two-block kernels: fc_out <= 48, fc_in <= 16; the generic kernel sizes its copy
+constexpr int KWS_HEAD_REST = 48 * 4 + 256 * 4 + 256;
+constexpr int KWS_HEAD_BYTES = KWS_HEAD_FCW + KWS_HEAD_REST;
+__host__ __device__ inline int nn_head_fcw_bytes(const KwsNnPlan &N) { return (N.fc_out * N.fc_in + 15) & ~15; }   // <= KWS_FC_W_MAX (plan)
+__host__ __device__ inline int nn_fcx_bytes(const KwsNnPlan &N) { return max(64, (N.fc_in + 15) & ~15); }         // per wave: the FC input vector
 struct NnHeadTab { const int8_t *fc_w; const int *fc_bias; const int *sm_exp; const uint8_t *sm_valid; };
-__device__ __forceinline__ NnHeadTab nn_head_stage(const KwsNnPlan &N, unsigned char *lds)      // lds: KWS_HEAD_BYTES, 16-byte aligned
+__device__ __forceinline__ NnHeadTab nn_head_stage(const KwsNnPlan &N, unsigned char *lds, int fcw_bytes = KWS_HEAD_FCW)   // 16-byte aligned
 {
     int8_t *fw = (int8_t *)lds;
-    int *fb = (int *)(lds + KWS_HEAD_FCW), *se = fb + 48;
+    int *fb = (int *)(lds + fcw_bytes), *se = fb + 48;
     uint8_t *sv = (uint8_t *)(se + 256);
     for (int i = threadIdx.x; i < N.fc_out * N.fc_in; i += blockDim.x) fw[i] = N.fc_w[i];
     for (int i = threadIdx.x; i < N.fc_out; i += blockDim.x) fb[i] = N.fc_bias[i];
@@ -97,27 +100,31 @@ __device__ __forceinline__ NnHeadTab nn_head_stage(const KwsNnPlan &N, unsigned 
     return t;                                                                                // caller: __syncthreads()
 }
 
-__device__ __forceinline__ void nn_head(const KwsNnPlan &N, const NnHeadTab &H, int *vec, int lane, int clip, float *__restrict__ scores,
-                                        const NnTaps &taps)
+__device__ __forceinline__ void nn_head(const KwsNnPlan &N, const NnHeadTab &H, const int8_t *xin, int *lg, int lane, int clip,
+                                        float *__restrict__ scores, const NnTaps &taps)
 {
     // ---- FULLY_CONNECTED (integer_ops/fully_connected.h:23-63): input = last pooled vector ------------------
-    const int8_t *xin = (const int8_t *)vec;
-    int logit = 0;
-    if (lane < N.fc_out) {
-        int acc = 0;
-        for (int d = 0; d < N.fc_in; ++d)
-            acc += ((int)H.fc_w[lane * N.fc_in + d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
-        acc += H.fc_bias[lane];
+    // int32 sums are exact, so the fc_in terms of an output are split over n_seg lanes (a power of two, 64 / fc_out or less)
+    // and reduced with shuffles; fc_in can be hundreds (conv -> pool 2 -> conv -> pool 2 -> Dense exports)
+    int n_seg = 1;
+    while (2 * n_seg * N.fc_out <= KWS_WAVE && 2 * n_seg <= N.fc_in) n_seg *= 2;
+    const int out = lane / n_seg, seg = lane - out * n_seg;
+    int acc = 0;
+    if (out < N.fc_out) {
+        const int8_t *wr = H.fc_w + out * N.fc_in;
+        for (int d = seg; d < N.fc_in; d += n_seg)
+            acc += ((int)wr[d] + N.fc_w_off) * ((int)xin[d] + N.fc_in_off);
+    }
+    for (int sft = 1; sft < n_seg; sft *= 2) acc += __shfl_xor(acc, sft);
+    if (out < N.fc_out && seg == 0) {
+        acc += H.fc_bias[out];
         acc = mbqm(acc, N.fc_mult, N.fc_shift) + N.fc_out_zp;
-        logit = min(max(acc, N.fc_act_min), N.fc_act_max);
+        const int lgt = min(max(acc, N.fc_act_min), N.fc_act_max);
+        lg[out] = lgt;
+        if (taps.fc) taps.fc[(size_t)clip * N.fc_out + out] = (int8_t)lgt;
     }
     WAVE_SYNC();
-    int *lg = vec + 16;     // logits as int32, after the (<=64 byte) pooled vector
-    if (lane < N.fc_out) {
-        lg[lane] = logit;
-        if (taps.fc) taps.fc[(size_t)clip * N.fc_out + lane] = (int8_t)logit;
-    }
-    WAVE_SYNC();
+    const int logit = lane < N.fc_out ? lg[lane] : 0;
     // ---- SOFTMAX int8 -> int8 (reference/softmax.h:66-144), every lane < n_labels redundantly ---------------
     if (lane < N.fc_out) {
         int mx = -128;
@@ -150,8 +157,9 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
 
     // ---- shared: weights + ADD tables of every block ---------------------------------------------------------
-    const NnHeadTab head = nn_head_stage(N, smem_raw);
-    unsigned char *sp = smem_raw + ((KWS_HEAD_BYTES + 15) & ~15);
+    const int fcw_bytes = nn_head_fcw_bytes(N), fcx_bytes = nn_fcx_bytes(N);
+    const NnHeadTab head = nn_head_stage(N, smem_raw, fcw_bytes);
+    unsigned char *sp = smem_raw + fcw_bytes + ((KWS_HEAD_REST + 15) & ~15);
     const int8_t *s_w[KWS_MAX_BLOCKS];
     const int8_t *s_lut[KWS_MAX_BLOCKS];
     int act_bytes = 0;
@@ -170,9 +178,10 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
     }
     act_bytes = (act_bytes + 15) & ~15;
     // per wave: two activation buffers (ping-pong) + a small vector for FC/softmax
-    int8_t *actA = (int8_t *)(sp + wave * (2 * act_bytes + 64 * 4));
+    int8_t *actA = (int8_t *)(sp + wave * (2 * act_bytes + fcx_bytes + 64 * 4));
     int8_t *actB = actA + act_bytes;
-    int *vec = (int *)(actB + act_bytes);
+    int8_t *fcx = actB + act_bytes;                    // the FULLY_CONNECTED input vector (last block's pooled output)
+    int *lgv = (int *)(fcx + fcx_bytes);               // logits
     __syncthreads();
 
     const int F = N.n_features;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                 r = min(max(r, k.act_min), k.act_max);
                 const int8_t o = k.has_lut ? s_lut[b][oc * 256 + (r + 128)] : (int8_t)r;
                 const int idx = pw * k.out_c + oc;
-                if (last) ((int8_t *)vec)[idx] = o;
+                if (last) fcx[idx] = o;
                 else nxt[(npl + pw) * ncp + oc] = o;
                 if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
             };
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
             mark(1 + b);
             int8_t *tmp = cur; cur = nxt; nxt = tmp;
         }
-        nn_head(N, head, vec, lane, clip, scores, taps);
+        nn_head(N, head, fcx, lgv, lane, clip, scores, taps);
         mark(1 + KWS_MAX_BLOCKS);
     }
     if (profiling && lane == 0)
@@ -547,7 +556,7 @@ __device__ __forceinline__ void nn_mfma_clip(const NnMfmaCtx<CP> &c, const KwsNn
         if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + k1.pool_w * k1.out_c + oc2] = o;
     }
     WAVE_SYNC();
-    nn_head(N, head, vec, lane, clip, scores, taps);
+    nn_head(N, head, (const int8_t *)vec, vec + 16, lane, clip, scores, taps);
 }
 
 template <int CP>
@@ -655,7 +664,8 @@ static bool nn_fits_mfma(const KwsNnPlan &N)
     const KwsConvBlock &a = N.blk[0], &b = N.blk[1];
     if (a.depthwise || b.depthwise) return false;
     return (a.in_cpad == 16 || a.in_cpad <= 64) && a.taps <= 8 && a.out_c <= 32 && a.in_w <= 64 && a.pool == KWS_MFMA_POOL && a.pool_stride == KWS_MFMA_POOL &&
-           a.pool_w <= KWS_MFMA_POOL && b.in_cpad == 32 && b.taps <= 8 && b.out_c <= 16 && b.in_w <= 16 && b.pool_w == 1 &&
+           a.pool_w <= KWS_MFMA_POOL && a.out_w == a.pool_w * KWS_MFMA_POOL &&       // whole windows only: this kernel pools every row it computes
+           b.in_cpad == 32 && b.taps <= 8 && b.out_c <= 16 && b.in_w <= 16 && b.pool_w == 1 &&
            b.pool >= b.out_w && N.fc_in == b.out_c;
 }
 
@@ -691,7 +701,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
 }
 size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves)
 {
-    size_t s = (KWS_HEAD_BYTES + 15) & ~15;
+    size_t s = (size_t)nn_head_fcw_bytes(N) + ((KWS_HEAD_REST + 15) & ~15);
     int act = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlock &k = N.blk[b];
@@ -701,7 +711,7 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves)
         act = ab > act ? ab : act;
     }
     act = (act + 15) & ~15;
-    return s + (size_t)n_waves * (2 * act + 64 * 4);
+    return s + (size_t)n_waves * (2 * act + nn_fcx_bytes(N) + 64 * 4);
 }
 
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,

@@ -263,7 +263,7 @@ EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
             else if (ph == 1 && pw == cur_w) { f = pl.p[3]; s = pl.p[1]; if (pl.p[4] != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "2-D pool"); out_n = py.dim4(2); }
             else return fail(KWS_ERROR_UNSUPPORTED_MODEL, "pool %zu is not over the time axis", i);
             const int po = h_out_size(pl.p[0], cur_w, f, s, 1);
-            if (po != out_n || h_pad_amount(s, 1, cur_w, f, po) != 0 || (po - 1) * s + f > cur_w || f > 8 || pl.p[5] != 0)
+            if (po != out_n || h_pad_amount(s, 1, cur_w, f, po) != 0 || (po - 1) * s >= cur_w || f > 8 || pl.p[5] != 0)
                 return fail(KWS_ERROR_UNSUPPORTED_MODEL, "pool %zu window/padding outside the kernel's limits", i);
             k.pool = f; k.pool_stride = s; k.pool_w = po;
             cur = pl.out[0]; cur_w = po;
@@ -306,7 +306,7 @@ EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         const Tensor *bias = (fc.in.size() > 2 && fc.in[2] >= 0) ? &m.t[fc.in[2]] : nullptr;
         N.fc_in = w.dims.back(); N.fc_out = w.dims[0];
         const KwsConvBlock &lb = N.blk[N.n_blocks - 1];
-        if (N.fc_in != lb.pool_w * lb.out_c || N.fc_in > 64 || N.fc_out > 48 || N.fc_out != N.n_labels || !w.is_const ||
+        if (N.fc_in != lb.pool_w * lb.out_c || N.fc_in > KWS_FC_IN_MAX || N.fc_in * N.fc_out > KWS_FC_W_MAX || N.fc_out > 48 || N.fc_out != N.n_labels || !w.is_const ||
             w.type != TYPE_I8 || (int)w.nbytes != N.fc_in * N.fc_out || y.type != TYPE_I8 ||
             (bias && (!bias->is_const || bias->type != TYPE_I32 || (int)bias->nbytes != N.fc_out * 4)))
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "FULLY_CONNECTED shape %dx%d outside the kernel's limits", N.fc_out, N.fc_in);
@@ -442,7 +442,7 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
             else if (ph == 1 && pw == cur_w) { f = pl.p[3]; s = pl.p[1]; if (pl.p[4] != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "2-D pool"); out_n = py.dim4(2); }
             else return fail(KWS_ERROR_UNSUPPORTED_MODEL, "pool %zu is not over the time axis", i);
             const int po = h_out_size(pl.p[0], cur_w, f, s, 1);
-            if (po != out_n || h_pad_amount(s, 1, cur_w, f, po) != 0 || (po - 1) * s + f > cur_w || f > 8)
+            if (po != out_n || h_pad_amount(s, 1, cur_w, f, po) != 0 || (po - 1) * s >= cur_w || f > 8)
                 return fail(KWS_ERROR_UNSUPPORTED_MODEL, "pool %zu window/padding outside the kernel's limits", i);
             k.pool = f; k.pool_stride = s; k.pool_w = po;
             h_act_range_f32(pl.p[5], &k.pool_min, &k.pool_max);
@@ -470,7 +470,7 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
         const Tensor *bias = (fc.in.size() > 2 && fc.in[2] >= 0) ? &m.t[fc.in[2]] : nullptr;
         N.fc_in = w.dims.back(); N.fc_out = w.dims[0];
         const KwsConvBlockF32 &lb = N.blk[N.n_blocks - 1];
-        if (N.fc_in != lb.pool_w * lb.out_c || N.fc_in > 64 || N.fc_out > 48 || N.fc_out != N.n_labels || !w.is_const ||
+        if (N.fc_in != lb.pool_w * lb.out_c || N.fc_in > KWS_FC_IN_MAX || N.fc_in * N.fc_out * 4 > KWS_FC_W_MAX || N.fc_out > 48 || N.fc_out != N.n_labels || !w.is_const ||
             (int)w.nbytes != N.fc_in * N.fc_out * 4)
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "FULLY_CONNECTED shape %dx%d outside the kernel's limits", N.fc_out, N.fc_in);
         h_act_range_f32(fc.p[0], &N.fc_min, &N.fc_max);

@@ -60,6 +60,10 @@ struct KwsConvBlock {
     const int8_t *add_lut;     // [out_c][256] ADD(bias tensor)+ReLU folded: out = lut[c][x+128]
 };
 
+// FULLY_CONNECTED limits: input vector length, and weights per model (their LDS copy: bytes for int8, floats * 4 for float32)
+#define KWS_FC_IN_MAX 1024
+#define KWS_FC_W_MAX 32768
+
 struct KwsNnPlan {
     int n_blocks;
     KwsConvBlock blk[KWS_MAX_BLOCKS];

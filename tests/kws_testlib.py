@@ -588,6 +588,11 @@ SYNTH_SPECS = {
     "mfma_mix": dict(seed=23, ncep=13, blocks=((24, 4, 1), (40, 2, 1), (32, 3, 1), (8, 3, 7)), n_labels=4),
     # one 32-row tile with 64-byte rows (40 channels after a pooled block), then an even-tap pooled tail
     "mfma_mix2": dict(seed=24, ncep=13, blocks=((40, 3, 7), (16, 3, 1), (8, 2, 7)), n_labels=3),
+    # the shape of Edge Impulse's default 1-D conv export: Conv(8, k3) - MaxPool(2) - Conv(16, k3) - MaxPool(2) - Dense over
+    # 12 x 16 = 192 inputs (a FULLY_CONNECTED input far longer than the shipped models' 10)
+    "ei_default": dict(seed=30, ncep=13, blocks=((8, 3, -2), (16, 3, -2)), n_labels=4),           # negative pool: VALID (49 -> 24 -> 12)
+    "ei_default_same": dict(seed=32, ncep=13, blocks=((8, 3, 2), (16, 3, 2)), n_labels=4),           # SAME pooling, ragged last windows: 49 -> 25 -> 13
+    "ei_default40": dict(seed=31, num_filters=40, ncep=40, low=300, high=0, blocks=((16, 3, -2), (32, 3, -2), (32, 3, 1)), n_labels=12),
     "dscnn_b": dict(seed=22, ncep=10, blocks=(("dw", 2, 7, 7, 3), ("pw", 12, 1), ("dw", 1, 3, 7, 1)), n_labels=3),
     # BASELINE config 5 as worded: 49x40 MFCC, deeper depthwise-separable CNN, 10 keywords (+ noise/unknown); synthetic weights
     "cfg5_dscnn": dict(seed=50, num_filters=40, ncep=40, low=300, high=0, n_labels=12,

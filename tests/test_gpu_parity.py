@@ -304,7 +304,8 @@ def test_many_streams_continuous_mode(pkg, gpu476, l476, oracle):
 
 
 from kws_testlib import SYNTH_SPECS  # noqa: E402
-SYNTH_MODELS = [SYNTH_SPECS[k] for k in ("seed1", "seed2", "seed4", "seed5", "seed6", "seed7")]
+SYNTH_MODELS = [SYNTH_SPECS[k] for k in ("seed1", "seed2", "seed4", "seed5", "seed6", "seed7")] + [
+    dict(seed=3, blocks=((24, 7, 7),), n_labels=6)]                      # one block: FULLY_CONNECTED over 7 x 24 = 168 inputs
 
 
 @pytest.mark.parametrize("kw", SYNTH_MODELS, ids=lambda kw: "seed%d" % kw["seed"])
@@ -335,7 +336,7 @@ def test_synthetic_models_of_the_same_graph_family(kw, pkg, oracle, tmp_path):
 
 def test_unsupported_models_fail_loudly(pkg, oracle):
     from kws_testlib import synth_model_blob
-    for kw in (dict(seed=3, blocks=((24, 7, 7),), n_labels=6),          # FULLY_CONNECTED input of 168 > kernel limit
+    for kw in (dict(seed=3, blocks=((64, 3, 1),), n_labels=6),          # FULLY_CONNECTED input of 49 x 64 = 3136 > kernel limit (1024)
                dict(seed=8, ncep=40),                                     # 40 cepstra > 32 mel filters
                ):
         with pytest.raises(pkg.KwsError) as e:

@@ -25,7 +25,7 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
          (out_channels, taps, pool)              CONV_2D 1xK (+ optional int32 bias) -> ADD(int8 per-channel)+ReLU -> MAX_POOL
          ("dw", depth_mult, taps, pool, act)     DEPTHWISE_CONV_2D 1xK with int32 bias and fused activation -> MAX_POOL
          ("pw", out_channels, act)               CONV_2D 1x1 with int32 bias and fused activation (pointwise)
-       (pool 1 = no pooling node; act: TfLiteFusedActivation 0 none, 1 relu, 3 relu6).
+       (pool 1 = no pooling node, a negative pool = VALID padding: the ragged tail of the time axis is dropped; act: TfLiteFusedActivation 0 none, 1 relu, 3 relu6).
        Frame geometry is the shipped one (49 frames)."""
     rng = np.random.default_rng(seed)
     n_frames = 49
@@ -60,14 +60,16 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
     cur = t
     def add_pool(pool):
         nonlocal cur, w
-        if pool <= 1:
+        if pool in (0, 1):
             return
+        valid = pool < 0                                                # negative: VALID padding (floor, a ragged tail is dropped)
+        pool = abs(pool)
         t4 = T(9, [1, w, 1, c_out], scale=[cur_scale], zero=[cur_zp])
         node(0, [cur, shape_const([1, w, 1, c_out])], [t4])
-        pw = (w + pool - 1) // pool
-        assert (pw - 1) * pool + pool <= w, "pool must tile the time axis"
+        pw = w // pool if valid else (w + pool - 1) // pool
+        assert pw >= 1 and (pw - 1) * pool < w           # SAME: the last window may be ragged (clipped to the tensor)
         tp = T(9, [1, pw, 1, c_out], scale=[cur_scale], zero=[cur_zp])
-        node(3, [t4], [tp], [1, 1, pool, 1, pool, 0])                   # SAME, stride (w1,hP), filter (w1,hP)
+        node(3, [t4], [tp], [2 if valid else 1, 1, pool, 1, pool, 0])   # VALID / SAME, stride (w1,hP), filter (w1,hP)
         w = pw
         t5 = T(9, [1, 1, w, c_out], scale=[cur_scale], zero=[cur_zp])
         node(0, [tp, shape_const([1, 1, w, c_out])], [t5])
@@ -122,7 +124,7 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
             ta = T(9, [1, w, oc], scale=[a_scale], zero=[-128])
             node(2, [t3, tbq], [ta], [1])                                   # ReLU
             cur, cur_scale, cur_zp = ta, a_scale, -128
-        if pool > 1:
+        if pool not in (0, 1):
             add_pool(pool)
         elif add_bias:                                                      # back to NHWC for the next convolution
             t6 = T(9, [1, 1, w, oc], scale=[cur_scale], zero=[cur_zp])
