@@ -598,3 +598,40 @@ SYNTH_SPECS = {
     "cfg5_dscnn": dict(seed=50, num_filters=40, ncep=40, low=300, high=0, n_labels=12,
                        blocks=((32, 5, 1), ("dw", 1, 5, 1, 1), ("pw", 32, 1), ("dw", 1, 5, 7, 1), ("pw", 32, 1), ("dw", 1, 3, 7, 1), ("pw", 12, 0))),
 }
+
+
+def random_graph_spec(seed):
+    """A random member of the 1-D conv graph family within the kernels' documented limits (for the fuzz tests): 1-4 blocks of
+    CONV_2D / depthwise / pointwise, taps 1-8, channels 4-48, pooling 1 / 2 / 3 / 7 with SAME (positive) or VALID (negative)
+    padding, 2-12 labels.  Returns synth_model_blob keyword arguments, or None when the draw leaves the limits."""
+    rng = np.random.default_rng(1000 + seed)
+    ncep = int(rng.choice([10, 13, 16, 20]))
+    w, c = 49, ncep
+    blocks = []
+    for b in range(int(rng.integers(1, 5))):
+        kind = rng.choice(["conv", "conv", "conv", "dw", "pw"]) if b else "conv"
+        pool = int(rng.choice([1, 1, 2, -2, 3, -3, 7]))
+        if kind == "conv":
+            oc = int(rng.choice([4, 8, 12, 16, 24, 30, 32, 40, 48]))
+            blocks.append((oc, int(rng.integers(1, 9)), pool))
+            c = oc
+        elif kind == "dw":
+            mult = int(rng.choice([1, 1, 2]))
+            if c * mult > 64:
+                return None
+            blocks.append(("dw", mult, int(rng.choice([3, 5, 7])), pool, int(rng.choice([0, 1, 3]))))
+            c = c * mult
+        else:
+            oc = int(rng.choice([8, 12, 16, 32]))
+            blocks.append(("pw", oc, int(rng.choice([0, 1]))))
+            c = oc
+            pool = 1
+        if pool not in (0, 1):
+            p = abs(pool)
+            w = w // p if pool < 0 else (w + p - 1) // p
+        if w < 1:
+            return None
+    n_labels = int(rng.integers(2, 13))
+    if w * c > 1024 or w * c * n_labels * 4 > 32768:
+        return None
+    return dict(seed=500 + seed, ncep=ncep, blocks=tuple(blocks), n_labels=n_labels, conv_bias=bool(rng.integers(0, 2)))

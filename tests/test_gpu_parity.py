@@ -803,3 +803,56 @@ def test_run_classifier_latency_mode_matches_batch_path(pkg, gpu476, oracle, tmp
             gm.close()
     finally:
         gpu476.set_default()
+
+
+def test_random_graphs_on_gpu(pkg, oracle, tmp_path):
+    """Fuzz: the random graphs of test_random_graphs_through_reference_op_registrations (there held to the reference's op code)
+    on the HIP path: int8 -- every block's pooled tensor, FC and softmax outputs exactly; float32 twins -- logits bit for bit,
+    scores within 1e-6.  Draws the plan refuses (outside documented limits) must fail loudly with KWS_ERROR_UNSUPPORTED_MODEL."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dequantize_model import dequantize
+    from kws_testlib import OracleModel, random_graph_spec, synth_model_blob
+    rng = np.random.default_rng(10)
+    n_ok = n_refused = 0
+    for seed in range(150):
+        kw = random_graph_spec(seed)
+        if kw is None:
+            continue
+        blob = synth_model_blob(**kw)
+        try:
+            gm = pkg.Model(blob=blob)
+        except pkg.KwsError as e:
+            assert e.code == -18, (seed, kw)
+            n_refused += 1
+            continue
+        p = tmp_path / ("fz%d.kwsm" % seed)
+        p.write_bytes(blob)
+        om = OracleModel(oracle, str(p))
+        qs = rng.integers(-128, 128, (40, om.n_features)).astype(np.int8)
+        s, pooled, fc, out = gm.nn_batch(qs)
+        for i in range(0, 40, 3):
+            o, taps = om.nn_invoke(qs[i], taps=True)
+            assert (out[i] == o).all(), (seed, kw)
+            assert (fc[i] == taps[len(taps) - 2]).all(), (seed, kw)
+        gm.close()
+        bf = dequantize(blob)
+        try:
+            gf = pkg.Model(blob=bf)
+        except pkg.KwsError as e:                     # float weights of a wide graph can exceed the CU's LDS: refused, loudly
+            assert e.code == -18, (seed, kw)
+            n_ok += 1
+            continue
+        pf = tmp_path / ("fz%df.kwsm" % seed)
+        pf.write_bytes(bf)
+        of = OracleModel(oracle, str(pf))
+        x = (rng.standard_normal((24, of.n_features)) * np.float32(4.0)).astype(np.float32)
+        sg, lg = _f32_logits(pkg, gf, x)
+        n_t = len(of.tensor_bytes)
+        for i in range(0, 24, 2):
+            so, taps = of.nn_invoke_f32(x[i], taps=True)
+            assert (bits(lg[i]) == bits(taps[n_t - 2])).all(), (seed, kw)
+            assert np.abs(sg[i] - so).max() <= F32_SCORE_TOL, (seed, kw)
+        gf.close()
+        n_ok += 1
+    assert n_ok >= 60, (n_ok, n_refused)

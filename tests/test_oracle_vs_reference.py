@@ -250,3 +250,36 @@ def test_l432_mfe_block_normalisation_pinned(oracle, reference):
             mel, _ = reference.mfe(x, c)
             want = r432.cmvnw(mel, c.win_size, False, True).reshape(-1)
             assert _same_bits_or_both_nan(want, oracle.extract_mfe(x, cfg.copy(**kw))), kw
+
+
+def test_random_graphs_through_reference_op_registrations(oracle, reference, tmp_path):
+    """Fuzz: ~100 random members of the graph family (kws_testlib.random_graph_spec), int8 and float32 twins, every tensor of
+    the reference's op registrations == the restatement.  The same draws are replayed on the GPU (test_random_graphs_on_gpu)."""
+    from kws_testlib import OracleModel, random_graph_spec, synth_model_blob
+    from dequantize_model import dequantize
+    rng = np.random.default_rng(9)
+    n_ok = 0
+    for seed in range(150):
+        kw = random_graph_spec(seed)
+        if kw is None:
+            continue
+        blob = synth_model_blob(**kw)
+        for kind, b in (("i8", blob), ("f32", dequantize(blob))):
+            p = tmp_path / ("fz%d%s.kwsm" % (seed, kind))
+            p.write_bytes(b)
+            om = OracleModel(oracle, str(p))
+            for it in range(3):
+                if kind == "i8":
+                    x = rng.integers(-128, 128, om.n_features).astype(np.int8)
+                    out, taps = reference.graph_run(b, x)
+                    oo, ot = om.nn_invoke(x, taps=True)
+                    assert (out == oo).all(), (seed, kw)
+                    assert all((a == t).all() for a, t in zip(taps, ot) if a.dtype == np.int8), (seed, kw)
+                else:
+                    x = (rng.standard_normal(om.n_features) * np.float32(4.0)).astype(np.float32)
+                    out, taps = reference.graph_run(b, x)
+                    oo, ot = om.nn_invoke_f32(x, taps=True)
+                    assert all((bits(a) == bits(t)).all() for a, t in zip(taps[:-1], ot[:-1]) if a.dtype == np.float32), (seed, kw)
+                    assert np.abs(out - oo).max() <= 1e-7, (seed, kw)
+        n_ok += 1
+    assert n_ok >= 75, n_ok
