@@ -635,3 +635,17 @@ def random_graph_spec(seed):
     if w * c > 1024 or w * c * n_labels * 4 > 32768:
         return None
     return dict(seed=500 + seed, ncep=ncep, blocks=tuple(blocks), n_labels=n_labels, conv_bias=bool(rng.integers(0, 2)))
+
+
+def random_dsp_spec(seed):
+    """A random MFCC configuration the GPU kernel is built for (fft 256, 32 or 40 filters, 49 frames): cepstra, CMVN window and
+    the filterbank's frequency range vary.  Returns (MfccConfig keyword overrides, synth_model_blob keyword arguments)."""
+    rng = np.random.default_rng(7000 + seed)
+    nf = int(rng.choice([32, 40]))
+    ncep = int(rng.integers(2, nf + 1))
+    win = int(rng.choice([17, 21, 33, 51, 75, 101, 121, 137])) if ncep > 16 and nf == 40 else int(rng.choice([13, 15, 33, 51, 101, 137]))
+    low = int(rng.choice([0, 50, 300, 600]))
+    high = int(rng.choice([0, 3500, 4000, 6000]))
+    cfg_kw = dict(num_filters=nf, num_cepstral=ncep, win_size=win, low_frequency=low, high_frequency=high)
+    blob_kw = dict(seed=900 + seed, num_filters=nf, ncep=ncep, win_size=win, low=low, high=high, blocks=((8, 3, 7), (4, 3, 7)), n_labels=3)
+    return cfg_kw, blob_kw

@@ -856,3 +856,28 @@ def test_random_graphs_on_gpu(pkg, oracle, tmp_path):
         gf.close()
         n_ok += 1
     assert n_ok >= 60, (n_ok, n_refused)
+
+
+def test_random_mfcc_configurations_on_gpu(pkg, oracle):
+    """Fuzz: the random DSP configurations of test_random_mfcc_configurations on the HIP path, features bit for bit against the
+    restatement (which the CPU test holds to the reference); configurations the kernel is not built for (e.g. a mel filter with
+    more taps than it keeps in registers) must be refused with KWS_ERROR_UNSUPPORTED_MODEL."""
+    from kws_testlib import L476_CONFIG, random_dsp_spec, synth_model_blob
+    sp = special_clips()
+    clips = np.concatenate([oracle.synth(21, 0, 10), np.stack([sp["impulses"], sp["ramp"], sp["zeros"], sp["alternating_fullscale"]])])
+    n_ok = n_refused = 0
+    for seed in range(40):
+        cfg_kw, blob_kw = random_dsp_spec(seed)
+        try:
+            gm = pkg.Model(blob=synth_model_blob(**blob_kw))
+        except pkg.KwsError as e:
+            assert e.code == -18, (seed, cfg_kw)
+            n_refused += 1
+            continue
+        cfg = L476_CONFIG().copy(**cfg_kw)
+        _, f, _ = gm.run_classifier_batch(clips, want_features=True)
+        for i, c in enumerate(clips):
+            assert (bits(f[i]) == bits(oracle.extract_mfcc(c, cfg))).all(), (seed, cfg_kw, i)
+        gm.close()
+        n_ok += 1
+    assert n_ok >= 25, (n_ok, n_refused)

@@ -283,3 +283,15 @@ def test_random_graphs_through_reference_op_registrations(oracle, reference, tmp
                     assert np.abs(out - oo).max() <= 1e-7, (seed, kw)
         n_ok += 1
     assert n_ok >= 75, n_ok
+
+
+def test_random_mfcc_configurations(oracle, reference):
+    """Fuzz: 40 random DSP configurations within the GPU kernel's build (kws_testlib.random_dsp_spec): the reference's
+    extract_mfcc_features == the restatement, bit for bit; replayed on the GPU by test_random_mfcc_configurations_on_gpu."""
+    from kws_testlib import random_dsp_spec
+    clips = list(oracle.synth(21, 0, 2)) + [special_clips()["impulses"], special_clips()["ramp"]]
+    for seed in range(40):
+        cfg_kw, _ = random_dsp_spec(seed)
+        cfg = L476_CONFIG().copy(**cfg_kw)
+        for c in clips:
+            assert (bits(oracle.extract_mfcc(c, cfg)) == bits(reference.extract_mfcc(c, cfg))).all(), (seed, cfg_kw)
