@@ -4,7 +4,8 @@ Every clip of `rounds` full batches (default 2 x 65 536) goes through the HIP pa
 (oracle/, one worker process per host core), for the shipped int8 impulse and for the 49x40 fp32 headline graph: MFCC
 features compared bit for bit, int8 input tensors and int8-model scores exactly, float-model scores within 1e-6.
 Then 3 000 windows per model go through run_classifier() one by one (the latency-mode kernel) and must equal the batch path's
-scores bit for bit.  Writes one summary line per model and check; exit status 1 on any difference.
+scores bit for bit, and 4 096 continuous-mode streams advance 14 slices with every 16th stream followed by the restated
+run_classifier_continuous().  Writes one summary line per model and check; exit status 1 on any difference.
 """
 import multiprocessing as mp
 import os
@@ -103,6 +104,33 @@ def main():
         print("%s: run_classifier() (latency-mode kernel) on %d windows: %d differ from the batch path" % (name, n_lat, diff), flush=True)
         bad += 1 if diff else 0
         gm.close()
+    # continuous mode: 4096 streams in lock step (state in HBM) for 14 slices; every 16th stream is followed by the restated
+    # run_classifier_continuous() slice by slice
+    from kws_testlib import OracleContinuous
+    S, steps = 4096, 14
+    gm = pkg.Model(os.path.join(MODELS, "l476_no_yes.kwsm"), device=0)
+    om = OracleModel(o, os.path.join(MODELS, "l476_no_yes.kwsm"))
+    audio = o.synth(555, 0, S * 4).reshape(S, 4 * 16000)[:, :steps * 4000]
+    d_audio = torch.from_numpy(np.ascontiguousarray(audio)).to("cuda:0")
+    sb = pkg.StreamBatch(gm, S)
+    watch = list(range(0, S, 16))
+    ocs = {i: OracleContinuous(om) for i in watch}
+    for oc in ocs.values():
+        oc.init()
+    scores = torch.empty((S, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    diff = 0
+    for k in range(steps):
+        sl = d_audio[:, k * 4000:(k + 1) * 4000].contiguous()
+        produced = sb.step_device(sl.data_ptr(), 4000, scores.data_ptr())
+        torch.cuda.synchronize()
+        got = scores.cpu().numpy()
+        for i in watch:
+            rc, p_, want = ocs[i].step(audio[i, k * 4000:(k + 1) * 4000])
+            diff += int(rc != 0 or p_ != produced or (p_ and (got[i].view(np.uint32) != want.view(np.uint32)).any()))
+    print("l476_no_yes.kwsm: %d streams x %d slices in continuous mode, %d streams followed by the oracle: %d differing steps" % (S, steps, len(watch), diff), flush=True)
+    bad += 1 if diff else 0
+    sb.close()
+    gm.close()
     sys.exit(1 if bad else 0)
 
 
