@@ -21,6 +21,7 @@ MODELS_DIR = os.path.join(ROOT, "models")
 DEFAULT_MODEL = os.path.join(MODELS_DIR, "l476_no_yes.kwsm")
 
 EI_IMPULSE_OK = 0
+MODE_EXACT, MODE_FAST = 0, 1
 ERROR_NAMES = {0: "EI_IMPULSE_OK", -1: "EI_IMPULSE_ERROR_SHAPES_DONT_MATCH", -2: "EI_IMPULSE_CANCELED",
                -3: "EI_IMPULSE_TFLITE_ERROR", -5: "EI_IMPULSE_DSP_ERROR", -6: "EI_IMPULSE_TFLITE_ARENA_ALLOC_FAILED",
                -7: "EI_IMPULSE_CUBEAI_ERROR", -8: "EI_IMPULSE_ALLOC_FAILED", -17: "KWS_ERROR_NO_MODEL",
@@ -38,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
-    "kws_extract_mfe_batch_device",
+    "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count",
     "kws_synth_clips_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
@@ -84,6 +85,10 @@ def lib():
                   "kws_model_is_float", "kws_filter_count"):
             getattr(L, f).argtypes = [vp]
         L.kws_label.restype = C.c_char_p
+        L.kws_set_mode.argtypes = [vp, i32]
+        L.kws_get_mode.argtypes = [vp]
+        L.kws_fast_is_fused.argtypes = [vp]
+        L.kws_fast_fallback_count.argtypes = [vp, C.POINTER(sz)]
         L.kws_nn_kernel_name.restype = C.c_char_p
         L.kws_nn_kernel_name.argtypes = [vp]
         L.kws_label.argtypes = [vp, i32]
@@ -178,6 +183,19 @@ class Model:
         if getattr(self, "h", None):
             self.L.kws_destroy(self.h)
             self.h = None
+
+    def set_mode(self, mode):
+        """MODE_EXACT (default) or MODE_FAST (include/kws/kws.h)"""
+        _check(self.L.kws_set_mode(self.h, mode))
+
+    @property
+    def fast_is_fused(self):
+        return bool(self.L.kws_fast_is_fused(self.h))
+
+    def fast_fallback_count(self):
+        n = C.c_size_t()
+        _check(self.L.kws_fast_fallback_count(self.h, C.byref(n)))
+        return n.value
 
     def set_default(self):
         _check(self.L.kws_set_default_model(self.h))

@@ -25,6 +25,7 @@ EI_IMPULSE_ERROR kws_create(const void *blob, size_t nbytes, int device, kws_han
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
     EI_IMPULSE_ERROR e = build_dsp_plan(h);
     if (e == EI_IMPULSE_OK) e = build_nn_plan(h);
+    if (e == EI_IMPULSE_OK) e = build_fast_plans(h);
     if (e != EI_IMPULSE_OK) { kws_destroy(h); return e; }
     h->maf.assign(h->model.labels.size(), ei_impulse_maf{});
     *out = h;
@@ -51,6 +52,7 @@ void kws_destroy(kws_handle *h)
     for (void *p : h->dev_allocs) (void)hipFree(p);
     if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
+    if (h->d_flags) (void)hipFree(h->d_flags);
     for (int k = 0; k < 2; ++k) {
         for (void *p : { (void *)h->pipe.pcm[k], (void *)h->pipe.s[k], (void *)h->pipe.f[k], (void *)h->pipe.q[k] }) if (p) (void)hipFree(p);
         if (h->pipe.st[k]) (void)hipStreamDestroy(h->pipe.st[k]);
@@ -89,6 +91,41 @@ EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B)
     return EI_IMPULSE_OK;
 }
 
+EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode)
+{
+    if (!h || (mode != KWS_MODE_EXACT && mode != KWS_MODE_FAST)) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_set_mode: bad argument");
+    if (mode == KWS_MODE_FAST && !h->fast_plain_ok) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%s", h->fast_why.c_str());
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->mode = mode;
+    return EI_IMPULSE_OK;
+}
+int kws_get_mode(const kws_handle *h) { return h->mode; }
+int kws_fast_is_fused(const kws_handle *h) { return h->fast_fused_ok ? 1 : 0; }
+EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count)
+{
+    if (!h || !count) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    *count = 0;
+    if (!h->d_flags) return EI_IMPULSE_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, h->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+    *count = (size_t)n;
+    return EI_IMPULSE_OK;
+}
+
+static EI_IMPULSE_ERROR ensure_flags(kws_handle *h, size_t B)
+{
+    if (B + 1 <= h->flags_cap) return EI_IMPULSE_OK;
+    if (h->d_flags) (void)hipFree(h->d_flags);
+    h->d_flags = nullptr; h->flags_cap = 0;
+    HIP_TRY(hipMalloc((void **)&h->d_flags, (B + 1) * sizeof(int)));
+    h->flags_cap = B + 1;
+    return EI_IMPULSE_OK;
+}
+
+static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *fx, bool want_f, int8_t *q,
+                                             hipStream_t s);
 int grid_cap_mfcc(const kws_handle *h) { return h->n_cu * 8; }
 int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 
@@ -207,6 +244,7 @@ EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
+    if (h->mode == KWS_MODE_FAST) return classify_fast_device(h, pcm, B, nullptr, features, true, q_in, (hipStream_t)stream);
     return mfcc_fused_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
 }
 
@@ -264,6 +302,39 @@ EI_IMPULSE_ERROR kws_run_inference_batch_device(kws_handle *h, const float *feat
 // extract_mfcc_features + the network for B windows in HBM.  float models: f must be a [B][n_features] buffer (the network
 // reads it); int8 models: q must be a [B][n_features] buffer, f is optional (the float feature matrix only leaves the chip
 // when somebody asks for it: the cepstra stay in LDS)
+// KWS_MODE_FAST: the fast kernel over every clip, then the exact kernels over the clips it listed as ill-conditioned (the list and
+// its length stay in HBM: nothing synchronises).  fx: feature scratch / output [B][n_features] (exact re-runs of float graphs and
+// un-fused graphs read it), q: int8 tensor [B][n_features] for int8 graphs; want_f: the caller asked for the feature matrix.
+static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *fx, bool want_f, int8_t *q,
+                                             hipStream_t s)
+{
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
+    EI_IMPULSE_ERROR e = ensure_flags(h, B);
+    if (e) return e;
+    HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+    const bool fused = scores && h->is_float && h->fast_fused_ok;
+    const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
+    int rc = kws_launch_fast(h->dsp, FP, fused ? h->d_fast_fused : h->d_fast_plain, pcm, (int)B, scores, (fused && !want_f) ? nullptr : fx, q, h->nn.in_scale, h->nn.in_zp,
+                             h->d_flags, h->d_flags + 1, h->n_cu, s);
+    if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
+    if (scores && !fused) {
+        if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, nullptr, s))) return e; }
+        else {
+            rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
+            if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
+    }
+    // exact re-run of the listed clips, indexed by their own clip numbers
+    rc = kws_launch_mfcc_fused(h->dsp, pcm, 0, (int)B, fx, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s, h->d_flags);
+    if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (!scores) return EI_IMPULSE_OK;
+    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags);
+    else rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
+    if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
+}
+
 static EI_IMPULSE_ERROR classify_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *f, int8_t *q, hipStream_t s)
 {
     EI_IMPULSE_ERROR e;
@@ -288,6 +359,9 @@ EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *p
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
+    if (h->mode == KWS_MODE_FAST)
+        return classify_fast_device(h, pcm, B, scores, features ? features : h->s_mfcc, features != nullptr,
+                                    h->is_float ? nullptr : (q_in ? q_in : h->s_q), (hipStream_t)stream);
     return classify_device(h, pcm, B, scores, h->is_float ? (features ? features : h->s_mfcc) : features,
                            h->is_float ? nullptr : (q_in ? q_in : h->s_q), (hipStream_t)stream);
 }

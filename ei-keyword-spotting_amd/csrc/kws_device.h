@@ -21,6 +21,11 @@
 
 #define KWS_WAVE 64
 
+// Optional clip selection: KWS_MODE_FAST hands clips whose cmvnw is ill-conditioned back to the exact kernels as a list in HBM
+// (sel[0] = how many, sel[1 + i] = clip index); the kernels then walk the list instead of 0..n_clips-1.
+__device__ __forceinline__ int sel_count(const int *sel, int n_clips) { return sel ? min(sel[0], n_clips) : n_clips; }
+__device__ __forceinline__ int sel_clip(const int *sel, int i) { return sel ? sel[1 + i] : i; }
+
 // Wave-local LDS hand-off: lanes of ONE wave exchange data through LDS.  LDS operations of a wave execute in
 // issue order, so only the compiler has to be kept from reordering (same idiom as rocPRIM's wave barrier).
 #define WAVE_SYNC()                                                   \

@@ -1,0 +1,217 @@
+// kws_fast_plan.cpp -- tables and LDS layout of KWS_MODE_FAST (kws_fast.h).  Like kws_plan.cpp: everything that does not depend on
+// the audio is computed once per model on the host and uploaded.
+#include "kws_internal.h"
+
+static const int kLdsBytes = 160 * 1024;
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Shared by the fused and the plain (features / int8 tensor to HBM) plans: mel taps, DCT fragments, cmvnw tables.
+static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vector<float> &shared)
+{
+    const Model &m = h->model;
+    const DspCfg &c = m.dsp;
+    const KwsDspPlan &P = h->dsp;
+    const int NF = c.num_filters, nfr = P.n_frames, ncep = c.num_cepstral;
+    if (c.fft_length != 256) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: fft_length %d (kernel is built for 256)", c.fft_length);
+    if (NF % 8 != 0 || NF / 8 > KWS_FAST_DCT_GROUPS || NF < 8)
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d mel filters (multiples of 8 up to %d)", NF, 8 * KWS_FAST_DCT_GROUPS);
+    // cmvnw row/column split: 16 columns x 4 groups of 13 rows, or 20 columns x 3 groups of 17 rows
+    if (ncep <= 16 && nfr <= 52) { F.cr = 13; F.cg = 16; }
+    else if (nfr <= 51) { F.cr = 17; F.cg = 20; }
+    else return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d frames x %d cepstra outside the cmvnw layouts", nfr, ncep);
+    if (nfr < 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d frames", nfr);
+
+    // ---- mel taps (feature.hpp:54-171 through h_filterbank, the same table the exact kernel gathers from) -----------------
+    const uint32_t fs_hz = m.frequency;
+    const uint32_t high = c.high_frequency == 0 ? fs_hz / 2 : (uint32_t)c.high_frequency;
+    const std::vector<float> fb = h_filterbank(NF, P.n_bins, fs_hz, (uint32_t)c.low_frequency, high);
+    int bmin = P.n_bins, bmax = -1, max_nz = 0;
+    std::vector<std::vector<std::pair<int, float>>> taps(NF);
+    for (int j = 0; j < NF; j++) {
+        for (int k = 0; k < P.n_bins; k++) {
+            const float w = fb[(size_t)k * NF + j];
+            if (w != 0.0f) { taps[j].push_back({ k, w }); bmin = std::min(bmin, k); bmax = std::max(bmax, k); }
+        }
+        max_nz = std::max(max_nz, (int)taps[j].size());
+    }
+    if (bmax < 0) { bmin = 0; bmax = 0; }
+    if (max_nz > KWS_FAST_NZ_MAX) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: mel filter with %d taps (at most %d)", max_nz, KWS_FAST_NZ_MAX);
+    if (bmax > P.n_bins - 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: a mel filter reads the Nyquist bin");
+    F.bmin = bmin;
+    F.nbins = bmax - bmin + 1;
+    F.pstride = F.nbins | 1;
+    F.nz = max_nz <= 4 ? 4 : max_nz <= 8 ? 8 : KWS_FAST_NZ_MAX;
+    F.nf2p = 0;
+    if (NF > 32) { int p = 1; while (p < NF - 32) p <<= 1; F.nf2p = p; }
+    auto tap_table = [&](auto filter_of_lane) {
+        std::vector<float2> t((size_t)KWS_FAST_WAVE * F.nz);
+        for (int lane = 0; lane < KWS_FAST_WAVE; lane++) {
+            const int j = filter_of_lane(lane);
+            for (int n = 0; n < F.nz; n++) {
+                int off = 0; float w = 0.0f;
+                if (j >= 0 && j < NF && n < (int)taps[j].size()) { off = taps[j][n].first - bmin; w = taps[j][n].second; }
+                float offbits;
+                memcpy(&offbits, &off, sizeof(float));
+                t[(size_t)lane * F.nz + n] = make_float2(offbits, w);
+            }
+        }
+        return t;
+    };
+    const std::vector<float2> t1 = tap_table([&](int lane) { return lane & 31; });
+    const std::vector<float2> t2 = tap_table([&](int lane) { return F.nf2p ? 32 + (lane & (F.nf2p - 1)) : -1; });
+
+    // ---- DCT-II operand fragments (numpy.hpp:378-401: X[n] = 2 sum_k x[k] cos(pi n (2k+1) / 2N), ortho scale) -----------
+    F.dct_groups = NF / 8;
+    F.dct_nt = (NF / 2 + 1 + 15) / 16;
+    if (F.dct_nt > 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: DCT output tiles");
+    F.stale_scale = P.dct_s1;
+    std::vector<float> frag((size_t)F.dct_groups * 2 * F.dct_nt * KWS_FAST_WAVE, 0.0f);
+    for (int g = 0; g < F.dct_groups; g++)
+        for (int i = 0; i < 2; i++)
+            for (int nt = 0; nt < F.dct_nt; nt++)
+                for (int lane = 0; lane < KWS_FAST_WAVE; lane++) {
+                    const int k = 8 * g + 2 * (lane >> 4) + i, n = 16 * nt + (lane & 15);
+                    double v = 0.0;
+                    if (n <= NF / 2) v = 2.0 * cos(M_PI * (double)n * (double)(2 * k + 1) / (double)(2 * NF)) * (double)(n == 0 ? P.dct_s0 : P.dct_s1);
+                    frag[(((size_t)g * 2 + i) * F.dct_nt + nt) * KWS_FAST_WAVE + lane] = (float)v;
+                }
+
+    // ---- cmvnw tables (processing.hpp:326-389 over numpy::pad_1d_symmetric's row order, numpy.hpp:479-541) ---------------
+    std::vector<int> pmap;
+    h_pad_map(nfr, P.pad, pmap);
+    const int ng = KWS_FAST_WAVE / F.cg, win = c.win_size;
+    F.inv_win = 1.0f / (float)win;
+    F.guard = 2e-3f;
+    F.cnt_off = (int)shared.size();
+    shared.resize(shared.size() + (size_t)ng * nfr, 0.0f);
+    for (int g = 0; g < ng; g++) {
+        const int r0 = g * F.cr;
+        if (r0 >= nfr) continue;
+        for (int p = r0; p < r0 + win; p++) shared[(size_t)F.cnt_off + (size_t)g * nfr + pmap[p]] += 1.0f;
+    }
+    if (shared.size() & 1) shared.push_back(0.0f);
+    F.upd_off = (int)shared.size();
+    shared.resize(shared.size() + 2 * (size_t)nfr, 0.0f);
+    // filled once the image's row stride is known (offsets are in floats): see finish_fast_plan
+    EI_IMPULSE_ERROR e;
+    if ((e = h->upload(t1, &F.taps1))) return e;
+    if ((e = h->upload(t2, &F.taps2))) return e;
+    if ((e = h->upload(frag, &F.dct_frag))) return e;
+    return EI_IMPULSE_OK;
+}
+
+static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vector<float> &shared, int need_f, int need_r1)
+{
+    const KwsDspPlan &P = h->dsp;
+    const int nfr = P.n_frames;
+    std::vector<int> pmap;
+    h_pad_map(nfr, P.pad, pmap);
+    for (int r = 0; r + 1 < nfr; r++) {
+        const int drop = pmap[r] * F.fs, add = pmap[r + P.win_size] * F.fs;
+        memcpy(&shared[(size_t)F.upd_off + 2 * r], &drop, sizeof(int));
+        memcpy(&shared[(size_t)F.upd_off + 2 * r + 1], &add, sizeof(int));
+    }
+    while (shared.size() & 3) shared.push_back(0.0f);
+    F.shared_floats = (int)shared.size();
+    F.f_floats = round_up(std::max(F.f_rows * F.fs, need_f), 4);
+    F.r1_floats = round_up(std::max(2 * KWS_FAST_ZF + KWS_FAST_MEL_CHUNK * F.pstride, need_r1), 4);
+    F.wave_floats = F.f_floats + F.r1_floats;
+    const int avail = kLdsBytes / 4 - F.shared_floats;
+    F.n_waves = std::min(8, avail / F.wave_floats);
+    if (F.n_waves < 4) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
+                                   F.shared_floats * 4, F.wave_floats * 4);
+    EI_IMPULSE_ERROR e = h->upload(shared, &F.shared_init);
+    if (e) return e;
+    std::vector<KwsFastPlan> one(1, F);
+    return h->upload(one, &F == &h->fast_fused ? &h->d_fast_fused : &h->d_fast_plain);
+}
+
+// plain form: extract_mfcc_features only; the feature matrix and / or the int8 input tensor go to HBM
+static EI_IMPULSE_ERROR build_fast_plain(kws_handle *h)
+{
+    KwsFastPlan &F = h->fast_plain;
+    memset(&F, 0, sizeof(F));
+    std::vector<float> shared;
+    EI_IMPULSE_ERROR e = build_fast_dsp(h, F, shared);
+    if (e) return e;
+    F.fs = h->dsp.n_filters + 4;
+    F.f_halo = 0;
+    F.f_rows = h->dsp.n_frames;
+    F.fuse = 0;
+    F.n_labels = (int)h->model.labels.size();
+    return finish_fast_plan(h, F, shared, 0, 0);
+}
+
+// fused form: float32 graphs made of CONV_2D blocks only
+static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
+{
+    KwsFastPlan &F = h->fast_fused;
+    memset(&F, 0, sizeof(F));
+    if (!h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the fused network is float32 (int8 graphs keep their exact kernels)");
+    const KwsNnPlanF32 &N = h->nnf;
+    if (N.n_blocks > KWS_FAST_MAX_BLOCKS) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d conv blocks", N.n_blocks);
+    if (N.fc_out > KWS_FAST_WAVE) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d outputs", N.fc_out);
+    std::vector<float> shared;
+    EI_IMPULSE_ERROR e = build_fast_dsp(h, F, shared);
+    if (e) return e;
+    F.fuse = 1;
+    F.n_blocks = N.n_blocks;
+    F.n_labels = N.n_labels;
+    F.fs = h->dsp.n_filters + 4;
+    int need[2] = { 0, 0 };                     // floats each image region must hold beyond its first use
+    for (int b = 0; b < N.n_blocks; b++) {
+        const KwsConvBlockF32 &s = N.blk[b];
+        KwsFastBlock &k = F.blk[b];
+        if (s.depthwise) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: DEPTHWISE_CONV_2D blocks run on the exact kernel");
+        k.in_w = s.in_w; k.in_c = s.in_c; k.in_cp = round_up(s.in_c, 8);
+        k.out_c = s.out_c; k.taps = s.taps; k.pad_left = s.pad_left; k.out_w = s.out_w;
+        k.pool = s.pool; k.pool_stride = s.pool_stride; k.pool_w = s.pool_w;
+        k.in_rows = s.in_w + s.taps - 1;
+        k.in_stride = b == 0 ? F.fs : k.in_cp + 4;
+        k.m_tiles = (s.out_w + 15) / 16; k.n_tiles = (s.out_c + 15) / 16;
+        if (k.m_tiles > 4 || k.n_tiles > 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: conv block %d is %d x %d outputs (at most 64 x 32)", b, s.out_w, s.out_c);
+        if (b == 0 && (k.in_cp > h->dsp.n_filters || s.in_w != h->dsp.n_frames || s.in_c != h->dsp.n_cepstral))
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: first conv block does not read the feature matrix");
+        k.stage_stride = s.out_c | 1;
+        k.has_add = s.has_add;
+        k.conv_min = s.conv_min; k.conv_max = s.conv_max; k.add_min = s.add_min; k.add_max = s.add_max;
+        k.pool_min = s.pool_min; k.pool_max = s.pool_max;
+        // weights [out_c][taps][in_c] -> [tap][c / 2][out_c][2], channels zero-padded to in_cp
+        const std::vector<float> &w = h->hostf.w[b];
+        k.w_off = (int)shared.size();
+        shared.resize(shared.size() + (size_t)k.taps * k.in_cp * k.out_c, 0.0f);
+        for (int tap = 0; tap < k.taps; tap++)
+            for (int ch = 0; ch < k.in_c; ch++)
+                for (int n = 0; n < k.out_c; n++)
+                    shared[(size_t)k.w_off + (((size_t)tap * (k.in_cp / 2) + ch / 2) * k.out_c + n) * 2 + (ch & 1)] =
+                        w[((size_t)n * k.taps + tap) * k.in_c + ch];
+        k.bias_off = (int)shared.size();
+        shared.insert(shared.end(), h->hostf.bias[b].begin(), h->hostf.bias[b].end());
+        k.addc_off = (int)shared.size();
+        shared.insert(shared.end(), h->hostf.addc[b].begin(), h->hostf.addc[b].end());
+        if (shared.size() & 1) shared.push_back(0.0f);
+        // image regions: block b reads region b & 1 (0 = F, 1 = R1), stages its un-pooled outputs there, writes region (b+1) & 1
+        const bool pooled = k.pool > 1 || k.pool_stride > 1;
+        if (b > 0) need[b & 1] = std::max(need[b & 1], k.in_rows * k.in_stride);
+        if (pooled) need[b & 1] = std::max(need[b & 1], k.out_w * k.stage_stride);
+        if (b + 1 == N.n_blocks) need[(b + 1) & 1] = std::max(need[(b + 1) & 1], k.pool_w * k.out_c);
+    }
+    F.f_halo = F.blk[0].pad_left;
+    F.f_rows = F.blk[0].in_rows;
+    F.fc_in = N.fc_in; F.fc_out = N.fc_out; F.fc_min = N.fc_min; F.fc_max = N.fc_max; F.beta = N.beta;
+    F.fc_w_off = (int)shared.size();
+    shared.insert(shared.end(), h->hostf.fc_w.begin(), h->hostf.fc_w.end());
+    F.fc_b_off = (int)shared.size();
+    shared.insert(shared.end(), h->hostf.fc_b.begin(), h->hostf.fc_b.end());
+    return finish_fast_plan(h, F, shared, need[0], need[1]);
+}
+
+EI_IMPULSE_ERROR build_fast_plans(kws_handle *h)
+{
+    h->fast_plain_ok = build_fast_plain(h) == EI_IMPULSE_OK;
+    if (!h->fast_plain_ok) h->fast_why = kws_last_error();
+    h->fast_fused_ok = h->fast_plain_ok && build_fast_fused(h) == EI_IMPULSE_OK;
+    if (h->fast_plain_ok && !h->fast_fused_ok) h->fast_why = kws_last_error();
+    return EI_IMPULSE_OK;
+}

@@ -16,6 +16,7 @@
 
 #include "../../include/kws/kws.h"
 #include "kws_plan.h"
+#include "kws_fast.h"
 
 // launchers in kws_mfcc.hip, kws_nn_int8.hip, kws_nn_f32.hip, kws_misc.hip
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
@@ -25,18 +26,20 @@ int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shi
 int kws_launch_mfe(const KwsDspPlan &P, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap, hipStream_t stream);
 int kws_launch_mfe_norm(float *feat, int n_clips, int rows, int cols, int win, const int *pad_map, int prow, int grid_cap, hipStream_t stream);
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
-                          float in_scale, int in_zp, int grid_cap, hipStream_t stream);
+                          float in_scale, int in_zp, int grid_cap, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,
                                int in_zp, int grid_cap, long long *prof_out, hipStream_t stream);
 int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
                        int *ran_nn, hipStream_t stream);
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
-                      float *tap_logits, int n_cu, hipStream_t stream);
+                      float *tap_logits, int n_cu, hipStream_t stream, const int *sel = nullptr);
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);
 void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
-                  int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream);
+                  int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream, const int *sel = nullptr);
+int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
+                    int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
 size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves);
@@ -161,6 +164,16 @@ struct kws_handle {
     bool feature_buffer_full = false;
     bool cont_first_run = false;
     std::vector<ei_impulse_maf> maf;
+    // KWS_MODE_FAST (kws_fast.h): host copies of a float graph's constants (the fused plan re-lays them out), the two plans,
+    // and the list of clips the fast kernel hands back to the exact kernels
+    struct HostF32 { std::vector<float> w[KWS_MAX_BLOCKS], bias[KWS_MAX_BLOCKS], addc[KWS_MAX_BLOCKS], fc_w, fc_b; } hostf;
+    KwsFastPlan fast_plain{}, fast_fused{};
+    const KwsFastPlan *d_fast_plain = nullptr, *d_fast_fused = nullptr;     // the same plans in device memory
+    bool fast_plain_ok = false, fast_fused_ok = false;
+    std::string fast_why;
+    int mode = KWS_MODE_EXACT;
+    int *d_flags = nullptr;       // [0] = count, [1 + i] = clip index
+    size_t flags_cap = 0;
 
     template <typename T> EI_IMPULSE_ERROR upload(const std::vector<T> &v, const T **out)
     {
@@ -177,6 +190,7 @@ struct kws_handle {
 // kws_plan.cpp: execution plans (tables computed once per model, uploaded to HBM)
 EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h);
 EI_IMPULSE_ERROR build_nn_plan(kws_handle *h);
+EI_IMPULSE_ERROR build_fast_plans(kws_handle *h);     // kws_fast_plan.cpp; never fatal: sets fast_*_ok
 
 // kws_api.cpp: stage launchers shared with the stream / SDK entry points (kws_sdk.cpp); internal, not exported
 #define KWS_INTERNAL __attribute__((visibility("hidden")))

@@ -179,7 +179,7 @@ template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF = 32, bool PROF = 
 __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws_mfcc_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips,
                                                             float *__restrict__ features, int8_t *__restrict__ q_out,
                                                             float in_scale, int in_zp, const float *__restrict__ wrap, int out_stride,
-                                                            long long *prof_out = nullptr)
+                                                            long long *prof_out = nullptr, const int *__restrict__ sel = nullptr)
 {
     constexpr int CHF = 2 * CHP + (LW ? 2 : 0);          // frame slots per power-spectrum row (stride)
     constexpr int MELS = NF + 1, NCEPT = NF / 2 + 1;     // DCT only produces outputs 0..NF/2 (fast-dct-fft.cpp:71)
@@ -233,7 +233,9 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
     }
     const int fp0 = LW ? wave * CHP : 0;                    // first frame pair of this wave
 
-    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+    const int n_sel = sel_count(sel, n_clips);
+    for (int ci = blockIdx.x; ci < n_sel; ci += gridDim.x) {
+        const int clip = sel_clip(sel, ci);
         const void *xbase = F32IN ? (const void *)((const float *)pcm_v + (size_t)clip * P.n_samples)
                                   : (const void *)((const int16_t *)pcm_v + (size_t)clip * P.n_samples);
         // software prefetch, two frame pairs deep: the samples of pair p+2 are requested before pair p is transformed
@@ -564,7 +566,7 @@ constexpr int KWS_LAT_CHP = 4, KWS_LAT_WAVES = 7, KWS_LAT_MAX_CLIPS = 16;
 
 template <bool F32IN, bool WITH_CMVN, bool PROF>
 static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, float *out, int8_t *q_out, float in_scale, int in_zp,
-                         const float *wrap, int out_stride, int grid_cap, long long *prof, hipStream_t stream)
+                         const float *wrap, int out_stride, int grid_cap, long long *prof, hipStream_t stream, const int *sel = nullptr)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
@@ -576,46 +578,46 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
             const dim3 blk(KWS_WAVE * KWS_LAT_WAVES);
             if (P.n_filters == 40 && P.max_nz <= 8)
                 hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, 8, 40, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
             else if (P.n_filters == 40)
                 hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, KWS_MAXNZ, 40, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
             else if (P.max_nz <= 4)
                 hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, 4, 32, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
             else
                 hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, KWS_MAXNZ, 32, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
             return (int)hipGetLastError();
         }
     }
     if (P.n_filters == 40 && P.max_nz <= 8 && WITH_CMVN && P.n_cepstral > 16)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
     else if (P.n_filters == 40 && P.max_nz <= 8)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
     else if (P.n_filters == 40 && P.max_nz <= KWS_MAXNZ)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
     else if (P.n_filters != 32)
         return (int)hipErrorInvalidValue;
     else if (P.max_nz <= 4)
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 4, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
-                           n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                           n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
     else
         hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof);
+                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
     return (int)hipGetLastError();
 }
 
 // extract_mfcc_features (+ quantisation) for n_clips windows in one launch
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
-                          float in_scale, int in_zp, int grid_cap, hipStream_t stream)
+                          float in_scale, int in_zp, int grid_cap, hipStream_t stream, const int *sel)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
-    return pcm_is_float ? launch_mfcc_t<true, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream)
-                        : launch_mfcc_t<false, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream);
+    return pcm_is_float ? launch_mfcc_t<true, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream, sel)
+                        : launch_mfcc_t<false, true, false>(P, pcm, n_clips, features, q_out, in_scale, in_zp, nullptr, 0, grid_cap, nullptr, stream, sel);
 }
 
 int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips, float *features, int8_t *q_out, float in_scale,

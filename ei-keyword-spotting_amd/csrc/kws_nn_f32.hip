@@ -270,7 +270,8 @@ __host__ __device__ __forceinline__ NnfLayout nnf_layout(const KwsNnPlanF32 &N)
 template <int MAXT>     // threads per workgroup the build allows: 1024 (<= 128 VGPRs) or 512 (<= 256 VGPRs, vectorised conv steps)
 __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__restrict__ Np, const float *__restrict__ features,
                                                           int n_clips, float *__restrict__ scores,
-                                                          float *__restrict__ tap_logits, long long *__restrict__ prof)
+                                                          float *__restrict__ tap_logits, long long *__restrict__ prof,
+                                                          const int *__restrict__ sel)
 {
     // the plan is read from memory (scalar loads, any block index); by value in the kernel arguments the compiler copies it to
     // scratch as soon as a block is indexed dynamically
@@ -315,7 +316,9 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
         const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
         return ((lo | hi | N.n_features) & 3) == 0 && ((tot + 3) >> 2) <= 64 * NNF_PF && N.n_blocks > 1;
     }();
-    for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
+    const int n_sel = sel_count(sel, n_clips);
+    for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci += gridDim.x * n_waves) {
+        const int clip = sel_clip(sel, ci);
         {
             const KwsConvBlockF32 &k = N.blk[0];
             const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
@@ -395,9 +398,10 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
             if (b == 0 && MAXT <= 512 && pf_ok) {
                 // block 0 (most of the clip's time) is done: request the NEXT clip's feature vector now, so that it arrives
                 // while the short tail blocks, FC and softmax run (phases with little VALU work and nothing to prefetch)
-                const int nclip = clip + gridDim.x * n_waves;
-                have_pf = nclip < n_clips;
+                const int nci = ci + gridDim.x * n_waves;
+                have_pf = nci < n_sel;
                 if (have_pf) {
+                    const int nclip = sel_clip(sel, nci);
                     const KwsConvBlockF32 &k0 = N.blk[0];
                     const int lo4 = (k0.pad_left * k0.in_c) >> 2, hi4 = lo4 + ((k0.in_w * k0.in_c) >> 2);
                     const float4 *src4 = (const float4 *)(features + (size_t)nclip * N.n_features);
@@ -515,7 +519,7 @@ int kws_nn_f32_waves(const KwsNnPlanF32 &N)
 }
 
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
-                      float *tap_logits, int n_cu, hipStream_t stream)
+                      float *tap_logits, int n_cu, hipStream_t stream, const int *sel)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
@@ -531,9 +535,9 @@ int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const f
     }
     if (n_waves <= 8)
         hipLaunchKernelGGL(kws_nn_f32_kernel<512>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, d_plan, features, n_clips,
-                           scores, tap_logits, kws_dev_f32_prof);
+                           scores, tap_logits, kws_dev_f32_prof, sel);
     else
         hipLaunchKernelGGL(kws_nn_f32_kernel<1024>, dim3(grid), dim3(KWS_WAVE * n_waves), smem, stream, d_plan, features, n_clips,
-                           scores, tap_logits, kws_dev_f32_prof);
+                           scores, tap_logits, kws_dev_f32_prof, sel);
     return (int)hipGetLastError();
 }

@@ -76,6 +76,7 @@ struct NnTaps {            // optional debug outputs for the parity tests (all i
     int8_t *fc;            // [fc_out]
     int8_t *out_q;         // [n_labels]
     long long *prof;       // development aid: shader-clock totals per phase of wave 0 of workgroup 0 (generic kernel), or NULL
+    const int *sel;        // optional clip selection (kws_device.h sel_count / sel_clip), or NULL
 };
 
 // FULLY_CONNECTED (integer_ops/fully_connected.h:23-63) + SOFTMAX int8->int8 (reference/softmax.h:66-144) for one clip.
@@ -190,7 +191,9 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
     const bool profiling = taps.prof != nullptr && blockIdx.x == 0 && wave == 0;
     long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;
     auto mark = [&](int i) { if (profiling) { const long long now = clock64(); ph[i] += now - tlast; tlast = now; } };
-    for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
+    const int n_sel = sel_count(taps.sel, n_clips);
+    for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci += gridDim.x * n_waves) {
+        const int clip = sel_clip(taps.sel, ci);
         // ---- stage the int8 input as [pad_left + t][in_cpad], padding = zero point ((x + offset) == 0) -------
         {
             const KwsConvBlock &k = N.blk[0];
@@ -581,7 +584,9 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
     __syncthreads();
     const int F = N.n_features;
     const unsigned inv_c = (1u << 20) / (unsigned)k1.in_c + 1u;          // i / in_c == (i * inv_c) >> 20 for i < n_features <= 4096
-    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+    const int n_sel = sel_count(taps.sel, n_clips);
+    for (int ci = blockIdx.x * KWS_NN_WAVES + wave; ci < n_sel; ci += gridDim.x * KWS_NN_WAVES) {
+        const int clip = sel_clip(taps.sel, ci);
         // ---- int8 input tensor [time][in_c] -> LDS rows of CP bytes at row (time + pad_left) --------------------
         const int8_t *src = q_in + (size_t)clip * F;
         if ((k1.in_c & 3) == 0) {                          // four channels per copy (feature vector and rows 4-byte aligned)
@@ -715,13 +720,13 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves)
 }
 
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
-                  int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream)
+                  int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream, const int *sel)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
-    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q, kws_dev_nn_prof };
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q, kws_dev_nn_prof, sel };
     if (nn_fits_mfma(N) && !kws_force_scalar_nn) {
         if (N.blk[0].in_cpad == 16)
             hipLaunchKernelGGL(kws_nn_mfma_kernel<16>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);

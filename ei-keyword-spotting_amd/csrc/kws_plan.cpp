@@ -454,6 +454,7 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
         if ((e = h->upload(wv, &k.w))) return e;
         if ((e = h->upload(bv, &k.bias))) return e;
         if ((e = h->upload(av, &k.addc))) return e;
+        h->hostf.w[N.n_blocks] = wv; h->hostf.bias[N.n_blocks] = bv; h->hostf.addc[N.n_blocks] = av;
         kws_nn_f32_pick_blocking(&k);
         N.n_blocks++;
     }
@@ -479,6 +480,7 @@ static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h)
         EI_IMPULSE_ERROR e;
         if ((e = h->upload(wv, &N.fc_w))) return e;
         if ((e = h->upload(bv, &N.fc_bias))) return e;
+        h->hostf.fc_w = wv; h->hostf.fc_b = bv;
         cur = fc.out[0];
         i++;
     }

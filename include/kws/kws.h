@@ -41,6 +41,25 @@ int kws_pooled_tap_bytes(const kws_handle *h);           /* bytes/clip of the po
 const char *kws_nn_kernel_name(const kws_handle *h);    /* which network kernel serves this model (diagnostics) */
 int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI_CLASSIFIER_TFLITE_INPUT_QUANTIZED == 0) */
 
+/* ---- arithmetic mode of the batch hot path (kws_run_classifier_batch*, kws_extract_mfcc_batch_device) --------------------
+ * KWS_MODE_EXACT (default): every floating-point operation replays the reference's order: MFCC features bit-identical, int8 graphs
+ *   bit-identical end to end, float32 scores within 1e-6.
+ * KWS_MODE_FAST: the tolerance BASELINE.json grants (1e-4 on float32 scores) is spent where the reference's operation order is
+ *   expensive: fp32 power spectrum, DCT on the matrix cores, O(1) running-sum cmvnw, and -- float32 graphs of CONV_2D blocks --
+ *   the network on v_mfma_f32_16x16x4_f32 in the same launch (the feature matrix never leaves the chip).  The FFT keeps
+ *   KissFFT's order.  Clips whose cmvnw is ill-conditioned (near-constant column) are detected and re-run by the exact
+ *   kernels inside the same call, so their results are the exact mode's.  int8 graphs: fast MFCC + the exact int8 network;
+ *   an int8 input value may then differ by one step where a feature sits on a rounding boundary.
+ * The SDK entry points (run_classifier ...), the stage API and the stream API always run the exact kernels. */
+#define KWS_MODE_EXACT 0
+#define KWS_MODE_FAST 1
+EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode);   /* KWS_ERROR_UNSUPPORTED_MODEL if the model's DSP block is outside the fast kernel */
+int kws_get_mode(const kws_handle *h);
+/* 1: KWS_MODE_FAST runs this model's network fused behind the MFCC block (float32 CONV_2D graphs); 0: features go through HBM */
+int kws_fast_is_fused(const kws_handle *h);
+/* clips the last KWS_MODE_FAST call on this handle handed back to the exact kernels (synchronises the device) */
+EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
+
 /* The model used by the SDK-style entry points run_classifier()/run_inference().  If none was set,
  * the first call loads the file named by the environment variable KWS_MODEL on device KWS_DEVICE (0). */
 EI_IMPULSE_ERROR kws_set_default_model(kws_handle *h);
