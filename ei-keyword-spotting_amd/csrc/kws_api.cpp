@@ -257,6 +257,21 @@ void kws_dev_set_nn_prof(long long *dev_buf) { kws_dev_nn_prof = dev_buf; }
 // development/test aid (not in the public headers): force the generic dot4 NN kernel
 void kws_dev_force_scalar_nn(int on) { kws_force_scalar_nn = on; }
 
+// development aid (not in the public headers): per-phase shader-clock totals of wave 0 of workgroup 0 of the fast kernel
+EI_IMPULSE_ERROR kws_dev_fast_phase_profile(kws_handle *h, const int16_t *pcm, size_t B, float *scores, long long *prof_dev)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->fast_plain_ok) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%s", h->fast_why.c_str());
+    EI_IMPULSE_ERROR e = ensure_flags(h, B);
+    if (e) return e;
+    HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), nullptr));
+    const bool fused = h->is_float && h->fast_fused_ok;
+    int rc = kws_launch_fast_prof(h->dsp, fused ? h->fast_fused : h->fast_plain, fused ? h->d_fast_fused : h->d_fast_plain, pcm, (int)B, scores,
+                                  h->d_flags, h->d_flags + 1, h->n_cu, prof_dev, nullptr);
+    if (rc) return fail(KWS_ERROR_HIP, "launch failed");
+    return EI_IMPULSE_OK;
+}
+
 // development aid (not in the public headers): per-phase shader-clock totals of workgroup 0 of kernel 1
 EI_IMPULSE_ERROR kws_dev_mfcc_phase_profile(kws_handle *h, const int16_t *pcm, size_t B, float *features, long long *prof_dev)
 {

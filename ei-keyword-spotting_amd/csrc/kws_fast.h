@@ -18,7 +18,8 @@
 #include "kws_plan.h"
 
 #define KWS_FAST_MAX_BLOCKS 4
-#define KWS_FAST_NZ_MAX 12        // longest mel filter kept in registers
+#define KWS_FAST_NZ_MAX 12        // longest mel filter (filters 0..31) kept in registers
+#define KWS_FAST_NZ2 8            // longest of filters 32..39
 #define KWS_FAST_DCT_GROUPS 5     // NF / 8 <= 5: DCT operand fragments kept in registers
 #define KWS_FAST_MEL_CHUNK 8      // frames whose power spectra are buffered before a mel pass
 #define KWS_FAST_WAVE 64
@@ -40,18 +41,21 @@ struct KwsFastBlock {
 struct KwsFastPlan {
     // ---- mel stage: power spectra of KWS_FAST_MEL_CHUNK frames, bins [bmin, bmin + nbins) only, then lane = filter
     int bmin, nbins, pstride;
-    int nz;                       // taps per filter kept in registers (template parameter of the launch: 4, 8 or 12)
+    int nz;                       // longest of filters 0..31 (template parameter of the launch: 4, 8 or 12)
     int nf2p;                     // filters >= 32 are served nf2p (a power of two) per frame slot; 0: at most 32 filters
-    const float2 *taps1;          // [64][nz]  {offset into a frame's power row (as float bits of an int), weight}: filter lane & 31
-    const float2 *taps2;          // [64][nz]  same for filter 32 + lane % nf2p
+    // a filter's taps are consecutive bins: first bin as an offset into a frame's power row + weights (zero beyond the filter's end)
+    const int *tap_start1;        // [64]                       filter lane & 31
+    const float *tap_w1;          // [64][KWS_FAST_NZ_MAX]
+    const int *tap_start2;        // [64]                       filter 32 + lane % nf2p
+    const float *tap_w2;          // [64][KWS_FAST_NZ2]
     // ---- DCT on the matrix cores
     int dct_groups, dct_nt;       // NF / 8 k-groups, ceil((NF/2+1) / 16) output tiles
     const float *dct_frag;        // [dct_groups][2][dct_nt][64] B fragments: 2 cos(pi n (2k+1) / 2NF) * ortho scale
     float stale_scale;            // sqrtf(1/(2NF)): coefficients above NF/2 keep the log-mel input x 2 x this (fast-dct-fft.cpp:71)
     // ---- cmvnw
     int cr, cg;                   // rows per lane, columns per pass (13 x 16 or 17 x 20)
-    int cnt_off, upd_off;         // shared LDS: cnt[64/cg][n_frames] window multiplicities of each row group's first window;
-                                  // upd[n_frames] {offset of the padded row leaving, entering} (floats, F-image relative)
+    int cnt_off, upd_off;         // shared LDS: cnt[64/cg][n_frames rounded up to 8] window multiplicities of each row group's first
+                                  // window; upd[n_frames] = offset of the padded row leaving | entering << 16 (floats, image relative)
     float inv_win;
     float guard;                  // a window with std < guard * max(1, |mean|) sends the clip to the exact kernels
     // ---- per-wave LDS: F image [f_rows][fs] (log-mel -> cepstra -> features, SAME-padding rows of block 0 included) + R1

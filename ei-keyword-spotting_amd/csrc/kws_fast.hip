@@ -4,6 +4,10 @@
 // float32 graph -- the CONV_2D / ADD / MAX_POOL_2D / FULLY_CONNECTED / SOFTMAX chain (TFL/kernels/internal/reference/conv.h:28-99,
 // add.h:179-215, pooling.h:189-237, fully_connected.h:26-60, softmax.h:31-63) with the convolutions on v_mfma_f32_16x16x4_f32.
 // Eight waves of a workgroup share the weights in LDS; nothing but the PCM and the scores crosses HBM.
+//
+// With 14 KB of LDS per wave only two waves fit a SIMD, so every phase is written to keep its own memory operations in
+// flight: loads of a phase are issued as one batch before the arithmetic that consumes them, tile counts are template
+// parameters (no predicated code inside the contraction loops), and the convolution loops fetch one k-step ahead.
 #include "kws_device.h"
 #include "kws_fast.h"
 
@@ -51,104 +55,124 @@ __device__ __forceinline__ FastRaw fast_fetch(const int16_t *x, int s0, int n_sa
 //  at time -pad_left and its padding rows hold zeros, so SAME padding needs no predicate).  Tiles of 16 rows x 16 channels,
 //  k-steps of 4 (tap, channel) pairs; a lane fetches two k-steps' operands with one 8-byte read each:
 //      A: image[(16 mt + l % 16 + tap) * stride + 8 cg + 2 (l / 16) + {0, 1}]
-//      B: w[tap][4 cg + l / 16][n][{0, 1}]                          (layout built by kws_fast_plan.cpp)
-//  Every accumulator (<= 4 x 2 tiles) stays in registers until the contraction is complete: only then is the input image dead
-//  and may be overwritten by the un-pooled staging image.
+//      B: w[tap][4 cg + l / 16][n][{0, 1}]  =  w2[(4 it + l / 16) * out_c + n],  it = tap * (in_cp / 8) + cg
+//  Every accumulator (MT x NT tiles) stays in registers until the contraction is complete: only then is the input image dead
+//  and may be overwritten by the un-pooled staging image.  The operands of step it + 1 are requested before the MFMAs of
+//  step it are issued.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_conv_block(const KwsFastBlock &k, float *__restrict__ in, float *__restrict__ out,
-                                                const float *__restrict__ shared, int lane, int out_stride, int out_halo,
-                                                int out_rows, int out_cp)
+template <int MT, int NT>
+__device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ stage,
+                                                int sstride, int shalo, const float *__restrict__ shared, int lane)
 {
     const int lm = lane & 15, lq = lane >> 4;
-    const int MT = k.m_tiles, NT = k.n_tiles;
-    v4f acc[4][2];
+    v4f acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = v4f{ 0.f, 0.f, 0.f, 0.f };
-    const int ncg = k.in_cp >> 3;
-    const float *arow = in + lm * k.in_stride + 2 * lq;
-    const float *wl = shared + k.w_off;
-    const int n0 = min(lm, k.out_c - 1), n1 = min(16 + lm, k.out_c - 1);
-    const int mstep = 16 * k.in_stride;
-    for (int tap = 0; tap < k.taps; ++tap) {
-        const float *at = arow + tap * k.in_stride;
-        const float *wt = wl + ((size_t)(tap * (k.in_cp >> 1) + lq) * k.out_c) * 2;
-        for (int cg = 0; cg < ncg; ++cg) {
-            float2 a[4], b[2];
-            b[0] = *(const float2 *)(wt + (size_t)(4 * cg * k.out_c + n0) * 2);
-            if (NT > 1) b[1] = *(const float2 *)(wt + (size_t)(4 * cg * k.out_c + n1) * 2);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{ 0.f, 0.f, 0.f, 0.f };
+    const int in_stride = k.in_stride, out_c = k.out_c;
+    const int ncg = k.in_cp >> 3, n_it = k.taps * ncg;
+    const float *ap = in + lm * in_stride + 2 * lq;
+    const float2 *bp[NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                if (mt < MT) a[mt] = *(const float2 *)(at + mt * mstep + 8 * cg);
+    for (int nt = 0; nt < NT; ++nt) bp[nt] = (const float2 *)(shared + k.w_off) + lq * out_c + min(16 * nt + lm, out_c - 1);
+    const int mstep = 16 * in_stride, bstep = 4 * out_c;
+    float2 a[MT], b[NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (mt < MT) {
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[0].x, acc[mt][0], 0, 0, 0);
-                    if (NT > 1) acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[1].x, acc[mt][1], 0, 0, 0);
-                }
-            }
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const float2 *)(ap + mt * mstep);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (mt < MT) {
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[0].y, acc[mt][0], 0, 0, 0);
-                    if (NT > 1) acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[1].y, acc[mt][1], 0, 0, 0);
-                }
-            }
-        }
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *bp[nt];
+    int cg = 0;
+    for (int it = 0; it < n_it; ++it) {
+        // operands of the next step (the last step re-reads its own: no branch around the loads)
+        const bool more = it + 1 < n_it;
+        if (more) { ++cg; if (cg == ncg) { cg = 0; ap += in_stride - 8 * (ncg - 1); } else ap += 8; }
+        float2 an[MT], bn[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) an[mt] = *(const float2 *)(ap + mt * mstep);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { if (more) bp[nt] += bstep; bn[nt] = *bp[nt]; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
     }
     // ---- epilogue: bias, fused activation, ADD(constant) + activation (conv.h:88-93, add.h:200-212) ---------------------
-    const bool pooled = k.pool > 1 || k.pool_stride > 1;
-    float *stage = pooled ? in : out;                        // the input image is dead: every A operand is in a register
-    const int sstride = pooled ? k.stage_stride : out_stride, shalo = pooled ? 0 : out_halo;
+    const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max;
+    const bool has_add = k.has_add != 0;
+    const int out_w = k.out_w;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * nt + lm;
+        const int nc = min(n, out_c - 1);
+        const float bias = shared[k.bias_off + nc], addc = shared[k.addc_off + nc];
+        float *sp = stage + shalo * sstride + n;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * mt + 4 * lq + i;
+                float v = acc[mt][nt][i] + bias;
+                v = fminf(fmaxf(v, cmin), cmax);
+                if (has_add) { v = v + addc; v = fminf(fmaxf(v, amin), amax); }
+                if (row < out_w && n < out_c) sp[row * sstride] = v;
+            }
+        }
+    }
+}
+
+// Block epilogue shared by every tile shape: zero the SAME-padding rows of the next block's image, then either nothing (the
+// tiles were written straight into it) or MAX_POOL_2D over time from the staging image (pooling.h:189-237: windows clipped to the
+// image, then the activation clamp).  Items = (pooled row, channel incl. the k-padding channels, which receive zeros).
+__device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__restrict__ stage, float *__restrict__ out, int lane,
+                                          int out_stride, int out_halo, int out_rows, int out_cp, bool pooled)
+{
+    const int top = out_halo * out_stride, bot0 = (out_halo + k.pool_w) * out_stride, bot = out_rows * out_stride;
+    for (int i = lane; i < top + (bot - bot0); i += KWS_WAVE) out[i < top ? i : bot0 + (i - top)] = 0.0f;
+    const int items = k.pool_w * out_cp;
+    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;        // i / out_cp == (i * inv) >> 20 for i < 4096, out_cp <= 64
+    const int sstride = k.stage_stride, out_w = k.out_w, out_c = k.out_c, pool = k.pool, pstr = k.pool_stride;
+    const float pmin = k.pool_min, pmax = k.pool_max;
+    float *img = out + out_halo * out_stride;
     if (!pooled) {
-        // SAME-padding rows and the k-padding columns of the next block's image
-        for (int i = lane; i < out_rows * out_stride; i += KWS_WAVE) {
-            const int r = i / out_stride, c = i - r * out_stride;
-            if (r < out_halo || r >= out_halo + k.out_w || (c >= k.out_c && c < out_cp)) out[i] = 0.0f;
+        for (int i = lane; i < items; i += KWS_WAVE) {
+            const int p = (int)(((unsigned)i * inv) >> 20), c = i - p * out_cp;
+            if (c >= out_c) img[p * out_stride + c] = 0.0f;
         }
+        return;
     }
+    for (int i0 = 0; i0 < items; i0 += 2 * KWS_WAVE) {
+        float v[2][8];
+        int p[2], c[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        if (nt < NT) {
-            const int n = 16 * nt + lm;
-            const int nc = min(n, k.out_c - 1);
-            const float bias = shared[k.bias_off + nc], addc = shared[k.addc_off + nc];
+        for (int u = 0; u < 2; ++u) {
+            const int i = min(i0 + u * KWS_WAVE + lane, items - 1);
+            p[u] = (int)(((unsigned)i * inv) >> 20);
+            c[u] = i - p[u] * out_cp;
+            const float *sp = stage + p[u] * pstr * sstride + min(c[u], out_c - 1);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (mt < MT) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int row = 16 * mt + 4 * lq + i;
-                        float v = acc[mt][nt][i] + bias;
-                        v = fminf(fmaxf(v, k.conv_min), k.conv_max);
-                        if (k.has_add) { v = v + addc; v = fminf(fmaxf(v, k.add_min), k.add_max); }
-                        if (row < k.out_w && n < k.out_c) stage[(shalo + row) * sstride + n] = v;
-                    }
-                }
+            for (int j = 0; j < 8; ++j) {
+                // a clipped or unused slot re-reads a row of the window: the maximum is unchanged
+                const int r = (j < pool) ? min(p[u] * pstr + j, out_w - 1) : p[u] * pstr;
+                v[u][j] = sp[(r - p[u] * pstr) * sstride];
             }
         }
-    }
-    WAVE_SYNC();
-    if (pooled) {
-        // MAX_POOL_2D over time (pooling.h:189-237): windows clipped to the image, then the activation clamp
-        for (int i = lane; i < out_rows * out_stride; i += KWS_WAVE) {
-            const int r = i / out_stride, c = i - r * out_stride;
-            const int p = r - out_halo;
-            float v = 0.0f;
-            bool wr = c < out_cp;
-            if (p >= 0 && p < k.pool_w && c < k.out_c) {
-                const int r0 = p * k.pool_stride;
-                float m = -FLT_MAX;
-                for (int j = 0; j < k.pool; ++j)
-                    if (r0 + j < k.out_w) m = fmaxf(m, stage[(r0 + j) * sstride + c]);
-                v = fminf(fmaxf(m, k.pool_min), k.pool_max);
-            } else if (p >= 0 && p < k.pool_w && c >= out_cp) {
-                wr = false;
-            }
-            if (wr) out[i] = v;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float m = v[u][0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) m = fmaxf(m, v[u][j]);
+            m = fminf(fmaxf(m, pmin), pmax);
+            if (i0 + u * KWS_WAVE + lane < items) img[p[u] * out_stride + c[u]] = c[u] < out_c ? m : 0.0f;
         }
-        WAVE_SYNC();
     }
 }
 
@@ -157,51 +181,66 @@ __device__ __forceinline__ void fast_conv_block(const KwsFastBlock &k, float *__
 //  the window of r minus padded row r plus padded row r + win, so running sums of d = x - pivot and d * d (pivot = the column's
 //  first row: the sums stay small, var = Q/n - (S/n)^2 does not cancel) replace two win-term walks.  A lane owns one column and
 //  CR consecutive rows; the first window of a row group is sum_j cnt[g][j] d_j with the multiplicities tabulated by the host.
-//  Statistics stay in registers until every lane has read what it needs: only then are the rows overwritten.
+//  Three batches of loads per column block (the column, the update table, the rows the updates name); statistics and results
+//  stay in registers until every lane has read what it needs, only then are the rows overwritten.
 // ---------------------------------------------------------------------------------------------------------
 template <int CR, int CG, typename Emit>
-__device__ __forceinline__ bool fast_cmvn(float *__restrict__ F, const float *__restrict__ shared, const KwsFastPlan &FP, int lane,
-                                          int nfr, int ncep, Emit emit)
+__device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
+                                          float inv_win, float guard, int lane, int nfr, int ncep, Emit emit)
 {
     constexpr int NG = KWS_WAVE / CG;
     const int cgrp = min(lane / CG, NG - 1), cl = lane - (lane / CG) * CG;
     const bool lane_on = lane < NG * CG;
     const int r0 = cgrp * CR;
-    const float *cnt = shared + FP.cnt_off + cgrp * nfr;
-    const int2 *upd = (const int2 *)(shared + FP.upd_off);
-    const int fs = FP.fs;
-    float *img = F + FP.f_halo * fs;
+    const int nfr8 = (nfr + 7) & ~7;
+    const float *cnt = cnt_tab + cgrp * nfr8;          // rows padded to a multiple of 8 with zeros
     bool bad = false;
     for (int cb = 0; cb < ncep; cb += CG) {
         const int c = cb + cl;
         const bool act = lane_on && c < ncep && r0 < nfr;
         float *col = img + min(c, ncep - 1);
         const float piv = col[0];
-        float S = 0.0f, Q = 0.0f;
-        for (int j = 0; j < nfr; ++j) {
-            const float d = col[j * fs] - piv;
-            const float w = cnt[j];
-            const float wd = w * d;
-            S += wd;
-            Q = __fmaf_rn(wd, d, Q);
+        // the update table entries of this lane's rows, then the rows they name and the lane's own rows
+        int u[CR - 1];                                // leaving row offset | entering row offset << 16 (floats)
+#pragma unroll
+        for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0 + i, nfr - 1)];
+        float own[CR];
+#pragma unroll
+        for (int i = 0; i < CR; ++i) own[i] = col[min(r0 + i, nfr - 1) * fs];
+        // first window of the row group: sum_j cnt[j] d_j, eight rows per batch, two partial sums
+        float S0 = 0.0f, S1 = 0.0f, Q0 = 0.0f, Q1 = 0.0f;
+        for (int j0 = 0; j0 < nfr8; j0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = col[min(j0 + e, nfr - 1) * fs];
+            const float4 wa = *(const float4 *)(cnt + j0), wb = *(const float4 *)(cnt + j0 + 4);
+            const float w[8] = { wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w };
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float d0 = x[e] - piv, d1 = x[e + 1] - piv;
+                const float wd0 = w[e] * d0, wd1 = w[e + 1] * d1;
+                S0 += wd0; S1 += wd1;
+                Q0 = __fmaf_rn(wd0, d0, Q0); Q1 = __fmaf_rn(wd1, d1, Q1);
+            }
         }
-        float mean[CR], rstd[CR];
+        float dl[CR - 1], da[CR - 1];
+#pragma unroll
+        for (int i = 0; i < CR - 1; ++i) { dl[i] = col[u[i] & 0xffff] - piv; da[i] = col[(unsigned)u[i] >> 16] - piv; }
+        float S = S0 + S1, Q = Q0 + Q1;
+        float o[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) {
-            const int r = r0 + i;
-            const float m = S * FP.inv_win;
-            float var = __fmaf_rn(-m, m, Q * FP.inv_win);
+            const float m = S * inv_win;
+            float var = __fmaf_rn(-m, m, Q * inv_win);
             var = fmaxf(var, 0.0f);
             const float sd = __builtin_amdgcn_sqrtf(var);
-            mean[i] = m;
-            rstd[i] = __builtin_amdgcn_rcpf(sd + FLT_EPSILON);
-            if (act && r < nfr) bad |= sd < FP.guard * fmaxf(1.0f, fabsf(m + piv));
+            const float rstd = __builtin_amdgcn_rcpf(sd + FLT_EPSILON);
+            if (act && r0 + i < nfr) bad |= sd < guard * fmaxf(1.0f, fabsf(m + piv));
+            o[i] = ((own[i] - piv) - m) * rstd;
             if (i + 1 < CR) {
-                const int2 u = upd[min(r, nfr - 1)];
-                const float dl = col[u.x] - piv, da = col[u.y] - piv;
-                S = (S + da) - dl;
-                Q = __fmaf_rn(da, da, Q);
-                Q = __fmaf_rn(-dl, dl, Q);
+                S = (S + da[i]) - dl[i];
+                Q = __fmaf_rn(da[i], da[i], Q);
+                Q = __fmaf_rn(-dl[i], dl[i], Q);
             }
         }
         WAVE_SYNC();                                  // every lane's reads of this column block are done
@@ -209,9 +248,8 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ F, const float *__
         for (int i = 0; i < CR; ++i) {
             const int r = r0 + i;
             if (act && r < nfr) {
-                const float o = ((col[r * fs] - piv) - mean[i]) * rstd[i];
-                col[r * fs] = o;
-                emit(r, c, o);
+                col[r * fs] = o[i];
+                emit(r, c, o[i]);
             }
         }
     }
@@ -219,64 +257,80 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ F, const float *__
     return bad;
 }
 
+// PROF: development aid -- shader-clock totals per phase of wave 0 of workgroup 0 (tools/gpu_fast_phase_profile.py)
+#define KWS_FAST_NPHASE 10
+#define FPH(i) do { if (PROF) { const long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
-template <int NZ>
+// NZ: taps of mel filters 0..31 kept in registers (filters 32..39, when there are 40, keep KWS_FAST_NZ2); DG: DCT k-groups = filters / 8
+template <int NZ, int DG, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const KwsFastPlan *__restrict__ FPp, const int16_t *__restrict__ pcm, int n_clips,
                                                           float *__restrict__ scores, float *__restrict__ features,
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
-                                                          int *__restrict__ flag_count, int *__restrict__ flag_list)
+                                                          int *__restrict__ flag_count, int *__restrict__ flag_list,
+                                                          long long *__restrict__ prof_out = nullptr)
 {
     // the plan is read from memory (scalar loads, any block index); by value in the kernel arguments the compiler copies it to
     // scratch to index its blocks
     const KwsFastPlan &FP = *FPp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (KWS_WAVE - 1), wave = threadIdx.x >> 6;
-    const int half = lane >> 5, t = lane & 31;
     float *shared = lds;
     float *F = lds + FP.shared_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
     float *R1 = F + FP.f_floats;                                      // FFT buffers + power rows; later block 1's input image
     float *zw = R1, *pw = R1 + 2 * KWS_ZF;
     for (int i = threadIdx.x; i < FP.shared_floats; i += blockDim.x) shared[i] = FP.shared_init[i];
+    // the power rows are padded so that every filter can read its full tap count: the padding is only ever multiplied by zero
+    // weights, but it must be finite (LDS is not cleared between kernels)
+    for (int i = lane; i < KWS_FAST_MEL_CHUNK * FP.pstride; i += KWS_WAVE) pw[i] = 0.0f;
     __syncthreads();
 
-    // ---- per-lane constants, fixed for the whole launch (the FFT is kws_mfcc_kernel's: KissFFT's order, bit for bit) ------
-    const int k01 = t & 1, g01 = t >> 1;
-    const int n0 = (g01 >> 2) + 4 * (g01 & 3);
-    const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
-    const int K2 = t & 7, G2 = t >> 3;
-    const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
-    const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
-    const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
-    const int nfr = P.n_frames, ncep = P.n_cepstral, NF = P.n_filters;
+    const int nfr = P.n_frames, ncep = P.n_cepstral, NF = 8 * DG;
     const int n_pairs = (nfr + 1) >> 1;
-    const int fs = FP.fs, halo = FP.f_halo;
-    float *zb = zw + half * KWS_ZF;
-    int off1[NZ], off2[NZ];
-    float w1[NZ], w2[NZ];
-#pragma unroll
-    for (int n = 0; n < NZ; ++n) {
-        const float2 v1 = FP.taps1[lane * NZ + n], v2 = FP.taps2[lane * NZ + n];
-        off1[n] = __float_as_int(v1.x); w1[n] = v1.y;
-        off2[n] = __float_as_int(v2.x); w2[n] = v2.y;
-    }
-    float dB[KWS_FAST_DCT_GROUPS][2][2];
-#pragma unroll
-    for (int g = 0; g < KWS_FAST_DCT_GROUPS; ++g)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                dB[g][i][nt] = (g < FP.dct_groups && nt < FP.dct_nt) ? FP.dct_frag[((g * 2 + i) * FP.dct_nt + nt) * KWS_WAVE + lane] : 0.0f;
+    const int fs = FP.fs, halo = FP.f_halo, fuse = FP.fuse;
+    float *img = F + halo * fs;
+    constexpr int NZ2 = DG > 4 ? KWS_FAST_NZ2 : 1;
+    const float *dct_frag = FP.dct_frag;
     const int bmin = FP.bmin, bmax = FP.bmin + FP.nbins - 1, pstride = FP.pstride;
+    const int nf2p = FP.nf2p;
     const int n_waves = blockDim.x >> 6;
+    const float pre_cof = P.pre_cof, inv_fft = P.inv_fft;
+    const int frame_stride = P.frame_stride, n_samples = P.n_samples;
+    const float *cnt_tab = shared + FP.cnt_off;
+    const int *upd_tab = (const int *)(shared + FP.upd_off);
+    const float inv_win = FP.inv_win, guard = FP.guard, stale_scale = FP.stale_scale;
+    const int cr = FP.cr, f_rows = FP.f_rows, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
+    long long ph[KWS_FAST_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
     for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
-        const int16_t *xbase = pcm + (size_t)clip * P.n_samples;
-        FastRaw nxt = fast_fetch(xbase, min(half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
-        FastRaw nxt2 = fast_fetch(xbase, min(2 + half, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+        // ---- per-lane constants of the spectral phase (the FFT is kws_mfcc_kernel's: KissFFT's order, bit for bit).  They are
+        //      re-derived per clip from a lane index the compiler cannot see through: hoisted out of the clip loop, the FFT's
+        //      twiddles and the three dozen LDS addresses of the pair loop stay live through the DCT, cmvnw and convolution phases
+        //      and push those into scratch; re-deriving them costs ~60 L2-resident loads per clip.
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+        const int half = lane_c >> 5, t = lane_c & 31;
+        const int k01 = t & 1, g01 = t >> 1;
+        const int n0 = (g01 >> 2) + 4 * (g01 & 3);
+        const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
+        const int K2 = t & 7, G2 = t >> 3;
+        const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
+        const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
+        const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
+        float *zb = zw + half * KWS_ZF;
+        // a mel filter's taps are consecutive bins: first bin (as an offset into a frame's power row) + NZ weights, zero beyond its end
+        const int start1 = FP.tap_start1[lane_c], start2 = FP.tap_start2[lane_c];
+        float w1[NZ], w2[NZ2];
+    #pragma unroll
+        for (int n = 0; n < NZ; ++n) w1[n] = FP.tap_w1[lane_c * KWS_FAST_NZ_MAX + n];
+    #pragma unroll
+        for (int n = 0; n < NZ2; ++n) w2[n] = FP.tap_w2[lane_c * KWS_FAST_NZ2 + n];
+        const int16_t *xbase = pcm + (size_t)clip * n_samples;
+        FastRaw nxt = fast_fetch(xbase, min(half, nfr - 1) * frame_stride + 8 * t, n_samples);
+        FastRaw nxt2 = fast_fetch(xbase, min(2 + half, nfr - 1) * frame_stride + 8 * t, n_samples);
         // SAME-padding rows of block 0's image (the previous clip's staging image overwrote them)
-        if (FP.fuse) {
-            const int top = halo * fs, bot0 = (halo + nfr) * fs, bot = FP.f_rows * fs;
+        if (fuse) {
+            const int top = halo * fs, bot0 = (halo + nfr) * fs, bot = f_rows * fs;
             for (int i = lane; i < top + (bot - bot0); i += KWS_WAVE) F[i < top ? i : bot0 + (i - top)] = 0.0f;
         }
 
@@ -285,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             const int f = 2 * pr + half;
             const FastRaw cur = nxt;
             nxt = nxt2;
-            if (pr + 2 < n_pairs) nxt2 = fast_fetch(xbase, min(f + 4, nfr - 1) * P.frame_stride + 8 * t, P.n_samples);
+            if (pr + 2 < n_pairs) nxt2 = fast_fetch(xbase, min(f + 4, nfr - 1) * frame_stride + 8 * t, n_samples);
             float y[8];
             {
                 float prev = (float)cur.prev * (1.0f / 32768.0f);
@@ -294,16 +348,17 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                 for (int j = 0; j < 4; ++j) {
                     const float lo = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);
                     const float hi = (float)(short)(w[j] >> 16) * (1.0f / 32768.0f);
-                    const float pl = P.pre_cof * prev;
+                    const float pl = pre_cof * prev;
                     y[2 * j] = lo - pl;
-                    const float ph = P.pre_cof * lo;
-                    y[2 * j + 1] = hi - ph;
+                    const float ph_ = pre_cof * lo;
+                    y[2 * j + 1] = hi - ph_;
                     prev = hi;
                 }
             }
             *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);
             *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
             WAVE_SYNC();
+            FPH(0);
             // ---- kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32 (kiss_fft.cpp:15-84, 232-296) ---
             cf u[4];
             {
@@ -329,6 +384,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 #pragma unroll
             for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
             WAVE_SYNC();
+            FPH(1);
             // ---- kiss_fftr split (kiss_fftr.cpp:84-119) and the power spectrum, fp32: |X|^2 / fft_length ------------------
             const bool live = f < nfr;
             float *prow = pw + ((2 * pr + half) & (KWS_FAST_MEL_CHUNK - 1)) * pstride - bmin;
@@ -353,8 +409,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                 lo.i = (f1k.i + twv.i) * 0.5f;
                 hi.r = (f1k.r - twv.r) * 0.5f;
                 hi.i = (twv.i - f1k.i) * 0.5f;
-                const float plo = __fmaf_rn(lo.r, lo.r, lo.i * lo.i) * P.inv_fft;
-                const float phi = __fmaf_rn(hi.r, hi.r, hi.i * hi.i) * P.inv_fft;
+                const float plo = __fmaf_rn(lo.r, lo.r, lo.i * lo.i) * inv_fft;
+                const float phi = __fmaf_rn(hi.r, hi.r, hi.i * hi.i) * inv_fft;
                 if (k != KWS_NC / 2) {                               // bin 64 is written twice by the reference: the second store wins
                     esum += plo;
                     if (live && k >= bmin && k <= bmax) prow[k] = plo;
@@ -364,89 +420,134 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             }
             if (t == 0) {
                 const float dc = d0.x + d0.y, ny = d0.x - d0.y;
-                const float pdc = (dc * dc) * P.inv_fft, pny = (ny * ny) * P.inv_fft;
+                const float pdc = (dc * dc) * inv_fft, pny = (ny * ny) * inv_fft;
                 esum += pdc + pny;
                 if (live && bmin == 0) prow[0] = pdc;
             }
             // frame energy (feature.hpp:289-298): its log is parked in the image's last column until the DCT has run
             esum = half_wave_sum(esum);
-            if (t == 0 && live) F[(halo + f) * fs + fs - 1] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
+            if (t == 0 && live) img[f * fs + fs - 1] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
+            FPH(2);
             if ((pr & (KWS_FAST_MEL_CHUNK / 2 - 1)) != KWS_FAST_MEL_CHUNK / 2 - 1 && pr != n_pairs - 1) continue;
 
             // ---- mel filterbank for the buffered frames: dot_by_row as a register-tap gather, zero handling, log ----------
             WAVE_SYNC();
             const int fbase = (2 * pr) & ~(KWS_FAST_MEL_CHUNK - 1);
             const int nfc = min(KWS_FAST_MEL_CHUNK, nfr - fbase);
+            float macc[KWS_FAST_MEL_CHUNK / 2 + 1];
+            {
+                float xv[KWS_FAST_MEL_CHUNK / 2][NZ], xv2[NZ2];
+                // filters 32..NF-1: nf2p of them per frame slot, 64 / nf2p slots per pass (40 filters: 8 x 8, one pass)
+                const int j2 = 32 + (lane_c & (nf2p - 1)), sl2 = nf2p ? lane_c / max(nf2p, 1) : 0;
+                const float *p1 = pw + half * pstride + start1, *p2 = pw + min(sl2, KWS_FAST_MEL_CHUNK - 1) * pstride + start2;
 #pragma unroll
-            for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s) {       // filters 0..31: two frames per pass
-                const int slot = 2 * s + half;
-                const float *pr_ = pw + slot * pstride;
-                float acc = 0.0f;
+                for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s)     // filters 0..31: two frames per pass
 #pragma unroll
-                for (int n = 0; n < NZ; ++n) acc = __fmaf_rn(pr_[off1[n]], w1[n], acc);
-                if (acc == 0.0f) acc = FLT_EPSILON;                  // functions.hpp:63-69
-                if (slot < nfc && t < NF) F[(halo + fbase + slot) * fs + t] = fast_log(acc);
-            }
-            if (FP.nf2p) {                                            // filters 32..NF-1: nf2p per frame slot
-                const int fpp = KWS_WAVE / FP.nf2p;                   // frames per pass
-                const int j2 = 32 + (lane & (FP.nf2p - 1)), sl0 = lane / FP.nf2p;
-                for (int q = 0; q * fpp < KWS_FAST_MEL_CHUNK; ++q) {
-                    const int slot = sl0 + q * fpp;
-                    const float *pr_ = pw + slot * pstride;
+                    for (int n = 0; n < NZ; ++n) xv[s][n] = p1[2 * s * pstride + n];
+                if (DG > 4)
+#pragma unroll
+                    for (int n = 0; n < NZ2; ++n) xv2[n] = p2[n];
+#pragma unroll
+                for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s) {
                     float acc = 0.0f;
 #pragma unroll
-                    for (int n = 0; n < NZ; ++n) acc = __fmaf_rn(pr_[off2[n]], w2[n], acc);
-                    if (acc == 0.0f) acc = FLT_EPSILON;
-                    if (slot < nfc && j2 < NF) F[(halo + fbase + slot) * fs + j2] = fast_log(acc);
+                    for (int n = 0; n < NZ; ++n) acc = __fmaf_rn(xv[s][n], w1[n], acc);
+                    macc[s] = acc;
                 }
+                float acc2 = 0.0f;
+                if (DG > 4)
+#pragma unroll
+                    for (int n = 0; n < NZ2; ++n) acc2 = __fmaf_rn(xv2[n], w2[n], acc2);
+                macc[KWS_FAST_MEL_CHUNK / 2] = acc2;
+#pragma unroll
+                for (int s = 0; s <= KWS_FAST_MEL_CHUNK / 2; ++s) macc[s] = fast_log(macc[s] == 0.0f ? FLT_EPSILON : macc[s]);   // functions.hpp:63-69
+#pragma unroll
+                for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s) {
+                    const int slot = 2 * s + half;
+                    if (slot < nfc && t < NF) img[(fbase + slot) * fs + t] = macc[s];
+                }
+                if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2] = macc[KWS_FAST_MEL_CHUNK / 2];
             }
             WAVE_SYNC();
+            FPH(3);
         }
 
-        // ---- DCT-II (numpy.hpp:378-401) as [frames x NF] x [NF x NF/2+1] on the matrix cores, in place ------------------
+        // ---- DCT-II (numpy.hpp:378-401) as [frames x NF] x [NF x NF/2+1] on the matrix cores, in place: two rounds of two
+        //      16-frame tiles.  The transform's operand fragments are re-read per clip (L2-resident, 4 DG values per lane): kept in
+        //      registers across the clip loop they push the FFT's constants into scratch.
         {
-            const int lm = lane & 15, lq = lane >> 4;
-            const int mtiles = (nfr + 15) >> 4;
-            float *img = F + halo * fs;
-            for (int mt = 0; mt < mtiles; ++mt) {
-                const float *arow = img + (16 * mt + lm) * fs + 2 * lq;
-                float2 a[KWS_FAST_DCT_GROUPS];
+            int lane_l = lane;
+            asm volatile("" : "+v"(lane_l));                 // not loop-invariant as far as the compiler can tell
+            const int lm = lane_l & 15, lq = lane_l >> 4;
+            float dB[DG][2][2];
 #pragma unroll
-                for (int g = 0; g < KWS_FAST_DCT_GROUPS; ++g)
-                    if (g < FP.dct_groups) a[g] = *(const float2 *)(arow + 8 * g);
-                v4f acc[2] = { v4f{ 0.f, 0.f, 0.f, 0.f }, v4f{ 0.f, 0.f, 0.f, 0.f } };
+            for (int g = 0; g < DG; ++g)
 #pragma unroll
-                for (int g = 0; g < KWS_FAST_DCT_GROUPS; ++g) {
-                    if (g < FP.dct_groups) {
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, dB[g][0][nt], acc[nt], 0, 0, 0);
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, dB[g][1][nt], acc[nt], 0, 0, 0);
-                        }
-                    }
+                    for (int nt = 0; nt < 2; ++nt) dB[g][i][nt] = dct_frag[((g * 2 + i) * 2 + nt) * KWS_WAVE + lane_l];
+            const float *arow = img + lm * fs + 2 * lq;
+            float e0 = 0.0f;
+            if (lane_l < nfr) e0 = img[lane_l * fs + fs - 1];
+            v4f acc[4][2];
+#pragma unroll
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                float2 a[2][DG];
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int g = 0; g < DG; ++g) a[m2][g] = *(const float2 *)(arow + 16 * (2 * rnd + m2) * fs + 8 * g);
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) { acc[2 * rnd + m2][0] = v4f{ 0.f, 0.f, 0.f, 0.f }; acc[2 * rnd + m2][1] = v4f{ 0.f, 0.f, 0.f, 0.f }; }
+#pragma unroll
+                for (int g = 0; g < DG; ++g) {
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[2 * rnd + m2][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m2][g].x, dB[g][0][nt], acc[2 * rnd + m2][nt], 0, 0, 0);
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[2 * rnd + m2][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m2][g].y, dB[g][1][nt], acc[2 * rnd + m2][nt], 0, 0, 0);
                 }
+            }
+            WAVE_SYNC();                                     // every operand of the transform is in a register
+            // coefficients above NF/2 are never written by the reference's transform: they keep the log-mel input, doubled and
+            // scaled (fast-dct-fft.cpp:71-74, numpy.hpp:392-397); c0 <- log(frame energy) (feature.hpp:425-429)
+            const int nst = ncep - (NF / 2 + 1);
+            if (nst > 0) {
+                constexpr int NSTQ = ((NF / 2 - 1) * 52 + KWS_WAVE - 1) / KWS_WAVE;
+                const unsigned inv = (1u << 20) / (unsigned)nst + 1u;           // i / nst for i < 52 * 19
+                float stale[NSTQ];
+                int sidx[NSTQ];
+#pragma unroll
+                for (int q = 0; q < NSTQ; ++q) {
+                    const int i = min(lane_l + q * KWS_WAVE, nfr * nst - 1);
+                    const int r = (int)(((unsigned)i * inv) >> 20);
+                    sidx[q] = r * fs + NF / 2 + 1 + (i - r * nst);
+                    stale[q] = img[sidx[q]];
+                }
+#pragma unroll
+                for (int q = 0; q < NSTQ; ++q)
+                    if (lane_l + q * KWS_WAVE < nfr * nst) img[sidx[q]] = (stale[q] * 2.0f) * stale_scale;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int n = 16 * nt + lm;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * lq + i;
-                        if (r < nfr && n <= NF / 2 && n > 0) img[r * fs + n] = acc[nt][i];   // column 0 is replaced below
+                        if (r < nfr && n <= NF / 2 && n > 0) img[r * fs + n] = acc[mt][nt][i];
                     }
                 }
-            }
-            WAVE_SYNC();
-            // c0 <- log(frame energy) (feature.hpp:425-429); coefficients above NF/2 are never written by the reference's
-            // transform: they keep the log-mel input, doubled and scaled (fast-dct-fft.cpp:71-74, numpy.hpp:392-397)
-            if (lane < nfr) img[lane * fs] = img[lane * fs + fs - 1];
-            const int nst = ncep - (NF / 2 + 1);
-            if (nst > 0)
-                for (int i = lane; i < nfr * nst; i += KWS_WAVE) {
-                    const int r = i / nst, c = NF / 2 + 1 + (i - r * nst);
-                    img[r * fs + c] = (img[r * fs + c] * 2.0f) * FP.stale_scale;
-                }
+            if (lane_l < nfr) img[lane_l * fs] = e0;
             WAVE_SYNC();
         }
+        FPH(4);
 
         // ---- cmvnw + optional outputs (extract_mfcc_features' matrix, the int8 input tensor) --------------------------------
         float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
@@ -457,70 +558,115 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             if (qclip) qclip[idx] = quantize_feature(o, in_scale, in_zp);
         };
         bool bad;
-        if (FP.cr == 13) bad = fast_cmvn<13, 16>(F, shared, FP, lane, nfr, ncep, emit);
-        else bad = fast_cmvn<17, 20>(F, shared, FP, lane, nfr, ncep, emit);
+        int lane_m = lane;
+        asm volatile("" : "+v"(lane_m));
+        if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit);
+        else bad = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit);
         if (__any(bad)) {
             if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
         }
-        if (!FP.fuse) continue;
+        FPH(5);
+        if (!fuse) continue;
 
         // ---- the float32 graph: CONV_2D blocks ping-pong between the two images, then FULLY_CONNECTED and SOFTMAX ----------
         float *cur = F, *oth = R1;
-        for (int b = 0; b < FP.n_blocks; ++b) {
+        int lane_n = lane;
+        asm volatile("" : "+v"(lane_n));
+        for (int b = 0; b < n_blocks; ++b) {
             const KwsFastBlock &k = FP.blk[b];
-            const bool last = b + 1 == FP.n_blocks;
+            const bool last = b + 1 == n_blocks;
             const int o_stride = last ? k.out_c : FP.blk[b + 1].in_stride;
             const int o_halo = last ? 0 : FP.blk[b + 1].pad_left;
             const int o_rows = last ? k.pool_w : FP.blk[b + 1].in_rows;
             const int o_cp = last ? k.out_c : FP.blk[b + 1].in_cp;
-            fast_conv_block(k, cur, oth, shared, lane, o_stride, o_halo, o_rows, o_cp);
+            const bool pooled = k.pool > 1 || k.pool_stride > 1;
+            // un-pooled: straight into the next image; pooled: staged in this block's own (dead) input image
+            float *stage = pooled ? cur : oth;
+            const int sstride = pooled ? k.stage_stride : o_stride, shalo = pooled ? 0 : o_halo;
+            switch (k.m_tiles * 4 + k.n_tiles) {
+            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shalo, shared, lane_n); break;
+            case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shalo, shared, lane_n); break;
+            case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shalo, shared, lane_n); break;
+            case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shalo, shared, lane_n); break;
+            case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shalo, shared, lane_n); break;
+            default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shalo, shared, lane_n); break;
+            }
+            WAVE_SYNC();
+            fast_pool(k, stage, oth, lane_n, o_stride, o_halo, o_rows, o_cp, pooled);
+            WAVE_SYNC();
             float *tmp = cur; cur = oth; oth = tmp;
+            FPH(6 + (b > 0));
         }
         {
             // FULLY_CONNECTED (fully_connected.h:26-60): lane = output unit; SOFTMAX (softmax.h:31-63)
-            const float *wfc = shared + FP.fc_w_off + min(lane, FP.fc_out - 1) * FP.fc_in;
-            float tot = 0.0f;
-            for (int i = 0; i < FP.fc_in; ++i) tot = __fmaf_rn(cur[i], wfc[i], tot);
-            tot += shared[FP.fc_b_off + min(lane, FP.fc_out - 1)];
+            const int fc_in = FP.fc_in, fc_out = FP.fc_out;
+            const float *wfc = shared + FP.fc_w_off + min(lane_n, fc_out - 1) * fc_in;
+            float tot = 0.0f, tot1 = 0.0f;
+            int i = 0;
+            for (; i + 1 < fc_in; i += 2) { tot = __fmaf_rn(cur[i], wfc[i], tot); tot1 = __fmaf_rn(cur[i + 1], wfc[i + 1], tot1); }
+            if (i < fc_in) tot = __fmaf_rn(cur[i], wfc[i], tot);
+            tot = (tot + tot1) + shared[FP.fc_b_off + min(lane_n, fc_out - 1)];
             tot = fminf(fmaxf(tot, FP.fc_min), FP.fc_max);
-            const bool on = lane < FP.fc_out;
+            const bool on = lane_n < fc_out;
             const float mx = wave_max(on ? tot : -FLT_MAX);
             const float e = on ? expf((tot - mx) * FP.beta) : 0.0f;
             const float sum = wave_sum(e);
-            if (on) scores[(size_t)clip * FP.n_labels + lane] = e / sum;
+            if (on) scores[(size_t)clip * n_labels + lane_n] = e / sum;
         }
         WAVE_SYNC();
+        FPH(8);
     }
+    if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
+        for (int i = 0; i < KWS_FAST_NPHASE; ++i) prof_out[i] = ph[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
-//  launcher (called from kws_api.cpp)
+//  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
-template <int NZ>
-static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
-                         int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream)
+template <int NZ, int DG, bool PROF>
+static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
+                         float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
+                         long long *prof_out, hipStream_t stream)
 {
     const size_t smem = ((size_t)FP.shared_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_done = true;
     }
     const int per_wg = FP.n_waves;
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
-    hipLaunchKernelGGL(kws_fast_kernel<NZ>, dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores, features,
-                       q_out, in_scale, in_zp, flag_count, flag_list);
+    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
+                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out);
     return (int)hipGetLastError();
 }
 
-int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
-                    int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream)
+int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
+                    float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream)
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
-    if (FP.nz <= 4) return launch_fast_t<4>(P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, stream);
-    if (FP.nz <= 8) return launch_fast_t<8>(P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, stream);
-    return launch_fast_t<KWS_FAST_NZ_MAX>(P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, stream);
+#define KWS_FAST_ARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream
+    if (FP.dct_groups == 4)
+        return FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_ARGS)
+                                                                                    : launch_fast_t<KWS_FAST_NZ_MAX, 4, false>(KWS_FAST_ARGS);
+    if (FP.dct_groups == 5)
+        return FP.nz <= 4 ? launch_fast_t<4, 5, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false>(KWS_FAST_ARGS)
+                                                                                    : launch_fast_t<KWS_FAST_NZ_MAX, 5, false>(KWS_FAST_ARGS);
+    return (int)hipErrorInvalidValue;
+}
+
+// development aid: phase clocks (<= 4-tap builds only)
+int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
+                         int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    if (FP.nz > 4) return (int)hipErrorInvalidValue;
+    if (FP.dct_groups == 5)
+        return launch_fast_t<4, 5, true>(P, FP, d_plan, pcm, n_clips, scores, nullptr, nullptr, 1.0f, 0, flag_count, flag_list, n_cu, prof_out, stream);
+    if (FP.dct_groups == 4)
+        return launch_fast_t<4, 4, true>(P, FP, d_plan, pcm, n_clips, scores, nullptr, nullptr, 1.0f, 0, flag_count, flag_list, n_cu, prof_out, stream);
+    return (int)hipErrorInvalidValue;
 }

@@ -14,8 +14,7 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     const KwsDspPlan &P = h->dsp;
     const int NF = c.num_filters, nfr = P.n_frames, ncep = c.num_cepstral;
     if (c.fft_length != 256) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: fft_length %d (kernel is built for 256)", c.fft_length);
-    if (NF % 8 != 0 || NF / 8 > KWS_FAST_DCT_GROUPS || NF < 8)
-        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d mel filters (multiples of 8 up to %d)", NF, 8 * KWS_FAST_DCT_GROUPS);
+    if (NF != 32 && NF != 40) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d mel filters (the kernel is instantiated for 32 and 40)", NF);
     // cmvnw row/column split: 16 columns x 4 groups of 13 rows, or 20 columns x 3 groups of 17 rows
     if (ncep <= 16 && nfr <= 52) { F.cr = 13; F.cg = 16; }
     else if (nfr <= 51) { F.cr = 17; F.cg = 20; }
@@ -40,31 +39,40 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     if (bmax > P.n_bins - 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: a mel filter reads the Nyquist bin");
     F.bmin = bmin;
     F.nbins = bmax - bmin + 1;
-    F.pstride = F.nbins | 1;
-    F.nz = max_nz <= 4 ? 4 : max_nz <= 8 ? 8 : KWS_FAST_NZ_MAX;
-    F.nf2p = 0;
-    if (NF > 32) { int p = 1; while (p < NF - 32) p <<= 1; F.nf2p = p; }
-    auto tap_table = [&](auto filter_of_lane) {
-        std::vector<float2> t((size_t)KWS_FAST_WAVE * F.nz);
+    F.nf2p = NF > 32 ? 8 : 0;                      // 40 filters: filters 32..39, eight frame slots per pass
+    int nz1 = 0, nz2 = 0;
+    for (int j = 0; j < NF; j++) {
+        // taps must be consecutive bins (triangular filters are); zero weights inside a range would be kept as taps
+        for (size_t n = 1; n < taps[j].size(); n++)
+            if (taps[j][n].first != taps[j][n - 1].first + 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: mel filter %d has a gap", j);
+        (j < 32 ? nz1 : nz2) = std::max(j < 32 ? nz1 : nz2, (int)taps[j].size());
+    }
+    if (nz1 > KWS_FAST_NZ_MAX || nz2 > KWS_FAST_NZ2)
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: mel filters with %d / %d taps (at most %d / %d)", nz1, nz2, KWS_FAST_NZ_MAX, KWS_FAST_NZ2);
+    F.nz = nz1 <= 4 ? 4 : nz1 <= 8 ? 8 : KWS_FAST_NZ_MAX;
+    // a lane reads F.nz (resp. KWS_FAST_NZ2) consecutive bins from its filter's first one: the power rows are padded so that the
+    // reads of the last filters stay inside the chunk buffer
+    F.pstride = (F.nbins + std::max(F.nz, KWS_FAST_NZ2)) | 1;
+    auto tap_table = [&](auto filter_of_lane, int width, std::vector<int> &start, std::vector<float> &w) {
+        start.assign(KWS_FAST_WAVE, 0);
+        w.assign((size_t)KWS_FAST_WAVE * width, 0.0f);
         for (int lane = 0; lane < KWS_FAST_WAVE; lane++) {
             const int j = filter_of_lane(lane);
-            for (int n = 0; n < F.nz; n++) {
-                int off = 0; float w = 0.0f;
-                if (j >= 0 && j < NF && n < (int)taps[j].size()) { off = taps[j][n].first - bmin; w = taps[j][n].second; }
-                float offbits;
-                memcpy(&offbits, &off, sizeof(float));
-                t[(size_t)lane * F.nz + n] = make_float2(offbits, w);
-            }
+            if (j < 0 || j >= NF || taps[j].empty()) continue;
+            start[lane] = taps[j][0].first - bmin;
+            for (size_t n = 0; n < taps[j].size(); n++) w[(size_t)lane * width + n] = taps[j][n].second;
         }
-        return t;
     };
-    const std::vector<float2> t1 = tap_table([&](int lane) { return lane & 31; });
-    const std::vector<float2> t2 = tap_table([&](int lane) { return F.nf2p ? 32 + (lane & (F.nf2p - 1)) : -1; });
+    std::vector<int> s1, s2;
+    std::vector<float> tw1, tw2;
+    tap_table([&](int lane) { return lane & 31; }, KWS_FAST_NZ_MAX, s1, tw1);
+    tap_table([&](int lane) { return F.nf2p ? 32 + (lane & (F.nf2p - 1)) : -1; }, KWS_FAST_NZ2, s2, tw2);
 
     // ---- DCT-II operand fragments (numpy.hpp:378-401: X[n] = 2 sum_k x[k] cos(pi n (2k+1) / 2N), ortho scale) -----------
     F.dct_groups = NF / 8;
     F.dct_nt = (NF / 2 + 1 + 15) / 16;
     if (F.dct_nt > 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: DCT output tiles");
+    F.dct_nt = 2;                                 // the kernel always runs two 16-coefficient tiles
     F.stale_scale = P.dct_s1;
     std::vector<float> frag((size_t)F.dct_groups * 2 * F.dct_nt * KWS_FAST_WAVE, 0.0f);
     for (int g = 0; g < F.dct_groups; g++)
@@ -83,20 +91,23 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     const int ng = KWS_FAST_WAVE / F.cg, win = c.win_size;
     F.inv_win = 1.0f / (float)win;
     F.guard = 2e-3f;
+    while (shared.size() & 3) shared.push_back(0.0f);
     F.cnt_off = (int)shared.size();
-    shared.resize(shared.size() + (size_t)ng * nfr, 0.0f);
+    const int nfr8 = (nfr + 7) & ~7;              // rows padded with zero weights: the kernel reads eight at a time
+    shared.resize(shared.size() + (size_t)ng * nfr8, 0.0f);
     for (int g = 0; g < ng; g++) {
         const int r0 = g * F.cr;
         if (r0 >= nfr) continue;
-        for (int p = r0; p < r0 + win; p++) shared[(size_t)F.cnt_off + (size_t)g * nfr + pmap[p]] += 1.0f;
+        for (int p = r0; p < r0 + win; p++) shared[(size_t)F.cnt_off + (size_t)g * nfr8 + pmap[p]] += 1.0f;
     }
-    if (shared.size() & 1) shared.push_back(0.0f);
     F.upd_off = (int)shared.size();
-    shared.resize(shared.size() + 2 * (size_t)nfr, 0.0f);
+    shared.resize(shared.size() + (size_t)nfr, 0.0f);
     // filled once the image's row stride is known (offsets are in floats): see finish_fast_plan
     EI_IMPULSE_ERROR e;
-    if ((e = h->upload(t1, &F.taps1))) return e;
-    if ((e = h->upload(t2, &F.taps2))) return e;
+    if ((e = h->upload(s1, &F.tap_start1))) return e;
+    if ((e = h->upload(tw1, &F.tap_w1))) return e;
+    if ((e = h->upload(s2, &F.tap_start2))) return e;
+    if ((e = h->upload(tw2, &F.tap_w2))) return e;
     if ((e = h->upload(frag, &F.dct_frag))) return e;
     return EI_IMPULSE_OK;
 }
@@ -108,9 +119,8 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     std::vector<int> pmap;
     h_pad_map(nfr, P.pad, pmap);
     for (int r = 0; r + 1 < nfr; r++) {
-        const int drop = pmap[r] * F.fs, add = pmap[r + P.win_size] * F.fs;
-        memcpy(&shared[(size_t)F.upd_off + 2 * r], &drop, sizeof(int));
-        memcpy(&shared[(size_t)F.upd_off + 2 * r + 1], &add, sizeof(int));
+        const int packed = (pmap[r] * F.fs) | ((pmap[r + P.win_size] * F.fs) << 16);       // both < 65536
+        memcpy(&shared[(size_t)F.upd_off + r], &packed, sizeof(int));
     }
     while (shared.size() & 3) shared.push_back(0.0f);
     F.shared_floats = (int)shared.size();
@@ -170,6 +180,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         k.in_rows = s.in_w + s.taps - 1;
         k.in_stride = b == 0 ? F.fs : k.in_cp + 4;
         k.m_tiles = (s.out_w + 15) / 16; k.n_tiles = (s.out_c + 15) / 16;
+        if (k.m_tiles == 3) k.m_tiles = 4;       // tile shapes the kernel instantiates: {1, 2, 4} x {1, 2}
         if (k.m_tiles > 4 || k.n_tiles > 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: conv block %d is %d x %d outputs (at most 64 x 32)", b, s.out_w, s.out_c);
         if (b == 0 && (k.in_cp > h->dsp.n_filters || s.in_w != h->dsp.n_frames || s.in_c != h->dsp.n_cepstral))
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: first conv block does not read the feature matrix");

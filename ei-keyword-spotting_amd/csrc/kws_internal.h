@@ -40,6 +40,8 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
                     int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream);
+int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
+                         int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
 size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves);

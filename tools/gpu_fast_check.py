@@ -25,8 +25,8 @@ host = np.concatenate([o.synth(11, 0, n_par), np.stack(list(sp.values()))])
 B = host.shape[0]
 dev = torch.device("cuda:0")
 pcm = torch.from_numpy(host).to(dev)
-big = torch.empty((batch, 16000), dtype=torch.int16, device=dev)
-pkg.synth_clips_device(0, 0, batch, 16000, big.data_ptr())
+big = torch.empty((max(batch, 1), 16000), dtype=torch.int16, device=dev)
+pkg.synth_clips_device(0, 0, max(batch, 1), 16000, big.data_ptr())
 torch.cuda.synchronize()
 
 
@@ -72,10 +72,21 @@ for name in models:
     print("== %s  fused=%s  %d clips (+%d special): fallback %d" % (name, m.fast_is_fused, n_par, len(sp), nfb))
     print("   synthetic: max |dfeature| %.3g  max |dscore| %.3g  (scores-only call vs with features: %.3g)  nan: %d" %
           (df[:n_par].max(), ds[:n_par].max(), np.abs(s2 - s1).max(), int(np.isnan(s1).sum())))
+    badc = np.nonzero(df > 1e-3)[0]
+    if badc.size:
+        print("   clips with |dfeature| > 1e-3:", badc[:40], "n =", badc.size)
+        k = badc[0]
+        d = np.abs(f1[k] - f0[k]).reshape(m.n_frames, -1)
+        print("   clip %d: rows with diffs %s cols with diffs %s" % (k, np.nonzero(d.max(axis=1) > 1e-3)[0], np.nonzero(d.max(axis=0) > 1e-3)[0]))
+        print("   fast ", f1[k].reshape(m.n_frames, -1)[np.nonzero(d.max(axis=1) > 1e-3)[0][0]][:8])
+        print("   exact", f0[k].reshape(m.n_frames, -1)[np.nonzero(d.max(axis=1) > 1e-3)[0][0]][:8])
     if q0 is not None:
         print("   int8 input flips per clip: %.4f, clips whose scores changed: %d" % ((q1[:n_par] != q0[:n_par]).sum() / n_par, int((ds[:n_par] > 0).sum())))
     for i, k in enumerate(sp):
         print("   special %-22s |dfeature| %.3g |dscore| %.3g" % (k, df[n_par + i], ds[n_par + i]))
+    if batch <= 0:
+        m.close()
+        continue
     t_e, c_e = rate(m, pkg.MODE_EXACT)
     t_f, c_f = rate(m, pkg.MODE_FAST)
     print("   batch %d: exact %.3f ms (%.2f M clips/s)  fast %.3f ms (%.2f M clips/s)  checksum exact %.6f fast %.6f  fallback %d" %

@@ -1,0 +1,26 @@
+"""Development aid: per-phase shader-clock breakdown of kws_fast_kernel (wave 0 of workgroup 0, full-occupancy launch)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from __graft_entry__ import load_package
+pkg = load_package()
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "models", "cfg2_mfcc40_f32.kwsm")
+m = pkg.Model(path)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda")
+pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
+s = torch.empty((B, m.n_labels), dtype=torch.float32, device="cuda")
+prof = torch.zeros(16, dtype=torch.int64, device="cuda")
+L = pkg.lib()
+L.kws_dev_fast_phase_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+for _ in range(2):
+    rc = L.kws_dev_fast_phase_profile(m.h, pcm.data_ptr(), B, s.data_ptr(), prof.data_ptr())
+    torch.cuda.synchronize()
+p = prof.cpu().numpy()[:10]
+names = ["load+preemph", "fft", "split+power+energy", "mel+log", "dct", "cmvn", "conv block 0", "conv blocks 1+", "fc+softmax", "-"]
+tot = p.sum()
+nclips = max(1, B // (256 * 8))
+print(os.path.basename(path), "rc", rc, "clips by wave 0 ~", nclips, "total cycles", tot, "per clip", tot / nclips)
+for n, v in zip(names, p):
+    print("%-20s %12d  %5.1f%%  %8.0f cycles/clip" % (n, v, 100.0 * v / tot, v / nclips))
