@@ -21,7 +21,7 @@
 #define KWS_FAST_NZ_MAX 12        // longest mel filter (filters 0..31) kept in registers
 #define KWS_FAST_NZ2 8            // longest of filters 32..39
 #define KWS_FAST_DCT_GROUPS 5     // NF / 8 <= 5: DCT operand fragments kept in registers
-#define KWS_FAST_MEL_CHUNK 8      // frames whose power spectra are buffered before a mel pass
+#define KWS_FAST_MEL_CHUNK 4      // frames transformed per pass of the spectral loop (their power rows feed one mel pass)
 #define KWS_FAST_WAVE 64
 #define KWS_FAST_ZF 320           // floats per in-place FFT buffer (kws_device.h KWS_ZF)
 
@@ -29,8 +29,8 @@ struct KwsFastBlock {
     int in_w, in_c, in_cp;        // time steps, channels, channels padded to a multiple of 8 (the contraction's k-groups)
     int out_c, taps, pad_left, out_w;
     int pool, pool_stride, pool_w;
-    int in_stride;                // floats per activation row of the block's input image in LDS (== 4 mod 8)
-    int in_rows;                  // in_w + taps - 1 rows: SAME padding rows are part of the image and hold zeros
+    int in_stride;                // floats per activation row of the block's input image in LDS (in_w rows: SAME padding is
+                                  // applied to the operand registers, not stored)
     int m_tiles, n_tiles;         // 16-row / 16-channel output tiles (<= 4 x 2: every accumulator stays in registers)
     int stage_stride;             // row stride of the un-pooled staging image (odd)
     int w_off, bias_off, addc_off;   // float offsets into the workgroup's shared LDS block
@@ -58,8 +58,9 @@ struct KwsFastPlan {
                                   // window; upd[n_frames] = offset of the padded row leaving | entering << 16 (floats, image relative)
     float inv_win;
     float guard;                  // a window with std < guard * max(1, |mean|) sends the clip to the exact kernels
-    // ---- per-wave LDS: F image [f_rows][fs] (log-mel -> cepstra -> features, SAME-padding rows of block 0 included) + R1
-    int fs, f_halo, f_rows, f_floats, r1_floats, wave_floats, shared_floats, n_waves;
+    // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
+    //      R1 = four FFT buffers + four power rows, later the other activation image
+    int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;
     const float *shared_init;     // global image of the workgroup's shared LDS block (weights, biases, cmvnw tables)
     // ---- float32 network fused behind the features (fuse = 0: features / int8 tensor go to HBM instead)
     int fuse, n_blocks;

@@ -51,10 +51,11 @@ __device__ __forceinline__ FastRaw fast_fetch(const int16_t *x, int s0, int n_sa
 }
 
 // ---------------------------------------------------------------------------------------------------------
-//  One CONV_2D block on the matrix cores: out[m][n] = sum_{tap, c} in[m + tap][c] * w[n][tap][c]   (the image's rows start
-//  at time -pad_left and its padding rows hold zeros, so SAME padding needs no predicate).  Tiles of 16 rows x 16 channels,
-//  k-steps of 4 (tap, channel) pairs; a lane fetches two k-steps' operands with one 8-byte read each:
-//      A: image[(16 mt + l % 16 + tap) * stride + 8 cg + 2 (l / 16) + {0, 1}]
+//  One CONV_2D block on the matrix cores: out[m][n] = sum_{tap, c} in[m + tap - pad_left][c] * w[n][tap][c].  The image holds the
+//  in_w real rows only: an operand whose row falls outside it (SAME padding, or the rows a 16-row tile has beyond the image) is
+//  replaced by zero in the register -- padding rows in LDS would cost 1 KB per wave.  Tiles of 16 rows x 16 channels, k-steps of
+//  4 (tap, channel) pairs; a lane fetches two k-steps' operands with one 8-byte read each:
+//      A: image[(16 mt + l % 16 + tap - pad_left) * stride + 8 cg + 2 (l / 16) + {0, 1}]
 //      B: w[tap][4 cg + l / 16][n][{0, 1}]  =  w2[(4 it + l / 16) * out_c + n],  it = tap * (in_cp / 8) + cg
 //  Every accumulator (MT x NT tiles) stays in registers until the contraction is complete: only then is the input image dead
 //  and may be overwritten by the un-pooled staging image.  The operands of step it + 1 are requested before the MFMAs of
@@ -62,7 +63,7 @@ __device__ __forceinline__ FastRaw fast_fetch(const int16_t *x, int s0, int n_sa
 // ---------------------------------------------------------------------------------------------------------
 template <int MT, int NT>
 __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ stage,
-                                                int sstride, int shalo, const float *__restrict__ shared, int lane)
+                                                int sstride, const float *__restrict__ shared, int lane)
 {
     const int lm = lane & 15, lq = lane >> 4;
     v4f acc[MT][NT];
@@ -70,28 +71,48 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{ 0.f, 0.f, 0.f, 0.f };
-    const int in_stride = k.in_stride, out_c = k.out_c;
+    const int in_stride = k.in_stride, out_c = k.out_c, in_w = k.in_w;
     const int ncg = k.in_cp >> 3, n_it = k.taps * ncg;
-    const float *ap = in + lm * in_stride + 2 * lq;
-    const float2 *bp[NT];
+    // operand addresses as offsets from one LDS pointer each (pointers kept in an array lose their address space and every
+    // weight read becomes a flat_load): a lane part in a VGPR + a step part the scalar unit advances
+    const float *abase = in + (lm - k.pad_left) * in_stride + 2 * lq;
+    const float *wbase = shared + k.w_off + 2 * (lq * out_c);
+    int bl[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bp[nt] = (const float2 *)(shared + k.w_off) + lq * out_c + min(16 * nt + lm, out_c - 1);
-    const int mstep = 16 * in_stride, bstep = 4 * out_c;
+    for (int nt = 0; nt < NT; ++nt) bl[nt] = 2 * min(16 * nt + lm, out_c - 1);
+    const int mstep = 16 * in_stride, bstep = 8 * out_c, wrap = in_stride - 8 * (ncg - 1);
+    const int row0 = lm - k.pad_left;                       // image row of this lane's operand for tile 0, tap 0
+    // the zeroing is applied when a fetched operand is handed to the MFMAs, not at the load: the loads of a step then go out
+    // back to back and are only waited for after the previous step's MFMAs have been issued
+    auto clip_rows = [&](int tap, float2 (&v)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool in_img = (unsigned)(row0 + tap + 16 * mt) < (unsigned)in_w;
+            v[mt].x = in_img ? v[mt].x : 0.0f;
+            v[mt].y = in_img ? v[mt].y : 0.0f;
+        }
+    };
     float2 a[MT], b[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const float2 *)(ap + mt * mstep);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const float2 *)(abase + mt * mstep);
+    clip_rows(0, a);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *bp[nt];
-    int cg = 0;
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *(const float2 *)(wbase + bl[nt]);
+    int cg = 0, tap = 0, aoff = 0, boff = 0;
     for (int it = 0; it < n_it; ++it) {
-        // operands of the next step (the last step re-reads its own: no branch around the loads)
+        // operands of the next step, requested before this step's MFMAs are issued (the last step re-reads its own)
         const bool more = it + 1 < n_it;
-        if (more) { ++cg; if (cg == ncg) { cg = 0; ap += in_stride - 8 * (ncg - 1); } else ap += 8; }
+        const bool wr = cg + 1 == ncg;
+        aoff += more ? (wr ? wrap : 8) : 0;
+        boff += more ? bstep : 0;
+        tap += (more && wr) ? 1 : 0;
+        cg = wr ? 0 : cg + 1;
         float2 an[MT], bn[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) an[mt] = *(const float2 *)(ap + mt * mstep);
+        for (int mt = 0; mt < MT; ++mt) an[mt] = *(const float2 *)(abase + aoff + mt * mstep);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { if (more) bp[nt] += bstep; bn[nt] = *bp[nt]; }
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const float2 *)(wbase + boff + bl[nt]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -100,6 +121,8 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        clip_rows(tap, an);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
 #pragma unroll
@@ -114,7 +137,7 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         const int n = 16 * nt + lm;
         const int nc = min(n, out_c - 1);
         const float bias = shared[k.bias_off + nc], addc = shared[k.addc_off + nc];
-        float *sp = stage + shalo * sstride + n;
+        float *sp = stage + n;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -129,19 +152,16 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
     }
 }
 
-// Block epilogue shared by every tile shape: zero the SAME-padding rows of the next block's image, then either nothing (the
-// tiles were written straight into it) or MAX_POOL_2D over time from the staging image (pooling.h:189-237: windows clipped to the
-// image, then the activation clamp).  Items = (pooled row, channel incl. the k-padding channels, which receive zeros).
-__device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__restrict__ stage, float *__restrict__ out, int lane,
-                                          int out_stride, int out_halo, int out_rows, int out_cp, bool pooled)
+// Block epilogue shared by every tile shape: either the k-padding channels of the next image are zeroed (the tiles were written
+// straight into it) or MAX_POOL_2D over time runs from the staging image (pooling.h:189-237: windows clipped to the image, then
+// the activation clamp).  Items = (pooled row, channel incl. the k-padding channels, which receive zeros).
+__device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__restrict__ stage, float *__restrict__ img, int lane,
+                                          int out_stride, int out_cp, bool pooled)
 {
-    const int top = out_halo * out_stride, bot0 = (out_halo + k.pool_w) * out_stride, bot = out_rows * out_stride;
-    for (int i = lane; i < top + (bot - bot0); i += KWS_WAVE) out[i < top ? i : bot0 + (i - top)] = 0.0f;
     const int items = k.pool_w * out_cp;
     const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;        // i / out_cp == (i * inv) >> 20 for i < 4096, out_cp <= 64
     const int sstride = k.stage_stride, out_w = k.out_w, out_c = k.out_c, pool = k.pool, pstr = k.pool_stride;
     const float pmin = k.pool_min, pmax = k.pool_max;
-    float *img = out + out_halo * out_stride;
     if (!pooled) {
         for (int i = lane; i < items; i += KWS_WAVE) {
             const int p = (int)(((unsigned)i * inv) >> 20), c = i - p * out_cp;
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     float *shared = lds;
     float *F = lds + FP.shared_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
     float *R1 = F + FP.f_floats;                                      // FFT buffers + power rows; later block 1's input image
-    float *zw = R1, *pw = R1 + 2 * KWS_ZF;
+    float *zw = R1, *pw = R1 + 4 * KWS_ZF;                           // four in-place FFT buffers, then four power rows
     for (int i = threadIdx.x; i < FP.shared_floats; i += blockDim.x) shared[i] = FP.shared_init[i];
     // the power rows are padded so that every filter can read its full tap count: the padding is only ever multiplied by zero
     // weights, but it must be finite (LDS is not cleared between kernels)
@@ -286,20 +306,20 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     __syncthreads();
 
     const int nfr = P.n_frames, ncep = P.n_cepstral, NF = 8 * DG;
-    const int n_pairs = (nfr + 1) >> 1;
-    const int fs = FP.fs, halo = FP.f_halo, fuse = FP.fuse;
-    float *img = F + halo * fs;
+    const int n_quads = (nfr + 3) >> 2;
+    const int fs = FP.fs, fuse = FP.fuse;
+    float *img = F;                                                   // [n_frames][fs]
+    float *elog = F + nfr * fs;                                       // log frame energies, parked until the DCT has run
     constexpr int NZ2 = DG > 4 ? KWS_FAST_NZ2 : 1;
     const float *dct_frag = FP.dct_frag;
     const int bmin = FP.bmin, bmax = FP.bmin + FP.nbins - 1, pstride = FP.pstride;
-    const int nf2p = FP.nf2p;
     const int n_waves = blockDim.x >> 6;
     const float pre_cof = P.pre_cof, inv_fft = P.inv_fft;
     const int frame_stride = P.frame_stride, n_samples = P.n_samples;
     const float *cnt_tab = shared + FP.cnt_off;
     const int *upd_tab = (const int *)(shared + FP.upd_off);
     const float inv_win = FP.inv_win, guard = FP.guard, stale_scale = FP.stale_scale;
-    const int cr = FP.cr, f_rows = FP.f_rows, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
+    const int cr = FP.cr, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
     long long ph[KWS_FAST_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
     for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
         const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
         const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
-        float *zb = zw + half * KWS_ZF;
+        float *zb0 = zw + half * KWS_ZF;                       // sub-pair j transforms in zb0 + 2 j KWS_ZF
         // a mel filter's taps are consecutive bins: first bin (as an offset into a frame's power row) + NZ weights, zero beyond its end
         const int start1 = FP.tap_start1[lane_c], start2 = FP.tap_start2[lane_c];
         float w1[NZ], w2[NZ2];
@@ -326,119 +346,148 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     #pragma unroll
         for (int n = 0; n < NZ2; ++n) w2[n] = FP.tap_w2[lane_c * KWS_FAST_NZ2 + n];
         const int16_t *xbase = pcm + (size_t)clip * n_samples;
-        FastRaw nxt = fast_fetch(xbase, min(half, nfr - 1) * frame_stride + 8 * t, n_samples);
-        FastRaw nxt2 = fast_fetch(xbase, min(2 + half, nfr - 1) * frame_stride + 8 * t, n_samples);
-        // SAME-padding rows of block 0's image (the previous clip's staging image overwrote them)
-        if (fuse) {
-            const int top = halo * fs, bot0 = (halo + nfr) * fs, bot = f_rows * fs;
-            for (int i = lane; i < top + (bot - bot0); i += KWS_WAVE) F[i < top ? i : bot0 + (i - top)] = 0.0f;
+        // Four frames per pass: sub-pair j of pass q holds frames 4q + 2j + half.  Two independent transforms per lane keep the
+        // LDS round trips of one in the shadow of the other's arithmetic (two waves per SIMD cannot), and halve the wave
+        // synchronisations per clip.  Samples are requested two passes ahead.
+        FastRaw nxt[2], nxt2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            nxt[j] = fast_fetch(xbase, min(2 * j + half, nfr - 1) * frame_stride + 8 * t, n_samples);
+            nxt2[j] = fast_fetch(xbase, min(4 + 2 * j + half, nfr - 1) * frame_stride + 8 * t, n_samples);
         }
-
-        for (int pr = 0; pr < n_pairs; ++pr) {
-            // ---- 8 samples per lane (16 B, coalesced), int16 -> float, pre-emphasis (numpy.hpp:1289, processing.hpp:104) ---
-            const int f = 2 * pr + half;
-            const FastRaw cur = nxt;
-            nxt = nxt2;
-            if (pr + 2 < n_pairs) nxt2 = fast_fetch(xbase, min(f + 4, nfr - 1) * frame_stride + 8 * t, n_samples);
-            float y[8];
-            {
+        for (int q = 0; q < n_quads; ++q) {
+            // ---- 8 samples per lane and frame (16 B, coalesced), int16 -> float, pre-emphasis (numpy.hpp:1289, processing.hpp:104)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const FastRaw cur = nxt[j];
+                nxt[j] = nxt2[j];
+                if (q + 2 < n_quads) nxt2[j] = fast_fetch(xbase, min(4 * q + 8 + 2 * j + half, nfr - 1) * frame_stride + 8 * t, n_samples);
+                float y[8];
                 float prev = (float)cur.prev * (1.0f / 32768.0f);
                 const int w[4] = { cur.v.x, cur.v.y, cur.v.z, cur.v.w };
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);
-                    const float hi = (float)(short)(w[j] >> 16) * (1.0f / 32768.0f);
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = (float)(short)(w[i] & 0xffff) * (1.0f / 32768.0f);
+                    const float hi = (float)(short)(w[i] >> 16) * (1.0f / 32768.0f);
                     const float pl = pre_cof * prev;
-                    y[2 * j] = lo - pl;
+                    y[2 * i] = lo - pl;
                     const float ph_ = pre_cof * lo;
-                    y[2 * j + 1] = hi - ph_;
+                    y[2 * i + 1] = hi - ph_;
                     prev = hi;
                 }
+                float *zb = zb0 + 2 * j * KWS_ZF;
+                *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);
+                *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
             }
-            *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);
-            *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
             WAVE_SYNC();
             FPH(0);
             // ---- kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32 (kiss_fft.cpp:15-84, 232-296) ---
-            cf u[4];
+            cf u[2][4];
             {
-                cf la[4], lb[4];
+                cf la[2][4], lb[2][4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { la[i] = ld_cf(zb, n0 + 16 * i); lb[i] = ld_cf(zb, n0 + 16 * i + 64); }
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) u[i] = k01 ? csub(la[i], lb[i]) : cadd(la[i], lb[i]);
+                    for (int i = 0; i < 4; ++i) {
+                        la[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, n0 + 16 * i);
+                        lb[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, n0 + 16 * i + 64);
+                    }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[j][i] = k01 ? csub(la[j][i], lb[j][i]) : cadd(la[j][i], lb[j][i]);
             }
-            bfly4(u[0], u[1], u[2], u[3], a1, a2, a3);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st_cf(zb, 8 * g01 + k01 + 2 * i, u[i]);
+            for (int j = 0; j < 2; ++j) {
+                bfly4(u[j][0], u[j][1], u[j][2], u[j][3], a1, a2, a3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb0 + 2 * j * KWS_ZF, 8 * g01 + k01 + 2 * i, u[j][i]);
+            }
             WAVE_SYNC();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
-            bfly4(u[0], u[1], u[2], u[3], b1, b2, b3);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, u[i]);
+                for (int i = 0; i < 4; ++i) u[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, 32 * G2 + K2 + 8 * i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bfly4(u[j][0], u[j][1], u[j][2], u[j][3], b1, b2, b3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb0 + 2 * j * KWS_ZF, 32 * G2 + K2 + 8 * i, u[j][i]);
+            }
             WAVE_SYNC();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) u[i] = ld_cf(zb, t + 32 * i);
-            bfly4(u[0], u[1], u[2], u[3], c1, c2, c3);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, u[i]);
+                for (int i = 0; i < 4; ++i) u[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, t + 32 * i);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bfly4(u[j][0], u[j][1], u[j][2], u[j][3], c1, c2, c3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st_cf(zb0 + 2 * j * KWS_ZF, t + 32 * i, u[j][i]);
+            }
             WAVE_SYNC();
             FPH(1);
             // ---- kiss_fftr split (kiss_fftr.cpp:84-119) and the power spectrum, fp32: |X|^2 / fft_length ------------------
-            const bool live = f < nfr;
-            float *prow = pw + ((2 * pr + half) & (KWS_FAST_MEL_CHUNK - 1)) * pstride - bmin;
-            float esum = 0.0f;
-            cf fpk[2], fq[2];
+            cf fpk[2][2], fq[2][2];
+            float2 d0[2];
 #pragma unroll
-            for (int rep = 0; rep < 2; ++rep) {
-                const int k = t + 1 + 32 * rep;
-                fpk[rep] = ld_cf(zb, k);
-                fq[rep] = ld_cf(zb, KWS_NC - k);
-            }
-            const float2 d0 = *(const float2 *)zb;                  // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
+            for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int rep = 0; rep < 2; ++rep) {
-                const int k = t + 1 + 32 * rep;
-                const cf stw = rep ? st2 : st1;
-                cf fpnk; fpnk.r = fq[rep].r; fpnk.i = -fq[rep].i;
-                const cf f1k = cadd(fpk[rep], fpnk), f2k = csub(fpk[rep], fpnk);
-                const cf twv = cmul(f2k, stw);
-                cf lo, hi;
-                lo.r = (f1k.r + twv.r) * 0.5f;
-                lo.i = (f1k.i + twv.i) * 0.5f;
-                hi.r = (f1k.r - twv.r) * 0.5f;
-                hi.i = (twv.i - f1k.i) * 0.5f;
-                const float plo = __fmaf_rn(lo.r, lo.r, lo.i * lo.i) * inv_fft;
-                const float phi = __fmaf_rn(hi.r, hi.r, hi.i * hi.i) * inv_fft;
-                if (k != KWS_NC / 2) {                               // bin 64 is written twice by the reference: the second store wins
-                    esum += plo;
-                    if (live && k >= bmin && k <= bmax) prow[k] = plo;
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;
+                    fpk[j][rep] = ld_cf(zb0 + 2 * j * KWS_ZF, k);
+                    fq[j][rep] = ld_cf(zb0 + 2 * j * KWS_ZF, KWS_NC - k);
                 }
-                esum += phi;
-                if (live && KWS_NC - k >= bmin && KWS_NC - k <= bmax) prow[KWS_NC - k] = phi;
+                d0[j] = *(const float2 *)(zb0 + 2 * j * KWS_ZF);     // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
             }
-            if (t == 0) {
-                const float dc = d0.x + d0.y, ny = d0.x - d0.y;
-                const float pdc = (dc * dc) * inv_fft, pny = (ny * ny) * inv_fft;
-                esum += pdc + pny;
-                if (live && bmin == 0) prow[0] = pdc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int f = 4 * q + 2 * j + half;
+                const bool live = f < nfr;
+                float *prow = pw + (2 * j + half) * pstride - bmin;
+                float esum = 0.0f;
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;
+                    const cf stw = rep ? st2 : st1;
+                    cf fpnk; fpnk.r = fq[j][rep].r; fpnk.i = -fq[j][rep].i;
+                    const cf f1k = cadd(fpk[j][rep], fpnk), f2k = csub(fpk[j][rep], fpnk);
+                    const cf twv = cmul(f2k, stw);
+                    cf lo, hi;
+                    lo.r = (f1k.r + twv.r) * 0.5f;
+                    lo.i = (f1k.i + twv.i) * 0.5f;
+                    hi.r = (f1k.r - twv.r) * 0.5f;
+                    hi.i = (twv.i - f1k.i) * 0.5f;
+                    const float plo = __fmaf_rn(lo.r, lo.r, lo.i * lo.i) * inv_fft;
+                    const float phi = __fmaf_rn(hi.r, hi.r, hi.i * hi.i) * inv_fft;
+                    if (k != KWS_NC / 2) {                           // bin 64 is written twice by the reference: the second store wins
+                        esum += plo;
+                        if (live && k >= bmin && k <= bmax) prow[k] = plo;
+                    }
+                    esum += phi;
+                    if (live && KWS_NC - k >= bmin && KWS_NC - k <= bmax) prow[KWS_NC - k] = phi;
+                }
+                if (t == 0) {
+                    const float dc = d0[j].x + d0[j].y, ny = d0[j].x - d0[j].y;
+                    const float pdc = (dc * dc) * inv_fft, pny = (ny * ny) * inv_fft;
+                    esum += pdc + pny;
+                    if (live && bmin == 0) prow[0] = pdc;
+                }
+                // frame energy (feature.hpp:289-298): its log is parked until the DCT has run
+                esum = half_wave_sum(esum);
+                if (t == 0 && live) elog[f] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
             }
-            // frame energy (feature.hpp:289-298): its log is parked in the image's last column until the DCT has run
-            esum = half_wave_sum(esum);
-            if (t == 0 && live) img[f * fs + fs - 1] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
             FPH(2);
-            if ((pr & (KWS_FAST_MEL_CHUNK / 2 - 1)) != KWS_FAST_MEL_CHUNK / 2 - 1 && pr != n_pairs - 1) continue;
 
-            // ---- mel filterbank for the buffered frames: dot_by_row as a register-tap gather, zero handling, log ----------
+            // ---- mel filterbank for the four frames: dot_by_row as a register-tap gather, zero handling, log ----------
             WAVE_SYNC();
-            const int fbase = (2 * pr) & ~(KWS_FAST_MEL_CHUNK - 1);
+            const int fbase = 4 * q;
             const int nfc = min(KWS_FAST_MEL_CHUNK, nfr - fbase);
             float macc[KWS_FAST_MEL_CHUNK / 2 + 1];
             {
                 float xv[KWS_FAST_MEL_CHUNK / 2][NZ], xv2[NZ2];
-                // filters 32..NF-1: nf2p of them per frame slot, 64 / nf2p slots per pass (40 filters: 8 x 8, one pass)
-                const int j2 = 32 + (lane_c & (nf2p - 1)), sl2 = nf2p ? lane_c / max(nf2p, 1) : 0;
+                // filters 32..39: eight of them per frame slot, lanes 0..31 (40 filters only)
+                const int j2 = 32 + (lane_c & 7), sl2 = lane_c >> 3;
                 const float *p1 = pw + half * pstride + start1, *p2 = pw + min(sl2, KWS_FAST_MEL_CHUNK - 1) * pstride + start2;
 #pragma unroll
                 for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s)     // filters 0..31: two frames per pass
@@ -488,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                     for (int nt = 0; nt < 2; ++nt) dB[g][i][nt] = dct_frag[((g * 2 + i) * 2 + nt) * KWS_WAVE + lane_l];
             const float *arow = img + lm * fs + 2 * lq;
             float e0 = 0.0f;
-            if (lane_l < nfr) e0 = img[lane_l * fs + fs - 1];
+            if (lane_l < nfr) e0 = elog[lane_l];
             v4f acc[4][2];
 #pragma unroll
             for (int rnd = 0; rnd < 2; ++rnd) {
@@ -576,23 +625,21 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             const KwsFastBlock &k = FP.blk[b];
             const bool last = b + 1 == n_blocks;
             const int o_stride = last ? k.out_c : FP.blk[b + 1].in_stride;
-            const int o_halo = last ? 0 : FP.blk[b + 1].pad_left;
-            const int o_rows = last ? k.pool_w : FP.blk[b + 1].in_rows;
             const int o_cp = last ? k.out_c : FP.blk[b + 1].in_cp;
             const bool pooled = k.pool > 1 || k.pool_stride > 1;
             // un-pooled: straight into the next image; pooled: staged in this block's own (dead) input image
             float *stage = pooled ? cur : oth;
-            const int sstride = pooled ? k.stage_stride : o_stride, shalo = pooled ? 0 : o_halo;
+            const int sstride = pooled ? k.stage_stride : o_stride;
             switch (k.m_tiles * 4 + k.n_tiles) {
-            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shalo, shared, lane_n); break;
-            case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shalo, shared, lane_n); break;
-            case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shalo, shared, lane_n); break;
-            case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shalo, shared, lane_n); break;
-            case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shalo, shared, lane_n); break;
-            default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shalo, shared, lane_n); break;
+            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n); break;
+            case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n); break;
+            case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shared, lane_n); break;
+            case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shared, lane_n); break;
+            case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shared, lane_n); break;
+            default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shared, lane_n); break;
             }
             WAVE_SYNC();
-            fast_pool(k, stage, oth, lane_n, o_stride, o_halo, o_rows, o_cp, pooled);
+            fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
             WAVE_SYNC();
             float *tmp = cur; cur = oth; oth = tmp;
             FPH(6 + (b > 0));

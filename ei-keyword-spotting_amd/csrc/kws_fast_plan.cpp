@@ -124,8 +124,8 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     }
     while (shared.size() & 3) shared.push_back(0.0f);
     F.shared_floats = (int)shared.size();
-    F.f_floats = round_up(std::max(F.f_rows * F.fs, need_f), 4);
-    F.r1_floats = round_up(std::max(2 * KWS_FAST_ZF + KWS_FAST_MEL_CHUNK * F.pstride, need_r1), 4);
+    F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4);
+    F.r1_floats = round_up(std::max(4 * KWS_FAST_ZF + KWS_FAST_MEL_CHUNK * F.pstride, need_r1), 4);
     F.wave_floats = F.f_floats + F.r1_floats;
     const int avail = kLdsBytes / 4 - F.shared_floats;
     F.n_waves = std::min(8, avail / F.wave_floats);
@@ -145,9 +145,7 @@ static EI_IMPULSE_ERROR build_fast_plain(kws_handle *h)
     std::vector<float> shared;
     EI_IMPULSE_ERROR e = build_fast_dsp(h, F, shared);
     if (e) return e;
-    F.fs = h->dsp.n_filters + 4;
-    F.f_halo = 0;
-    F.f_rows = h->dsp.n_frames;
+    F.fs = h->dsp.n_filters;
     F.fuse = 0;
     F.n_labels = (int)h->model.labels.size();
     return finish_fast_plan(h, F, shared, 0, 0);
@@ -168,7 +166,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
     F.fuse = 1;
     F.n_blocks = N.n_blocks;
     F.n_labels = N.n_labels;
-    F.fs = h->dsp.n_filters + 4;
+    F.fs = h->dsp.n_filters;
     int need[2] = { 0, 0 };                     // floats each image region must hold beyond its first use
     for (int b = 0; b < N.n_blocks; b++) {
         const KwsConvBlockF32 &s = N.blk[b];
@@ -177,7 +175,6 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         k.in_w = s.in_w; k.in_c = s.in_c; k.in_cp = round_up(s.in_c, 8);
         k.out_c = s.out_c; k.taps = s.taps; k.pad_left = s.pad_left; k.out_w = s.out_w;
         k.pool = s.pool; k.pool_stride = s.pool_stride; k.pool_w = s.pool_w;
-        k.in_rows = s.in_w + s.taps - 1;
         k.in_stride = b == 0 ? F.fs : k.in_cp + 4;
         k.m_tiles = (s.out_w + 15) / 16; k.n_tiles = (s.out_c + 15) / 16;
         if (k.m_tiles == 3) k.m_tiles = 4;       // tile shapes the kernel instantiates: {1, 2, 4} x {1, 2}
@@ -204,12 +201,10 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         if (shared.size() & 1) shared.push_back(0.0f);
         // image regions: block b reads region b & 1 (0 = F, 1 = R1), stages its un-pooled outputs there, writes region (b+1) & 1
         const bool pooled = k.pool > 1 || k.pool_stride > 1;
-        if (b > 0) need[b & 1] = std::max(need[b & 1], k.in_rows * k.in_stride);
+        if (b > 0) need[b & 1] = std::max(need[b & 1], k.in_w * k.in_stride);
         if (pooled) need[b & 1] = std::max(need[b & 1], k.out_w * k.stage_stride);
         if (b + 1 == N.n_blocks) need[(b + 1) & 1] = std::max(need[(b + 1) & 1], k.pool_w * k.out_c);
     }
-    F.f_halo = F.blk[0].pad_left;
-    F.f_rows = F.blk[0].in_rows;
     F.fc_in = N.fc_in; F.fc_out = N.fc_out; F.fc_min = N.fc_min; F.fc_max = N.fc_max; F.beta = N.beta;
     F.fc_w_off = (int)shared.size();
     shared.insert(shared.end(), h->hostf.fc_w.begin(), h->hostf.fc_w.end());
