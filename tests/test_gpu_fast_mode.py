@@ -1,0 +1,255 @@
+"""-m gpu: KWS_MODE_FAST (include/kws/kws.h) against the C oracle.  Bar (BASELINE.json north_star): float32 scores within 1e-4
+of the reference's; int8 graphs exact from the int8 input tensor on, with the input-tensor flip rate reported and bounded.
+Clips whose cmvnw is ill-conditioned must come out exactly as in KWS_MODE_EXACT (they are re-run by the exact kernels)."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+from kws_testlib import GOLDEN, MODELS, ROOT, Oracle, OracleModel, bits, special_clips
+
+pytestmark = pytest.mark.gpu
+
+FAST_SCORE_TOL = 1e-4          # north_star: "per-class scores match the reference C path within 1e-4 fp32"
+EXACT_SCORE_TOL = 1e-6         # KWS_MODE_EXACT's float bar (device expf in the softmax)
+FAST_FEATURE_TOL = 2e-3        # |feature - oracle| for clips the fast kernel keeps (well-conditioned cmvnw)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+_W = {}
+
+
+def _oracle_worker(args):
+    path, seed, first, n = args
+    if path not in _W:
+        o = _W.setdefault("oracle", Oracle())
+        _W[path] = OracleModel(o, path)
+    om, o = _W[path], _W["oracle"]
+    s, f, q = om.run_batch(o.synth(seed, first, n), want_features=True)
+    return first, s, f, q
+
+
+def oracle_all(path, seed, B, chunk=512):
+    """scores, features, int8 tensors of synthetic clips [0, B) of `seed` from the oracle, one worker per host core"""
+    om = OracleModel(Oracle(), path)
+    s = np.zeros((B, om.n_labels), np.float32)
+    f = np.zeros((B, om.n_features), np.float32)
+    q = np.zeros((B, om.n_features), np.int8)
+    jobs = [(path, seed, i, min(chunk, B - i)) for i in range(0, B, chunk)]
+    with mp.get_context("spawn").Pool(len(os.sched_getaffinity(0))) as pool:
+        for first, ss, ff, qq in pool.imap_unordered(_oracle_worker, jobs):
+            s[first:first + len(ss)], f[first:first + len(ss)], q[first:first + len(ss)] = ss, ff, qq
+    return s, f, q
+
+
+def run_device(pkg, gm, mode, pcm_t, want_f=True):
+    import torch
+    n = pcm_t.shape[0]
+    gm.set_mode(mode)
+    s = torch.zeros((n, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    f = torch.zeros((n, gm.n_features), dtype=torch.float32, device="cuda:0") if want_f else None
+    q = torch.zeros((n, gm.n_features), dtype=torch.int8, device="cuda:0") if (want_f and not gm.is_float) else None
+    gm.run_classifier_batch_device(pcm_t.data_ptr(), n, s.data_ptr(), f.data_ptr() if want_f else None, q.data_ptr() if q is not None else None)
+    torch.cuda.synchronize()
+    return s.cpu().numpy(), (f.cpu().numpy() if want_f else None), (q.cpu().numpy() if q is not None else None)
+
+
+@pytest.mark.parametrize("name", ["cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm"])
+def test_fast_mode_float_scores_within_1e4_of_the_oracle_on_a_full_batch(name, pkg):
+    """BASELINE configs[1] size: every one of 65 536 synthetic clips through the fused fast kernel and through the oracle."""
+    import torch
+    path = os.path.join(MODELS, name)
+    gm = pkg.Model(path, device=0)
+    assert gm.fast_is_fused
+    B, seed = 65536, 4100
+    pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(seed, 0, B, 16000, pcm.data_ptr())
+    s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+    n_fallback = gm.fast_fallback_count()
+    s2, _, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm, want_f=False)           # scores only: the features never leave the chip
+    so, fo, _ = oracle_all(path, seed, B)
+    d_s, d_f = np.abs(s - so).max(), np.abs(f - fo).max()
+    print("\n%s fast mode, %d clips: max |score - oracle| = %.3g, max |feature - oracle| = %.3g, %d clips re-run exactly"
+          % (name, B, d_s, d_f, n_fallback))
+    assert not np.isnan(s).any()
+    assert d_s <= FAST_SCORE_TOL
+    assert d_f <= FAST_FEATURE_TOL
+    assert (s2 == s).all()
+    assert n_fallback < B // 100                         # synthetic clips are well-conditioned: the fast kernel keeps them
+    assert (np.abs(s.sum(1) - 1.0) <= 1e-5).all()
+    gm.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "l476_no_yes.kwsm", "cfg2_mfcc40_int8.kwsm"])
+def test_fast_mode_special_and_golden_clips(name, pkg, oracle):
+    """The six known-answer clips and the golden fixtures' clips.  Constant / silent clips have columns whose
+    cmvnw output is decided by the reference's own rounding sequence (the "silence canary"): the fast kernel must hand them
+    back, and their results are then the exact mode's."""
+    import torch
+    path = os.path.join(MODELS, name)
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    sp = special_clips()
+    g = np.load(os.path.join(GOLDEN, "e2e_l476.npz"))
+    gold = np.concatenate([oracle.synth(int(seed), 0, int(g["clips_per_seed"])) for seed in g["seeds"]])
+    host = np.concatenate([np.stack(list(sp.values())), gold])
+    pcm = torch.from_numpy(host).to("cuda:0")
+    s, f, q = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+    n_fb = gm.fast_fallback_count()
+    se, fe, qe = run_device(pkg, gm, pkg.MODE_EXACT, pcm)
+    so, fo, qo = om.run_batch(host, want_features=True)
+    names = list(sp)
+    for k in ("zeros", "alternating_fullscale", "min"):                   # every frame identical: constant columns
+        i = names.index(k)
+        assert (bits(f[i]) == bits(fe[i])).all() and (bits(f[i]) == bits(fo[i])).all(), k
+        assert (bits(s[i]) == bits(se[i])).all(), k
+    assert n_fb >= 3
+    if gm.is_float:
+        assert np.abs(s - so).max() <= FAST_SCORE_TOL
+    else:
+        # the network is exact from the int8 tensor on: the oracle's network on the GPU's tensor gives the GPU's scores
+        for i in range(len(host)):
+            assert (bits(om.dequantize(om.nn_invoke(q[i]))) == bits(s[i])).all(), i
+        flips = int((q != qo).sum())
+        print("\n%s: %d of %d int8 input values differ from the oracle's on %d clips" % (name, flips, q.size, len(host)))
+        assert flips <= q.size // 2000
+    gm.close()
+
+
+@pytest.mark.parametrize("name", ["l476_no_yes.kwsm", "cfg2_mfcc40_int8.kwsm"])
+def test_fast_mode_int8_models_flip_rate_and_exact_network(name, pkg, oracle):
+    """int8 graphs in fast mode: fast MFCC + the exact int8 network.  Reported: how many int8 input values land on the other
+    side of a rounding boundary, and how many clips' scores change because of it."""
+    import torch
+    path = os.path.join(MODELS, name)
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    assert not gm.fast_is_fused
+    B, seed = 8192, 4200
+    pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(seed, 0, B, 16000, pcm.data_ptr())
+    s, f, q = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+    so, fo, qo = oracle_all(path, seed, B)
+    flips = (q != qo).sum(axis=1)
+    changed = (s != so).any(axis=1)
+    print("\n%s fast mode, %d clips: %.4f int8 input flips per clip (%d values per clip), %d clips with a changed score, "
+          "max |feature - oracle| = %.3g" % (name, B, flips.mean(), q.shape[1], int(changed.sum()), np.abs(f - fo).max()))
+    assert np.abs(f - fo).max() <= FAST_FEATURE_TOL
+    assert np.abs(q.astype(np.int32) - qo.astype(np.int32)).max() <= 1        # a flip is one quantisation step
+    assert flips.mean() <= 0.1 and changed.mean() <= 0.02
+    assert not changed[flips == 0].any()                                      # same tensor => same scores, bit for bit
+    for i in np.nonzero(changed)[0][:64]:
+        assert (bits(om.dequantize(om.nn_invoke(q[i]))) == bits(s[i])).all(), i
+    gm.close()
+
+
+def test_fast_mode_ill_conditioned_batch_is_rerun_exactly(pkg, gpu_models=("cfg2_mfcc40_f32.kwsm", "l476_no_yes.kwsm")):
+    """A batch made only of constant / silent / repeated-frame clips: every clip is handed back, results are bit-identical to
+    KWS_MODE_EXACT."""
+    import torch
+    rng = np.random.default_rng(5)
+    B = 300
+    host = np.zeros((B, 16000), np.int16)
+    for i in range(B):
+        kind = i % 3
+        if kind == 1:
+            host[i] = rng.integers(-32768, 32767)                              # a constant
+        elif kind == 2:
+            host[i] = np.tile(rng.integers(-3000, 3000, 320).astype(np.int16), 50)   # every frame the same samples
+    pcm = torch.from_numpy(host).to("cuda:0")
+    for name in gpu_models:
+        gm = pkg.Model(os.path.join(MODELS, name), device=0)
+        s, f, q = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+        assert gm.fast_fallback_count() == B, name
+        se, fe, qe = run_device(pkg, gm, pkg.MODE_EXACT, pcm)
+        assert (bits(s) == bits(se)).all() and (bits(f) == bits(fe)).all(), name
+        if q is not None:
+            assert (q == qe).all()
+        gm.close()
+
+
+def test_fast_mode_edge_batches_and_mode_switch(pkg, oracle):
+    import torch
+    path = os.path.join(MODELS, "cfg2_mfcc40_f32.kwsm")
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    for n in (1, 3, 65, 2049):                                                  # below / above one clip per wave of the grid
+        host = oracle.synth(91, 10 * n, n)
+        pcm = torch.from_numpy(host).to("cuda:0")
+        s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+        so = om.run_batch(host)
+        assert np.abs(s - so).max() <= FAST_SCORE_TOL, n
+        se, fe, _ = run_device(pkg, gm, pkg.MODE_EXACT, pcm)                    # switching back restores the exact path
+        _, feo, _ = om.run_batch(host, want_features=True)
+        assert (bits(fe) == bits(feo)).all() and np.abs(se - so).max() <= EXACT_SCORE_TOL, n
+    gm.set_mode(pkg.MODE_FAST)
+    s = torch.zeros((1, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    gm.run_classifier_batch_device(torch.zeros((1, 16000), dtype=torch.int16, device="cuda:0").data_ptr(), 0, s.data_ptr())   # empty batch
+    with pytest.raises(pkg.KwsError):
+        gm.set_mode(7)
+    gm.close()
+
+
+def test_fast_mode_unfused_float_graph_and_extract_mfcc(pkg, oracle):
+    """A float graph with DEPTHWISE_CONV_2D blocks keeps its exact network kernel behind the fast MFCC kernel; the
+    extract_mfcc_features entry point follows the mode too."""
+    import torch
+    path = os.path.join(MODELS, "cfg5_dscnn_mfcc40_f32.kwsm")
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    assert not gm.fast_is_fused
+    B = 1024
+    host = oracle.synth(77, 0, B)
+    pcm = torch.from_numpy(host).to("cuda:0")
+    s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+    so, fo, _ = om.run_batch(host, want_features=True)
+    assert np.abs(s - so).max() <= FAST_SCORE_TOL and np.abs(f - fo).max() <= FAST_FEATURE_TOL
+    f2 = torch.zeros((B, gm.n_features), dtype=torch.float32, device="cuda:0")
+    gm.extract_mfcc_batch_device(pcm.data_ptr(), B, f2.data_ptr())
+    torch.cuda.synchronize()
+    assert (bits(f2.cpu().numpy()) == bits(f)).all()
+    gm.close()
+
+
+def test_fast_mode_random_mfcc_configurations(pkg, oracle):
+    """The random DSP configurations of the exact-mode fuzz test (32 / 40 filters, 2..40 cepstra, cmvnw windows 13..137, filterbank
+    ranges) through the fast kernel: features within tolerance of the restatement, or bit-identical where the clip was handed
+    back; configurations outside the fast kernel are refused by kws_set_mode with KWS_ERROR_UNSUPPORTED_MODEL."""
+    import torch
+    from kws_testlib import L476_CONFIG, random_dsp_spec, synth_model_blob
+    clips = oracle.synth(21, 0, 24)
+    pcm = torch.from_numpy(clips).to("cuda:0")
+    n_ok = n_refused = 0
+    worst = 0.0
+    for seed in range(40):
+        cfg_kw, blob_kw = random_dsp_spec(seed)
+        try:
+            gm = pkg.Model(blob=synth_model_blob(**blob_kw))
+        except pkg.KwsError as e:
+            assert e.code == -18
+            continue
+        try:
+            gm.set_mode(pkg.MODE_FAST)
+        except pkg.KwsError as e:
+            assert e.code == -18, (seed, cfg_kw)
+            n_refused += 1
+            gm.close()
+            continue
+        cfg = L476_CONFIG().copy(**cfg_kw)
+        _, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+        fo = np.stack([oracle.extract_mfcc(c, cfg) for c in clips])
+        worst = max(worst, float(np.abs(f - fo).max()))
+        assert np.abs(f - fo).max() <= FAST_FEATURE_TOL, (seed, cfg_kw)
+        gm.close()
+        n_ok += 1
+    print("\nfast mode over %d random MFCC configurations (%d outside the fast kernel): max |feature - oracle| = %.3g" % (n_ok, n_refused, worst))
+    assert n_ok >= 25, (n_ok, n_refused)
