@@ -3,19 +3,27 @@
 
 Headline workload = BASELINE.json configs[1] as worded: batch 65 536 synthetic 1 s @ 16 kHz clips, 40-band MFCC (49x40),
 2-Conv CNN, fp32, 1x MI355X.  The reference ships no such model, so the graph is generated with
-seeded weights (tools/synth_model.py + tools/dequantize_model.py -> models/cfg2_mfcc40_f32.kwsm); the DSP block is the
-reference's own code path for that configuration (bit-exact, tests/golden/mfcc40_l476.npz).  At N = 1 the same run also
-times the model the reference DOES ship (49x13 MFCC, int8), its fp32 twin and the int8 form of the headline graph (the two
-readings of BASELINE configs[3]); they are reported under "also" in the same JSON line.
+seeded weights (tools/synth_model.py + tools/dequantize_model.py -> models/cfg2_mfcc40_f32.kwsm); its DSP block is the
+reference's own code path for that configuration.
 
-One "step" = one pass of the hot path over one batch of B synthetic 1 s @ 16 kHz int16 clips per GPU, the clips
-already resident in HBM (generated on the device by kws_synth_clips_device).  N > 1: one process per GPU
-(torch.distributed / RCCL), clips sharded contiguously, no data-path collective except the all-gather of the
-per-clip scores (16 B/clip) which is inside the timed region.  Weak scaling: per-GPU batch fixed.
+Two arithmetic modes of the same library are timed (include/kws/kws.h):
+  * KWS_MODE_FAST  -- the headline `value`: scores within 1e-4 of the reference's (the tolerance BASELINE.json's north_star
+    states; tests/test_gpu_fast_mode.py holds every one of 65 536 clips to it), MFCC + network in ONE kernel launch;
+  * KWS_MODE_EXACT -- MFCC features bit-identical to the reference's, scores within 1e-6; reported under "modes".
+At N = 1 the same run also times the model the reference DOES ship (49x13 MFCC, int8) and the other BASELINE configurations;
+they are reported under "also".
+
+One "step" = one pass of the hot path over one batch of B synthetic 1 s @ 16 kHz int16 clips per GPU, the clips already
+resident in HBM (generated on the device by kws_synth_clips_device).  N > 1: one process per GPU, clips sharded contiguously
+(rank r owns clips [r*B, (r+1)*B)), no data-path collective except the all-gather of the per-clip scores (16 B/clip) over RCCL
+(kws_allgather_scores, the library's C ABI on librccl), which is inside the timed region and also timed on its own.
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run, 127.0.0.1).  Default clips
+per GPU: 65 536 (configs[1]); 131 072 at N = 8, i.e. BASELINE configs[2]'s 1 M clips over 8 GPUs.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how roofline / cpu_baseline are defined.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -24,7 +32,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-
 
 SHIPPED_MODEL = os.path.join(ROOT, "models", "l476_no_yes.kwsm")            # BASELINE configs[3]: what the reference ships
 DEFAULT_MODEL = os.path.join(ROOT, "models", "cfg2_mfcc40_f32.kwsm")       # BASELINE configs[1] as worded
@@ -40,14 +47,31 @@ WORKLOADS = {
     "cfg5_dscnn_mfcc40_int8.kwsm": "BASELINE configs[4] shape: 49x40 MFCC + 7-block depthwise-separable CNN, 12 labels, int8, synthetic weights",
     "cfg5_dscnn_mfcc40_f32.kwsm": "BASELINE configs[4] shape: 49x40 MFCC + 7-block depthwise-separable CNN, 12 labels, fp32, synthetic weights",
 }
+CLIP_LEN = 16000
 
 
-def cpu_worker(kind, n_clips, seconds, model_path=DEFAULT_MODEL):
-    """Child process: run the CPU path over n_clips synthetic clips again and again for ~`seconds`; prints clips/s."""
+def default_batch(world):
+    """clips per GPU: configs[1]'s 65 536; at 8 GPUs configs[2]'s 1 M clips / 8"""
+    return 131072 if world == 8 else 65536
+
+
+def lib_sha256():
+    p = os.path.join(ROOT, "ei-keyword-spotting_amd", "libkws_mi355x.so")
+    try:
+        return hashlib.sha256(open(p, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+#  CPU baseline (N = 1 only): the reference itself, compiled from its own sources (oracle/_ref), on the host cores
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_worker(kind, n_clips, seconds, model_path=DEFAULT_MODEL, first_clip=0):
+    """Child process: run the CPU path over n_clips DISTINCT synthetic clips (again if time remains) for ~`seconds`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from kws_testlib import Oracle, OracleModel, Reference
     o = Oracle()
-    clips = o.synth(0, 0, n_clips)
+    clips = o.synth(0, first_clip, n_clips)
     if kind == "reference" and os.path.samefile(model_path, SHIPPED_MODEL):
         run = Reference().time_run                       # the reference's run_classifier() with its compiled-in model
     elif kind == "reference":
@@ -56,11 +80,14 @@ def cpu_worker(kind, n_clips, seconds, model_path=DEFAULT_MODEL):
     else:
         run = OracleModel(o, model_path).time_run
     run(clips[:4], 1)
-    done, spent = 0, 0.0
+    done, spent, chunk = 0, 0.0, 250
     while spent < seconds:
-        spent += run(clips, 1)
-        done += n_clips
-    print(done / spent)
+        for i in range(0, n_clips, chunk):
+            spent += run(clips[i:i + chunk], 1)
+            done += len(clips[i:i + chunk])
+            if spent >= seconds and done >= n_clips:
+                break
+    print(done / spent, done)
 
 
 def usable_cores():
@@ -82,211 +109,361 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(seconds=8.0, model_path=DEFAULT_MODEL):
-    """The reference SDK (oracle/_ref, compiled from the unmodified sources) on the host cores, one PROCESS per core
-    (the reference keeps state in globals: non-reentrant), for a bounded time.  The shipped model runs through the
-    reference's run_classifier(); any other model file through the reference's extract_mfcc_features() + the reference's
-    TFLite-Micro op registrations driven by the model file (oracle/ref_driver.cpp eiref_time_graph_classifier)."""
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds=10.0, model_path=DEFAULT_MODEL, n_clips=2000):
+    """The reference SDK (oracle/_ref, compiled from the unmodified sources) on the host cores, one PROCESS per core (the
+    reference keeps state in globals: non-reentrant), each over its own 2 000 distinct seed-0 clips, for a bounded time.  The
+    shipped model runs through the reference's run_classifier(); any other model file through the reference's
+    extract_mfcc_features() + the reference's TFLite-Micro op registrations driven by the model file."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from kws_testlib import have_reference
     kind = "reference" if have_reference() else "port"
     cores = usable_cores()
-    n_clips = 64
     cmd = [sys.executable, os.path.abspath(__file__), "--model", model_path, "--cpu-worker", kind, str(n_clips)]
-    single = subprocess.run(cmd + ["2.0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-    try:
-        single = float(single.stdout.strip().splitlines()[-1])
-    except Exception:
-        single = float("nan")
     t0 = time.time()
-    procs = [subprocess.Popen(cmd + [str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-             for _ in range(cores)]
-    rates = []
+    procs = [subprocess.Popen(cmd + [str(seconds), str(k * n_clips)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for k in range(cores)]
+    rates, clips = [], 0
     for p in procs:
         out, _ = p.communicate()
         try:
-            rates.append(float(out.strip().splitlines()[-1]))
+            r, d = out.strip().splitlines()[-1].split()
+            rates.append(float(r))
+            clips += int(d)
         except Exception:
             pass
     wall = time.time() - t0
-    return {"value": round(sum(rates), 1), "unit": "clips/s", "cores": len(rates), "kind": kind,
-            "per_core": round(sum(rates) / max(1, len(rates)), 1), "single_process": round(single, 1),
-            "kwsm_file": os.path.basename(model_path),
-            "sample": "%d concurrent processes, each looping the reference's MFCC + network over %d seed-0 synthetic clips "
-                      "for %.0f s (%.1f s wall incl. start-up)" % (len(rates), n_clips, seconds, wall)}
+    return {"value": round(sum(rates), 1), "unit": "clips/s", "cores": len(rates), "kind": kind, "cpu": cpu_model_name(),
+            "per_core": round(sum(rates) / max(1, len(rates)), 1), "kwsm_file": os.path.basename(model_path),
+            "sample": "%d concurrent processes (one per usable core), each running the reference's MFCC + network over its own %d "
+                      "distinct seed-0 synthetic clips for >= %.0f s: %d clips in all (%.1f s wall incl. start-up)"
+                      % (len(rates), n_clips, seconds, clips, wall)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+#  the timed region.  A backend owns one rank's resident batch and knows how to run one step on it; GpuBackend is the product
+#  (libkws_mi355x.so through its C ABI), CpuOracleBackend exists for the world-size-2 gloo test and --dry-run-cpu only.
+# ---------------------------------------------------------------------------------------------------------------------
+class GpuBackend:
+    def __init__(self, pkg, local_rank, rank, world, B, use_comm):
+        import torch
+        self.torch, self.pkg = torch, pkg
+        self.rank, self.world, self.B = rank, world, B
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.local_rank = local_rank
+        self.pcm = torch.empty((B, CLIP_LEN), dtype=torch.int16, device=self.dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        pkg.synth_clips_device(0, rank * B, B, CLIP_LEN, self.pcm.data_ptr(), self.stream)     # this rank's shard
+        self.comm = None
+        self.use_comm = use_comm
+        self.model = None
+
+    def make_comm(self, unique_id):
+        self.comm = self.pkg.Comm(unique_id, self.world, self.rank, self.local_rank)
+
+    def load(self, model_path, mode):
+        torch = self.torch
+        self.close_model()
+        m = self.model = self.pkg.Model(model_path, device=self.local_rank)
+        assert m.clip_samples == CLIP_LEN
+        m.set_mode(self.pkg.MODE_FAST if mode == "fast" else self.pkg.MODE_EXACT)
+        self.scores = torch.empty((self.B, m.n_labels), dtype=torch.float32, device=self.dev)
+        self.gathered = torch.empty((self.world * self.B, m.n_labels), dtype=torch.float32, device=self.dev) if self.use_comm else self.scores
+        return {"labels": m.n_labels, "is_float": m.is_float, "nn_kernel": m.nn_kernel, "fused": bool(m.fast_is_fused and m.is_float and mode == "fast")}
+
+    def events(self, steps):
+        self.ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+    def step(self, k=None):
+        m = self.model
+        if k is not None:
+            self.ev[k][0].record()
+        m.run_classifier_batch_device(self.pcm.data_ptr(), self.B, self.scores.data_ptr(), None, None, self.stream)   # the hot path
+        if k is not None:
+            self.ev[k][1].record()
+        if self.use_comm:
+            self.comm.allgather_scores(self.scores.data_ptr(), self.gathered.data_ptr(), self.B, m.n_labels, self.stream)
+        if k is not None:
+            self.ev[k][2].record()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def phase_ms(self, steps):
+        return (sum(e[0].elapsed_time(e[1]) for e in self.ev) / steps, sum(e[1].elapsed_time(e[2]) for e in self.ev) / steps)
+
+    def checksum(self):
+        return float(self.gathered.double().sum().item())
+
+    def fallback(self):
+        return self.model.fast_fallback_count()
+
+    def close_model(self):
+        if self.model is not None:
+            self.model.close()
+            self.model = None
+
+
+class CpuOracleBackend:
+    """Test double: the oracle on the host in place of the GPU library, torch.distributed (gloo) in place of RCCL.  Used by
+    tests/test_distributed_cpu.py and --dry-run-cpu to exercise the sharding / gather / timing code that bench.py runs."""
+
+    def __init__(self, rank, world, B):
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from kws_testlib import Oracle
+        self.torch = torch
+        self.rank, self.world, self.B = rank, world, B
+        self.oracle = Oracle()
+        self.pcm = self.oracle.synth(0, rank * B, B)                 # this rank's shard, same generator as the device's
+        self.use_comm = world > 1
+        self.t = [0.0, 0.0]
+
+    def make_comm(self, unique_id):
+        pass
+
+    def load(self, model_path, mode):
+        from kws_testlib import OracleModel
+        self.model = OracleModel(self.oracle, model_path)
+        self.scores = self.torch.zeros((self.B, self.model.n_labels), dtype=self.torch.float32)
+        self.gathered = self.torch.zeros((self.world * self.B, self.model.n_labels), dtype=self.torch.float32) if self.use_comm else self.scores
+        return {"labels": self.model.n_labels, "is_float": bool(self.oracle.L.kwso_model_is_float(self.model.h)),
+                "nn_kernel": "oracle (CPU test double)", "fused": False}
+
+    def events(self, steps):
+        self.t = [0.0, 0.0]
+
+    def step(self, k=None):
+        import torch.distributed as dist
+        t0 = time.perf_counter()
+        self.scores.copy_(self.torch.from_numpy(self.model.run_batch(self.pcm)))
+        t1 = time.perf_counter()
+        if self.use_comm:
+            dist.all_gather_into_tensor(self.gathered, self.scores)
+        if k is not None:
+            self.t[0] += (t1 - t0) * 1e3
+            self.t[1] += (time.perf_counter() - t1) * 1e3
+
+    def sync(self):
+        pass
+
+    def phase_ms(self, steps):
+        return self.t[0] / steps, self.t[1] / steps
+
+    def checksum(self):
+        return float(self.gathered.double().sum().item())
+
+    def fallback(self):
+        return 0
+
+    def close_model(self):
+        pass
+
+
+def timed_steps(backend, steps, warmup, barrier, max_over_ranks):
+    """W untimed steps, then exactly K steps bracketed by barrier + device synchronisation on both sides; the MAX over ranks."""
+    backend.events(steps)
+    for _ in range(warmup):
+        backend.step()
+    backend.sync(); barrier(); backend.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        backend.step(k)
+    backend.sync(); barrier(); backend.sync()
+    return max_over_ranks(time.perf_counter() - t0)
+
+
+def measure(backend, model_path, mode, steps, warmup, barrier, max_over_ranks):
+    info = backend.load(model_path, mode)
+    dt = timed_steps(backend, steps, warmup, barrier, max_over_ranks)
+    ms_path, ms_gather = backend.phase_ms(steps)
+    res = dict(info, model=os.path.basename(model_path), mode=mode, dt=dt, ms_path=ms_path, ms_gather=ms_gather, checksum=backend.checksum(),
+               fallback=backend.fallback() if mode == "fast" else 0)
+    backend.close_model()
+    return res
+
+
+def pmc_for(kernel, model, batch):
+    """HBM traffic / SQ counters of `kernel` from rocprofv3 PMC passes of this same command (tools/profile_round.sh), used only
+    when they were taken with the library that is running now (SHA-256 of libkws_mi355x.so recorded next to them)."""
+    sha = lib_sha256()
+    best = None
+    prof = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        f = os.path.join(prof, d, "traffic.json")
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("lib_sha256") == sha and j.get("model") == model and j.get("batch") == batch and kernel in j.get("kernels", {}):
+            best = (os.path.join("profiles", d), j["kernels"][kernel], j.get("sq", {}).get(kernel))
+    return best
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="clips per GPU per step")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 65536; 131072 at 8 GPUs = 1 M clips)")
     ap.add_argument("--model", default=DEFAULT_MODEL)
+    ap.add_argument("--mode", choices=["fast", "exact"], default="fast", help="which arithmetic mode is the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra workloads timed at N = 1")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra workloads / the other mode timed at N = 1")
     ap.add_argument("--force-collective", action="store_true",
-                    help="initialise RCCL and all-gather the scores even with one rank (smoke test of the N > 1 path on a 1-GPU box)")
-    ap.add_argument("--cpu-worker", nargs=3, metavar=("KIND", "N_CLIPS", "SECONDS"))
+                    help="create the RCCL communicator and all-gather the scores even with one rank (the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="no GPU: the oracle stands in for the library and gloo for RCCL (exercises sharding, gather and timing code)")
+    ap.add_argument("--cpu-worker", nargs=4, metavar=("KIND", "N_CLIPS", "SECONDS", "FIRST_CLIP"))
     a = ap.parse_args()
     if a.cpu_worker:
-        cpu_worker(a.cpu_worker[0], int(a.cpu_worker[1]), float(a.cpu_worker[2]), a.model)
+        cpu_worker(a.cpu_worker[0], int(a.cpu_worker[1]), float(a.cpu_worker[2]), a.model, int(a.cpu_worker[3]))
         return
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves, one per GPU, and pass rank 0's JSON line through
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    B = a.batch if a.batch > 0 else (64 if a.dry_run_cpu else default_batch(world))
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.dry_run_cpu:
         cpu = cpu_baseline(model_path=a.model)                     # before the GPU is touched: children never see a HIP context
 
     import torch
     import torch.distributed as dist
-    sys.path.insert(0, ROOT)
-    from __graft_entry__ import load_package
-    pkg = load_package()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or a.force_collective
+    use_comm = world > 1 or a.force_collective
+    # control plane (barrier, max over ranks, the communicator's id): gloo over 127.0.0.1; data plane: RCCL through the C ABI
     saved_stdout = None
-    if use_dist:
-        # RCCL prints a version banner on stdout when it initialises; this process's stdout carries exactly one JSON line,
-        # so fd 1 points at stderr while the process group exists
+    if use_comm:
+        # gloo and RCCL print connection / version banners on stdout when they initialise; this process's stdout carries exactly
+        # one JSON line, so fd 1 points at stderr while the process group and the communicator exist
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        if "MASTER_ADDR" not in os.environ:                        # plain `python bench.py --force-collective`
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
-    B = a.batch
-    n = 16000
-    # this rank's shard of the global batch: clips [rank*B, (rank+1)*B), resident in HBM before timing
-    pcm = torch.empty((B, n), dtype=torch.int16, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    pkg.synth_clips_device(0, rank * B, B, n, pcm.data_ptr(), stream)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
+    def barrier():
+        if use_comm:
             dist.barrier()
-        torch.cuda.synchronize()
 
-    def measure(model_path, steps, warmup, collective):
-        """K timed steps of the hot path over the resident batch with the given model; returns the result fields."""
-        model = pkg.Model(model_path, device=local_rank)
-        assert model.clip_samples == n
-        C, F = model.n_labels, model.n_features
-        feats = torch.empty((B, F), dtype=torch.float32, device=dev)
-        is_float = model.is_float
-        q = None if is_float else torch.empty((B, F), dtype=torch.int8, device=dev)
-        scores = torch.empty((B, C), dtype=torch.float32, device=dev)
-        gathered = torch.empty((world * B, C), dtype=torch.float32, device=dev) if collective else scores
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    def max_over_ranks(dt):
+        if not use_comm:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-        def step(k=None):
-            if k is not None:
-                ev[k][0].record()
-            model.extract_mfcc_batch_device(pcm.data_ptr(), B, feats.data_ptr(), None if is_float else q.data_ptr(), stream)   # extract_mfcc_features
-            if k is not None:
-                ev[k][1].record()
-            if is_float:
-                model.run_inference_batch_device(feats.data_ptr(), B, scores.data_ptr(), stream)      # the float network
-            else:
-                model.nn_batch_device(q.data_ptr(), B, scores.data_ptr(), stream)                     # the int8 network
-            if k is not None:
-                ev[k][2].record()
-            if collective:
-                dist.all_gather_into_tensor(gathered, scores)
+    if a.dry_run_cpu:
+        backend = CpuOracleBackend(rank, world, B)
+    else:
+        sys.path.insert(0, ROOT)
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        backend = GpuBackend(pkg, local_rank, rank, world, B, use_comm)
+        if use_comm:
+            ids = [pkg.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            backend.make_comm(ids[0])
 
-        for _ in range(warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            step(k)
-        fence()
-        dt = time.perf_counter() - t0
-        if collective:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        res = {"model": os.path.basename(model_path), "dt": dt, "is_float": is_float, "nn_kernel": model.nn_kernel,
-               "ms_mfcc": sum(e[0].elapsed_time(e[1]) for e in ev) / steps,
-               "ms_nn": sum(e[1].elapsed_time(e[2]) for e in ev) / steps,
-               "checksum": float(gathered.double().sum().item()), "labels": C}
-        model.close()
-        return res
+    r = measure(backend, a.model, a.mode, a.steps, a.warmup, barrier, max_over_ranks)
+    others, also = [], []
+    if world == 1 and not a.no_also and not a.dry_run_cpu:
+        side_steps = max(20, a.steps // 4)
+        others.append(measure(backend, a.model, "exact" if a.mode == "fast" else "fast", side_steps, a.warmup, barrier, max_over_ranks))
+        for mp_ in ALSO_MODELS:
+            if not os.path.samefile(mp_, a.model):
+                for md in ("fast", "exact"):
+                    also.append(measure(backend, mp_, md, side_steps, min(a.warmup, 5), barrier, max_over_ranks))
 
-    r = measure(a.model, a.steps, a.warmup, use_dist)
-    also = []
-    if world == 1 and not a.no_also:
-        for mp in ALSO_MODELS:
-            if not os.path.samefile(mp, a.model):
-                also.append(measure(mp, a.steps, a.warmup, False))
-
-    if use_dist:
+    if not a.dry_run_cpu and backend.comm is not None:
+        backend.comm.close()
+    if use_comm:
         dist.destroy_process_group()
+    if saved_stdout is not None:
         import ctypes
         sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)                             # the banner may still sit in the C library's buffer
+        ctypes.CDLL(None).fflush(None)                             # a banner may still sit in the C library's buffer
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
-    if rank == 0:
-        dt, ms_mfcc, ms_nn, is_float = r["dt"], r["ms_mfcc"], r["ms_nn"], r["is_float"]
-        algo_bytes = 16000 * 2 + r["labels"] * 4          # SURVEY 8(d): int16 PCM in + C float scores out, per clip
-        achieved = algo_bytes * B / (ms_mfcc * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (profiles/r01_pmc/), per launch
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic.json")))
-            if pmc.get("batch") == B and pmc.get("model") == r["model"]:
-                traffic = pmc["kernels"]["kws_mfcc_kernel"]["traffic_bytes"]
-        except Exception:
-            pass
+    if rank != 0:
+        return
 
-        # what actually bounds the kernel: rocprofv3 SQ counters of this same command (profiles/r01h_pmc_util/), headline model only
-        valu = None
-        try:
-            if traffic is not None:
-                u = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_util", "summary.json")))["kernels"]["kws_mfcc_kernel"]
-                valu = {"VALUBusy_pct": round(u["VALUBusy"], 1), "VALUUtilization_pct": round(u["VALUUtilization"], 1),
-                        "valu_instructions_per_clip": round(u["VALU_instructions_per_clip"]),
-                        "source": "profiles/r01h_pmc_util/summary.json (rocprofv3 --pmc, separate passes)"}
-        except Exception:
-            pass
+    def workload(name):
+        return WORKLOADS.get(name, name) + "; %d clips of 1 s @ 16 kHz int16 per GPU resident in HBM" % B
 
-        def workload(name):
-            return WORKLOADS.get(name, name) + "; %d clips of 1 s @ 16 kHz int16 per GPU resident in HBM" % B
+    def parity(x):
+        if x["mode"] == "fast":
+            return ("scores within 1e-4 of the reference's (KWS_MODE_FAST; ill-conditioned clips re-run exactly)" if x["is_float"] else
+                    "KWS_MODE_FAST: MFCC within tolerance, network bit-exact from the int8 tensor on (an input value may move one step at a "
+                    "rounding boundary)") + " -- tests/test_gpu_fast_mode.py"
+        return ("MFCC features + logits bit-exact, scores <= 1e-6 vs the reference's float kernels" if x["is_float"]
+                else "bit-exact vs reference") + " -- tests/test_gpu_parity.py"
 
-        def parity(fl):
-            return ("MFCC features + logits bit-exact, scores <= 1e-6 vs the reference's float kernels" if fl
-                    else "bit-exact vs reference") + " (tests/test_gpu_parity.py)"
-        out = {
-            "metric": "1s@16kHz clips/sec (MFCC+CNN)", "value": round(world * B * a.steps / dt, 1), "unit": "clips/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32+f64 (MFCC) / %s (CNN)" % ("f32" if is_float else "i8"), "data": "synthetic",
-            "config": {"workload": workload(r["model"]), "clips_per_gpu": B, "global_batch": world * B, "kwsm_file": r["model"],
-                       "parity": parity(is_float), "collective": "all_gather(scores) over RCCL" if use_dist else "none"},
-            "roofline": {"bound": "hbm", "kernel": "kws_mfcc_kernel", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc)",
-                         "algorithmic_bytes_per_launch": algo_bytes * B, "algorithmic_bytes_per_clip": algo_bytes,
-                         "kernel_ms": {"kws_mfcc_kernel": round(ms_mfcc, 4), r["nn_kernel"]: round(ms_nn, 4)},
-                         "note": "the kernel is VALU-issue-bound (order-constrained fp32/fp64 arithmetic of the reference), not HBM-bound; see valu",
-                         "valu": valu},
-            "checksum": r["checksum"],
-        }
-        if also:
-            out["also"] = [{"kwsm_file": x["model"], "workload": workload(x["model"]), "value": round(B * a.steps / x["dt"], 1),
-                            "unit": "clips/s", "ms_per_step": round(x["dt"] / a.steps * 1e3, 4),
-                            "dtype": "f32+f64 (MFCC) / %s (CNN)" % ("f32" if x["is_float"] else "i8"), "parity": parity(x["is_float"]),
-                            "kernel_ms": {"kws_mfcc_kernel": round(x["ms_mfcc"], 4), x["nn_kernel"]: round(x["ms_nn"], 4)},
-                            "hbm_frac_mfcc_kernel": round((16000 * 2 + x["labels"] * 4) * B / (x["ms_mfcc"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-                           for x in also]
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+    def dominant(x):
+        return "kws_fast_kernel" if x["mode"] == "fast" else "kws_mfcc_kernel"
+
+    def dtype(x):
+        return ("f32 (MFCC, KissFFT-order FFT) / %s (CNN)" if x["mode"] == "fast" else "f32+f64 (MFCC) / %s (CNN)") % ("f32" if x["is_float"] else "i8")
+
+    algo_bytes = CLIP_LEN * 2 + r["labels"] * 4          # SURVEY 8(d): int16 PCM in + C float scores out, per clip
+    achieved = algo_bytes * B / (r["ms_path"] * 1e-3) / 1e9
+    pmc = pmc_for(dominant(r), r["model"], B) if not a.dry_run_cpu else None
+    roof = {"bound": "hbm", "kernel": dominant(r), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc[1]["traffic_bytes"] if pmc else None,
+            "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; only reported when the PMC passes under profiles/ were "
+                            "taken with the library that is running: SHA-256 match)",
+            "traffic_source": pmc[0] if pmc else None,
+            "algorithmic_bytes_per_launch": algo_bytes * B, "algorithmic_bytes_per_clip": algo_bytes,
+            "hot_path_ms": round(r["ms_path"], 4),
+            "hot_path_ms_note": "HIP events on the launch stream around the hot-path call of every timed step (fast mode, fused graph: one "
+                                "kws_fast_kernel launch + three empty-list launches of the exact kernels; exact mode: kws_mfcc_kernel + the network kernel)",
+            "note": "not HBM-bound: two waves per SIMD (14 KB of LDS per wave), VALU / LDS / MFMA issue and LDS round trips bound the kernel; see valu",
+            "valu": pmc[2] if pmc else None}
+    out = {
+        "metric": "1s@16kHz clips/sec (MFCC+CNN)", "value": round(world * B * a.steps / r["dt"], 1), "unit": "clips/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(r["dt"] / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype(r),
+        "data": "synthetic" + (" (DRY RUN ON CPU: oracle + gloo stand in for the GPU library + RCCL; not a measurement)" if a.dry_run_cpu else ""),
+        "config": {"workload": workload(r["model"]), "mode": r["mode"], "clips_per_gpu": B, "global_batch": world * B, "kwsm_file": r["model"],
+                   "parity": parity(r), "network_fused_into_mfcc_kernel": r["fused"], "clips_rerun_by_exact_kernels_last_step": r["fallback"],
+                   "collective": ("all_gather(scores) over RCCL (kws_allgather_scores, %d ranks)" % world) if use_comm else "none",
+                   "lib_sha256": lib_sha256()},
+        "collective": {"allgather_ms_per_step": round(r["ms_gather"], 4), "inside_timed_region": True, "ranks": world} if use_comm else None,
+        "roofline": roof,
+        "checksum": r["checksum"],
+    }
+
+    def line(x, steps):
+        return {"kwsm_file": x["model"], "mode": x["mode"], "workload": workload(x["model"]), "value": round(B * steps / x["dt"], 1),
+                "unit": "clips/s", "ms_per_step": round(x["dt"] / steps * 1e3, 4), "steps": steps, "dtype": dtype(x), "parity": parity(x),
+                "network_kernel": "fused into kws_fast_kernel" if x["fused"] else x["nn_kernel"],
+                "hbm_frac": round((CLIP_LEN * 2 + x["labels"] * 4) * B / (x["ms_path"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    if others:
+        out["modes"] = [line(r, a.steps)] + [line(x, max(20, a.steps // 4)) for x in others]
+    if also:
+        out["also"] = [line(x, max(20, a.steps // 4)) for x in also]
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
     "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count",
+    "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_allgather_scores", "kws_comm_destroy",
     "kws_synth_clips_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
@@ -85,6 +86,12 @@ def lib():
                   "kws_model_is_float", "kws_filter_count"):
             getattr(L, f).argtypes = [vp]
         L.kws_label.restype = C.c_char_p
+        L.kws_comm_unique_id.argtypes = [vp, sz]
+        L.kws_comm_create.argtypes = [vp, sz, i32, i32, i32, C.POINTER(vp)]
+        L.kws_comm_world_size.argtypes = [vp]
+        L.kws_comm_rank.argtypes = [vp]
+        L.kws_allgather_scores.argtypes = [vp, vp, vp, sz, i32, vp]
+        L.kws_comm_destroy.argtypes = [vp]
         L.kws_set_mode.argtypes = [vp, i32]
         L.kws_get_mode.argtypes = [vp]
         L.kws_fast_is_fused.argtypes = [vp]
@@ -279,6 +286,31 @@ class StreamBatch:
         if getattr(self, "sb", None):
             self.L.kws_streams_destroy(self.sb)
             self.sb = None
+
+
+class Comm:
+    """RCCL communicator of one rank (kws_comm): the all-gather of the per-clip scores over xGMI, through the C ABI."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _check(lib().kws_comm_unique_id(buf, Comm.ID_BYTES))
+        return bytes(buf.raw)
+
+    def __init__(self, unique_id, world_size, rank, device):
+        self.L = lib()
+        c = C.c_void_p()
+        _check(self.L.kws_comm_create(unique_id, len(unique_id), world_size, rank, device, C.byref(c)))
+        self.c, self.world_size, self.rank = c, world_size, rank
+
+    def allgather_scores(self, local_ptr, all_ptr, clips_per_rank, label_count, stream=None):
+        _check(self.L.kws_allgather_scores(self.c, local_ptr, all_ptr, clips_per_rank, label_count, stream))
+
+    def close(self):
+        if getattr(self, "c", None):
+            self.L.kws_comm_destroy(self.c)
+            self.c = None
 
 
 def synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream=None):

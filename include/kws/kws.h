@@ -131,6 +131,23 @@ EI_IMPULSE_ERROR kws_streams_init(kws_stream_batch *sb);            /* run_class
 EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *slices, size_t slice_samples,
                                          const float *end_of_signal, float *scores, int *produced, void *stream);
 
+/* ---- multi-GPU: clips shard contiguously over the GPUs of one node (rank r owns clips [r*B, (r+1)*B)), tables are
+ * replicated, nothing is exchanged inside the pipeline; the one collective is the all-gather of the per-clip scores over xGMI.
+ * It goes through RCCL's C API (librccl is opened on first use: single-GPU applications do not need it).  One process per GPU:
+ * rank 0 obtains the 128-byte id and hands it to the other ranks with whatever started them (environment, file, MPI, a socket --
+ * bench.py uses torch.distributed); every rank then creates its communicator on its own device.
+ *   all_scores [world_size * clips_per_rank][label_count] float, device: rank-major = global clip order.  Asynchronous on
+ * `stream` (the same stream as the batch call that produced local_scores: no synchronisation in between). */
+#define KWS_COMM_ID_BYTES 128
+typedef struct kws_comm kws_comm;
+EI_IMPULSE_ERROR kws_comm_unique_id(void *id, size_t nbytes);
+EI_IMPULSE_ERROR kws_comm_create(const void *id, size_t nbytes, int world_size, int rank, int device, kws_comm **out);
+int kws_comm_world_size(const kws_comm *c);
+int kws_comm_rank(const kws_comm *c);
+EI_IMPULSE_ERROR kws_allgather_scores(kws_comm *c, const float *local_scores, float *all_scores, size_t clips_per_rank, int label_count,
+                                      void *stream);
+void kws_comm_destroy(kws_comm *c);
+
 /* deterministic synthetic clips generated directly in HBM (include/kws/kws_synth.h) */
 EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len,
                                         int16_t *out, void *stream);

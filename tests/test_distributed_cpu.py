@@ -47,3 +47,60 @@ def test_two_rank_gather_equals_single_process(oracle, l476):
     want = l476.run_batch(oracle.synth(0, 0, world * per_rank))
     assert got.shape == (world * per_rank, 4)
     assert (got == want).all()
+
+
+def _bench_worker(rank, world, port, per_rank, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo")
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def max_over_ranks(dt):
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    backend = bench.CpuOracleBackend(rank, world, per_rank)
+    res = bench.measure(backend, os.path.join(MODELS, "l476_no_yes.kwsm"), "exact", 2, 1, dist.barrier, max_over_ranks)
+    if rank == 0:
+        ret.put((backend.gathered.numpy().copy(), res["dt"], res["ms_gather"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_shards_and_gathers(oracle, l476):
+    """The code bench.py times -- measure() / timed_steps() with its sharding (rank r owns clips [r*B, (r+1)*B)) and the gather --
+    at world size 2 under gloo, the oracle standing in for the GPU library: the gathered scores are the single-process ones."""
+    world, per_rank = 2, 5
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, per_rank, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, dt, ms_gather = ret.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = l476.run_batch(oracle.synth(0, 0, world * per_rank))
+    assert got.shape == want.shape and (got == want).all()
+    assert dt > 0 and ms_gather >= 0
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself and prints exactly one JSON line with n_gpus = 2
+    (--dry-run-cpu: no GPU here); its checksum is the sum of the scores of the 2 x B clips of the global batch."""
+    import json
+    import subprocess
+    from bench import default_batch
+    assert default_batch(1) == 65536 and default_batch(8) * 8 == 1 << 20
+    env = dict(os.environ, MASTER_PORT=str(33500 + os.getpid() % 2000))
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "1",
+                          "--batch", "4", "--model", os.path.join(MODELS, "l476_no_yes.kwsm"), "--mode", "exact"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["collective"]["ranks"] == 2
+    assert abs(j["checksum"] - 8.0) < 0.1                       # 8 softmax rows

@@ -1,0 +1,54 @@
+"""-m gpu: bench.py's N > 1 path on the 1-GPU box: the RCCL communicator of the C ABI (kws_comm_* / kws_allgather_scores) at
+world size 1, inside bench.py's own timed region, and directly."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kws_testlib import MODELS, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_force_collective_on_one_gpu():
+    env = dict(os.environ, MASTER_PORT=str(35500 + os.getpid() % 2000))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "5", "--warmup", "2",
+                          "--batch", "4096", "--no-cpu-baseline", "--no-also"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout                                      # banners of gloo / RCCL are kept off stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["config"]["mode"] == "fast" and j["config"]["clips_per_gpu"] == 4096
+    assert j["collective"]["ranks"] == 1 and j["collective"]["allgather_ms_per_step"] > 0
+    assert "RCCL" in j["config"]["collective"]
+    assert abs(j["checksum"] - 4096.0) < 0.05                               # the gathered scores: 4096 softmax rows
+    assert j["value"] > 1e5 and j["roofline"]["kernel"] == "kws_fast_kernel"
+
+
+def test_allgather_scores_c_abi_world_size_one():
+    sys.path.insert(0, ROOT)
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    gm = pkg.Model(os.path.join(MODELS, "l476_no_yes.kwsm"), device=0)
+    B = 300
+    pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(3, 0, B, 16000, pcm.data_ptr())
+    s = torch.zeros((B, 4), dtype=torch.float32, device="cuda:0")
+    allg = torch.zeros((B, 4), dtype=torch.float32, device="cuda:0")
+    comm = pkg.Comm(pkg.Comm.unique_id(), 1, 0, 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    gm.run_classifier_batch_device(pcm.data_ptr(), B, s.data_ptr(), None, None, stream)
+    comm.allgather_scores(s.data_ptr(), allg.data_ptr(), B, 4, stream)     # same stream: no synchronisation in between
+    torch.cuda.synchronize()
+    assert torch.equal(allg, s) and float(s.sum()) > 0
+    with pytest.raises(pkg.KwsError):
+        pkg.Comm(b"\0" * 16, 1, 0, 0)                                       # id too short
+    comm.close()
+    gm.close()
