@@ -177,7 +177,7 @@ class Model:
         self.h = h
         self.device = device
         self.n_labels = self.L.kws_label_count(h)
-        self.labels = [self.L.kws_label(h, i).decode() for i in range(self.n_labels)]
+        self.labels = [self.L.kws_label(h, i).decode(errors="replace") for i in range(self.n_labels)]
         self.n_features = self.L.kws_feature_count(h)
         self.clip_samples = self.L.kws_clip_samples(h)
         self.n_frames = self.L.kws_frame_count(h)

@@ -48,7 +48,9 @@ EI_IMPULSE_ERROR kws_create_from_file(const char *path, int device, kws_handle *
 void kws_destroy(kws_handle *h)
 {
     if (!h) return;
+    kws_sdk_forget_default(h);
     (void)hipSetDevice(h->device);
+    if (h->scratch_ev) { (void)hipEventSynchronize(h->scratch_ev); (void)hipEventDestroy(h->scratch_ev); }
     for (void *p : h->dev_allocs) (void)hipFree(p);
     if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
@@ -233,6 +235,7 @@ EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfc
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
+    ScratchUse use(h, (hipStream_t)stream);
     return cmvn_nn_device(h, mfcc, B, features, q_in, scores, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -244,6 +247,7 @@ EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
+    ScratchUse use(h, (hipStream_t)stream);
     if (h->mode == KWS_MODE_FAST) return classify_fast_device(h, pcm, B, nullptr, features, true, q_in, (hipStream_t)stream);
     return mfcc_fused_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
 }
@@ -309,6 +313,7 @@ EI_IMPULSE_ERROR kws_run_inference_batch_device(kws_handle *h, const float *feat
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
+    ScratchUse use(h, (hipStream_t)stream);
     int rc = kws_launch_quantize(features, h->s_q, B * h->model.nn_input_frame_size, h->nn.in_scale, h->nn.in_zp, (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "quantise kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return kws_nn_batch_device(h, h->s_q, B, scores, nullptr, nullptr, nullptr, stream);
@@ -374,6 +379,7 @@ EI_IMPULSE_ERROR kws_run_classifier_batch_device(kws_handle *h, const int16_t *p
     std::lock_guard<std::mutex> lk(h->mu);
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
+    ScratchUse use(h, (hipStream_t)stream);
     if (h->mode == KWS_MODE_FAST)
         return classify_fast_device(h, pcm, B, scores, features ? features : h->s_mfcc, features != nullptr,
                                     h->is_float ? nullptr : (q_in ? q_in : h->s_q), (hipStream_t)stream);

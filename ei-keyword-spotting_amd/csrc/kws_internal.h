@@ -139,6 +139,11 @@ struct kws_handle {
     float *s_mfcc = nullptr;      // cepstra before CMVN, [B][n_features]
     int8_t *s_q = nullptr;
     size_t s_cap = 0;
+    // the scratch (and the fast mode's clip list) is shared by every call on this handle: a call on another stream than the
+    // previous one first waits for it (see ScratchUse)
+    hipEvent_t scratch_ev = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
     // host-buffer entry point (kws_run_classifier_batch): two streams, each with its own chunk-sized device buffers, so that
     // the PCIe transfer of one chunk overlaps the kernels of the other; allocated once, grown on demand
     struct HostPipe {
@@ -189,6 +194,22 @@ struct kws_handle {
     }
 };
 
+// Brackets a call that uses the handle's scratch on stream s (h->mu held): orders it behind the previous such call when that one
+// was enqueued on a different stream, and records where this one ends.
+struct ScratchUse {
+    kws_handle *h;
+    hipStream_t s;
+    ScratchUse(kws_handle *h_, hipStream_t s_) : h(h_), s(s_)
+    {
+        if (!h->scratch_ev) (void)hipEventCreateWithFlags(&h->scratch_ev, hipEventDisableTiming);
+        if (h->scratch_used && h->scratch_stream != s && h->scratch_ev) (void)hipStreamWaitEvent(s, h->scratch_ev, 0);
+    }
+    ~ScratchUse()
+    {
+        if (h->scratch_ev && hipEventRecord(h->scratch_ev, s) == hipSuccess) { h->scratch_stream = s; h->scratch_used = true; }
+    }
+};
+
 // kws_plan.cpp: execution plans (tables computed once per model, uploaded to HBM)
 EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h);
 EI_IMPULSE_ERROR build_nn_plan(kws_handle *h);
@@ -198,6 +219,7 @@ EI_IMPULSE_ERROR build_fast_plans(kws_handle *h);     // kws_fast_plan.cpp; neve
 #define KWS_INTERNAL __attribute__((visibility("hidden")))
 extern "C" {
 KWS_INTERNAL EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B);
+KWS_INTERNAL void kws_sdk_forget_default(kws_handle *h);      // kws_sdk.cpp: kws_destroy() of the installed default model
 KWS_INTERNAL int grid_cap_mfcc(const kws_handle *h);
 KWS_INTERNAL int grid_cap_nn(const kws_handle *h);
 KWS_INTERNAL EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,

@@ -120,10 +120,37 @@ bool parse_model(const void *blob, size_t nbytes, Model &m)
         n.beta = r.f32();
     }
     if (r.bad || m.t_in >= nt || m.t_out >= nt) return false;
+    // Per-op operand contract: the plan builders (kws_plan.cpp) index in[] / out[] / dims / scale without further checks, so a
+    // blob must satisfy it here.  Mandatory operands are real tensor ids; only the bias slot (in[2]) of a convolution or of
+    // FULLY_CONNECTED may be -1 (absent).  Every tensor an op touches has at least one dimension; activations of CONV_2D /
+    // DEPTHWISE_CONV_2D / MAX_POOL_2D are 4-D; every int8 tensor an op touches carries a scale and a zero point (checked above
+    // for all int8 tensors: nq >= 1).
+    auto real = [&](int v) { return v >= 0 && v < (int)nt; };
     for (auto &n : m.n) {
-        for (int v : n.in) if (v >= (int)nt) return false;
-        for (int v : n.out) if (v < 0 || v >= (int)nt) return false;
+        size_t need_in = 1, need_out = 1;
+        switch (n.op) {
+        case OP_RESHAPE: need_in = 1; break;                                 // in[1] (the shape operand) is optional
+        case OP_CONV_2D: case OP_DEPTHWISE_CONV_2D: case OP_FULLY_CONNECTED: need_in = 2; break;
+        case OP_ADD: need_in = 2; break;
+        case OP_MAX_POOL_2D: case OP_SOFTMAX: need_in = 1; break;
+        default: return false;                                                // unknown op code
+        }
+        if (n.in.size() < need_in || n.out.size() < need_out) return false;
+        for (size_t k = 0; k < n.in.size(); k++) {
+            const bool optional = (k >= need_in);
+            if (!real(n.in[k]) && !(optional && n.in[k] == -1)) return false;
+        }
+        for (int v : n.out) if (!real(v)) return false;
+        for (size_t k = 0; k < n.in.size(); k++)
+            if (real(n.in[k]) && m.t[n.in[k]].dims.empty()) return false;
+        for (int v : n.out) if (m.t[v].dims.empty()) return false;
+        if (n.op == OP_CONV_2D || n.op == OP_DEPTHWISE_CONV_2D) {
+            if (m.t[n.in[0]].dims.size() != 4 || m.t[n.in[1]].dims.size() != 4 || m.t[n.out[0]].dims.size() != 4) return false;
+        }
+        if (n.op == OP_MAX_POOL_2D && (m.t[n.in[0]].dims.size() != 4 || m.t[n.out[0]].dims.size() != 4)) return false;
+        if (n.op == OP_FULLY_CONNECTED && m.t[n.in[1]].dims.size() != 2) return false;
     }
+    if (m.t[m.t_in].dims.empty() || m.t[m.t_out].dims.empty() || m.labels.empty()) return false;
     return true;
 }
 

@@ -220,8 +220,9 @@ EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
             if (a_id != cur && b_id == cur) std::swap(a_id, b_id);
             const Tensor &t1 = m.t[ad.in[0]], &t2 = m.t[ad.in[1]], &to = m.t[ad.out[0]];
             const Tensor &cb = m.t[b_id];
-            if (a_id != cur || !cb.is_const || cb.type != TYPE_I8 || (int)cb.nbytes != out_c || cb.dims.back() != out_c)
-                return fail(KWS_ERROR_UNSUPPORTED_MODEL, "ADD %zu is not a per-channel constant add", i);
+            if (a_id != cur || !cb.is_const || cb.type != TYPE_I8 || (int)cb.nbytes != out_c || cb.dims.back() != out_c ||
+                t1.type != TYPE_I8 || t2.type != TYPE_I8 || to.type != TYPE_I8)
+                return fail(KWS_ERROR_UNSUPPORTED_MODEL, "ADD %zu is not a per-channel constant int8 add", i);
             // CalculateOpData, add.cc:271-309
             const int left_shift = 20;
             const double twice_max = 2 * (double)std::max(t1.scale[0], t2.scale[0]);
@@ -298,6 +299,8 @@ EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         if (N.blk[b].pool_w != N.blk[b + 1].in_w || N.blk[b].out_c != N.blk[b + 1].in_c)
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "conv blocks do not chain");
     // FULLY_CONNECTED (fully_connected.cc:322-396)
+    if (i < m.n.size() && m.n[i].op == OP_FULLY_CONNECTED && (m.t[m.n[i].in[1]].type != TYPE_I8 || m.t[m.n[i].out[0]].type != TYPE_I8))
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "FULLY_CONNECTED tensor types");
     if (i >= m.n.size() || m.n[i].op != OP_FULLY_CONNECTED || m.n[i].in[0] != cur)
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "expected FULLY_CONNECTED after the conv blocks");
     {
@@ -350,6 +353,11 @@ EI_IMPULSE_ERROR build_nn_plan(kws_handle *h)
         if ((e = h->upload(ex, &N.sm_exp))) return e;
         if ((e = h->upload(valid, &N.sm_valid))) return e;
     }
+    // the generic kernel keeps every block's weights and ADD tables in LDS: a model that does not fit fails here, at load time,
+    // not at its first inference
+    if (!kws_nn_uses_mfma(N) && kws_nn_smem_bytes(N, 4) > 158 * 1024)
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 model needs %zu B of LDS in the generic network kernel (at most %d)",
+                    kws_nn_smem_bytes(N, 4), 158 * 1024);
     return EI_IMPULSE_OK;
 }
 

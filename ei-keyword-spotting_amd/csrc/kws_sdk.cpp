@@ -75,9 +75,8 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
     *produced = 0;
     // extract_mfcc_per_slice_features: every step but the first claims one more frame length (ei_run_dsp.h:319-325)
     size_t n_claimed = slice_samples;
-    const bool grown = sb->first_run;
+    const bool grown = sb->first_run;           // committed below, once the slice has been accepted and enqueued
     if (grown) n_claimed += (size_t)(m.dsp.frame_length * (float)m.frequency);
-    sb->first_run = true;
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
     const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)m.dsp.num_cepstral;
@@ -92,6 +91,7 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
     float *feat = sb->feat[sb->cur];
     EI_IMPULSE_ERROR e = spectral_device(h, P, slices, 0, S, feat + sb->slice_offset, wrap, st, (int)F);
     if (e) return e;
+    sb->first_run = true;
     if (!sb->full) {
         sb->slice_offset += feature_size;
         if (sb->slice_offset > (F - feature_size)) { sb->full = true; sb->slice_offset -= feature_size; }
@@ -100,7 +100,10 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
     {
         std::lock_guard<std::mutex> lk(h->mu);
         e = ensure_scratch(h, S);
-        if (!e) e = cmvn_nn_device(h, feat, S, nullptr, nullptr, scores, nullptr, nullptr, nullptr, st);
+        if (!e) {
+            ScratchUse use(h, st);
+            e = cmvn_nn_device(h, feat, S, nullptr, nullptr, scores, nullptr, nullptr, nullptr, st);
+        }
     }
     if (e) return e;
     int rc = kws_launch_maf(scores, sb->running_sum, sb->maf_buf, (int)(S * C), (int)sb->buf_idx, kMafTaps, st);
@@ -146,12 +149,35 @@ static kws_handle *g_default = nullptr;
 static bool g_default_owned = false;
 static std::mutex g_default_mu;
 
-EI_IMPULSE_ERROR kws_set_default_model(kws_handle *h)
+// kws_destroy(h) of the handle that is installed as the default model: the SDK entry points must not find it any more
+void kws_sdk_forget_default(kws_handle *h)
 {
     std::lock_guard<std::mutex> lk(g_default_mu);
-    if (g_default && g_default_owned && g_default != h) kws_destroy(g_default);
-    g_default = h;
-    g_default_owned = false;
+    if (g_default == h) { g_default = nullptr; g_default_owned = false; }
+}
+
+// The application's ei_impulse_result_t is sized by ITS EI_CLASSIFIER_LABEL_COUNT (include/kws/ei_compat.h publishes it as
+// kws_app_label_count; absent when the caller is not a C program built with that header, e.g. ctypes).  Writing a result of
+// another label count would run past the caller's struct.
+extern "C" { __attribute__((weak)) extern const int kws_app_label_count; }
+static EI_IMPULSE_ERROR check_result_layout(const kws_handle *h)
+{
+    if (&kws_app_label_count && kws_app_label_count != (int)h->model.labels.size())
+        return fail(EI_IMPULSE_ERROR_SHAPES_DONT_MATCH, "the application was compiled for EI_CLASSIFIER_LABEL_COUNT = %d, the loaded model has %zu labels",
+                    kws_app_label_count, h->model.labels.size());
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_set_default_model(kws_handle *h)
+{
+    kws_handle *old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);
+        if (g_default && g_default_owned && g_default != h) old = g_default;
+        g_default = h;
+        g_default_owned = false;
+    }
+    if (old) kws_destroy(old);                 // outside the lock: kws_destroy() asks whether it destroys the default
     return EI_IMPULSE_OK;
 }
 
@@ -196,6 +222,7 @@ EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result
     kws_handle *h = kws_default_model();
     if (!h) return kws_last_error_code() != EI_IMPULSE_OK ? kws_last_error_code() : KWS_ERROR_NO_MODEL;   // why the default model is missing
     if (!fmatrix || !fmatrix->buffer || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (EI_IMPULSE_ERROR le = check_result_layout(h)) return le;
     const size_t F = h->model.nn_input_frame_size, C = h->model.labels.size();
     if ((size_t)fmatrix->rows * fmatrix->cols != F) return fail(EI_IMPULSE_ERROR_SHAPES_DONT_MATCH, "feature matrix is %ux%u, model needs %zu", fmatrix->rows, fmatrix->cols, F);
     HIP_TRY(hipSetDevice(h->device));
@@ -247,6 +274,7 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     kws_handle *h = kws_default_model();
     if (!h) return kws_last_error_code() != EI_IMPULSE_OK ? kws_last_error_code() : KWS_ERROR_NO_MODEL;   // why the default model is missing
     if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (EI_IMPULSE_ERROR le = check_result_layout(h)) return le;
     const size_t n = h->model.raw_sample_count, C = h->model.labels.size();
     // The reference sizes its frame count from signal->total_length (ei_run_dsp.h:277-286); a length that yields another
     // feature count than the model's is EIDSP_MATRIX_SIZE_MISMATCH there (-> EI_IMPULSE_DSP_ERROR).
@@ -300,6 +328,7 @@ void run_classifier_init(void)
 {
     kws_handle *h = kws_default_model();
     if (!h) return;
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
     h->slice_offset = 0;
     h->feature_buffer_full = false;
     h->cont_first_run = false;
@@ -324,6 +353,9 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     kws_handle *h = kws_default_model();
     if (!h) return kws_last_error_code() != EI_IMPULSE_OK ? kws_last_error_code() : KWS_ERROR_NO_MODEL;   // why the default model is missing
     if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    EI_IMPULSE_ERROR le = check_result_layout(h);
+    if (le) return le;
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);                               // the reference is non-reentrant: callers are serialised
     const Model &m = h->model;
     const size_t F = m.nn_input_frame_size, C = m.labels.size();
     const int ncep = m.dsp.num_cepstral;
@@ -347,7 +379,6 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     }
     const size_t needed = (size_t)(nf - 1) * stride + frame_len;                // last sample any frame reads
     const size_t n_x = std::max(n_claimed, needed) + 16;
-    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
     EI_IMPULSE_ERROR e = ensure_ws(h, n_x);
     if (e) return e;
     kws_handle::Ws &w = h->ws;

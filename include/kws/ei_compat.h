@@ -81,6 +81,15 @@ typedef struct {
     ei_impulse_result_timing_t timing;
 } ei_impulse_result_t;
 
+/* The result layout this translation unit is compiled for.  The reference compiles model and application together; here the
+ * model is loaded at run time, so the library compares this number with the loaded model's label count before it writes into
+ * an ei_impulse_result_t and returns EI_IMPULSE_ERROR_SHAPES_DONT_MATCH on a mismatch (a weak definition: one copy per program;
+ * the library sees it when the application is linked against it). */
+#ifndef KWS_BUILDING_LIBRARY
+__attribute__((weak)) extern const int kws_app_label_count;
+__attribute__((weak)) const int kws_app_label_count = EI_CLASSIFIER_LABEL_COUNT;
+#endif
+
 typedef struct {
     uint32_t buf_idx;
     float running_sum;

@@ -5,6 +5,12 @@
  * from the reference's generated MODEL/tflite-model/trained_model_compiled.cpp:70-328 and
  * MODEL/model-parameters/model_metadata.h:38-132).
  *
+ * Streams and concurrency: a handle owns one set of scratch buffers (the int8 input tensor / the cepstra of the combined entry
+ * points, the fast mode's clip list).  Calls on ONE handle are ordered by the library: a call enqueued on a different stream than
+ * the handle's previous call first makes its stream wait (hipStreamWaitEvent) for that previous call's work, so two streams on
+ * one handle are safe but do not overlap; for overlap use one handle per stream.  Growing the scratch (a larger batch than any
+ * before) synchronises the device.
+ *
  * Plain C ABI: pointers and sizes only.  `*_device` entry points take DEVICE pointers and a
  * hipStream_t passed as void* (NULL = default stream) and are asynchronous; the others take host
  * pointers and synchronise.  All return EI_IMPULSE_ERROR values (0 = EI_IMPULSE_OK).

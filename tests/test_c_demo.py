@@ -62,3 +62,13 @@ def test_c_demo_output_matches_reference_restatement(tmp_path, oracle, l476):
         else:
             vals = np.float32(re.findall(r" ([0-9.]+)(?=  |$)", ln))
             assert np.abs(vals - s).max() < 6e-6, (ln, s)
+
+
+@pytest.mark.gpu
+def test_c_demo_refuses_a_model_of_another_label_count(tmp_path):
+    """The demo is compiled for EI_CLASSIFIER_LABEL_COUNT = 4 (include/kws/ei_compat.h publishes it as kws_app_label_count); a
+    12-label model would write past its ei_impulse_result_t: run_classifier() answers EI_IMPULSE_ERROR_SHAPES_DONT_MATCH."""
+    exe = _build(tmp_path)
+    env = dict(os.environ, KWS_MODEL=os.path.join(MODELS, "cfg5_dscnn_mfcc40_int8.kwsm"))
+    r = subprocess.run([exe, "1"], env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "(-1)" in r.stdout, r.stdout + r.stderr
