@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "ei_read_timer_us", "ei_printf", "ei_printf_float",
     "kws_create", "kws_create_from_file", "kws_destroy", "kws_last_error", "kws_label_count", "kws_label",
     "kws_feature_count", "kws_clip_samples", "kws_frame_count", "kws_pooled_tap_bytes", "kws_model_is_float",
-    "kws_nn_f32_batch_device", "kws_nn_kernel_name", "kws_mfe_batch_device", "kws_filter_count", "kws_set_default_model",
+    "kws_nn_f32_batch_device", "kws_nn_kernel_name", "kws_mfcc_kernel_name", "kws_mfe_batch_device", "kws_filter_count", "kws_set_default_model",
     "kws_default_model", "kws_run_classifier_batch_device", "kws_run_classifier_batch",
     "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
@@ -98,6 +98,8 @@ def lib():
         L.kws_fast_fallback_count.argtypes = [vp, C.POINTER(sz)]
         L.kws_nn_kernel_name.restype = C.c_char_p
         L.kws_nn_kernel_name.argtypes = [vp]
+        L.kws_mfcc_kernel_name.restype = C.c_char_p
+        L.kws_mfcc_kernel_name.argtypes = [vp]
         L.kws_label.argtypes = [vp, i32]
         L.kws_set_default_model.argtypes = [vp]
         L.kws_default_model.restype = vp
@@ -185,6 +187,7 @@ class Model:
         self.pooled_tap_bytes = self.L.kws_pooled_tap_bytes(h)
         self.is_float = bool(self.L.kws_model_is_float(h))
         self.nn_kernel = self.L.kws_nn_kernel_name(h).decode()
+        self.mfcc_kernel = self.L.kws_mfcc_kernel_name(h).decode()
 
     def close(self):
         if getattr(self, "h", None):

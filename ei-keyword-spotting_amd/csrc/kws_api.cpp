@@ -55,6 +55,7 @@ void kws_destroy(kws_handle *h)
     if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    for (void *p : { (void *)h->g_ws, (void *)h->g_mfcc, (void *)h->g_feat }) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         for (void *p : { (void *)h->pipe.pcm[k], (void *)h->pipe.s[k], (void *)h->pipe.f[k], (void *)h->pipe.q[k] }) if (p) (void)hipFree(p);
         if (h->pipe.st[k]) (void)hipStreamDestroy(h->pipe.st[k]);
@@ -75,6 +76,7 @@ int kws_frame_count(const kws_handle *h) { return h->dsp.n_frames; }
 int kws_filter_count(const kws_handle *h) { return h->dsp.n_filters; }
 int kws_pooled_tap_bytes(const kws_handle *h) { return h->pooled_tap_bytes; }
 int kws_model_is_float(const kws_handle *h) { return h->is_float ? 1 : 0; }
+const char *kws_mfcc_kernel_name(const kws_handle *h) { return h->dsp.generic ? "kws_spectral_generic_kernel" : "kws_mfcc_kernel"; }
 const char *kws_nn_kernel_name(const kws_handle *h)
 {
     return h->is_float ? "kws_nn_f32_kernel" : kws_nn_uses_mfma(h->nn) ? "kws_nn_mfma_kernel" : "kws_nn_kernel";
@@ -131,11 +133,40 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
 int grid_cap_mfcc(const kws_handle *h) { return h->n_cu * 8; }
 int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 
+// buffers of the general MFCC kernels for a batch of B windows
+EI_IMPULSE_ERROR ensure_generic(kws_handle *h, size_t B)
+{
+    std::lock_guard<std::mutex> lk(h->g_mu);
+    const size_t need_ws = kws_generic_ws_bytes(h->dsp, grid_cap_mfcc(h));
+    if (need_ws > h->g_ws_bytes) {
+        if (h->g_ws) (void)hipFree(h->g_ws);
+        h->g_ws = nullptr; h->g_ws_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&h->g_ws, need_ws));
+        h->g_ws_bytes = need_ws;
+    }
+    if (B > h->g_cap) {
+        for (void *p : { (void *)h->g_mfcc, (void *)h->g_feat }) if (p) (void)hipFree(p);
+        h->g_mfcc = h->g_feat = nullptr; h->g_cap = 0;
+        const size_t F = h->model.nn_input_frame_size;
+        HIP_TRY(hipMalloc((void **)&h->g_mfcc, std::max<size_t>(B * F, 1) * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&h->g_feat, std::max<size_t>(B * F, 1) * sizeof(float)));
+        h->g_cap = B;
+    }
+    return EI_IMPULSE_OK;
+}
+
 // speechpy::feature::mfcc for B windows (kernel 1)
 EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
                                         const float *wrap, hipStream_t s, int out_stride)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (h->dsp.generic) {
+        EI_IMPULSE_ERROR e = ensure_generic(h, 0);
+        if (e) return e;
+        int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, h->g_ws, grid_cap_mfcc(h), s);
+        if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
     int rc = kws_launch_spectral(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, grid_cap_mfcc(h), s);
     if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
@@ -146,6 +177,15 @@ EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void 
 EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (h->dsp.generic) {
+        // cepstra -> g_mfcc, then cmvnw + quantisation (the general kernels are two launches; the cepstra go through HBM)
+        EI_IMPULSE_ERROR e = ensure_generic(h, B);
+        if (e) return e;
+        int rc = kws_launch_spectral_generic(h->dsp, pcm, is_float, (int)B, h->g_mfcc, nullptr, 0, h->g_ws, grid_cap_mfcc(h), s);
+        if (!rc) rc = kws_launch_cmvn_generic(h->dsp, h->g_mfcc, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, s);
+        if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
     int rc = kws_launch_mfcc_fused(h->dsp, pcm, is_float, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s);
     if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
@@ -169,6 +209,20 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     int ran_nn = 0;
+    if (h->dsp.generic) {
+        if (h->is_float && (q || tap_pooled || tap_fc || tap_out)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 outputs requested from a float32 model");
+        EI_IMPULSE_ERROR e = ensure_generic(h, B);
+        if (e) return e;
+        float *f = features ? features : (h->is_float ? h->g_feat : nullptr);
+        int8_t *qq = h->is_float ? nullptr : (q ? q : h->s_q);
+        int rc = kws_launch_cmvn_generic(h->dsp, mfcc, (int)B, f, qq, h->nn.in_scale, h->nn.in_zp, s);
+        if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (!scores) return EI_IMPULSE_OK;
+        if (h->is_float) return nn_f32_device(h, f, B, scores, nullptr, s);
+        rc = kws_launch_nn(h->nn, qq, (int)B, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out, grid_cap_nn(h), s);
+        if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (h->is_float) {
         if (q || tap_pooled || tap_fc || tap_out) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 outputs requested from a float32 model");
         float *f = features ? features : h->s_mfcc;
@@ -199,8 +253,13 @@ EI_IMPULSE_ERROR kws_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t 
 {
     if (!h || !pcm || !mel) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
-    if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->dsp.generic) {
+        KwsDspPlan P = h->dsp;
+        P.mfe_mel = mel; P.mfe_energy = energy;
+        return spectral_device(h, P, pcm, 0, B, nullptr, nullptr, (hipStream_t)stream);
+    }
+    if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
     int rc = kws_launch_mfe(h->dsp, pcm, (int)B, mel, energy, grid_cap_mfcc(h), (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "MFE kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
@@ -210,6 +269,7 @@ EI_IMPULSE_ERROR kws_extract_mfe_batch_device(kws_handle *h, const int16_t *pcm,
 {
     if (!h || !pcm || !features) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (h->dsp.generic) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "the MFE block's normalisation kernel serves the tuned configurations only");
     if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
     // the MFE block hands the raw signal to feature::mfe (ei_run_dsp.h:398-400; extract_mfcc_features wraps it in the

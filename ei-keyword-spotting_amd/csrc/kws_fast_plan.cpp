@@ -13,6 +13,8 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     const DspCfg &c = m.dsp;
     const KwsDspPlan &P = h->dsp;
     const int NF = c.num_filters, nfr = P.n_frames, ncep = c.num_cepstral;
+    if (P.generic) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode serves the configurations of the tuned MFCC kernel (fft 256, 32 / 40 filters, "
+                                                            "up to 52 aligned frames); this model runs on the general kernels");
     if (c.fft_length != 256) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: fft_length %d (kernel is built for 256)", c.fft_length);
     if (NF != 32 && NF != 40) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d mel filters (the kernel is instantiated for 32 and 40)", NF);
     // cmvnw row/column split: 16 columns x 4 groups of 13 rows, or 20 columns x 3 groups of 17 rows

@@ -43,6 +43,12 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
 int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
+// kws_generic.hip: the exact MFCC block for configurations outside the tuned kernel (KwsDspPlan::generic)
+size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid);
+int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
+                                int out_stride, float *ws, int grid, hipStream_t stream);
+int kws_launch_cmvn_generic(const KwsDspPlan &P, const float *mfcc, int n_clips, float *features, int8_t *q_out, float in_scale, int in_zp,
+                            hipStream_t stream);
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
 size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves);
 extern int kws_force_scalar_nn;
@@ -141,6 +147,10 @@ struct kws_handle {
     size_t s_cap = 0;
     // the scratch (and the fast mode's clip list) is shared by every call on this handle: a call on another stream than the
     // previous one first waits for it (see ScratchUse)
+    // general MFCC kernels (KwsDspPlan::generic): per-workgroup transform scratch, cepstra and feature buffers, grown on demand
+    float *g_ws = nullptr, *g_mfcc = nullptr, *g_feat = nullptr;
+    size_t g_ws_bytes = 0, g_cap = 0;
+    std::mutex g_mu;
     hipEvent_t scratch_ev = nullptr;
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
@@ -221,6 +231,7 @@ extern "C" {
 KWS_INTERNAL EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B);
 KWS_INTERNAL void kws_sdk_forget_default(kws_handle *h);      // kws_sdk.cpp: kws_destroy() of the installed default model
 KWS_INTERNAL int grid_cap_mfcc(const kws_handle *h);
+KWS_INTERNAL EI_IMPULSE_ERROR ensure_generic(kws_handle *h, size_t B);
 KWS_INTERNAL int grid_cap_nn(const kws_handle *h);
 KWS_INTERNAL EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
                                  const float *wrap, hipStream_t s, int out_stride = 0);

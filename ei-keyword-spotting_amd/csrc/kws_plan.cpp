@@ -28,6 +28,8 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     const int frame_len = (int)roundf((float)fs * c.frame_length);
     const float stride_f = roundf((float)fs * c.frame_stride);
     const int stride = (int)stride_f;
+    if (frame_len < 1 || stride_f < 1.0f || (size_t)frame_len > (size_t)m.raw_sample_count || m.raw_sample_count > (1u << 30))
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "framing: %u samples, frame length %d, stride %g", m.raw_sample_count, frame_len, (double)stride_f);
     const size_t diff = (size_t)m.raw_sample_count - (size_t)frame_len;
     const int nfr = (int)floorf((float)diff / stride_f);
     P.n_samples = (int)m.raw_sample_count;
@@ -47,18 +49,39 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     P.dct_s0 = sqrtf(1.0f / (float)(4 * N));
     P.dct_s1 = sqrtf(1.0f / (float)(2 * N));
 
-    // what the gfx950 kernels implement (kws_device.h: KWS_FFT, KWS_NF_MAX, KWS_MAXF ...)
+    // What the tuned kernel (kws_mfcc.hip) is instantiated for: fft 256, 32 or 40 filters, up to 52 frames, 16-byte aligned
+    // frames, short mel filters.  Everything else the reference accepts goes to the general kernels (kws_generic.hip).
     if (c.axes != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC block with %d axes", c.axes);
-    if (c.fft_length != 256 || (c.num_filters != 32 && c.num_filters != 40))
-        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC kernel is built for fft_length 256 and 32 or 40 filters (got %d / %d)",
-                    c.fft_length, c.num_filters);
-    if (frame_len < c.fft_length || c.pre_shift != 1 || (c.win_size & 1) == 0 || nfr < 1 || nfr > kws_mfcc_max_frames(c.num_filters) ||
-        c.num_cepstral < 1 || c.num_cepstral > c.num_filters || (stride * 2) % 16 != 0 || (P.n_samples * 2) % 16 != 0 ||
-        (nfr - 1) * stride + c.fft_length > P.n_samples || nfr + 2 * P.pad > kws_mfcc_max_prow() || c.win_size > kws_mfcc_max_win(c.num_cepstral) || nfr > kws_mfcc_max_frames_for(c.num_filters, c.num_cepstral) || c.win_size < ((c.num_filters == 40 && c.num_cepstral > 16) ? 17 : 13) ||
-        nfr > 4 * kws_mfcc_cmvn_rows() ||
+    const int used = std::min(frame_len, c.fft_length);
+    if (c.fft_length < 4 || (c.fft_length & 1) || N < 2 || (N & 1) || N > 128 || c.pre_shift != 1 || (c.win_size & 1) == 0 || c.win_size < 1 ||
+        nfr < 1 || stride < 1 || c.num_cepstral < 1 || c.num_cepstral > N || (long)(nfr - 1) * stride + used > (long)P.n_samples ||
         (size_t)nfr * c.num_cepstral != m.nn_input_frame_size)
-        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC framing outside the kernel's limits (frames %d, frame_len %d, stride %d, "
-                    "cepstra %d, win %d, shift %d)", nfr, frame_len, stride, c.num_cepstral, c.win_size, c.pre_shift);
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC configuration outside the kernels (fft %d, filters %d, frames %d, frame_len %d, stride %d, "
+                    "cepstra %d, win %d, shift %d)", c.fft_length, N, nfr, frame_len, stride, c.num_cepstral, c.win_size, c.pre_shift);
+    auto factor = [](int n, int *fac) {                         // kf_factor: 4s, then 2s, then 3, 5, 7 ...; returns levels or -1
+        int p = 4, levels = 0;
+        const double floor_sqrt = floor(sqrt((double)n));
+        do {
+            while (n % p) {
+                switch (p) { case 4: p = 2; break; case 2: p = 3; break; default: p += 2; break; }
+                if (p > floor_sqrt) p = n;
+            }
+            n /= p;
+            if (p > 5 || levels >= 12) return -1;               // kf_bfly_generic (other primes) is not restated
+            fac[2 * levels] = p; fac[2 * levels + 1] = n;
+            levels++;
+        } while (n > 1);
+        return levels;
+    };
+    P.fft_levels = factor(c.fft_length / 2, P.fft_fac);
+    P.dct_levels = factor(N / 2, P.dct_fac);
+    if (P.fft_levels < 0 || P.dct_levels < 0)
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fft_length %d / %d filters need a radix other than 2, 3, 4, 5", c.fft_length, N);
+    const bool tuned = c.fft_length == 256 && (N == 32 || N == 40) && frame_len >= c.fft_length && nfr <= kws_mfcc_max_frames(N) &&
+                       (stride * 2) % 16 == 0 && (P.n_samples * 2) % 16 == 0 && nfr + 2 * P.pad <= kws_mfcc_max_prow() &&
+                       c.win_size <= kws_mfcc_max_win(c.num_cepstral) && nfr <= kws_mfcc_max_frames_for(N, c.num_cepstral) &&
+                       c.win_size >= ((N == 40 && c.num_cepstral > 16) ? 17 : 13) && nfr <= 4 * kws_mfcc_cmvn_rows();
+    P.generic = tuned ? 0 : 1;
 
     std::vector<float2> tw, stw, dtw, dstw;
     h_twiddles(c.fft_length / 2, tw);
@@ -73,7 +96,7 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     }
     // the kernel carries the DCT constants as literals (kws_dct_tables.h, tools/gen_dct_tables.cpp): they must be exactly
     // what this host computes in the reference's way, or the features would silently differ
-    {
+    if (!P.generic) {
         bool same;
         if (N == 32) same = dct_tables_match<32>(dtw, dstw, dcos, dsin, P.dct_s0, P.dct_s1);
         else same = dct_tables_match<40>(dtw, dstw, dcos, dsin, P.dct_s0, P.dct_s1);
@@ -94,8 +117,7 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     }
     fstart[N] = (int)fbin.size();
     P.max_nz = max_nz;
-    if (max_nz > kws_mfcc_max_nz())
-        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "mel filter with %d taps (kernel keeps at most %d in registers)", max_nz, kws_mfcc_max_nz());
+    if (max_nz > kws_mfcc_max_nz()) P.generic = 1;            // the tuned kernel keeps a filter's taps in registers
     std::vector<int> pmap;
     h_pad_map(nfr, P.pad, pmap);
 

@@ -32,6 +32,11 @@ struct KwsDspPlan {
     const float *dct_cos;    // [n_filters/2+1] cosf((float)(i*pi/(2N)))    fast-dct-fft.cpp:71-74
     const float *dct_sin;
     const int *pad_map;      // [n_frames+2*pad] numpy::pad_1d_symmetric row map   numpy.hpp:479-541
+    // configurations outside the tuned kernel's instantiations run on the general kernels (kws_generic.hip): kf_factor's factor
+    // lists (kiss_fft.cpp:303-324: p, m pairs) of the frame transform (fft_len / 2 points) and of the DCT's (n_filters / 2 points)
+    int generic;
+    int fft_levels, dct_levels;
+    int fft_fac[24], dct_fac[24];
     // per launch, WITH_CMVN = false only: when set the kernel stops after speechpy::feature::mfe (feature.hpp:193-318)
     // and writes the mel energies [window][frame][filter] and frame energies [window][frame] (both after zero handling)
     float *mfe_mel, *mfe_energy;

@@ -80,8 +80,8 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
     const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)m.dsp.num_cepstral;
-    if (nf < 1 || nf > kws_mfcc_max_frames(h->dsp.n_filters) || feature_size > F || sb->slice_offset + feature_size > F ||
-        (size_t)(nf - 1) * stride + h->dsp.fft_len > slice_samples || (slice_samples * 2) % 16 != 0)
+    if (nf < 1 || (!h->dsp.generic && nf > kws_mfcc_max_frames(h->dsp.n_filters)) || feature_size > F || sb->slice_offset + feature_size > F ||
+        (size_t)(nf - 1) * stride + std::min(h->dsp.fft_len, frame_len) > slice_samples || (!h->dsp.generic && (slice_samples * 2) % 16 != 0))
         return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples (claimed %zu) yields %d frames", slice_samples, n_claimed, nf);
     KwsDspPlan P = h->dsp;
     P.n_samples = (int)slice_samples;      // memory stride between the streams' slices
@@ -372,7 +372,7 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
     const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)ncep;
-    if (nf < 1 || feature_size > F || h->slice_offset + feature_size > F || nf > kws_mfcc_max_frames(h->dsp.n_filters)) {
+    if (nf < 1 || feature_size > F || h->slice_offset + feature_size > F || (!h->dsp.generic && nf > kws_mfcc_max_frames(h->dsp.n_filters))) {
         ei_printf("ERR: MFCC failed (%d)\n", -1002);                           // EIDSP_MATRIX_SIZE_MISMATCH
         ei_printf("ERR: Failed to run DSP process (%d)\n", -1002);
         return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples yields %d frames", n_claimed, nf);

@@ -1,0 +1,111 @@
+"""-m gpu: MFCC configurations outside the tuned kernel's instantiations (fft_length 128 / 512, overlapping frames -> 98 frames,
+clips of other lengths incl. unaligned ones, other mel filter counts, wide mel filters) run on the general kernels
+(csrc/kws_generic.hip) and are bit-identical to the oracle -- the cases of tests/test_oracle_vs_reference.py::test_mfcc_configs
+and ::test_short_clips (which hold the oracle to the compiled reference), through the HIP path instead of being refused."""
+import os
+
+import numpy as np
+import pytest
+
+from kws_testlib import L476_CONFIG, ROOT, OracleModel, bits, special_clips, synth_model_blob
+
+pytestmark = pytest.mark.gpu
+
+BLOCKS = dict(blocks=((8, 3, 7), (4, 3, 7)), n_labels=3)
+CASES = {
+    "fft512": dict(fft_length=512),                                  # zero-padded frames
+    "fft128_win51": dict(fft_length=128, win_size=51),               # truncated frames
+    "stride10ms_win31": dict(frame_stride=0.01, win_size=31),        # overlapping frames: 98 of them
+    "pre_cof0": dict(pre_cof=0.0),
+    "clip4000": dict(raw_samples=4000, blocks=((8, 3, 1), (4, 3, 1))),
+    "clip640_one_frame": dict(raw_samples=640, blocks=((8, 3, 1), (4, 3, 1))),      # 1 frame (no pooling: SAME pooling of 1-2 rows
+    "clip1000": dict(raw_samples=1000, blocks=((8, 3, 1), (4, 3, 1))),               # would need padding, which the network plan refuses)
+    "clip15999_unaligned": dict(raw_samples=15999),
+    "filters24": dict(num_filters=24, ncep=10),                      # DCT of 24 points: radix 4, 3
+    "filters64_wide": dict(num_filters=64, ncep=20, high=0),         # 64 filters
+    "filters20_0_8000": dict(num_filters=20, ncep=12, low=0, high=0),  # few, wide filters: more than 12 taps each
+    "fft1024_filters36": dict(fft_length=1024, num_filters=36, ncep=17, frame_length=0.05, frame_stride=0.025, win_size=21,
+                              blocks=((8, 3, 1), (4, 3, 1))),
+}
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_general_mfcc_kernels_bit_exact(name, pkg, oracle, tmp_path):
+    kw = dict(BLOCKS, **CASES[name])
+    blob = synth_model_blob(seed=3, **kw)
+    path = str(tmp_path / "m.kwsm")
+    open(path, "wb").write(blob)
+    om = OracleModel(oracle, path)
+    gm = pkg.Model(blob=blob)
+    n = om.raw_sample_count
+    sp = special_clips()
+    clips = np.concatenate([oracle.synth(5, 0, 70, n), np.stack([sp["impulses"][:n], sp["zeros"][:n], sp["alternating_fullscale"][:n]])])
+    s, f, q = gm.run_classifier_batch(clips, want_features=True)
+    so, fo, qo = om.run_batch(clips, want_features=True)
+    assert (bits(f) == bits(fo)).all(), name
+    assert (q == qo).all() and (bits(s) == bits(so)).all(), name
+    # the stage API: cepstra before cmvnw, then cmvnw + inference
+    import torch
+    d = torch.from_numpy(np.ascontiguousarray(clips)).to("cuda:0")
+    mf = torch.zeros((len(clips), gm.n_features), dtype=torch.float32, device="cuda:0")
+    gm.mfcc_batch_device(d.data_ptr(), len(clips), mf.data_ptr())
+    torch.cuda.synchronize()
+    cfg = om.cfg
+    want = np.stack([oracle.mfcc_nocmvn(c, cfg).reshape(-1) for c in clips[:8]])
+    assert (bits(mf[:8].cpu().numpy()) == bits(want)).all(), name
+    s2 = torch.zeros((len(clips), gm.n_labels), dtype=torch.float32, device="cuda:0")
+    gm.cmvn_inference_batch_device(mf.data_ptr(), len(clips), s2.data_ptr())
+    torch.cuda.synchronize()
+    assert (bits(s2.cpu().numpy()) == bits(so)).all(), name
+    if gm.mfcc_kernel == "kws_spectral_generic_kernel":
+        with pytest.raises(pkg.KwsError):
+            gm.set_mode(pkg.MODE_FAST)                  # the fast kernel is built for the tuned configurations only
+    else:
+        # short aligned clips and pre_cof = 0 are tuned configurations (listed because test_mfcc_configs / test_short_clips list
+        # them): the fast kernel serves them too, when it has at least two frames to normalise over
+        assert name in ("pre_cof0", "clip4000", "clip640_one_frame", "clip1000")
+        if gm.n_frames >= 2:
+            gm.set_mode(pkg.MODE_FAST)
+            _, f2, _ = gm.run_classifier_batch(clips[:70], want_features=True)
+            assert np.abs(f2 - fo[:70]).max() <= 2e-3, name
+    gm.close()
+
+
+def test_general_kernels_float_model_and_drop_in_entry_points(pkg, oracle, tmp_path):
+    """A float32 twin on a general configuration, and run_classifier() / run_classifier_continuous() through it."""
+    import ctypes
+    import subprocess
+    import sys
+    blob = synth_model_blob(seed=4, **BLOCKS, fft_length=512, frame_stride=0.01, win_size=31)
+    p8, pf = str(tmp_path / "i8.kwsm"), str(tmp_path / "f32.kwsm")
+    open(p8, "wb").write(blob)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dequantize_model.py"), p8, pf])
+    gm = pkg.Model(pf)
+    om = OracleModel(oracle, pf)
+    clips = oracle.synth(8, 0, 40)
+    s, f, _ = gm.run_classifier_batch(clips, want_features=True)
+    so, fo, _ = om.run_batch(clips, want_features=True)
+    assert (bits(f) == bits(fo)).all() and np.abs(s - so).max() <= 1e-6
+    gm.set_default()
+    res = pkg.result_struct(gm.n_labels)()
+    for ci in range(3):
+        buf = clips[ci].astype(np.float32) / np.float32(32768)
+
+        @pkg.GET_DATA_FN
+        def get_data(offset, length, out):
+            ctypes.memmove(out, buf[offset:offset + length].ctypes.data, 4 * length)
+            return 0
+        sig = pkg.Signal(get_data=get_data, total_length=16000)
+        assert pkg.lib().run_classifier(ctypes.byref(sig), ctypes.byref(res), False) == 0
+        got = np.float32([res.classification[i].value for i in range(gm.n_labels)])
+        assert np.abs(got - so[ci]).max() <= 1e-6
+    gm.close()

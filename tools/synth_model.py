@@ -20,15 +20,19 @@ import eon_import  # noqa: E402
 
 
 def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4,
-                     conv_bias=False, add_bias=True, num_filters=32):
+                     conv_bias=False, add_bias=True, num_filters=32, raw_samples=16000, fft_length=256, frame_length=0.02,
+                     frame_stride=0.02, pre_cof=0.98):
     """blocks: sequence of
          (out_channels, taps, pool)              CONV_2D 1xK (+ optional int32 bias) -> ADD(int8 per-channel)+ReLU -> MAX_POOL
          ("dw", depth_mult, taps, pool, act)     DEPTHWISE_CONV_2D 1xK with int32 bias and fused activation -> MAX_POOL
          ("pw", out_channels, act)               CONV_2D 1x1 with int32 bias and fused activation (pointwise)
        (pool 1 = no pooling node, a negative pool = VALID padding: the ragged tail of the time axis is dropped; act: TfLiteFusedActivation 0 none, 1 relu, 3 relu6).
-       Frame geometry is the shipped one (49 frames)."""
+       Frame geometry defaults to the shipped one (1 s at 16 kHz, 20 ms frames and stride: 49 frames); raw_samples / frame_length /
+       frame_stride / fft_length / pre_cof change the DSP block (the frame count follows speechpy's rule, processing.hpp:260-284)."""
     rng = np.random.default_rng(seed)
-    n_frames = 49
+    flen_s = int(round(16000 * np.float32(frame_length)))
+    n_frames = int(np.floor(np.float32(raw_samples - flen_s) / np.float32(round(16000 * np.float32(frame_stride)))))
+    assert n_frames >= 1
     F = n_frames * ncep
     tensors, nodes = [], []
 
@@ -143,10 +147,10 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
     tso = T(9, [1, n_labels], scale=[0.00390625], zero=[-128])
     node(5, [tfo], [tso], beta=1.0)
     meta = {"labels": ["label%d" % i for i in range(n_labels)],
-            "dsp": {"axes": 1, "num_cepstral": ncep, "frame_length": 0.02, "frame_stride": 0.02, "num_filters": num_filters,
-                    "fft_length": 256, "win_size": win_size, "low_frequency": low, "high_frequency": high,
-                    "pre_cof": 0.98, "pre_shift": 1},
-            "raw_sample_count": 16000, "frequency": 16000, "nn_input_frame_size": F}
+            "dsp": {"axes": 1, "num_cepstral": ncep, "frame_length": frame_length, "frame_stride": frame_stride, "num_filters": num_filters,
+                    "fft_length": fft_length, "win_size": win_size, "low_frequency": low, "high_frequency": high,
+                    "pre_cof": pre_cof, "pre_shift": 1},
+            "raw_sample_count": raw_samples, "frequency": 16000, "nn_input_frame_size": F}
     return eon_import.serialise(tensors, nodes, t_in, tso, meta)
 
 
