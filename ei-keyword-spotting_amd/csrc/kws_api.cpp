@@ -160,6 +160,13 @@ EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void 
                                         const float *wrap, hipStream_t s, int out_stride)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (h->model.dsp.block == DSP_BLOCK_MFE && !P.mfe_mel) {
+        // the MFE block's per-window stage is speechpy::feature::mfe itself (extract_mfe_per_slice_features, L432 ei_run_dsp.h:420-470)
+        if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
+        int rc = kws_launch_mfe(P, pcm, is_float, (int)B, mfcc, nullptr, wrap, out_stride, grid_cap_mfcc(h), s);
+        if (rc) return fail(KWS_ERROR_HIP, "MFE kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (h->dsp.generic) {
         EI_IMPULSE_ERROR e = ensure_generic(h, 0);
         if (e) return e;
@@ -177,6 +184,18 @@ EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void 
 EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    if (h->model.dsp.block == DSP_BLOCK_MFE) {
+        // extract_mfe_features (L432 classifier/ei_run_dsp.h:369-418): feature::mfe, cmvnw(win, false, true) + numpy::normalize, then
+        // the input quantisation of an int8 graph.  The float feature matrix is needed either way.
+        if (!features) return fail(KWS_ERROR_BAD_ARGUMENT, "the MFE block needs a float feature buffer");
+        if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
+        const KwsDspPlan &P = h->dsp;
+        int rc = kws_launch_mfe(P, pcm, is_float, (int)B, features, nullptr, nullptr, 0, grid_cap_mfcc(h), s);
+        if (!rc) rc = kws_launch_mfe_norm(features, (int)B, P.n_frames, P.n_filters, P.win_size, P.pad_map, P.n_frames + 2 * P.pad, grid_cap_nn(h), s);
+        if (!rc && q) rc = kws_launch_quantize(features, q, B * h->model.nn_input_frame_size, h->nn.in_scale, h->nn.in_zp, s);
+        if (rc) return fail(KWS_ERROR_HIP, "MFE block launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (h->dsp.generic) {
         // cepstra -> g_mfcc, then cmvnw + quantisation (the general kernels are two launches; the cepstra go through HBM)
         EI_IMPULSE_ERROR e = ensure_generic(h, B);
@@ -209,6 +228,23 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     int ran_nn = 0;
+    if (h->model.dsp.block == DSP_BLOCK_MFE) {
+        // calc_cepstral_mean_and_var_normalization_mfe on a copy of the mel matrices (L432 classifier/ei_run_classifier.h:745-775)
+        if (h->is_float && (q || tap_pooled || tap_fc || tap_out)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 outputs requested from a float32 model");
+        const KwsDspPlan &P = h->dsp;
+        const size_t F = h->model.nn_input_frame_size;
+        float *f = features ? features : h->s_mfcc;
+        int8_t *qq = h->is_float ? nullptr : (q ? q : h->s_q);
+        HIP_TRY(hipMemcpyAsync(f, mfcc, B * F * sizeof(float), hipMemcpyDeviceToDevice, s));
+        int rc = kws_launch_mfe_norm(f, (int)B, P.n_frames, P.n_filters, P.win_size, P.pad_map, P.n_frames + 2 * P.pad, grid_cap_nn(h), s);
+        if (!rc && qq) rc = kws_launch_quantize(f, qq, B * F, h->nn.in_scale, h->nn.in_zp, s);
+        if (rc) return fail(KWS_ERROR_HIP, "MFE normalisation launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (!scores) return EI_IMPULSE_OK;
+        if (h->is_float) return nn_f32_device(h, f, B, scores, nullptr, s);
+        rc = kws_launch_nn(h->nn, qq, (int)B, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out, grid_cap_nn(h), s);
+        if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (h->dsp.generic) {
         if (h->is_float && (q || tap_pooled || tap_fc || tap_out)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 outputs requested from a float32 model");
         EI_IMPULSE_ERROR e = ensure_generic(h, B);
@@ -260,7 +296,7 @@ EI_IMPULSE_ERROR kws_mfe_batch_device(kws_handle *h, const int16_t *pcm, size_t 
         return spectral_device(h, P, pcm, 0, B, nullptr, nullptr, (hipStream_t)stream);
     }
     if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
-    int rc = kws_launch_mfe(h->dsp, pcm, (int)B, mel, energy, grid_cap_mfcc(h), (hipStream_t)stream);
+    int rc = kws_launch_mfe(h->dsp, pcm, 0, (int)B, mel, energy, nullptr, 0, grid_cap_mfcc(h), (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "MFE kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
 }
@@ -280,7 +316,7 @@ EI_IMPULSE_ERROR kws_extract_mfe_batch_device(kws_handle *h, const int16_t *pcm,
     // cmvn_columns<17, 20> (more than 16 columns) walks 3 x 17 rows and needs a window of at least 17 rows; <13, 16>: 4 x 13, 13
     if (rows > (cols > 16 ? 51 : 52) || P.win_size < (cols > 16 ? 17 : 13))
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%d frames x %d filters, window %d outside the MFE normalisation kernel's limits", rows, cols, P.win_size);
-    int rc = kws_launch_mfe(P, pcm, (int)B, features, nullptr, grid_cap_mfcc(h), (hipStream_t)stream);
+    int rc = kws_launch_mfe(P, pcm, 0, (int)B, features, nullptr, nullptr, 0, grid_cap_mfcc(h), (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "MFE kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     rc = kws_launch_mfe_norm(features, (int)B, rows, cols, P.win_size, P.pad_map, rows + 2 * P.pad, grid_cap_nn(h), (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "MFE normalisation kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -422,7 +458,7 @@ static EI_IMPULSE_ERROR classify_device(kws_handle *h, const int16_t *pcm, size_
         e = mfcc_fused_device(h, pcm, 0, B, f, nullptr, s);
         return e ? e : nn_f32_device(h, f, B, scores, nullptr, s);
     }
-    e = mfcc_fused_device(h, pcm, 0, B, f, q, s);
+    e = mfcc_fused_device(h, pcm, 0, B, (f || h->model.dsp.block != DSP_BLOCK_MFE) ? f : h->s_mfcc, q, s);
     if (e) return e;
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     int rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
@@ -491,7 +527,8 @@ EI_IMPULSE_ERROR kws_run_classifier_batch(kws_handle *h, const int16_t *pcm, siz
         const size_t nb = std::min(chunk, B - off);
         he = hipMemcpyAsync(p.pcm[k], pcm + off * n, nb * n * sizeof(int16_t), hipMemcpyHostToDevice, p.st[k]);
         if (he != hipSuccess) break;
-        e = classify_device(h, p.pcm[k], nb, p.s[k], (h->is_float || features) ? p.f[k] : nullptr, h->is_float ? nullptr : p.q[k], p.st[k]);
+        e = classify_device(h, p.pcm[k], nb, p.s[k], (h->is_float || features || h->model.dsp.block == DSP_BLOCK_MFE) ? p.f[k] : nullptr,
+                            h->is_float ? nullptr : p.q[k], p.st[k]);
         if (e) break;
         he = hipMemcpyAsync(scores + off * C, p.s[k], nb * C * sizeof(float), hipMemcpyDeviceToHost, p.st[k]);
         if (he == hipSuccess && features) he = hipMemcpyAsync(features + off * F, p.f[k], nb * F * sizeof(float), hipMemcpyDeviceToHost, p.st[k]);

@@ -13,6 +13,7 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     const DspCfg &c = m.dsp;
     const KwsDspPlan &P = h->dsp;
     const int NF = c.num_filters, nfr = P.n_frames, ncep = c.num_cepstral;
+    if (c.block != DSP_BLOCK_MFCC) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode serves the MFCC block");
     if (P.generic) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode serves the configurations of the tuned MFCC kernel (fft 256, 32 / 40 filters, "
                                                             "up to 52 aligned frames); this model runs on the general kernels");
     if (c.fft_length != 256) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: fft_length %d (kernel is built for 256)", c.fft_length);

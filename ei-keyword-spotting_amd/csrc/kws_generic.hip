@@ -194,7 +194,7 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
                 acc += prod;
             }
             if (acc == 0.0f) acc = FLT_EPSILON;
-            if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f) * NF + j] = acc;
+            if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)f * NF + j] = acc;
             w_mel[(size_t)j * GL] = fast_log(acc);
         }
         if (P.mfe_mel) continue;                                   // MFE block: no log / DCT output
@@ -262,7 +262,7 @@ int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
-    if (out_stride == 0) out_stride = P.n_frames * P.n_cepstral;
+    if (out_stride == 0) out_stride = P.n_frames * (P.mfe_mel ? P.n_filters : P.n_cepstral);
     const long items = (long)n_clips * ((P.n_frames + GL - 1) / GL);
     if (items < grid) grid = (int)items;
     if (pcm_is_float)

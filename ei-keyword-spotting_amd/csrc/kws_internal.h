@@ -23,7 +23,8 @@ int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, 
                         int out_stride, int grid_cap, hipStream_t stream);
 int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream);
 int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream);
-int kws_launch_mfe(const KwsDspPlan &P, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap, hipStream_t stream);
+int kws_launch_mfe(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mel_out, float *energy_out, const float *wrap,
+                   int out_stride, int grid_cap, hipStream_t stream);
 int kws_launch_mfe_norm(float *feat, int n_clips, int rows, int cols, int win, const int *pad_map, int prow, int grid_cap, hipStream_t stream);
 int kws_launch_mfcc_fused(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *features, int8_t *q_out,
                           float in_scale, int in_zp, int grid_cap, hipStream_t stream, const int *sel = nullptr);
@@ -93,9 +94,13 @@ struct Node {
     int p[8] = { 0 };
     float beta = 0;
 };
+// which extract_fn the model's ei_dsp_blocks[] entry names (MODEL/model-parameters/dsp_blocks.h:29-36): extract_mfcc_features, or
+// extract_mfe_features of the newer SDK copy (nucleo-l432 .../classifier/ei_run_dsp.h:369-418)
+enum { DSP_BLOCK_MFCC = 0, DSP_BLOCK_MFE = 1 };
 struct DspCfg {
     int axes, num_cepstral, num_filters, fft_length, win_size, low_frequency, high_frequency, pre_shift;
     float frame_length, frame_stride, pre_cof;
+    int block = DSP_BLOCK_MFCC;
 };
 struct Model {
     std::vector<Tensor> t;

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
                     }
                     if (acc == 0.0f) acc = FLT_EPSILON;                                // functions.hpp:63-69
                     if constexpr (!WITH_CMVN)
-                        if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + t] = acc;
+                        if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)(f_base + fr) * NF + t] = acc;
                     sm_mel[(f_base + fr) * MELS + t] = fast_log(acc);
                 }
             } else {
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
                                 float a = acc[u];
                                 if (a == 0.0f) a = FLT_EPSILON;
                                 if constexpr (!WITH_CMVN)
-                                    if (P.mfe_mel) P.mfe_mel[((size_t)clip * nfr + f_base + fr) * NF + lane] = a;
+                                    if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)(f_base + fr) * NF + lane] = a;
                                 sm_mel[(f_base + fr) * MELS + lane] = fast_log(a);
                             }
                         }
@@ -564,51 +564,65 @@ constexpr int KWS_CHP = 9;
 // latency mode: 7 waves x 8 frames per window (56 >= KWS_MAXF), taken for float-sample calls of at most 16 windows
 constexpr int KWS_LAT_CHP = 4, KWS_LAT_WAVES = 7, KWS_LAT_MAX_CLIPS = 16;
 
+// One row per instantiation of the tuned kernel: the first row whose limits cover the model's DSP block is launched.  Shapes
+// outside every row run on the general kernels (kws_generic.hip; KwsDspPlan::generic is set by build_dsp_plan from the same limits).
+struct MfccLaunchArgs {
+    dim3 grid, block;
+    hipStream_t stream;
+    KwsDspPlan P;
+    const void *pcm;
+    int n_clips;
+    float *out;
+    int8_t *q_out;
+    float in_scale;
+    int in_zp;
+    const float *wrap;
+    int out_stride;
+    long long *prof;
+    const int *sel;
+};
+template <int CHP, bool F32IN, bool WITH_CMVN, int NZ, int NF, bool PROF, bool WIDE, int LW>
+static void mfcc_launch(const MfccLaunchArgs &a)
+{
+    hipLaunchKernelGGL((kws_mfcc_kernel<CHP, F32IN, WITH_CMVN, NZ, NF, PROF, WIDE, LW>), a.grid, a.block, 0, a.stream, a.P, a.pcm, a.n_clips, a.out,
+                       a.q_out, a.in_scale, a.in_zp, a.wrap, a.out_stride, a.prof, a.sel);
+}
+struct MfccVariant {
+    int n_filters, max_nz;      // mel filters; longest filter the variant keeps in registers
+    int min_cepstra;            // WIDE cmvnw layout (20 columns x 3 row groups): only worth it above 16 cepstra, needs WITH_CMVN
+    bool latency;               // one workgroup of KWS_LAT_WAVES waves per window (a handful of float-sample windows)
+    void (*launch)(const MfccLaunchArgs &);
+};
+
 template <bool F32IN, bool WITH_CMVN, bool PROF>
 static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, float *out, int8_t *q_out, float in_scale, int in_zp,
                          const float *wrap, int out_stride, int grid_cap, long long *prof, hipStream_t stream, const int *sel = nullptr)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
-    const int grid = n_clips < grid_cap ? n_clips : grid_cap;
-    if constexpr (F32IN && WITH_CMVN && !PROF) {
-        // a handful of windows (run_classifier(): one): one workgroup of KWS_LAT_WAVES waves per window instead of one wave
-        if (n_clips <= KWS_LAT_MAX_CLIPS && P.n_frames <= 2 * KWS_LAT_CHP * KWS_LAT_WAVES && (P.n_filters == 32 || P.n_filters == 40) &&
-            P.max_nz <= KWS_MAXNZ) {
-            const dim3 blk(KWS_WAVE * KWS_LAT_WAVES);
-            if (P.n_filters == 40 && P.max_nz <= 8)
-                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, 8, 40, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-            else if (P.n_filters == 40)
-                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, KWS_MAXNZ, 40, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-            else if (P.max_nz <= 4)
-                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, 4, 32, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-            else
-                hipLaunchKernelGGL((kws_mfcc_kernel<KWS_LAT_CHP, true, true, KWS_MAXNZ, 32, false, false, KWS_LAT_WAVES>), dim3(n_clips), blk, 0, stream, P,
-                                   pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-            return (int)hipGetLastError();
-        }
+    static const MfccVariant table[] = {
+        // latency shape first (float samples + cmvnw only): run_classifier() and other calls of at most KWS_LAT_MAX_CLIPS windows
+        { 40, 8, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, 8, 40, false, false, KWS_LAT_WAVES> : nullptr },
+        { 40, KWS_MAXNZ, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, KWS_MAXNZ, 40, false, false, KWS_LAT_WAVES> : nullptr },
+        { 32, 4, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, 4, 32, false, false, KWS_LAT_WAVES> : nullptr },
+        { 32, KWS_MAXNZ, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, KWS_MAXNZ, 32, false, false, KWS_LAT_WAVES> : nullptr },
+        // throughput shape: one wave per clip, persistent grid
+        { 40, 8, 17, false, WITH_CMVN ? mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, WITH_CMVN, 0> : nullptr },
+        { 40, 8, 0, false, mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, false, 0> },
+        { 40, KWS_MAXNZ, 0, false, mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 40, PROF, false, 0> },
+        { 32, 4, 0, false, mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, 4, 32, PROF, false, 0> },
+        { 32, KWS_MAXNZ, 0, false, mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 32, PROF, false, 0> },
+    };
+    const bool few = n_clips <= KWS_LAT_MAX_CLIPS && P.n_frames <= 2 * KWS_LAT_CHP * KWS_LAT_WAVES;
+    for (const MfccVariant &v : table) {
+        if (!v.launch || v.n_filters != P.n_filters || P.max_nz > v.max_nz || P.n_cepstral < v.min_cepstra || (v.latency && !few)) continue;
+        MfccLaunchArgs a = { v.latency ? dim3(n_clips) : dim3(n_clips < grid_cap ? n_clips : grid_cap),
+                             dim3(KWS_WAVE * (v.latency ? KWS_LAT_WAVES : 1)), stream, P, pcm, n_clips, out, q_out, in_scale, in_zp, wrap,
+                             out_stride, prof, sel };
+        v.launch(a);
+        return (int)hipGetLastError();
     }
-    if (P.n_filters == 40 && P.max_nz <= 8 && WITH_CMVN && P.n_cepstral > 16)
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, true>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-    else if (P.n_filters == 40 && P.max_nz <= 8)
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-    else if (P.n_filters == 40 && P.max_nz <= KWS_MAXNZ)
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 40, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-    else if (P.n_filters != 32)
-        return (int)hipErrorInvalidValue;
-    else if (P.max_nz <= 4)
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, 4, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P, pcm,
-                           n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-    else
-        hipLaunchKernelGGL((kws_mfcc_kernel<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 32, PROF>), dim3(grid), dim3(KWS_WAVE), 0, stream, P,
-                           pcm, n_clips, out, q_out, in_scale, in_zp, wrap, out_stride, prof, sel);
-    return (int)hipGetLastError();
+    return (int)hipErrorInvalidValue;         // no instantiation: build_dsp_plan routes such shapes to the general kernels
 }
 
 // extract_mfcc_features (+ quantisation) for n_clips windows in one launch
@@ -638,15 +652,16 @@ int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, 
                         : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream);
 }
 
-// speechpy::feature::mfe (feature.hpp:193-318) for n_clips windows: mel energies + frame energies
-int kws_launch_mfe(const KwsDspPlan &P0, const void *pcm, int n_clips, float *mel_out, float *energy_out, int grid_cap,
-                   hipStream_t stream)
+// speechpy::feature::mfe (feature.hpp:193-318) for n_clips windows: mel energies + frame energies.  out_stride: floats between
+// consecutive windows' mel matrices (0 = packed, n_frames * n_filters); wrap as in kws_launch_spectral.
+int kws_launch_mfe(const KwsDspPlan &P0, const void *pcm, int pcm_is_float, int n_clips, float *mel_out, float *energy_out, const float *wrap,
+                   int out_stride, int grid_cap, hipStream_t stream)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     KwsDspPlan P = P0;
     P.mfe_mel = mel_out;
     P.mfe_energy = energy_out;
-    return launch_mfcc_t<false, false, false>(P, pcm, n_clips, nullptr, nullptr, 0.f, 0, nullptr, P.n_frames * P.n_cepstral, grid_cap,
-                                              nullptr, stream);
+    if (out_stride == 0) out_stride = P.n_frames * P.n_filters;
+    return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, nullptr, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream)
+                        : launch_mfcc_t<false, false, false>(P, pcm, n_clips, nullptr, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream);
 }
-

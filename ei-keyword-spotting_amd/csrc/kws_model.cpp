@@ -65,7 +65,8 @@ bool parse_model(const void *blob, size_t nbytes, Model &m)
 {
     if (nbytes < 8 || memcmp(blob, "KWSM", 4) != 0) return false;
     Reader r{ (const uint8_t *)blob + 4, (const uint8_t *)blob + nbytes };
-    if (r.u32() != 1) return false;
+    const uint32_t version = r.u32();
+    if (version != 1 && version != 2) return false;
     uint32_t nt = r.u32(), nn = r.u32(), nl = r.u32();
     m.t_in = r.u32(); m.t_out = r.u32();
     m.raw_sample_count = r.u32(); m.frequency = r.u32(); m.nn_input_frame_size = r.u32();
@@ -73,6 +74,8 @@ bool parse_model(const void *blob, size_t nbytes, Model &m)
     d.axes = r.i32(); d.num_cepstral = r.i32(); d.num_filters = r.i32(); d.fft_length = r.i32(); d.win_size = r.i32();
     d.low_frequency = r.i32(); d.high_frequency = r.i32(); d.pre_shift = r.i32();
     d.frame_length = r.f32(); d.frame_stride = r.f32(); d.pre_cof = r.f32();
+    d.block = version == 2 ? r.i32() : DSP_BLOCK_MFCC;          // version 2: the DSP block type follows
+    if (d.block != DSP_BLOCK_MFCC && d.block != DSP_BLOCK_MFE) return false;
     if (r.bad || nt > 4096 || nn > 4096 || nl > 1024) return false;
     for (uint32_t i = 0; i < nl; i++) {
         uint32_t len = r.u32();

@@ -39,11 +39,14 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     P.fft_len = c.fft_length;
     P.n_bins = c.fft_length / 2 + 1;
     P.n_filters = c.num_filters;
-    P.n_cepstral = c.num_cepstral;
+    // columns of the feature matrix: cepstra, or -- MFE block (extract_mfe_features) -- the mel filters themselves
+    const bool mfe = c.block == DSP_BLOCK_MFE;
+    const int ncep = mfe ? c.num_filters : c.num_cepstral;
+    P.n_cepstral = ncep;
     P.win_size = c.win_size;
     P.pad = (int)(uint16_t)((c.win_size - 1) / 2);
     P.pre_shift = c.pre_shift;
-    P.pre_cof = c.pre_cof;
+    P.pre_cof = mfe ? 0.0f : c.pre_cof;        // the MFE block hands the raw signal to feature::mfe (L432 ei_run_dsp.h:398-400)
     P.inv_fft = (float)(1.0 / (double)(float)c.fft_length);
     const int N = c.num_filters;
     P.dct_s0 = sqrtf(1.0f / (float)(4 * N));
@@ -54,10 +57,10 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     if (c.axes != 1) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC block with %d axes", c.axes);
     const int used = std::min(frame_len, c.fft_length);
     if (c.fft_length < 4 || (c.fft_length & 1) || N < 2 || (N & 1) || N > 128 || c.pre_shift != 1 || (c.win_size & 1) == 0 || c.win_size < 1 ||
-        nfr < 1 || stride < 1 || c.num_cepstral < 1 || c.num_cepstral > N || (long)(nfr - 1) * stride + used > (long)P.n_samples ||
-        (size_t)nfr * c.num_cepstral != m.nn_input_frame_size)
+        nfr < 1 || stride < 1 || ncep < 1 || ncep > N || (long)(nfr - 1) * stride + used > (long)P.n_samples ||
+        (size_t)nfr * ncep != m.nn_input_frame_size)
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFCC configuration outside the kernels (fft %d, filters %d, frames %d, frame_len %d, stride %d, "
-                    "cepstra %d, win %d, shift %d)", c.fft_length, N, nfr, frame_len, stride, c.num_cepstral, c.win_size, c.pre_shift);
+                    "cepstra %d, win %d, shift %d)", c.fft_length, N, nfr, frame_len, stride, ncep, c.win_size, c.pre_shift);
     auto factor = [](int n, int *fac) {                         // kf_factor: 4s, then 2s, then 3, 5, 7 ...; returns levels or -1
         int p = 4, levels = 0;
         const double floor_sqrt = floor(sqrt((double)n));
@@ -79,9 +82,12 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fft_length %d / %d filters need a radix other than 2, 3, 4, 5", c.fft_length, N);
     const bool tuned = c.fft_length == 256 && (N == 32 || N == 40) && frame_len >= c.fft_length && nfr <= kws_mfcc_max_frames(N) &&
                        (stride * 2) % 16 == 0 && (P.n_samples * 2) % 16 == 0 && nfr + 2 * P.pad <= kws_mfcc_max_prow() &&
-                       c.win_size <= kws_mfcc_max_win(c.num_cepstral) && nfr <= kws_mfcc_max_frames_for(N, c.num_cepstral) &&
-                       c.win_size >= ((N == 40 && c.num_cepstral > 16) ? 17 : 13) && nfr <= 4 * kws_mfcc_cmvn_rows();
+                       c.win_size <= kws_mfcc_max_win(ncep) && nfr <= kws_mfcc_max_frames_for(N, ncep) &&
+                       c.win_size >= ((N == 40 && ncep > 16) ? 17 : 13) && nfr <= 4 * kws_mfcc_cmvn_rows();
     P.generic = tuned ? 0 : 1;
+    if (mfe && (!tuned || nfr > (N > 16 ? 51 : 52) || c.win_size < (N > 16 ? 17 : 13)))
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFE block: %d frames x %d filters, window %d outside the normalisation kernel's limits (tuned "
+                    "configurations only)", nfr, N, c.win_size);
 
     std::vector<float2> tw, stw, dtw, dstw;
     h_twiddles(c.fft_length / 2, tw);

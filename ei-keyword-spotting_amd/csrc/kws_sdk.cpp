@@ -79,7 +79,7 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
     if (grown) n_claimed += (size_t)(m.dsp.frame_length * (float)m.frequency);
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
-    const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)m.dsp.num_cepstral;
+    const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)h->dsp.n_cepstral;
     if (nf < 1 || (!h->dsp.generic && nf > kws_mfcc_max_frames(h->dsp.n_filters)) || feature_size > F || sb->slice_offset + feature_size > F ||
         (size_t)(nf - 1) * stride + std::min(h->dsp.fft_len, frame_len) > slice_samples || (!h->dsp.generic && (slice_samples * 2) % 16 != 0))
         return fail(EI_IMPULSE_DSP_ERROR, "slice of %zu samples (claimed %zu) yields %d frames", slice_samples, n_claimed, nf);
@@ -358,7 +358,7 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);                               // the reference is non-reentrant: callers are serialised
     const Model &m = h->model;
     const size_t F = m.nn_input_frame_size, C = m.labels.size();
-    const int ncep = m.dsp.num_cepstral;
+    const int ncep = h->dsp.n_cepstral;         // columns of the feature matrix (mel filters for an MFE block)
     if (h->cont_features.size() != F) h->cont_features.assign(F, 0.0f);         // static_features_matrix (calloc'd)
     HIP_TRY(hipSetDevice(h->device));
     uint64_t dsp_start_ms = ei_read_timer_ms();

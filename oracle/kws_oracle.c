@@ -751,6 +751,7 @@ struct kwso_model {
     uint32_t n_tensors, n_nodes, n_labels, t_in, t_out;
     uint32_t raw_sample_count, frequency, nn_input_frame_size;
     kwso_mfcc_config dsp;
+    int dsp_block;                    /* 0: extract_mfcc_features, 1: extract_mfe_features (L432 SDK copy) */
     char **labels;
     o_tensor *t;
     o_node *n;
@@ -777,7 +778,8 @@ kwso_model *kwso_model_load(const void *blob, size_t nbytes)
     rd r = { (const uint8_t *)blob, (const uint8_t *)blob + nbytes, 0 };
     if (nbytes < 8 || memcmp(blob, "KWSM", 4) != 0) return NULL;
     r.p += 4;
-    if (rd_u32(&r) != 1) return NULL;
+    const uint32_t version = rd_u32(&r);
+    if (version != 1 && version != 2) return NULL;
     kwso_model *m = (kwso_model *)calloc(1, sizeof(*m));
     if (!m) return NULL;
     m->n_tensors = rd_u32(&r); m->n_nodes = rd_u32(&r); m->n_labels = rd_u32(&r);
@@ -788,6 +790,7 @@ kwso_model *kwso_model_load(const void *blob, size_t nbytes)
     m->dsp.win_size = rd_i32(&r); m->dsp.low_frequency = rd_i32(&r); m->dsp.high_frequency = rd_i32(&r);
     m->dsp.pre_shift = rd_i32(&r);
     m->dsp.frame_length = rd_f32(&r); m->dsp.frame_stride = rd_f32(&r); m->dsp.pre_cof = rd_f32(&r);
+    m->dsp_block = version == 2 ? rd_i32(&r) : 0;     /* 0: extract_mfcc_features, 1: extract_mfe_features (L432 SDK copy) */
     m->dsp.sampling_frequency = (int)m->frequency;
     if (r.bad || m->n_tensors > 4096 || m->n_nodes > 4096 || m->n_labels > 1024) { kwso_model_free(m); return NULL; }
     m->labels = (char **)calloc(m->n_labels ? m->n_labels : 1, sizeof(char *));
@@ -837,6 +840,9 @@ kwso_model *kwso_model_load(const void *blob, size_t nbytes)
 }
 
 int kwso_model_label_count(const kwso_model *m) { return (int)m->n_labels; }
+int kwso_model_dsp_block(const kwso_model *m) { return m->dsp_block; }
+/* columns of the feature matrix: cepstra (MFCC block) or mel filters (MFE block) */
+static int feature_cols(const kwso_model *m) { return m->dsp_block == 1 ? m->dsp.num_filters : m->dsp.num_cepstral; }
 const char *kwso_model_label(const kwso_model *m, int i) { return m->labels[i]; }
 int kwso_model_feature_count(const kwso_model *m) { return (int)m->nn_input_frame_size; }
 int kwso_model_raw_sample_count(const kwso_model *m) { return (int)m->raw_sample_count; }
@@ -1429,9 +1435,14 @@ int kwso_run_classifier_batch(const kwso_model *m, const int16_t *pcm, size_t n,
     int rc = 0;
     for (size_t b = 0; b < B && rc == 0; b++) {
         const int nf = kwso_num_frames(n, &m->dsp);
-        if (nf < 1 || (size_t)nf * (size_t)m->dsp.num_cepstral > F) { rc = -5; break; }
+        if (nf < 1 || (size_t)nf * (size_t)feature_cols(m) > F) { rc = -5; break; }
         memset(feat, 0, sizeof(float) * F);
-        rc = kwso_extract_mfcc(pcm + b * n, n, &m->dsp, feat);
+        if (m->dsp_block == 1) {
+            kwso_mfcc_config c = m->dsp;
+            c.pre_cof = 0.0f;                  /* extract_mfe_features hands the raw signal to feature::mfe (L432 ei_run_dsp.h:398-400) */
+            rc = kwso_extract_mfe(pcm + b * n, n, &c, feat);
+        } else
+            rc = kwso_extract_mfcc(pcm + b * n, n, &m->dsp, feat);
         if (rc) { rc = -5; break; }   /* EI_IMPULSE_DSP_ERROR */
         if (kwso_model_is_float(m)) {
             memset(q, 0, F);
@@ -1519,13 +1530,23 @@ int kwso_continuous_step(kwso_continuous *s, const int16_t *slice, size_t n, con
     s->first_run = 1;
     const int nf = kwso_num_frames(n_claimed, c);
     if (nf < 1) return -5;
-    const size_t feature_size = (size_t)nf * (size_t)c->num_cepstral;
+    const size_t feature_size = (size_t)nf * (size_t)feature_cols(m);
     if (feature_size > F) return -5;                 /* EIDSP_MATRIX_SIZE_MISMATCH */
     if (s->slice_offset + feature_size > F) return -5;
     float eos0 = 0.0f;
     const float *eos = end_of_signal;
     if (!eos && n_claimed != n) eos = &eos0;         /* the reference's calloc'd buffer when get_data refused */
-    int rc = mfcc_ex(slice, n, n_claimed, c, s->features + s->slice_offset, eos);
+    int rc;
+    if (m->dsp_block == 1) {
+        /* extract_mfe_per_slice_features (L432 classifier/ei_run_dsp.h:420-470): feature::mfe of the slice, nothing else */
+        kwso_mfcc_config cm = *c;
+        cm.pre_cof = 0.0f;
+        float *en = (float *)malloc(sizeof(float) * (size_t)nf);
+        if (!en) return -8;
+        rc = mfe_ex(slice, n, n_claimed, &cm, s->features + s->slice_offset, en, eos);
+        free(en);
+    } else
+        rc = mfcc_ex(slice, n, n_claimed, c, s->features + s->slice_offset, eos);
     if (rc) return -5;
     if (!s->feature_buffer_full) {
         s->slice_offset += feature_size;
@@ -1538,7 +1559,10 @@ int kwso_continuous_step(kwso_continuous *s, const int16_t *slice, size_t n, con
         float *cm = (float *)malloc(sizeof(float) * F);
         if (!cm) return -8;
         memcpy(cm, s->features, sizeof(float) * F);
-        rc = kwso_cmvnw(cm, (int)(F / (size_t)c->num_cepstral), c->num_cepstral, c->win_size, 1);
+        if (m->dsp_block == 1)      /* calc_cepstral_mean_and_var_normalization_mfe (L432 classifier/ei_run_classifier.h:745-775) */
+            rc = kwso_cmvnw_scale(cm, (int)(F / (size_t)c->num_filters), c->num_filters, c->win_size, 0, 1);
+        else
+            rc = kwso_cmvnw(cm, (int)(F / (size_t)c->num_cepstral), c->num_cepstral, c->win_size, 1);
         if (rc == 0) rc = kwso_run_inference(m, cm, scores);
         free(cm);
         if (rc) return rc;

@@ -83,6 +83,7 @@ typedef struct kwso_model kwso_model;
 kwso_model *kwso_model_load(const void *blob, size_t nbytes);
 void        kwso_model_free(kwso_model *m);
 int         kwso_model_label_count(const kwso_model *m);
+int         kwso_model_dsp_block(const kwso_model *m);   /* 0: MFCC block, 1: MFE block (L432 SDK copy) */
 const char *kwso_model_label(const kwso_model *m, int i);
 int         kwso_model_feature_count(const kwso_model *m);
 int         kwso_model_raw_sample_count(const kwso_model *m);

@@ -352,9 +352,10 @@ int eiref_graph_run(const uint8_t *blob, size_t nbytes, const void *input, size_
     using namespace graphrun;
     if (nbytes < 8 || memcmp(blob, "KWSM", 4) != 0) return -1;
     Rd r{ blob + 4, blob + nbytes, false };
-    if (r.u32() != 1) return -1;
+    const uint32_t version = r.u32();
+    if (version != 1 && version != 2) return -1;
     const uint32_t nt = r.u32(), nn = r.u32(), nl = r.u32(), t_in = r.u32(), t_out = r.u32();
-    for (int i = 0; i < 3 + 8 + 3; i++) r.u32();                      /* sizes + dsp block: not needed here */
+    for (int i = 0; i < 3 + 8 + 3 + (version == 2 ? 1 : 0); i++) r.u32();   /* sizes + dsp block: not needed here */
     for (uint32_t i = 0; i < nl; i++) { uint32_t len = r.u32(); r.bytes(len); }
     if (r.bad || nt > 4096 || nn > 4096 || t_in >= nt || t_out >= nt) return -1;
     allocs.clear(); scratch.clear();

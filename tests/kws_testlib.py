@@ -84,7 +84,7 @@ class Oracle:
         L.kwso_model_load.restype = C.c_void_p
         L.kwso_model_load.argtypes = [C.c_void_p, C.c_size_t]
         L.kwso_model_free.argtypes = [C.c_void_p]
-        for f in ("label_count", "feature_count", "raw_sample_count", "tensor_count"):
+        for f in ("label_count", "feature_count", "raw_sample_count", "tensor_count", "dsp_block"):
             getattr(L, "kwso_model_" + f).argtypes = [C.c_void_p]
         L.kwso_model_label.restype = C.c_char_p
         L.kwso_model_label.argtypes = [C.c_void_p, C.c_int]

@@ -253,3 +253,45 @@ def test_fast_mode_random_mfcc_configurations(pkg, oracle):
         n_ok += 1
     print("\nfast mode over %d random MFCC configurations (%d outside the fast kernel): max |feature - oracle| = %.3g" % (n_ok, n_refused, worst))
     assert n_ok >= 25, (n_ok, n_refused)
+
+
+@pytest.mark.parametrize("name,mode", [("cfg5_dscnn_mfcc40_int8.kwsm", "exact"), ("cfg5_dscnn_mfcc40_f32.kwsm", "exact"),
+                                       ("cfg5_dscnn_mfcc40_int8.kwsm", "fast"), ("cfg2_mfcc40_f32.kwsm", "fast")])
+def test_full_size_properties_other_workloads(name, mode, pkg, oracle):
+    """BASELINE configs[4]'s model (49x40 MFCC + 7-block depthwise-separable CNN, 12 labels) and the fast mode of the headline
+    graph at the full 65 536 clips: (a) permuting the batch permutes the scores bit for bit, (b) duplicated clips give identical
+    rows, (c) a strided sample of rows equals the oracle (exact mode: int8 bit for bit, float within 1e-6; fast mode: within 1e-4 /
+    the int8 network exact on the GPU's own tensor), (d) rows are softmaxes."""
+    import torch
+    path = os.path.join(MODELS, name)
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    gm.set_mode(pkg.MODE_FAST if mode == "fast" else pkg.MODE_EXACT)
+    B, C = 65536, gm.n_labels
+    pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
+    pcm[1::4096] = pcm[0::4096]
+    scores = torch.empty((B, C), dtype=torch.float32, device="cuda:0")
+    gm.run_classifier_batch_device(pcm.data_ptr(), B, scores.data_ptr())
+    torch.cuda.synchronize()
+    s = scores.cpu().numpy()
+    assert (s[1::4096] == s[0::4096]).all()                                                  # (b)
+    perm = torch.randperm(B, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))
+    pcm2 = pcm[perm].contiguous()
+    scores2 = torch.empty_like(scores)
+    gm.run_classifier_batch_device(pcm2.data_ptr(), B, scores2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(scores2, scores[perm])                                                # (a)
+    idx = np.arange(5, B, 2731)
+    host = pcm[torch.from_numpy(idx).cuda()].cpu().numpy()
+    so = om.run_batch(host)
+    if gm.is_float:
+        assert np.abs(s[idx] - so).max() <= (FAST_SCORE_TOL if mode == "fast" else EXACT_SCORE_TOL)      # (c)
+        assert (np.abs(s.sum(1) - 1.0) <= 1e-5).all()                                        # (d)
+    elif mode == "exact":
+        assert (bits(s[idx]) == bits(so)).all()
+    else:
+        assert (s[idx] != so).any(axis=1).mean() <= 0.05                                     # a few clips: an input value on a rounding boundary
+    if not gm.is_float:
+        assert (np.abs(s * 256 - np.round(s * 256)) == 0).all() and (np.abs(s.sum(1) - 1.0) <= 8 / 256).all()
+    gm.close()

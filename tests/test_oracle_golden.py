@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from kws_testlib import GOLDEN, L476_CONFIG, bits, special_clips
+from kws_testlib import GOLDEN, L476_CONFIG, ROOT, bits, special_clips
 
 
 def _load(name):
@@ -232,3 +232,30 @@ def test_synthetic_graph_goldens(oracle, tmp_path):
                     o, taps = om.nn_invoke_f32(xf[k], taps=True)
                     assert (bits(taps[n_t - 2]) == bits(g[name + "_f32_logits"][k])).all(), (name, k)
                     assert np.abs(o - g[name + "_f32_scores"][k]).max() <= 1e-7
+
+
+def test_mfe_model_golden(oracle, tmp_path):
+    """A model whose DSP block is MFE (blob version 2), one-shot and in continuous mode, against vectors composed from the
+    reference's own leaves (tools/make_golden.py mfe_model: feature::mfe of the L476 build, cmvnw + normalize of the L432
+    headers, the graph through the reference's op registrations)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_golden import MFE_MODEL_KW
+    from kws_testlib import OracleContinuous, OracleModel, synth_model_blob
+    g = np.load(os.path.join(GOLDEN, "mfe_model_l432.npz"))
+    path = str(tmp_path / "mfe.kwsm")
+    open(path, "wb").write(synth_model_blob(**MFE_MODEL_KW))
+    om = OracleModel(oracle, path)
+    assert oracle.L.kwso_model_dsp_block(om.h) == 1 and om.n_features == 49 * 32
+    sp = special_clips()
+    clips = np.concatenate([oracle.synth(int(g["seed"]), int(g["first"]), int(g["n"])), np.stack([sp[str(k)] for k in g["special_names"]])])
+    s, f, q = om.run_batch(clips, want_features=True)
+    assert (bits(f) == bits(g["features"])).all() and (q == g["q"]).all() and (bits(s) == bits(g["scores"])).all()
+    audio = oracle.synth(int(g["cont_audio_seed"]), 0, 3).reshape(-1)
+    oc = OracleContinuous(om)
+    oc.init()
+    for k in range(len(g["cont_produced"])):
+        rc, produced, sc = oc.step(audio[k * 4000:(k + 1) * 4000])
+        assert rc == 0 and produced == bool(g["cont_produced"][k]), k
+        if produced:
+            assert (bits(sc) == bits(g["cont_scores"][k])).all(), k

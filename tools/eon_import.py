@@ -11,7 +11,7 @@ test oracle (kwso_model_load) understand.  Only *data* is extracted (tensor shap
 parameters, weight bytes, op parameters, labels, DSP settings) -- no reference code.
 
 Blob layout (all little endian, 4-byte aligned):
-  char  magic[4] = "KWSM"; u32 version = 1
+  char  magic[4] = "KWSM"; u32 version = 1 (MFCC block) | 2 (one more i32 behind pre_cof: DSP block type, 0 = MFCC, 1 = MFE)
   u32 n_tensors, n_nodes, n_labels, input_tensor, output_tensor
   u32 raw_sample_count, sampling_frequency, nn_input_frame_size
   dsp : i32 axes, num_cepstral, num_filters, fft_length, win_size, low_frequency, high_frequency, pre_shift
@@ -130,12 +130,15 @@ def _pad4(b):
 
 def serialise(tensors, nodes, t_in, t_out, meta):
     d = meta["dsp"]
-    out = [b"KWSM", struct.pack("<I", 1),
+    block = int(d.get("block", 0))             # 0: MFCC (extract_mfcc_features), 1: MFE (extract_mfe_features, the newer SDK copy)
+    out = [b"KWSM", struct.pack("<I", 2 if block else 1),
            struct.pack("<5I", len(tensors), len(nodes), len(meta["labels"]), t_in, t_out),
            struct.pack("<3I", meta["raw_sample_count"], meta["frequency"], meta["nn_input_frame_size"]),
            struct.pack("<8i3f", d["axes"], d["num_cepstral"], d["num_filters"], d["fft_length"], d["win_size"],
                        d["low_frequency"], d["high_frequency"], d["pre_shift"],
                        d["frame_length"], d["frame_stride"], d["pre_cof"])]
+    if block:
+        out.append(struct.pack("<i", block))
     for lab in meta["labels"]:
         b = lab.encode()
         out += [struct.pack("<I", len(b)), _pad4(b)]
@@ -167,12 +170,13 @@ def parse_blob(blob):
         return v
 
     (version,) = rd("I")
-    assert version == 1
+    assert version in (1, 2)
     nt, nn, nl, t_in, t_out = rd("5I")
     raw, freq, nnin = rd("3I")
     d = rd("8i3f")
     dsp = dict(zip(("axes", "num_cepstral", "num_filters", "fft_length", "win_size", "low_frequency", "high_frequency",
                     "pre_shift", "frame_length", "frame_stride", "pre_cof"), d))
+    dsp["block"] = rd("i")[0] if version == 2 else 0
     labels = []
     for _ in range(nl):
         (ln,) = rd("I")

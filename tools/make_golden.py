@@ -58,6 +58,80 @@ def mfe_block(ref, synth, cfg):
     print("mfe_block_l432.npz", os.path.getsize(os.path.join(GOLDEN, "mfe_block_l432.npz")), "bytes")
 
 
+MFE_MODEL_KW = dict(seed=77, blocks=((8, 3, 7), (4, 3, 7)), n_labels=3, dsp_block="mfe")     # 32 filters, 300-4000 Hz, cmvnw window 101
+
+
+def mfe_model(ref, synth, cfg):
+    """A model whose DSP block is MFE (synthetic graph: the reference ships none), composed from the reference's own leaves:
+    one-shot = extract_mfe_features (feature::mfe of the L476 build on the raw signal, cmvnw(win, false, true) + normalize of the
+    L432 headers) -> input quantisation -> the graph through the reference's op registrations; continuous = run_classifier_continuous
+    of the L432 copy (classifier/ei_run_classifier.h:185-296): per slice feature::mfe only (extract_mfe_per_slice_features; every
+    slice but the first claims one more frame length), rolling buffer, normalisation of a COPY of the full buffer, network,
+    2-tap moving average."""
+    from kws_testlib import OracleModel, ReferenceL432Dsp, synth_model_blob
+    r432 = ReferenceL432Dsp()
+    blob = synth_model_blob(**MFE_MODEL_KW)
+    tmp = os.path.join(GOLDEN, "_mfe_model_tmp.kwsm")
+    open(tmp, "wb").write(blob)
+    om = OracleModel(synth, tmp)                       # only for the input quantisation / output dequantisation leaves
+    os.remove(tmp)
+    c = cfg.copy(pre_cof=0.0)
+    NF, F = c.num_filters, 49 * c.num_filters
+
+    def infer(features):
+        q = om.quantize_input(features)
+        out, _ = ref.graph_run(blob, q)
+        return q, om.dequantize(out)
+    sp = special_clips()
+    clips = np.concatenate([synth.synth(9, 100, 10), np.stack([sp[k] for k in sorted(sp) if k != "zeros"])])
+    feats, qs, scores = [], [], []
+    for x in clips:
+        mel, _ = ref.mfe(x, c)
+        f = r432.cmvnw(mel, c.win_size, False, True).reshape(-1)
+        q, s = infer(f)
+        feats.append(f); qs.append(q); scores.append(s)
+    out = {"seed": np.int32(9), "first": np.int32(100), "n": np.int32(10), "special_names": np.array([k for k in sorted(sp) if k != "zeros"]),
+           "features": np.stack(feats), "q": np.stack(qs), "scores": np.stack(scores)}
+    # continuous mode: 3 s of audio = 12 slices
+    audio = synth.synth(14, 0, 3).reshape(-1)
+    buf = np.zeros(F, np.float32)
+    slice_offset, full, first_run = 0, False, False
+    maf = [dict(idx=0, run=np.float32(0), buf=np.zeros(2, np.float32)) for _ in range(om.n_labels)]
+    prod, sc = [], []
+    flen = 320
+    for k in range(12):
+        sl = audio[k * 4000:(k + 1) * 4000]
+        claimed = 4000 + (flen if first_run else 0)
+        first_run = True
+        padded = np.concatenate([sl, np.zeros(claimed - 4000, np.int16)])       # the frame count comes from the claimed length; no frame reads beyond the slice
+        mel, _ = ref.mfe(padded, c)
+        fsz = mel.size
+        assert (mel.shape[0] - 1) * 320 + 320 <= 4000
+        buf[slice_offset:slice_offset + fsz] = mel.reshape(-1)
+        if not full:
+            slice_offset += fsz
+            if slice_offset > F - fsz:
+                full = True
+                slice_offset -= fsz
+        s = np.zeros(om.n_labels, np.float32)
+        if full:
+            _, s = infer(r432.cmvnw(buf.copy().reshape(49, NF), c.win_size, False, True).reshape(-1))
+            for i in range(om.n_labels):                                          # run_moving_average_filter
+                m = maf[i]
+                m["run"] = np.float32(m["run"] - m["buf"][m["idx"]])
+                m["run"] = np.float32(m["run"] + s[i])
+                m["buf"][m["idx"]] = s[i]
+                m["idx"] = (m["idx"] + 1) % 2
+                s[i] = np.float32(m["run"] / np.float32(2))
+            buf[:F - fsz] = buf[fsz:].copy()
+        prod.append(full); sc.append(s)
+    out["cont_audio_seed"] = np.int32(14)
+    out["cont_produced"] = np.array(prod)
+    out["cont_scores"] = np.stack(sc)
+    np.savez_compressed(os.path.join(GOLDEN, "mfe_model_l432.npz"), **out)
+    print("mfe_model_l432.npz", os.path.getsize(os.path.join(GOLDEN, "mfe_model_l432.npz")), "bytes")
+
+
 def graphs(ref):
     """Synthetic graphs (kws_testlib.SYNTH_SPECS; int8 and float32 twins) evaluated by the reference's own TFLite-Micro
     op registrations (eiref_graph_run): inputs are regenerated in the tests from the seed, outputs are stored."""
@@ -92,6 +166,8 @@ def main():
         return mfcc40(ref, Oracle(), L476_CONFIG())
     if "--only-mfe-block" in sys.argv:
         return mfe_block(ref, Oracle(), L476_CONFIG())
+    if "--only-mfe-model" in sys.argv:
+        return mfe_model(ref, Oracle(), L476_CONFIG())
     if "--only-graphs" in sys.argv:
         return graphs(ref)
     synth = Oracle()          # only used for kwso_synth_fill (shared integer generator)
@@ -210,6 +286,7 @@ def main():
     f32["logits"], f32["scores"] = np.stack(lg), np.stack(sc)
     np.savez_compressed(os.path.join(GOLDEN, "f32_twin_l476.npz"), **f32)
     mfcc40(ref, synth, cfg)
+    mfe_model(ref, synth, cfg)
     graphs(ref)
     for fn in ("leaves_l476.npz", "e2e_l476.npz", "deep_l476.npz", "continuous_l476.npz", "f32_twin_l476.npz"):
         print(fn, os.path.getsize(os.path.join(GOLDEN, fn)), "bytes")

@@ -9,7 +9,9 @@ kws_synth_kernel, which writes exactly batch * 32000 bytes.
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
 
 
@@ -28,7 +30,9 @@ def main():
     fetch, write, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     model = sys.argv[5] if len(sys.argv) > 5 else "cfg2_mfcc40_f32.kwsm"
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-    res = {"command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ei-keyword-spotting_amd", "libkws_mi355x.so")
+    res = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+           "command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
                       "--no-cpu-baseline --no-also  (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
            "batch": batch, "model": model, "unit": "bytes per launch",
            "correction": "counter values are KiB; FETCH_SIZE doubled (gfx950, 16-byte/lane coalesced streaming reads); "
@@ -40,6 +44,23 @@ def main():
         rd, wr = int(f.get(k, 0.0) * 1024 * 2), int(w.get(k, 0.0) * 1024)
         res["kernels"][k] = {"FETCH_SIZE_KiB_avg": f.get(k, 0.0), "WRITE_SIZE_KiB_avg": w.get(k, 0.0),
                              "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic_bytes": rd + wr}
+    # SQ counters of the same library, if tools/pmc_sets.sh wrote a summary next to the output
+    sq = os.path.join(os.path.dirname(os.path.abspath(out)), "summary.json")
+    if os.path.exists(sq):
+        res["sq"] = {}
+        for name, cs in json.load(open(sq)).items():
+            short = name.split("<")[0].strip()
+            if "SQ_INSTS_VALU" in cs and "SQ_WAVE_CYCLES" in cs:
+                res["sq"][short] = {"VALU_instructions_per_clip": round(cs["SQ_INSTS_VALU"] / batch, 1),
+                                    "MFMA_instructions_per_clip": round(cs.get("SQ_INSTS_MFMA", 0.0) / batch, 1),
+                                    "LDS_instructions_per_clip": round(cs.get("SQ_INSTS_LDS", 0.0) / batch, 1),
+                                    "SALU_instructions_per_clip": round(cs.get("SQ_INSTS_SALU", 0.0) / batch, 1),
+                                    "VALU_active_share_of_wave_cycles": round(cs.get("SQ_ACTIVE_INST_VALU", 0.0) / cs["SQ_WAVE_CYCLES"], 4),
+                                    "wait_share_of_wave_cycles": round(cs.get("SQ_WAIT_ANY", 0.0) / cs["SQ_WAVE_CYCLES"], 4),
+                                    "issue_stall_share_of_wave_cycles": round(cs.get("SQ_WAIT_INST_ANY", 0.0) / cs["SQ_WAVE_CYCLES"], 4),
+                                    "MFMA_busy_cycles_per_clip": round(cs.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / batch, 1),
+                                    "LDS_bank_conflict_share": round(cs.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, cs.get("SQ_LDS_IDX_ACTIVE", 1.0)), 4),
+                                    "source": "rocprofv3 --pmc, one pass per counter set (tools/pmc_sets.sh)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["kernels"], indent=1))
 
