@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
     "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count",
     "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_allgather_scores", "kws_comm_destroy",
-    "kws_synth_clips_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
+    "kws_synth_clips_device", "kws_mix_audio_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
 
@@ -115,6 +115,7 @@ def lib():
         L.kws_mfe_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.kws_extract_mfe_batch_device.argtypes = [vp, vp, sz, vp, vp]
         L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
+        L.kws_mix_audio_device.argtypes = [vp, vp, sz, vp, sz, vp, C.c_float, C.c_float, sz, sz, vp, vp]
         L.kws_streams_create.argtypes = [vp, sz, C.POINTER(vp)]
         L.kws_streams_destroy.argtypes = [vp]
         L.kws_streams_init.argtypes = [vp]
@@ -314,6 +315,11 @@ class Comm:
         if getattr(self, "c", None):
             self.L.kws_comm_destroy(self.c)
             self.c = None
+
+
+def mix_audio_device(words_ptr, word_len_ptr, word_stride, noise_ptr, noise_len, start_ptr, word_vol, bg_vol, n_clips, n, out_ptr, stream=None):
+    _check(lib().kws_mix_audio_device(words_ptr, word_len_ptr, word_stride, noise_ptr, noise_len, start_ptr, word_vol, bg_vol, n_clips, n,
+                                      out_ptr, stream))
 
 
 def synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream=None):

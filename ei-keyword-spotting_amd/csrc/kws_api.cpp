@@ -566,6 +566,18 @@ EI_IMPULSE_ERROR kws_nn_batch(kws_handle *h, const int8_t *q_in, size_t B, float
     return e;
 }
 
+EI_IMPULSE_ERROR kws_mix_audio_device(const float *words, const int *word_len, size_t word_stride, const float *noise, size_t noise_len,
+                                      const int *start, float word_vol, float bg_vol, size_t n_clips, size_t n, int16_t *out, void *stream)
+{
+    if (!out || (words && !word_len) || (noise && !start) || n == 0 || n > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_mix_audio_device: bad argument");
+    if (noise && noise_len < n) return fail(KWS_ERROR_BAD_ARGUMENT, "background track shorter than a clip");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(KWS_ERROR_HIP, "no HIP device available (libkws_mi355x has no CPU fallback)");
+    int rc = kws_launch_mix_audio(words, word_len, word_stride, noise, start, word_vol, bg_vol, (int)n, n_clips, out, (hipStream_t)stream);
+    if (rc) return fail(KWS_ERROR_HIP, "mix kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
+}
+
 EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, void *stream)
 {
     if (!out) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");

@@ -43,6 +43,8 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
                     int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream);
 int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream);
+int kws_launch_mix_audio(const float *words, const int *word_len, size_t word_stride, const float *noise, const int *start, float word_vol,
+                         float bg_vol, int n, size_t n_clips, int16_t *out, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
 // kws_generic.hip: the exact MFCC block for configurations outside the tuned kernel (KwsDspPlan::generic)
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid);

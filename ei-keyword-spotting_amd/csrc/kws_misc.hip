@@ -154,3 +154,46 @@ int kws_launch_mfe_norm(float *feat, int n_clips, int rows, int cols, int win, c
     hipLaunchKernelGGL(kws_mfe_norm_kernel, dim3(grid), dim3(KWS_WAVE * KWS_MFE_NORM_WAVES), 0, stream, feat, n_clips, rows, cols, win, pad_map, prow);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+//  mix_audio (/root/reference/dataset-curation.py:93-137), batched: one thread per output sample.
+//    word  : float32 waveform as librosa.load(sr = 16 kHz, mono) would return it, word_len[b] samples at words + b * word_stride;
+//            padded with zeros / truncated to n samples (lines 114-120); words == NULL: the "just background noise" case (107-109)
+//    noise : float32 background track; the clip takes noise[start[b] .. start[b] + n) (the reference draws start with Python's
+//            random.randint(0, len - n): the caller supplies it); noise == NULL: the word alone (123-124)
+//    out   = 0.5 * word_vol * word (a Python float product: double)  +  0.5 * bg_vol * noise (NumPy scalar * float32 array: float32)
+//            summed in double (list + ndarray), lines 134-135; then PCM16 as sf.write(..., subtype = "PCM_16") stores doubles:
+//            lrint(x * 32767), here saturated to the int16 range.
+//  PARITY UNPINNED: librosa / soundfile are not available where this was written, so neither the resampling (excluded: inputs are
+//  already 16 kHz mono) nor the PCM16 conversion rule could be checked against the reference; tests hold the kernel to the
+//  restatement in oracle/kws_oracle.c only.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void kws_mix_audio_kernel(const float *__restrict__ words, const int *__restrict__ word_len, size_t word_stride,
+                                     const float *__restrict__ noise, const int *__restrict__ start, float word_vol, float bg_vol, int n,
+                                     size_t total, int16_t *__restrict__ out)
+{
+    const float bgs = (float)(0.5 * (double)bg_vol);            // the scalar 0.5 * bg_vol, cast to the array's dtype
+    const double ws = 0.5 * (double)word_vol;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / (size_t)n;
+        const int i = (int)(e - b * (size_t)n);
+        double w = 0.0;
+        if (words && i < word_len[b]) w = (double)words[b * word_stride + i];
+        double x = noise ? ws * w + (double)(bgs * noise[(size_t)start[b] + i]) : w;        // no noise: the waveform itself is returned
+        x = rint(x * 32767.0);
+        x = x < -32768.0 ? -32768.0 : (x > 32767.0 ? 32767.0 : x);
+        out[e] = (int16_t)x;
+    }
+}
+
+int kws_launch_mix_audio(const float *words, const int *word_len, size_t word_stride, const float *noise, const int *start, float word_vol,
+                         float bg_vol, int n, size_t n_clips, int16_t *out, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_clips == 0) return 0;
+    const size_t total = n_clips * (size_t)n;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(kws_mix_audio_kernel, dim3(grid), dim3(256), 0, stream, words, word_len, word_stride, noise, start, word_vol, bg_vol, n,
+                       total, out);
+    return (int)hipGetLastError();
+}

@@ -155,6 +155,18 @@ EI_IMPULSE_ERROR kws_allgather_scores(kws_comm *c, const float *local_scores, fl
                                       void *stream);
 void kws_comm_destroy(kws_comm *c);
 
+/* ---- the step before the path: mix_audio of /root/reference/dataset-curation.py:93-137, batched on the GPU, so that a
+ * harness can feed real keyword / background recordings instead of synthetic clips.  Inputs are float32 waveforms already at the
+ * model's sampling rate (what librosa.load(sr = 16000, mono = True) returns: resampling is NOT part of this call):
+ *   words [n_clips] waveforms of word_len[b] samples at words + b * word_stride (device; NULL = background noise only),
+ *   noise one background track (device; NULL = no background), start[b] = first sample of clip b's window in it (the reference
+ *   draws it with random.randint(0, len(noise) - n); the caller supplies it),
+ *   out [n_clips][n] int16 = PCM16(0.5 * word_vol * word + 0.5 * bg_vol * noise[start .. start + n)), words padded with zeros or
+ *   truncated to n samples.  PARITY UNPINNED (librosa / soundfile unavailable when this was written): held to the restatement in
+ *   oracle/ only. */
+EI_IMPULSE_ERROR kws_mix_audio_device(const float *words, const int *word_len, size_t word_stride, const float *noise, size_t noise_len,
+                                      const int *start, float word_vol, float bg_vol, size_t n_clips, size_t n, int16_t *out, void *stream);
+
 /* deterministic synthetic clips generated directly in HBM (include/kws/kws_synth.h) */
 EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len,
                                         int16_t *out, void *stream);

@@ -1581,6 +1581,31 @@ int kwso_continuous_step(kwso_continuous *s, const int16_t *slice, size_t n, con
 }
 
 /* ====================================================================== */
+/*  mix_audio            /root/reference/dataset-curation.py:93-137        */
+/*  PARITY UNPINNED: the script needs librosa + soundfile, neither of      */
+/*  which exists in the build container; restated line by line from its    */
+/*  text, minus librosa.load's resampling (inputs are 16 kHz mono float32). */
+/* ====================================================================== */
+void kwso_mix_audio(const float *word, int word_len, const float *noise_window, float word_vol, float bg_vol, int n, int16_t *out)
+{
+    for (int i = 0; i < n; i++) {
+        double w = 0.0;                                     /* lines 107-109: no word -> zeros; 114-120: pad with zeros, truncate */
+        if (word && i < word_len) w = (double)word[i];
+        double x;
+        if (!noise_window) x = w;                           /* lines 123-124 */
+        else {
+            double a = 0.5 * (double)word_vol * w;          /* [0.5 * word_vol * i for i in waveform]: Python floats */
+            float b = (float)(0.5 * (double)bg_vol) * noise_window[i];   /* 0.5 * bg_vol * ndarray(float32): the scalar takes the array's dtype */
+            x = a + (double)b;                              /* list + ndarray -> float64 */
+        }
+        double r = rint(x * 32767.0);                       /* sf.write(subtype PCM_16) of doubles: lrint(x * 0x7FFF); saturated here */
+        if (r < -32768.0) r = -32768.0;
+        if (r > 32767.0) r = 32767.0;
+        out[i] = (int16_t)r;
+    }
+}
+
+/* ====================================================================== */
 /*  synthetic clips (shared integer generator, include/kws/kws_synth.h)    */
 /* ====================================================================== */
 #include "../include/kws/kws_synth.h"

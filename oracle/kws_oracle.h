@@ -122,6 +122,11 @@ void kwso_continuous_init(kwso_continuous *s);
 int  kwso_continuous_step(kwso_continuous *s, const int16_t *slice, size_t n, const float *end_of_signal, float *scores,
                           int *produced);
 
+/* mix_audio (/root/reference/dataset-curation.py:93-137) for one clip, without the resampling of librosa.load: word (may be NULL)
+ * of word_len float32 samples, noise window (may be NULL) of n samples -> PCM16.  PARITY UNPINNED: librosa / soundfile cannot be
+ * imported where this was written; restated from the script's text. */
+void kwso_mix_audio(const float *word, int word_len, const float *noise_window, float word_vol, float bg_vol, int n, int16_t *out);
+
 /* synthetic test clips: include/kws/kws_synth.h */
 void kwso_synth_fill(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out);
 

@@ -100,6 +100,7 @@ class Oracle:
         L.kwso_time_run_classifier.restype = C.c_double
         L.kwso_time_run_classifier.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.kwso_synth_fill.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.kwso_mix_audio.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]
         L.kwso_model_is_float.argtypes = [C.c_void_p]
         L.kwso_nn_invoke_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kwso_continuous_create.restype = C.c_void_p
@@ -107,6 +108,14 @@ class Oracle:
         L.kwso_continuous_free.argtypes = [C.c_void_p]
         L.kwso_continuous_init.argtypes = [C.c_void_p]
         L.kwso_continuous_step.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+
+    def mix_audio(self, word, noise_window, word_vol, bg_vol, n):
+        """mix_audio of dataset-curation.py:93-137 (PARITY UNPINNED, see oracle/kws_oracle.h); word / noise_window may be None"""
+        out = np.zeros(n, np.int16)
+        w = None if word is None else np.ascontiguousarray(word, np.float32)
+        b = None if noise_window is None else np.ascontiguousarray(noise_window, np.float32)
+        self.L.kwso_mix_audio(None if w is None else _ptr(w), 0 if w is None else w.size, None if b is None else _ptr(b), word_vol, bg_vol, n, _ptr(out))
+        return out
 
     # ---- clips
     def synth(self, seed, first, n, clip_len=CLIP_LEN):

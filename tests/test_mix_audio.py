@@ -1,0 +1,84 @@
+"""mix_audio (/root/reference/dataset-curation.py:93-137).  PARITY UNPINNED: the script cannot be imported here
+(librosa, soundfile), so the restatement in oracle/ is checked against the arithmetic the script's text spells out (NumPy's own
+promotion rules evaluate the same expression below), and the GPU kernel against the restatement."""
+import numpy as np
+import pytest
+
+from kws_testlib import ROOT
+
+
+def script_expression(word, noise_window, word_vol, bg_vol, n):
+    """lines 107-135 of the script evaluated by NumPy itself (minus librosa.load), then PCM16 as libsndfile stores doubles"""
+    if word is None:
+        waveform = [0] * n
+    else:
+        waveform = word
+        if len(waveform) < n:
+            waveform = np.append(waveform, np.zeros(int(n - len(waveform))))
+        waveform = waveform[:n]
+    if noise_window is not None:
+        # `i` is a float32 NumPy scalar when the word needed no padding: the NumPy 1.x of the script's day (2020) promotes
+        # python_float * float32_scalar to float64 (value-based casting); NumPy 2 would keep float32.  float(i) spells the former.
+        waveform = [0.5 * word_vol * float(i) for i in waveform] + (0.5 * bg_vol * noise_window)
+    x = np.asarray(waveform, np.float64)
+    return np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.int16)
+
+
+def cases():
+    rng = np.random.default_rng(3)
+    n = 16000
+    out = []
+    for word_len in (16000, 9000, 20000, 0):
+        word = (rng.standard_normal(word_len) * 0.2).astype(np.float32) if word_len else None
+        noise = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        out.append((word, noise, 1.0, 0.3))
+        out.append((word, None, 1.0, 1.0))
+    out.append(((rng.standard_normal(n) * 3).astype(np.float32), (rng.standard_normal(n) * 3).astype(np.float32), 1.0, 1.0))   # saturation
+    return out
+
+
+def test_restatement_follows_the_scripts_expression(oracle):
+    for word, noise, wv, bv in cases():
+        if word is None and noise is None:
+            continue
+        assert (oracle.mix_audio(word, noise, wv, bv, 16000) == script_expression(word, noise, wv, bv, 16000)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_mixer_equals_the_restatement(oracle):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    rng = np.random.default_rng(4)
+    B, n, stride = 33, 16000, 20000
+    words = (rng.standard_normal((B, stride)) * 0.2).astype(np.float32)
+    lens = rng.integers(0, stride + 1, B).astype(np.int32)
+    track = (rng.standard_normal(5 * n) * 0.1).astype(np.float32)
+    start = rng.integers(0, len(track) - n + 1, B).astype(np.int32)
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    dw, dl, dt, ds = d(words), d(lens), d(track), d(start)
+    out = torch.zeros((B, n), dtype=torch.int16, device="cuda")
+    pkg.mix_audio_device(dw.data_ptr(), dl.data_ptr(), stride, dt.data_ptr(), len(track), ds.data_ptr(), 0.8, 0.25, B, n, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b in range(B):
+        want = oracle.mix_audio(words[b, :lens[b]], track[start[b]:start[b] + n], 0.8, 0.25, n)
+        assert (got[b] == want).all(), b
+    # noise only / word only
+    pkg.mix_audio_device(None, None, 0, dt.data_ptr(), len(track), ds.data_ptr(), 1.0, 0.5, B, n, out.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy()[3] == oracle.mix_audio(None, track[start[3]:start[3] + n], 1.0, 0.5, n)).all()
+    pkg.mix_audio_device(dw.data_ptr(), dl.data_ptr(), stride, None, 0, None, 1.0, 0.5, B, n, out.data_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy()[5] == oracle.mix_audio(words[5, :lens[5]], None, 1.0, 0.5, n)).all()
+    # the mixed clips feed the hot path directly
+    import os
+    from kws_testlib import MODELS
+    gm = pkg.Model(os.path.join(MODELS, "l476_no_yes.kwsm"))
+    s = torch.zeros((B, 4), dtype=torch.float32, device="cuda")
+    gm.run_classifier_batch_device(out.data_ptr(), B, s.data_ptr())
+    torch.cuda.synchronize()
+    assert np.abs(s.cpu().numpy().sum(1) - 1).max() < 0.05
+    gm.close()
