@@ -224,8 +224,11 @@ EI_IMPULSE_ERROR nn_f32_device(kws_handle *h, const float *features, size_t B, f
 // cmvnw + quantise + (optionally) the network (kernel 2; the generic NN kernel follows when the graph does not fit
 // the matrix-core path)
 EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, float *features, int8_t *q, float *scores,
-                                       int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out, hipStream_t s)
+                                       int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out, hipStream_t s, int ring_rows, int ring_head)
 {
+    // ring_rows != 0: mfcc holds ring-indexed rolling buffers (continuous mode, kws_streams_*)
+    KwsDspPlan PR = h->dsp;
+    PR.ring_rows = ring_rows; PR.ring_head = ring_head;
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     int ran_nn = 0;
     if (h->model.dsp.block == DSP_BLOCK_MFE) {
@@ -235,8 +238,9 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
         const size_t F = h->model.nn_input_frame_size;
         float *f = features ? features : h->s_mfcc;
         int8_t *qq = h->is_float ? nullptr : (q ? q : h->s_q);
-        HIP_TRY(hipMemcpyAsync(f, mfcc, B * F * sizeof(float), hipMemcpyDeviceToDevice, s));
-        int rc = kws_launch_mfe_norm(f, (int)B, P.n_frames, P.n_filters, P.win_size, P.pad_map, P.n_frames + 2 * P.pad, grid_cap_nn(h), s);
+        int rc = kws_launch_unring(mfcc, f, (int)B, P.n_frames, P.n_filters, ring_rows, ring_head, s);      // the reference normalises a COPY
+        if (rc) return fail(KWS_ERROR_HIP, "copy kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        rc = kws_launch_mfe_norm(f, (int)B, P.n_frames, P.n_filters, P.win_size, P.pad_map, P.n_frames + 2 * P.pad, grid_cap_nn(h), s);
         if (!rc && qq) rc = kws_launch_quantize(f, qq, B * F, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "MFE normalisation launch failed: %s", hipGetErrorString((hipError_t)rc));
         if (!scores) return EI_IMPULSE_OK;
@@ -251,7 +255,12 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
         if (e) return e;
         float *f = features ? features : (h->is_float ? h->g_feat : nullptr);
         int8_t *qq = h->is_float ? nullptr : (q ? q : h->s_q);
-        int rc = kws_launch_cmvn_generic(h->dsp, mfcc, (int)B, f, qq, h->nn.in_scale, h->nn.in_zp, s);
+        int rc = 0;
+        if (ring_rows) {
+            rc = kws_launch_unring(mfcc, h->g_mfcc, (int)B, h->dsp.n_frames, h->dsp.n_cepstral, ring_rows, ring_head, s);
+            mfcc = h->g_mfcc;
+        }
+        if (!rc) rc = kws_launch_cmvn_generic(h->dsp, mfcc, (int)B, f, qq, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         if (!scores) return EI_IMPULSE_OK;
         if (h->is_float) return nn_f32_device(h, f, B, scores, nullptr, s);
@@ -262,19 +271,54 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
     if (h->is_float) {
         if (q || tap_pooled || tap_fc || tap_out) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 outputs requested from a float32 model");
         float *f = features ? features : h->s_mfcc;
-        int rc = kws_launch_cmvn_nn(h->dsp, h->nn, mfcc, (int)B, f, nullptr, nullptr, nullptr, 0, nullptr, nullptr, grid_cap_nn(h), &ran_nn, s);
+        int rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, f, nullptr, nullptr, nullptr, 0, nullptr, nullptr, grid_cap_nn(h), &ran_nn, s);
         if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return scores ? nn_f32_device(h, f, B, scores, nullptr, s) : EI_IMPULSE_OK;
     }
     int8_t *qq = q;
     if (scores && !qq) qq = h->s_q;           // the generic NN kernel reads the quantised tensor from HBM
-    int rc = kws_launch_cmvn_nn(h->dsp, h->nn, mfcc, (int)B, features, qq, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out,
+    int rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, features, qq, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out,
                                 grid_cap_nn(h), &ran_nn, s);
     if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (scores && !ran_nn) {
         rc = kws_launch_nn(h->nn, qq, (int)B, scores, tap_pooled, h->pooled_tap_bytes, tap_fc, tap_out, grid_cap_nn(h), s);
         if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
+    return EI_IMPULSE_OK;
+}
+
+// KWS_MODE_FAST for windows that arrive as cepstra (continuous mode): O(1) cmvnw + the network (fused for float graphs), then the
+// exact kernels over the windows the fast kernel listed as ill-conditioned.  Uses the handle's scratch (h->mu held by the caller).
+EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B, float *scores, hipStream_t s, int ring_rows, int ring_head)
+{
+    if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    EI_IMPULSE_ERROR e = ensure_flags(h, B);
+    if (e) return e;
+    HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+    KwsDspPlan PR = h->dsp;
+    PR.ring_rows = ring_rows; PR.ring_head = ring_head;
+    const bool fused = h->is_float && h->fast_fused_ok;
+    const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
+    float *fx = h->s_mfcc;
+    int8_t *q = h->is_float ? nullptr : h->s_q;
+    int rc = kws_launch_fast_from_cepstra(PR, FP, fused ? h->d_fast_fused : h->d_fast_plain, mfcc, (int)B, scores, fused ? nullptr : fx, q,
+                                          h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
+    if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (!fused) {
+        if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, nullptr, s))) return e; }
+        else {
+            rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
+            if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
+    }
+    // exact re-run of the listed windows (indexed by their own numbers)
+    int ran_nn = 0;
+    rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, h->is_float ? fx : nullptr, q, h->is_float ? nullptr : scores, nullptr, h->pooled_tap_bytes, nullptr,
+                            nullptr, grid_cap_nn(h), &ran_nn, s, h->d_flags);
+    if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags);
+    else if (!ran_nn) rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
+    if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
 }
 

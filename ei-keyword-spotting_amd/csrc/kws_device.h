@@ -35,6 +35,10 @@ __device__ __forceinline__ int sel_clip(const int *sel, int i) { return sel ? se
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
     } while (0)
 
+// rolling-buffer rows (KwsDspPlan::ring_*)
+__device__ __forceinline__ int ring_out_row(const KwsDspPlan &P, int r) { return P.ring_rows ? (P.ring_row0 + r) % P.ring_rows : r; }
+__device__ __forceinline__ int ring_in_row(const KwsDspPlan &P, int i) { return (P.ring_rows && i < P.ring_rows) ? (i + P.ring_head) % P.ring_rows : i; }
+
 struct cf { float r, i; };
 
 __device__ __forceinline__ cf cmul(cf a, cf b)   // C_MUL, _kiss_fft_guts.h: four products, one sub, one add

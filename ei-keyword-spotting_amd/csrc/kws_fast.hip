@@ -283,12 +283,14 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 
 // ---------------------------------------------------------------------------------------------------------
 // NZ: taps of mel filters 0..31 kept in registers (filters 32..39, when there are 40, keep KWS_FAST_NZ2); DG: DCT k-groups = filters / 8
-template <int NZ, int DG, bool PROF = false>
+// FROM_CEP: the windows arrive as cepstra before cmvnw [n_frames][n_cepstral] (continuous mode: the rolling buffers of kws_streams_*,
+// ring-indexed per KwsDspPlan::ring_*) instead of PCM: the kernel starts at cmvnw.
+template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false>
 __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const KwsFastPlan *__restrict__ FPp, const int16_t *__restrict__ pcm, int n_clips,
                                                           float *__restrict__ scores, float *__restrict__ features,
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,
-                                                          long long *__restrict__ prof_out = nullptr)
+                                                          long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr)
 {
     // the plan is read from memory (scalar loads, any block index); by value in the kernel arguments the compiler copies it to
     // scratch to index its blocks
@@ -303,6 +305,9 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     // the power rows are padded so that every filter can read its full tap count: the padding is only ever multiplied by zero
     // weights, but it must be finite (LDS is not cleared between kernels)
     for (int i = lane; i < KWS_FAST_MEL_CHUNK * FP.pstride; i += KWS_WAVE) pw[i] = 0.0f;
+    // from cepstra nothing fills the images' channel padding before the first convolution reads it (times zero weights)
+    if constexpr (FROM_CEP)
+        for (int i = lane; i < FP.wave_floats; i += KWS_WAVE) F[i] = 0.0f;
     __syncthreads();
 
     const int nfr = P.n_frames, ncep = P.n_cepstral, NF = 8 * DG;
@@ -345,6 +350,15 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         for (int n = 0; n < NZ; ++n) w1[n] = FP.tap_w1[lane_c * KWS_FAST_NZ_MAX + n];
     #pragma unroll
         for (int n = 0; n < NZ2; ++n) w2[n] = FP.tap_w2[lane_c * KWS_FAST_NZ2 + n];
+        if constexpr (FROM_CEP) {
+            const float *src = cep + (size_t)clip * (nfr * ncep);
+            const unsigned inv = (1u << 20) / (unsigned)ncep + 1u;           // i / ncep for i < 4096
+            for (int i = lane; i < nfr * ncep; i += KWS_WAVE) {
+                const int r = (int)(((unsigned)i * inv) >> 20), c = i - r * ncep;
+                img[r * fs + c] = src[ring_in_row(P, r) * ncep + c];
+            }
+            WAVE_SYNC();
+        } else {
         const int16_t *xbase = pcm + (size_t)clip * n_samples;
         // Four frames per pass: sub-pair j of pass q holds frames 4q + 2j + half.  Two independent transforms per lane keep the
         // LDS round trips of one in the shadow of the other's arithmetic (two waves per SIMD cannot), and halve the wave
@@ -597,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             WAVE_SYNC();
         }
         FPH(4);
+        }   // !FROM_CEP
 
         // ---- cmvnw + optional outputs (extract_mfcc_features' matrix, the int8 input tensor) --------------------------------
         float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
@@ -670,23 +685,23 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 // ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
-template <int NZ, int DG, bool PROF>
+template <int NZ, int DG, bool PROF, bool FROM_CEP = false>
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
-                         long long *prof_out, hipStream_t stream)
+                         long long *prof_out, hipStream_t stream, const float *cep = nullptr)
 {
     const size_t smem = ((size_t)FP.shared_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_done = true;
     }
     const int per_wg = FP.n_waves;
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
-    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
-                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out);
+    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
+                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep);
     return (int)hipGetLastError();
 }
 
@@ -703,6 +718,17 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
         return FP.nz <= 4 ? launch_fast_t<4, 5, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false>(KWS_FAST_ARGS)
                                                                                     : launch_fast_t<KWS_FAST_NZ_MAX, 5, false>(KWS_FAST_ARGS);
     return (int)hipErrorInvalidValue;
+}
+
+// cmvnw + (fused float network | features / int8 tensor) from cepstra in HBM, ring-indexed per P.ring_* (continuous mode)
+int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
+                                 float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    if (n_clips <= 0) return 0;
+    // mel taps / DCT are not part of this variant: one instantiation serves every model
+    return launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu,
+                                            nullptr, stream, cep);
 }
 
 // development aid: phase clocks (<= 4-tap builds only)

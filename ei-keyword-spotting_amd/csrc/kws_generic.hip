@@ -194,7 +194,7 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
                 acc += prod;
             }
             if (acc == 0.0f) acc = FLT_EPSILON;
-            if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)f * NF + j] = acc;
+            if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)ring_out_row(P, f) * NF + j] = acc;
             w_mel[(size_t)j * GL] = fast_log(acc);
         }
         if (P.mfe_mel) continue;                                   // MFE block: no log / DCT output
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
             w_in[(size_t)(NF - 1 - i) * GL] = w_mel[(size_t)(2 * i + 1) * GL];
         }
         g_rfft(w_in, w_tmp, w_spec, NF, P.dct_fac, P.dct_levels, P.dct_tw, P.dct_stw);
-        float *orow = mfcc_out + (size_t)clip * out_stride + (size_t)f * ncep;
+        float *orow = mfcc_out + (size_t)clip * out_stride + (size_t)ring_out_row(P, f) * ncep;
         for (int i = 0; i < ncep; i++) {
             float d;
             if (i <= half) {

@@ -22,7 +22,7 @@
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
                         int out_stride, int grid_cap, hipStream_t stream);
 int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream);
-int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream);
+int kws_launch_unring(const float *src, float *dst, int n_streams, int rows, int cols, int ring_rows, int head, hipStream_t stream);
 int kws_launch_mfe(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mel_out, float *energy_out, const float *wrap,
                    int out_stride, int grid_cap, hipStream_t stream);
 int kws_launch_mfe_norm(float *feat, int n_clips, int rows, int cols, int win, const int *pad_map, int prow, int grid_cap, hipStream_t stream);
@@ -32,7 +32,9 @@ int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips
                                int in_zp, int grid_cap, long long *prof_out, hipStream_t stream);
 int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
-                       int *ran_nn, hipStream_t stream);
+                       int *ran_nn, hipStream_t stream, const int *sel = nullptr);
+int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
+                                 float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream);
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
                       float *tap_logits, int n_cu, hipStream_t stream, const int *sel = nullptr);
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);
@@ -239,11 +241,12 @@ KWS_INTERNAL EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B);
 KWS_INTERNAL void kws_sdk_forget_default(kws_handle *h);      // kws_sdk.cpp: kws_destroy() of the installed default model
 KWS_INTERNAL int grid_cap_mfcc(const kws_handle *h);
 KWS_INTERNAL EI_IMPULSE_ERROR ensure_generic(kws_handle *h, size_t B);
+KWS_INTERNAL EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B, float *scores, hipStream_t s, int ring_rows, int ring_head);
 KWS_INTERNAL int grid_cap_nn(const kws_handle *h);
 KWS_INTERNAL EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
                                  const float *wrap, hipStream_t s, int out_stride = 0);
 KWS_INTERNAL EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s);
 KWS_INTERNAL EI_IMPULSE_ERROR nn_f32_device(kws_handle *h, const float *features, size_t B, float *scores, float *tap_logits, hipStream_t s);
 KWS_INTERNAL EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, float *features, int8_t *q, float *scores,
-                                int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out, hipStream_t s);
+                                int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out, hipStream_t s, int ring_rows = 0, int ring_head = 0);
 }

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
                     }
                     if (acc == 0.0f) acc = FLT_EPSILON;                                // functions.hpp:63-69
                     if constexpr (!WITH_CMVN)
-                        if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)(f_base + fr) * NF + t] = acc;
+                        if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)ring_out_row(P, f_base + fr) * NF + t] = acc;
                     sm_mel[(f_base + fr) * MELS + t] = fast_log(acc);
                 }
             } else {
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
                                 float a = acc[u];
                                 if (a == 0.0f) a = FLT_EPSILON;
                                 if constexpr (!WITH_CMVN)
-                                    if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)(f_base + fr) * NF + lane] = a;
+                                    if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)ring_out_row(P, f_base + fr) * NF + lane] = a;
                                 sm_mel[(f_base + fr) * MELS + lane] = fast_log(a);
                             }
                         }
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
             float *mrow = sm_mel + drow * MELS;
 #pragma unroll
             for (int i = 0; i < NF; ++i) v[i] = mrow[i];
-            float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + drow * ncep;
+            float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + ring_out_row(P, drow) * ncep;
             typedef KwsDctTab<NF> T;
             auto put = [&](int i, cf R) {
                 // in place (WITH_CMVN) every output is stored: columns >= ncep of the row are never read again and the

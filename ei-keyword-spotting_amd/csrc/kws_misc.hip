@@ -46,12 +46,17 @@ __global__ void kws_maf_kernel(float *__restrict__ scores, float *__restrict__ r
     }
 }
 
-__global__ void kws_shift_kernel(const float *__restrict__ src, float *__restrict__ dst, int n_streams, int F, int shift)
+// linear copy of ring-indexed rolling buffers (KwsDspPlan::ring_*): dst[stream][row][col] = src[stream][physical row][col].  Used where a
+// consumer wants plain rows (the general cmvnw kernel, the MFE normalisation, kws_streams_init) -- the tuned cmvnw + network kernel
+// reads the ring directly.
+__global__ void kws_unring_kernel(const float *__restrict__ src, float *__restrict__ dst, int n_streams, int rows, int cols, int ring_rows, int head)
 {
-    const size_t total = (size_t)n_streams * F;
+    const size_t F = (size_t)rows * cols, total = (size_t)n_streams * F;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % F);
-        dst[i] = (k < F - shift) ? src[i + shift] : src[i];     // the tail keeps its old values, as in the reference
+        const size_t st = i / F;
+        const int k = (int)(i - st * F), r = k / cols, c = k - r * cols;
+        const int pr = (ring_rows && r < ring_rows) ? (r + head) % ring_rows : r;
+        dst[i] = src[st * F + (size_t)pr * cols + c];
     }
 }
 
@@ -64,12 +69,13 @@ int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int
     return (int)hipGetLastError();
 }
 
-int kws_launch_shift(const float *src, float *dst, int n_streams, int F, int shift, hipStream_t stream)
+int kws_launch_unring(const float *src, float *dst, int n_streams, int rows, int cols, int ring_rows, int head, hipStream_t stream)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_streams <= 0) return 0;
-    size_t blocks = ((size_t)n_streams * F + 255) / 256;
-    hipLaunchKernelGGL(kws_shift_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, dst, n_streams, F, shift);
+    size_t blocks = ((size_t)n_streams * rows * cols + 255) / 256;
+    hipLaunchKernelGGL(kws_unring_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, dst, n_streams, rows, cols,
+                       ring_rows, head);
     return (int)hipGetLastError();
 }
 

@@ -646,9 +646,19 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
     const float in_scale = N.in_scale;
     const int in_zp = N.in_zp;
 
-    for (int clip = blockIdx.x * KWS_NN_WAVES + wave; clip < n_clips; clip += gridDim.x * KWS_NN_WAVES) {
+    const int n_sel = sel_count(taps.sel, n_clips);
+    for (int ci = blockIdx.x * KWS_NN_WAVES + wave; ci < n_sel; ci += gridDim.x * KWS_NN_WAVES) {
+        const int clip = sel_clip(taps.sel, ci);
         const float *src = mfcc + (size_t)clip * nfeat;
-        for (int i = lane; i < nfeat; i += 64) mf[i] = src[i];
+        if (P.ring_rows) {
+            const unsigned inv = (1u << 20) / (unsigned)ncep + 1u;          // i / ncep for i < 4096, ncep <= 64
+            for (int i = lane; i < nfeat; i += 64) {
+                const int r = (int)(((unsigned)i * inv) >> 20);
+                mf[i] = src[ring_in_row(P, r) * ncep + (i - r * ncep)];
+            }
+        } else {
+            for (int i = lane; i < nfeat; i += 64) mf[i] = src[i];
+        }
         WAVE_SYNC();
         cmvn_columns<13, 16>(mf, ncep, s_map, s_off[wave], lane, nfr, ncep, prow, win, [&](int row, int c, float o) {
             const int idx = row * ncep + c;
@@ -686,14 +696,14 @@ int kws_nn_uses_mfma(const KwsNnPlan &N) { return nn_fits_mfma(N) && !kws_force_
 // network ran inside this launch.
 int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfcc, int n_clips, float *features, int8_t *q_out,
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
-                       int *ran_nn, hipStream_t stream)
+                       int *ran_nn, hipStream_t stream, const int *sel)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     *ran_nn = 0;
     if (n_clips <= 0) return 0;
     int grid = (n_clips + KWS_NN_WAVES - 1) / KWS_NN_WAVES;
     if (grid > grid_cap) grid = grid_cap;
-    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q, kws_dev_nn_prof };
+    NnTaps taps = { tap_pooled, pooled_stride, tap_fc, tap_out_q, kws_dev_nn_prof, sel };
     if (scores && nn_fits_mfma(N) && N.blk[0].in_cpad == 16 && !kws_force_scalar_nn) {      // (64-byte rows: separate network launch)
         hipLaunchKernelGGL((kws_cmvn_nn_kernel<true>), dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, P, N, mfcc, n_clips,
                            features, q_out, scores, taps);

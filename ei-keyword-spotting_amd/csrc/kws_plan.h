@@ -37,6 +37,11 @@ struct KwsDspPlan {
     int generic;
     int fft_levels, dct_levels;
     int fft_fac[24], dct_fac[24];
+    // per launch, continuous mode: the rolling feature buffer of a stream is a ring over its first ring_rows rows (the rows behind
+    // them are the reference's never-written tail).  Producers (WITH_CMVN = false, MFE rows): output row r goes to physical row
+    // (ring_row0 + r) % ring_rows; consumers (kws_cmvn_nn_kernel, kws_unring_kernel): logical row i < ring_rows is physical row
+    // (i + ring_head) % ring_rows.  ring_rows = 0: plain rows.
+    int ring_rows, ring_row0, ring_head;
     // per launch, WITH_CMVN = false only: when set the kernel stops after speechpy::feature::mfe (feature.hpp:193-318)
     // and writes the mel energies [window][frame][filter] and frame energies [window][frame] (both after zero handling)
     float *mfe_mel, *mfe_energy;

@@ -11,11 +11,14 @@ struct kws_stream_batch {
     kws_handle *h = nullptr;
     size_t S = 0;
     float *feat[2] = { nullptr, nullptr };   // rolling cepstra buffers [S][F] (ping-pong for the shift)
-    int cur = 0;
     float *running_sum = nullptr, *maf_buf = nullptr;   // [S][C], [S][C][taps]
     float *zeros = nullptr;                   // [S] end-of-signal samples when the caller gives none
     size_t slice_offset = 0;
     bool full = false, first_run = false;     // first_run: like the reference's function-static, never reset
+    // Once the buffer is full the reference shifts it by one slice after every inference (ei_run_classifier.h:277-279).  Here the
+    // first ring_rows rows (everything up to the end of the slice being written) form a ring whose head advances instead; the rows
+    // behind them are the reference's never-written tail and stay in place.
+    int ring_rows = 0, head = 0;
     uint32_t buf_idx = 0;
 };
 static const int kMafTaps = EI_CLASSIFIER_SLICES_PER_MODEL_WINDOW >> 1;
@@ -33,6 +36,17 @@ EI_IMPULSE_ERROR kws_streams_init(kws_stream_batch *sb)          // run_classifi
     if (!sb) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(sb->h->device));
     const size_t C = sb->h->model.labels.size();
+    if (sb->ring_rows && sb->head) {
+        // run_classifier_init does not clear the feature buffer: put the rows back in plain order before slices are written
+        // linearly again
+        const KwsDspPlan &P = sb->h->dsp;
+        const int rows = (int)(sb->h->model.nn_input_frame_size / (size_t)P.n_cepstral);
+        int rc = kws_launch_unring(sb->feat[0], sb->feat[1], (int)sb->S, rows, P.n_cepstral, sb->ring_rows, sb->head, nullptr);
+        if (rc) return fail(KWS_ERROR_HIP, "copy kernel launch failed");
+        HIP_TRY(hipDeviceSynchronize());
+        std::swap(sb->feat[0], sb->feat[1]);
+    }
+    sb->ring_rows = 0; sb->head = 0;
     sb->slice_offset = 0;
     sb->full = false;
     sb->buf_idx = 0;
@@ -88,13 +102,27 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
     P.n_frames = nf;
     // x[-1] of the slice: the reference takes the sample at total_length-1, which lies beyond the slice once it has grown
     const float *wrap = grown ? (end_of_signal ? end_of_signal : sb->zeros) : nullptr;
-    float *feat = sb->feat[sb->cur];
-    EI_IMPULSE_ERROR e = spectral_device(h, P, slices, 0, S, feat + sb->slice_offset, wrap, st, (int)F);
+    float *feat = sb->feat[0];
+    const int ncols = h->dsp.n_cepstral, row0 = (int)(sb->slice_offset / (size_t)ncols);
+    EI_IMPULSE_ERROR e;
+    if (sb->ring_rows && row0 + nf != sb->ring_rows)
+        return fail(EI_IMPULSE_DSP_ERROR, "slice of %d frames in a window laid out for slices of %d", nf, sb->ring_rows - row0);
+    if (sb->ring_rows) {                        // steady state: this slice's rows go behind the ring's head
+        P.ring_rows = sb->ring_rows;
+        P.ring_row0 = row0 + sb->head;
+        e = spectral_device(h, P, slices, 0, S, feat, wrap, st, (int)F);
+    } else
+        e = spectral_device(h, P, slices, 0, S, feat + sb->slice_offset, wrap, st, (int)F);
     if (e) return e;
     sb->first_run = true;
     if (!sb->full) {
         sb->slice_offset += feature_size;
-        if (sb->slice_offset > (F - feature_size)) { sb->full = true; sb->slice_offset -= feature_size; }
+        if (sb->slice_offset > (F - feature_size)) {
+            sb->full = true;
+            sb->slice_offset -= feature_size;
+            sb->ring_rows = (int)((sb->slice_offset + feature_size) / (size_t)ncols);      // rows written so far; head = 0: still plain
+            sb->head = 0;
+        }
     }
     if (!sb->full) return EI_IMPULSE_OK;
     {
@@ -102,16 +130,18 @@ EI_IMPULSE_ERROR kws_streams_step_device(kws_stream_batch *sb, const int16_t *sl
         e = ensure_scratch(h, S);
         if (!e) {
             ScratchUse use(h, st);
-            e = cmvn_nn_device(h, feat, S, nullptr, nullptr, scores, nullptr, nullptr, nullptr, st);
+            if (h->mode == KWS_MODE_FAST && h->fast_plain_ok)
+                e = cmvn_nn_fast_device(h, feat, S, scores, st, sb->ring_rows, sb->head);
+            else
+                e = cmvn_nn_device(h, feat, S, nullptr, nullptr, scores, nullptr, nullptr, nullptr, st, sb->ring_rows, sb->head);
         }
     }
     if (e) return e;
     int rc = kws_launch_maf(scores, sb->running_sum, sb->maf_buf, (int)(S * C), (int)sb->buf_idx, kMafTaps, st);
     if (rc) return fail(KWS_ERROR_HIP, "moving-average kernel launch failed");
     if (++sb->buf_idx >= (uint32_t)kMafTaps) sb->buf_idx = 0;
-    rc = kws_launch_shift(feat, sb->feat[sb->cur ^ 1], (int)S, (int)F, (int)feature_size, st);
-    if (rc) return fail(KWS_ERROR_HIP, "shift kernel launch failed");
-    sb->cur ^= 1;
+    // "shift the feature buffer for new data": the ring's head moves on by one slice
+    sb->head = (sb->head + nf) % sb->ring_rows;
     *produced = 1;
     return EI_IMPULSE_OK;
 }

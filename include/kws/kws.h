@@ -57,7 +57,8 @@ int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI
  *   KissFFT's order.  Clips whose cmvnw is ill-conditioned (near-constant column) are detected and re-run by the exact
  *   kernels inside the same call, so their results are the exact mode's.  int8 graphs: fast MFCC + the exact int8 network;
  *   an int8 input value may then differ by one step where a feature sits on a rounding boundary.
- * The SDK entry points (run_classifier ...), the stage API and the stream API always run the exact kernels. */
+ * kws_streams_step_device follows the mode too (the slice's MFCC stays exact; the whole-window cmvnw + network take the fast
+ * kernel).  The SDK entry points (run_classifier ...) and the stage API always run the exact kernels. */
 #define KWS_MODE_EXACT 0
 #define KWS_MODE_FAST 1
 EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode);   /* KWS_ERROR_UNSUPPORTED_MODEL if the model's DSP block is outside the fast kernel */

@@ -295,3 +295,61 @@ def test_full_size_properties_other_workloads(name, mode, pkg, oracle):
     if not gm.is_float:
         assert (np.abs(s * 256 - np.round(s * 256)) == 0).all() and (np.abs(s.sum(1) - 1.0) <= 8 / 256).all()
     gm.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "l476_no_yes.kwsm", "cfg2_mfcc40_int8.kwsm"])
+def test_fast_mode_streams_follow_the_continuous_oracle(name, pkg, oracle):
+    """kws_streams_step_device in KWS_MODE_FAST: the slice's MFCC is exact, the whole-window cmvnw + network go through the fast
+    kernel reading the ring-indexed rolling buffers.  Float graphs: every score within 1e-4 of the restated
+    run_classifier_continuous(); int8 graphs: scores on the output grid, at most a few of them one step away.  Includes streams
+    of silence and DC (constant columns -> guard -> exact re-run) and a run_classifier_init() in the middle."""
+    import torch
+    from kws_testlib import OracleContinuous
+    path = os.path.join(MODELS, name)
+    gm = pkg.Model(path, device=0)
+    om = OracleModel(oracle, path)
+    gm.set_mode(pkg.MODE_FAST)
+    S = 24
+    audio = oracle.synth(31, 0, S * 3).reshape(S, 3 * 16000).copy()
+    audio[0] = 0
+    audio[1] = 1234
+    audio[2, 20000:] = 0                                                  # goes silent mid-stream
+    sb = pkg.StreamBatch(gm, S)
+    ocs = [OracleContinuous(om) for _ in range(S)]
+    for oc in ocs:
+        oc.init()
+    scores = torch.empty((S, gm.n_labels), dtype=torch.float32, device="cuda")
+    n_prod = n_diff = 0
+    worst = 0.0
+    for phase in range(2):
+        for k in range(11 if phase == 0 else 6):
+            sl = np.ascontiguousarray(audio[:, k * 4000:(k + 1) * 4000])
+            d = torch.from_numpy(sl).cuda()
+            produced = sb.step_device(d.data_ptr(), 4000, scores.data_ptr())
+            torch.cuda.synchronize()
+            got = scores.cpu().numpy()
+            for s in range(S):
+                rc, p, want = ocs[s].step(sl[s])
+                assert rc == 0 and p == produced, (name, phase, k, s)
+                if not p:
+                    continue
+                n_prod += 1
+                err = float(np.abs(got[s] - want).max())
+                worst = max(worst, err)
+                if gm.is_float:
+                    assert err <= FAST_SCORE_TOL, (name, phase, k, s, err)
+                else:
+                    n_diff += int(err > 0)
+                    assert err <= 2.5 / 256, (name, phase, k, s, err)
+                if s == 0:                                               # silence: constant columns -> exact path
+                    tol = 1e-6 if gm.is_float else 0.0
+                    assert err <= tol, (name, phase, k, s, err)
+        sb.init()
+        for oc in ocs:
+            oc.init()
+    assert n_prod > 100
+    if not gm.is_float:
+        assert n_diff <= max(2, n_prod // 50), (name, n_diff, n_prod)
+    assert gm.fast_fallback_count() >= 1                                  # last step: at least the silent stream
+    sb.close()
+    gm.close()

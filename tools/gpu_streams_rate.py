@@ -6,7 +6,9 @@ import torch
 from __graft_entry__ import load_package
 pkg = load_package()
 for name in (sys.argv[1:] or ["l476_no_yes.kwsm", "cfg2_mfcc40_f32.kwsm"]):
+  for mode in (pkg.MODE_EXACT, pkg.MODE_FAST):
     gm = pkg.Model(os.path.join(ROOT, "models", name), device=0)
+    gm.set_mode(mode)
     for S in (4096, 65536):
         sb = pkg.StreamBatch(gm, S)
         n_sl = 8
@@ -23,7 +25,7 @@ for name in (sys.argv[1:] or ["l476_no_yes.kwsm", "cfg2_mfcc40_f32.kwsm"]):
             sb.step_device(slices[(5 + k) % n_sl].data_ptr(), 4000, scores.data_ptr())
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        print("%s: %d streams, %.3f ms per 250 ms slice step = %.1f M slices/s = %.0f x real time per stream-second (%.0f k concurrent real-time streams)"
-              % (name, S, dt * 1e3, S / dt / 1e6, 0.25 / dt, S * 0.25 / dt / 1e3), flush=True)
+        print("%s [%s]: %d streams, %.3f ms per 250 ms slice step = %.1f M slices/s = %.0f x real time per stream-second (%.0f k concurrent real-time streams)"
+              % (name, "fast" if mode else "exact", S, dt * 1e3, S / dt / 1e6, 0.25 / dt, S * 0.25 / dt / 1e3), flush=True)
         sb.close()
     gm.close()
