@@ -21,7 +21,8 @@
 #define KWS_FAST_NZ_MAX 12        // longest mel filter (filters 0..31) kept in registers
 #define KWS_FAST_NZ2 8            // longest of filters 32..39
 #define KWS_FAST_DCT_GROUPS 5     // NF / 8 <= 5: DCT operand fragments kept in registers
-#define KWS_FAST_MEL_CHUNK 4      // frames transformed per pass of the spectral loop (their power rows feed one mel pass)
+#define KWS_FAST_MEL_CHUNK 8      /* frames per pass of the spectral loop: eight lanes per frame */
+#define KWS_FAST_XS 144           /* floats per frame of the FFT exchange buffer: 64 positions + 2 floats of padding per 8; = 16 mod 64 */      // frames transformed per pass of the spectral loop (their power rows feed one mel pass)
 #define KWS_FAST_WAVE 64
 #define KWS_FAST_ZF 320           // floats per in-place FFT buffer (kws_device.h KWS_ZF)
 

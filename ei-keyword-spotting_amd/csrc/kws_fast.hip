@@ -41,13 +41,44 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-struct FastRaw { int4 v; short prev; };
-__device__ __forceinline__ FastRaw fast_fetch(const int16_t *x, int s0, int n_samples)
+// Four consecutive samples x[e - 2 .. e + 1] (e even) as two dwords: complex FFT input n of a frame is (y[2n], y[2n + 1]) with
+// y[s] = x[s] - cof x[s - 1] (processing.hpp:104-106), so a point needs three of them.  4-byte aligned, not 8.
+typedef int fast_i2 __attribute__((ext_vector_type(2), aligned(4)));
+// The int16 -> float scale 2^-15 (numpy.hpp:1289) is not applied here: pre-emphasis, the FFT and the split are linear and every
+// one of their roundings commutes with a power of two, so the factor is folded -- exactly -- into the power spectrum's scale.
+__device__ __forceinline__ cf fast_point(fast_i2 v, float pre_cof)
 {
-    FastRaw r;
-    r.v = *(const int4 *)(x + s0);
-    r.prev = x[s0 == 0 ? n_samples - 1 : s0 - 1];     // x[-1] is the window's last sample (processing.hpp:68, 104-106)
-    return r;
+    const float prev = (float)(v.x >> 16);
+    const float lo = (float)(short)(v.y & 0xffff);
+    const float hi = (float)(v.y >> 16);
+    cf z;
+    const float pl = pre_cof * prev;
+    z.r = lo - pl;
+    const float ph_ = pre_cof * lo;
+    z.i = hi - ph_;
+    return z;
+}
+// kf_bfly4 with unit twiddles (k = 0): the three products by (1, 0) are exact up to the sign of a zero
+__device__ __forceinline__ void bfly4_unit(cf &f0, cf &f1, cf &f2, cf &f3)
+{
+    const cf s0 = f1, s1 = f2, s2 = f3;
+    cf s5 = csub(f0, s1);
+    f0 = cadd(f0, s1);
+    cf s3 = cadd(s0, s2), s4 = csub(s0, s2);
+    f2 = csub(f0, s3);
+    f0 = cadd(f0, s3);
+    f1.r = s5.r + s4.i;
+    f1.i = s5.i - s4.r;
+    f3.r = s5.r - s4.i;
+    f3.i = s5.i + s4.r;
+}
+// sum over the eight lanes of a frame group; every lane of the group receives it
+__device__ __forceinline__ float oct_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);       // row_half_mirror: lanes i <-> 7 - i
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -63,7 +94,7 @@ __device__ __forceinline__ FastRaw fast_fetch(const int16_t *x, int s0, int n_sa
 // ---------------------------------------------------------------------------------------------------------
 template <int MT, int NT>
 __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ stage,
-                                                int sstride, const float *__restrict__ shared, int lane)
+                                                int sstride, const float *__restrict__ shared, int lane, long long *t_loop = nullptr, long long *t_pre = nullptr)
 {
     const int lm = lane & 15, lq = lane >> 4;
     v4f acc[MT][NT];
@@ -99,6 +130,7 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b[nt] = *(const float2 *)(wbase + bl[nt]);
     int cg = 0, tap = 0, aoff = 0, boff = 0;
+    if (t_pre) *t_pre = clock64();
     for (int it = 0; it < n_it; ++it) {
         // operands of the next step, requested before this step's MFMAs are issued (the last step re-reads its own)
         const bool more = it + 1 < n_it;
@@ -109,9 +141,15 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         cg = wr ? 0 : cg + 1;
         float2 an[MT], bn[NT];
 #pragma unroll
+#ifdef KWS_EXP_NOLOAD
+        for (int mt = 0; mt < MT; ++mt) { an[mt] = a[mt]; asm volatile("" : "+v"(an[mt].x), "+v"(an[mt].y)); }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bn[nt] = b[nt]; asm volatile("" : "+v"(bn[nt].x), "+v"(bn[nt].y)); }
+#else
         for (int mt = 0; mt < MT; ++mt) an[mt] = *(const float2 *)(abase + aoff + mt * mstep);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const float2 *)(wbase + boff + bl[nt]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -128,6 +166,7 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
     }
+    if (t_loop) *t_loop = clock64();
     // ---- epilogue: bias, fused activation, ADD(constant) + activation (conv.h:88-93, add.h:200-212) ---------------------
     const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max;
     const bool has_add = k.has_add != 0;
@@ -278,7 +317,7 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 }
 
 // PROF: development aid -- shader-clock totals per phase of wave 0 of workgroup 0 (tools/gpu_fast_phase_profile.py)
-#define KWS_FAST_NPHASE 10
+#define KWS_FAST_NPHASE 12
 #define FPH(i) do { if (PROF) { const long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
@@ -300,26 +339,27 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     float *shared = lds;
     float *F = lds + FP.shared_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
     float *R1 = F + FP.f_floats;                                      // FFT buffers + power rows; later block 1's input image
-    float *zw = R1, *pw = R1 + 4 * KWS_ZF;                           // four in-place FFT buffers, then four power rows
+    float *xw = R1, *pw = R1;                                         // the FFT's exchange buffer; the power rows reuse it
     for (int i = threadIdx.x; i < FP.shared_floats; i += blockDim.x) shared[i] = FP.shared_init[i];
     // the power rows are padded so that every filter can read its full tap count: the padding is only ever multiplied by zero
     // weights, but it must be finite (LDS is not cleared between kernels)
-    for (int i = lane; i < KWS_FAST_MEL_CHUNK * FP.pstride; i += KWS_WAVE) pw[i] = 0.0f;
+    for (int i = lane; i < FP.r1_floats; i += KWS_WAVE) R1[i] = 0.0f;
     // from cepstra nothing fills the images' channel padding before the first convolution reads it (times zero weights)
     if constexpr (FROM_CEP)
         for (int i = lane; i < FP.wave_floats; i += KWS_WAVE) F[i] = 0.0f;
     __syncthreads();
 
     const int nfr = P.n_frames, ncep = P.n_cepstral, NF = 8 * DG;
-    const int n_quads = (nfr + 3) >> 2;
+    const int n_pass = (nfr + KWS_FAST_MEL_CHUNK - 1) / KWS_FAST_MEL_CHUNK;
     const int fs = FP.fs, fuse = FP.fuse;
     float *img = F;                                                   // [n_frames][fs]
     float *elog = F + nfr * fs;                                       // log frame energies, parked until the DCT has run
     constexpr int NZ2 = DG > 4 ? KWS_FAST_NZ2 : 1;
     const float *dct_frag = FP.dct_frag;
-    const int bmin = FP.bmin, bmax = FP.bmin + FP.nbins - 1, pstride = FP.pstride;
+    const int pstride = FP.pstride;
     const int n_waves = blockDim.x >> 6;
-    const float pre_cof = P.pre_cof, inv_fft = P.inv_fft;
+    // 1 / fft_length, the int16 scale 2^-15 squared and the split's two halvings: powers of two (the plan checks fft_length)
+    const float pre_cof = P.pre_cof, pscale = P.inv_fft * (1.0f / 1073741824.0f) * 0.25f;
     const int frame_stride = P.frame_stride, n_samples = P.n_samples;
     const float *cnt_tab = shared + FP.cnt_off;
     const int *upd_tab = (const int *)(shared + FP.upd_off);
@@ -334,15 +374,29 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         //      and push those into scratch; re-deriving them costs ~60 L2-resident loads per clip.
         int lane_c = lane;
         asm volatile("" : "+v"(lane_c));
+        // Eight lanes own a frame (eight frames per pass), a lane owns sixteen of its 128 complex points: kf_bfly2 (m = 1) and
+        // kf_bfly4 (m = 2) run on two blocks of eight output positions in registers, ONE exchange through LDS re-deals the
+        // points so that kf_bfly4 m = 8 and m = 32 run in registers too (kiss_fft.cpp:15-84, 232-296; every butterfly keeps the
+        // reference's operation order, only its lane changes).
+        const int fl = lane_c & 7, fg = lane_c >> 3;
+        // blocks fl (output positions 8 fl ..) and fl + 8: block j = 4 i1 + i2 reads input points i1 + 4 i2 + 16 i3 + 64 i4
+        const int nbA = (fl >> 2) + 4 * (fl & 3);
+        const cf a1 = to_cf(P.tw[16]), a2 = to_cf(P.tw[32]), a3 = to_cf(P.tw[48]);
+        const cf b1 = to_cf(P.tw[4 * fl]), b2 = to_cf(P.tw[8 * fl]), b3 = to_cf(P.tw[12 * fl]);
+        cf c1[4], c2[4], c3[4];
+    #pragma unroll
+        for (int a = 0; a < 4; ++a) { c1[a] = to_cf(P.tw[fl + 8 * a]); c2[a] = to_cf(P.tw[2 * (fl + 8 * a)]); c3[a] = to_cf(P.tw[3 * (fl + 8 * a)]); }
+        // split twiddles of this lane's eight bin pairs (k, 128 - k), k = fl + 8 a + 32 b for b < 2; lane 0's first pair is (64, 64)
+        cf stw[8];
+    #pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = fl + 8 * (q & 3) + 32 * (q >> 2);
+            stw[q] = to_cf(P.stw[(k == 0 ? KWS_NC / 2 : k) - 1]);
+        }
+        const int xwr = fg * KWS_FAST_XS + 18 * fl;                     // exchange buffer: position p of a frame at 2 p + 2 (p / 8)
+        const int xrd = fg * KWS_FAST_XS + 2 * fl;
+        const int partner = (lane_c & ~7) | ((8 - fl) & 7);
         const int half = lane_c >> 5, t = lane_c & 31;
-        const int k01 = t & 1, g01 = t >> 1;
-        const int n0 = (g01 >> 2) + 4 * (g01 & 3);
-        const cf a1 = to_cf(P.tw[16 * k01]), a2 = to_cf(P.tw[32 * k01]), a3 = to_cf(P.tw[48 * k01]);
-        const int K2 = t & 7, G2 = t >> 3;
-        const cf b1 = to_cf(P.tw[4 * K2]), b2 = to_cf(P.tw[8 * K2]), b3 = to_cf(P.tw[12 * K2]);
-        const cf c1 = to_cf(P.tw[t]), c2 = to_cf(P.tw[2 * t]), c3 = to_cf(P.tw[3 * t]);
-        const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
-        float *zb0 = zw + half * KWS_ZF;                       // sub-pair j transforms in zb0 + 2 j KWS_ZF
         // a mel filter's taps are consecutive bins: first bin (as an offset into a frame's power row) + NZ weights, zero beyond its end
         const int start1 = FP.tap_start1[lane_c], start2 = FP.tap_start2[lane_c];
         float w1[NZ], w2[NZ2];
@@ -360,176 +414,176 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             WAVE_SYNC();
         } else {
         const int16_t *xbase = pcm + (size_t)clip * n_samples;
-        // Four frames per pass: sub-pair j of pass q holds frames 4q + 2j + half.  Two independent transforms per lane keep the
-        // LDS round trips of one in the shadow of the other's arithmetic (two waves per SIMD cannot), and halve the wave
-        // synchronisations per clip.  Samples are requested two passes ahead.
-        FastRaw nxt[2], nxt2[2];
+        const int wrap_prev = (int)xbase[n_samples - 1];                 // x[-1] is the window's last sample (processing.hpp:68, 104-106)
+        // a point's four samples x[2n - 2 .. 2n + 1] of frame f, requested one pass ahead
+        auto fetch = [&](int q, fast_i2 (&raw)[2][8]) {
+            const int f = min(KWS_FAST_MEL_CHUNK * q + fg, nfr - 1);
+            const int16_t *xf = xbase + (f * frame_stride + 2 * nbA - 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            nxt[j] = fast_fetch(xbase, min(2 * j + half, nfr - 1) * frame_stride + 8 * t, n_samples);
-            nxt2[j] = fast_fetch(xbase, min(4 + 2 * j + half, nfr - 1) * frame_stride + 8 * t, n_samples);
-        }
-        for (int q = 0; q < n_quads; ++q) {
-            // ---- 8 samples per lane and frame (16 B, coalesced), int16 -> float, pre-emphasis (numpy.hpp:1289, processing.hpp:104)
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const FastRaw cur = nxt[j];
-                nxt[j] = nxt2[j];
-                if (q + 2 < n_quads) nxt2[j] = fast_fetch(xbase, min(4 * q + 8 + 2 * j + half, nfr - 1) * frame_stride + 8 * t, n_samples);
-                float y[8];
-                float prev = (float)cur.prev * (1.0f / 32768.0f);
-                const int w[4] = { cur.v.x, cur.v.y, cur.v.z, cur.v.w };
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float lo = (float)(short)(w[i] & 0xffff) * (1.0f / 32768.0f);
-                    const float hi = (float)(short)(w[i] >> 16) * (1.0f / 32768.0f);
-                    const float pl = pre_cof * prev;
-                    y[2 * i] = lo - pl;
-                    const float ph_ = pre_cof * lo;
-                    y[2 * i + 1] = hi - ph_;
-                    prev = hi;
+                for (int i = 0; i < 8; ++i) {
+                    const int16_t *src = xf + (4 * blk + 32 * (i >> 1) + 128 * (i & 1));
+                    if (blk == 0 && i == 0) src = src < xbase ? xbase : src;
+                    raw[blk][i] = *(const fast_i2 *)src;
                 }
-                float *zb = zb0 + 2 * j * KWS_ZF;
-                *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);
-                *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
-            }
-            WAVE_SYNC();
-            FPH(0);
-            // ---- kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32 (kiss_fft.cpp:15-84, 232-296) ---
-            cf u[2][4];
+        };
+        // the frames of the pass after that: one 64-byte segment per lane, requested a pass before the real requests so that
+        // those find their lines in the cache (a pass is shorter than an HBM round trip under load); the value is only handed to
+        // an empty asm statement a pass later, which is what keeps its register reserved until the data has arrived
+        auto touch = [&](int q) {
+            const int f = min(KWS_FAST_MEL_CHUNK * q + fg, nfr - 1);
+            return *(const volatile int *)(xbase + (f * frame_stride + 32 * fl));
+        };
+        fast_i2 nxt[2][8];
+        fetch(0, nxt);
+        int touched = n_pass > 1 ? touch(1) : 0;
+        for (int q = 0; q < n_pass; ++q) {
+            const int fbase = KWS_FAST_MEL_CHUNK * q;
+            const int f = fbase + fg;
+            const bool live = f < nfr;
+            cf u[4][4];                                                  // after the exchange: u[a][b] = position fl + 8 a + 32 b
             {
-                cf la[2][4], lb[2][4];
+                cf z[2][8];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        la[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, n0 + 16 * i);
-                        lb[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, n0 + 16 * i + 64);
-                    }
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) u[j][i] = k01 ? csub(la[j][i], lb[j][i]) : cadd(la[j][i], lb[j][i]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bfly4(u[j][0], u[j][1], u[j][2], u[j][3], a1, a2, a3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st_cf(zb0 + 2 * j * KWS_ZF, 8 * g01 + k01 + 2 * i, u[j][i]);
-            }
-            WAVE_SYNC();
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) u[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, 32 * G2 + K2 + 8 * i);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bfly4(u[j][0], u[j][1], u[j][2], u[j][3], b1, b2, b3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st_cf(zb0 + 2 * j * KWS_ZF, 32 * G2 + K2 + 8 * i, u[j][i]);
-            }
-            WAVE_SYNC();
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) u[j][i] = ld_cf(zb0 + 2 * j * KWS_ZF, t + 32 * i);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bfly4(u[j][0], u[j][1], u[j][2], u[j][3], c1, c2, c3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st_cf(zb0 + 2 * j * KWS_ZF, t + 32 * i, u[j][i]);
-            }
-            WAVE_SYNC();
-            FPH(1);
-            // ---- kiss_fftr split (kiss_fftr.cpp:84-119) and the power spectrum, fp32: |X|^2 / fft_length ------------------
-            cf fpk[2][2], fq[2][2];
-            float2 d0[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int rep = 0; rep < 2; ++rep) {
-                    const int k = t + 1 + 32 * rep;
-                    fpk[j][rep] = ld_cf(zb0 + 2 * j * KWS_ZF, k);
-                    fq[j][rep] = ld_cf(zb0 + 2 * j * KWS_ZF, KWS_NC - k);
+                    for (int i = 0; i < 8; ++i) z[blk][i] = fast_point(nxt[blk][i], pre_cof);
+                if (f == 0 && fl == 0) {                                 // the clip's first sample: its predecessor wraps
+                    fast_i2 v = nxt[0][0];
+                    v.y = v.x;
+                    v.x = wrap_prev << 16;
+                    z[0][0] = fast_point(v, pre_cof);
                 }
-                d0[j] = *(const float2 *)(zb0 + 2 * j * KWS_ZF);     // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
-            }
+                if (q + 1 < n_pass) fetch(q + 1, nxt);
+                asm volatile("" : : "v"(touched));
+                if (q + 2 < n_pass) touched = touch(q + 2);
+                FPH(0);
+                // kf_bfly2 (m = 1, twiddle 1) on the (i4 = 0, 1) pairs, then kf_bfly4 (m = 2) on the sums (k = 0) and the
+                // differences (k = 1): outputs 8 j + k + 2 i
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int f = 4 * q + 2 * j + half;
-                const bool live = f < nfr;
-                float *prow = pw + (2 * j + half) * pstride - bmin;
+                for (int blk = 0; blk < 2; ++blk) {
+                    cf sm[4], df[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sm[i] = cadd(z[blk][2 * i], z[blk][2 * i + 1]); df[i] = csub(z[blk][2 * i], z[blk][2 * i + 1]); }
+                    bfly4_unit(sm[0], sm[1], sm[2], sm[3]);
+                    bfly4(df[0], df[1], df[2], df[3], a1, a2, a3);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { z[blk][2 * i] = sm[i]; z[blk][2 * i + 1] = df[i]; }
+                }
+                // the exchange, half a frame at a time (64 positions per frame fit the buffer): block fl feeds b = 0, 1
+#pragma unroll
+                for (int rnd = 0; rnd < 2; ++rnd) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) *(float2 *)(xw + xwr + 2 * r) = make_float2(z[rnd][r].r, z[rnd][r].i);
+                    WAVE_SYNC();
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const float2 v = *(const float2 *)(xw + xrd + 18 * a + 72 * b);
+                            u[a][2 * rnd + b].r = v.x; u[a][2 * rnd + b].i = v.y;
+                        }
+                    WAVE_SYNC();
+                }
+            }
+            // kf_bfly4 m = 8 (k = fl) inside every block of 32, then m = 32 (k = fl + 8 a) across them
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bfly4(u[0][b], u[1][b], u[2][b], u[3][b], b1, b2, b3);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) bfly4(u[a][0], u[a][1], u[a][2], u[a][3], c1[a], c2[a], c3[a]);
+            FPH(1);
+            // ---- kiss_fftr split (kiss_fftr.cpp:84-119) and the power spectrum, fp32: |X|^2 / fft_length.  Bin pair (k, 128 - k)
+            //      needs positions k and 128 - k: the second lives in lane (8 - fl) % 8 at (3 - a, 3 - b) -- in lane 0 itself, one
+            //      position further -- so the lanes swap their upper halves.
+            {
+                float *prow = pw + fg * pstride;                     // bins 0 .. 127 (a row of a dead frame slot is written too, never read)
+                const bool lane0 = fl == 0;
                 float esum = 0.0f;
 #pragma unroll
-                for (int rep = 0; rep < 2; ++rep) {
-                    const int k = t + 1 + 32 * rep;
-                    const cf stw = rep ? st2 : st1;
-                    cf fpnk; fpnk.r = fq[j][rep].r; fpnk.i = -fq[j][rep].i;
-                    const cf f1k = cadd(fpk[j][rep], fpnk), f2k = csub(fpk[j][rep], fpnk);
-                    const cf twv = cmul(f2k, stw);
-                    cf lo, hi;
-                    lo.r = (f1k.r + twv.r) * 0.5f;
-                    lo.i = (f1k.i + twv.i) * 0.5f;
-                    hi.r = (f1k.r - twv.r) * 0.5f;
-                    hi.i = (twv.i - f1k.i) * 0.5f;
-                    const float plo = __fmaf_rn(lo.r, lo.r, lo.i * lo.i) * inv_fft;
-                    const float phi = __fmaf_rn(hi.r, hi.r, hi.i * hi.i) * inv_fft;
-                    if (k != KWS_NC / 2) {                           // bin 64 is written twice by the reference: the second store wins
-                        esum += plo;
-                        if (live && k >= bmin && k <= bmax) prow[k] = plo;
+                for (int qq = 0; qq < 8; ++qq) {
+                    const int a = qq & 3, b = qq >> 2;
+                    cf other;
+                    other.r = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(u[3 - a][3 - b].r)));
+                    other.i = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(u[3 - a][3 - b].i)));
+                    cf fpk = u[a][b];
+                    int k = fl + 8 * a + 32 * b;
+                    {
+                        // lane 0: 128 - k = 8 (16 - a - 4 b) is position index 16 - qq of the lane itself; its pair 0 is (64, 64)
+                        const int o = qq == 0 ? 8 : 16 - qq;
+                        other.r = lane0 ? u[o & 3][o >> 2].r : other.r;
+                        other.i = lane0 ? u[o & 3][o >> 2].i : other.i;
+                        if (qq == 0) { fpk.r = lane0 ? u[0][2].r : fpk.r; fpk.i = lane0 ? u[0][2].i : fpk.i; k = lane0 ? KWS_NC / 2 : k; }
                     }
+                    cf fpnk; fpnk.r = other.r; fpnk.i = -other.i;
+                    const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    const cf twv = cmul(f2k, stw[qq]);
+                    cf lo, hi;                                       // twice the reference's: the halving is part of pscale
+                    lo.r = f1k.r + twv.r;
+                    lo.i = f1k.i + twv.i;
+                    hi.r = f1k.r - twv.r;
+                    hi.i = twv.i - f1k.i;
+                    const float plo = __fmaf_rn(lo.r, lo.r, lo.i * lo.i) * pscale;
+                    const float phi = __fmaf_rn(hi.r, hi.r, hi.i * hi.i) * pscale;
+                    // bin 64 is written twice by the reference and the second store wins: same order here; its first value is not
+                    // part of the frame energy
+                    prow[k] = plo;
+                    esum += (qq == 0 && lane0) ? 0.0f : plo;
                     esum += phi;
-                    if (live && KWS_NC - k >= bmin && KWS_NC - k <= bmax) prow[KWS_NC - k] = phi;
+                    prow[KWS_NC - k] = phi;
                 }
-                if (t == 0) {
-                    const float dc = d0[j].x + d0[j].y, ny = d0[j].x - d0[j].y;
-                    const float pdc = (dc * dc) * inv_fft, pny = (ny * ny) * inv_fft;
+                if (fl == 0) {                                       // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
+                    const float dc = u[0][0].r + u[0][0].i, ny = u[0][0].r - u[0][0].i;
+                    const float pdc = (dc * dc) * (4.0f * pscale), pny = (ny * ny) * (4.0f * pscale);
                     esum += pdc + pny;
-                    if (live && bmin == 0) prow[0] = pdc;
+                    prow[0] = pdc;
                 }
                 // frame energy (feature.hpp:289-298): its log is parked until the DCT has run
-                esum = half_wave_sum(esum);
-                if (t == 0 && live) elog[f] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
+                esum = oct_sum(esum);
+                if (fl == 0 && live) elog[f] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
             }
             FPH(2);
 
-            // ---- mel filterbank for the four frames: dot_by_row as a register-tap gather, zero handling, log ----------
+            // ---- mel filterbank for the eight frames: dot_by_row as a register-tap gather, zero handling, log ----------
             WAVE_SYNC();
-            const int fbase = 4 * q;
             const int nfc = min(KWS_FAST_MEL_CHUNK, nfr - fbase);
-            float macc[KWS_FAST_MEL_CHUNK / 2 + 1];
             {
-                float xv[KWS_FAST_MEL_CHUNK / 2][NZ], xv2[NZ2];
-                // filters 32..39: eight of them per frame slot, lanes 0..31 (40 filters only)
+                // filters 0..31: lane half h takes frame slots 4 h .. 4 h + 3; filters 32..39 (40 filters only): one frame slot each
                 const int j2 = 32 + (lane_c & 7), sl2 = lane_c >> 3;
-                const float *p1 = pw + half * pstride + start1, *p2 = pw + min(sl2, KWS_FAST_MEL_CHUNK - 1) * pstride + start2;
+                const float *p1 = pw + 4 * half * pstride + start1, *p2 = pw + sl2 * pstride + start2;
+                float macc[5];
 #pragma unroll
-                for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s)     // filters 0..31: two frames per pass
+                for (int s2 = 0; s2 < 4; s2 += 2) {
+                    float xv[2][NZ];
 #pragma unroll
-                    for (int n = 0; n < NZ; ++n) xv[s][n] = p1[2 * s * pstride + n];
-                if (DG > 4)
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int n = 0; n < NZ; ++n) xv[s][n] = p1[(s2 + s) * pstride + n];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int n = 0; n < NZ; ++n) acc = __fmaf_rn(xv[s][n], w1[n], acc);
+                        macc[s2 + s] = acc;
+                    }
+                }
+                float acc2 = 0.0f;
+                if (DG > 4) {
+                    float xv2[NZ2];
 #pragma unroll
                     for (int n = 0; n < NZ2; ++n) xv2[n] = p2[n];
 #pragma unroll
-                for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int n = 0; n < NZ; ++n) acc = __fmaf_rn(xv[s][n], w1[n], acc);
-                    macc[s] = acc;
-                }
-                float acc2 = 0.0f;
-                if (DG > 4)
-#pragma unroll
                     for (int n = 0; n < NZ2; ++n) acc2 = __fmaf_rn(xv2[n], w2[n], acc2);
-                macc[KWS_FAST_MEL_CHUNK / 2] = acc2;
+                }
+                macc[4] = acc2;
 #pragma unroll
-                for (int s = 0; s <= KWS_FAST_MEL_CHUNK / 2; ++s) macc[s] = fast_log(macc[s] == 0.0f ? FLT_EPSILON : macc[s]);   // functions.hpp:63-69
+                for (int s = 0; s < 5; ++s) macc[s] = fast_log(macc[s] == 0.0f ? FLT_EPSILON : macc[s]);   // functions.hpp:63-69
 #pragma unroll
-                for (int s = 0; s < KWS_FAST_MEL_CHUNK / 2; ++s) {
-                    const int slot = 2 * s + half;
+                for (int s = 0; s < 4; ++s) {
+                    const int slot = 4 * half + s;
                     if (slot < nfc && t < NF) img[(fbase + slot) * fs + t] = macc[s];
                 }
-                if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2] = macc[KWS_FAST_MEL_CHUNK / 2];
+                if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2] = macc[4];
             }
             WAVE_SYNC();
             FPH(3);
@@ -645,8 +699,9 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             // un-pooled: straight into the next image; pooled: staged in this block's own (dead) input image
             float *stage = pooled ? cur : oth;
             const int sstride = pooled ? k.stage_stride : o_stride;
+            long long t_loop = 0, t_pre = 0, *tl = (PROF && b == 0) ? &t_loop : nullptr, *tp = (PROF && b == 0) ? &t_pre : nullptr;
             switch (k.m_tiles * 4 + k.n_tiles) {
-            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n); break;
+            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n, tl, tp); break;
             case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n); break;
             case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shared, lane_n); break;
             case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shared, lane_n); break;
@@ -654,6 +709,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shared, lane_n); break;
             }
             WAVE_SYNC();
+            if (PROF && b == 0) { ph[9] += t_loop - t_pre; ph[10] += clock64() - t_loop; ph[11] += t_pre - tlast; }
             fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
             WAVE_SYNC();
             float *tmp = cur; cur = oth; oth = tmp;

@@ -1,6 +1,7 @@
 // kws_fast_plan.cpp -- tables and LDS layout of KWS_MODE_FAST (kws_fast.h).  Like kws_plan.cpp: everything that does not depend on
 // the audio is computed once per model on the host and uploaded.
 #include "kws_internal.h"
+#include <cstdlib>
 
 static const int kLdsBytes = 160 * 1024;
 
@@ -40,6 +41,9 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     if (bmax < 0) { bmin = 0; bmax = 0; }
     if (max_nz > KWS_FAST_NZ_MAX) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: mel filter with %d taps (at most %d)", max_nz, KWS_FAST_NZ_MAX);
     if (bmax > P.n_bins - 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: a mel filter reads the Nyquist bin");
+    // the power rows hold every bin below Nyquist: the spectral phase stores without looking at the filters' range
+    bmin = 0;
+    bmax = P.n_bins - 2;
     F.bmin = bmin;
     F.nbins = bmax - bmin + 1;
     F.nf2p = NF > 32 ? 8 : 0;                      // 40 filters: filters 32..39, eight frame slots per pass
@@ -128,11 +132,12 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     while (shared.size() & 3) shared.push_back(0.0f);
     F.shared_floats = (int)shared.size();
     F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4);
-    F.r1_floats = round_up(std::max(4 * KWS_FAST_ZF + KWS_FAST_MEL_CHUNK * F.pstride, need_r1), 4);
+    F.r1_floats = round_up(std::max(std::max(KWS_FAST_MEL_CHUNK * KWS_FAST_XS, KWS_FAST_MEL_CHUNK * F.pstride), need_r1), 4);
     F.wave_floats = F.f_floats + F.r1_floats;
     const int avail = kLdsBytes / 4 - F.shared_floats;
     F.n_waves = std::min(8, avail / F.wave_floats);
-    if (F.n_waves < 4) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
+    if (const char *ev = getenv("KWS_DEV_FAST_WAVES")) F.n_waves = std::max(1, std::min(F.n_waves, atoi(ev)));   // development aid (occupancy experiments)
+    if (F.n_waves < 4 && !getenv("KWS_DEV_FAST_WAVES")) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
                                    F.shared_floats * 4, F.wave_floats * 4);
     EI_IMPULSE_ERROR e = h->upload(shared, &F.shared_init);
     if (e) return e;

@@ -17,10 +17,10 @@ L.kws_dev_fast_phase_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctype
 for _ in range(2):
     rc = L.kws_dev_fast_phase_profile(m.h, pcm.data_ptr(), B, s.data_ptr(), prof.data_ptr())
     torch.cuda.synchronize()
-p = prof.cpu().numpy()[:10]
-names = ["load+preemph", "fft", "split+power+energy", "mel+log", "dct", "cmvn", "conv block 0", "conv blocks 1+", "fc+softmax", "-"]
-tot = p.sum()
-nclips = max(1, B // (256 * 8))
+p = prof.cpu().numpy()[:12]
+names = ["load+preemph", "fft", "split+power+energy", "mel+log", "dct", "cmvn", "conv block 0", "conv blocks 1+", "fc+softmax", "(block 0: k loop)", "(block 0: epilogue)", "(block 0: preamble)"]
+tot = p[:9].sum()
+nclips = max(1, B // (256 * int(os.environ.get("KWS_DEV_FAST_WAVES", "8"))))
 print(os.path.basename(path), "rc", rc, "clips by wave 0 ~", nclips, "total cycles", tot, "per clip", tot / nclips)
 for n, v in zip(names, p):
     print("%-20s %12d  %5.1f%%  %8.0f cycles/clip" % (n, v, 100.0 * v / tot, v / nclips))
