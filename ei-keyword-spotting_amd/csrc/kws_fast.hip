@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // an empty asm statement a pass later, which is what keeps its register reserved until the data has arrived
         auto touch = [&](int q) {
             const int f = min(KWS_FAST_MEL_CHUNK * q + fg, nfr - 1);
-            return *(const volatile int *)(xbase + (f * frame_stride + 32 * fl));
+            return *(const int *)(xbase + (f * frame_stride + 32 * fl));
         };
         fast_i2 nxt[2][8];
         fetch(0, nxt);
