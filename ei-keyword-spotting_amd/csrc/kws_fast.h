@@ -22,6 +22,7 @@
 #define KWS_FAST_NZ2 8            // longest of filters 32..39
 #define KWS_FAST_DCT_GROUPS 5     // NF / 8 <= 5: DCT operand fragments kept in registers
 #define KWS_FAST_MEL_CHUNK 8      /* frames per pass of the spectral loop: eight lanes per frame */
+#define KWS_FAST_CMVN_EXT 8
 #define KWS_FAST_XS 144           /* floats per frame of the FFT exchange buffer: 64 positions + 2 floats of padding per 8; = 16 mod 64 */      // frames transformed per pass of the spectral loop (their power rows feed one mel pass)
 #define KWS_FAST_WAVE 64
 #define KWS_FAST_ZF 320           // floats per in-place FFT buffer (kws_device.h KWS_ZF)
@@ -57,6 +58,8 @@ struct KwsFastPlan {
     int cr, cg;                   // rows per lane, columns per pass (13 x 16 or 17 x 20)
     int cnt_off, upd_off;         // shared LDS: cnt[64/cg][n_frames rounded up to 8] window multiplicities of each row group's first
                                   // window; upd[n_frames] = offset of the padded row leaving | entering << 16 (floats, image relative)
+    int ext_off;                  // shared LDS, or -1: per row group [1 + 2 * KWS_FAST_CMVN_EXT] = base multiplicity m0 of its first window,
+                                  // then (row offset as int bits, extra multiplicity) for the rows counted more than m0 times
     float inv_win;
     float guard;                  // a window with std < guard * max(1, |mean|) sends the clip to the exact kernels
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];

@@ -243,9 +243,13 @@ __device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__
 //  Three batches of loads per column block (the column, the update table, the rows the updates name); statistics and results
 //  stay in registers until every lane has read what it needs, only then are the rows overwritten.
 // ---------------------------------------------------------------------------------------------------------
+//  ext_tab != NULL (win_size > 2 n_frames, the usual shapes): the first window counts every row m0 times and at most
+//  KWS_FAST_CMVN_EXT rows more, so it is m0 x (the column's plain sums, gathered from the row groups' own rows with
+//  ds_bpermute) + those few rows, instead of a walk over every row.
 template <int CR, int CG, typename Emit>
 __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                          float inv_win, float guard, int lane, int nfr, int ncep, Emit emit)
+                                          float inv_win, float guard, int lane, int nfr, int ncep, Emit emit,
+                                          const float *__restrict__ ext_tab)
 {
     constexpr int NG = KWS_WAVE / CG;
     const int cgrp = min(lane / CG, NG - 1), cl = lane - (lane / CG) * CG;
@@ -254,20 +258,58 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
     const int nfr8 = (nfr + 7) & ~7;
     const float *cnt = cnt_tab + cgrp * nfr8;          // rows padded to a multiple of 8 with zeros
     bool bad = false;
+    // column-independent table entries: the update table of this lane's rows, the first window's extra rows
+    int u[CR - 1];                                    // leaving row offset | entering row offset << 16 (floats)
+#pragma unroll
+    for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0 + i, nfr - 1)];
+    int xo[KWS_FAST_CMVN_EXT];
+    float we[KWS_FAST_CMVN_EXT], m0 = 0.0f;
+    if (ext_tab) {
+        const float *ext = ext_tab + cgrp * (1 + 2 * KWS_FAST_CMVN_EXT);
+        m0 = ext[0];
+#pragma unroll
+        for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) { xo[e] = __float_as_int(ext[1 + 2 * e]); we[e] = ext[2 + 2 * e]; }
+    }
     for (int cb = 0; cb < ncep; cb += CG) {
         const int c = cb + cl;
         const bool act = lane_on && c < ncep && r0 < nfr;
         float *col = img + min(c, ncep - 1);
+        // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name
         const float piv = col[0];
-        // the update table entries of this lane's rows, then the rows they name and the lane's own rows
-        int u[CR - 1];                                // leaving row offset | entering row offset << 16 (floats)
-#pragma unroll
-        for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0 + i, nfr - 1)];
         float own[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) own[i] = col[min(r0 + i, nfr - 1) * fs];
+        float dl[CR - 1], da[CR - 1];
+#pragma unroll
+        for (int i = 0; i < CR - 1; ++i) { dl[i] = col[u[i] & 0xffff]; da[i] = col[(unsigned)u[i] >> 16]; }
         // first window of the row group: sum_j cnt[j] d_j, eight rows per batch, two partial sums
         float S0 = 0.0f, S1 = 0.0f, Q0 = 0.0f, Q1 = 0.0f;
+        if (ext_tab) {
+            float xe[KWS_FAST_CMVN_EXT];
+#pragma unroll
+            for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) xe[e] = col[xo[e]];
+            float T0 = 0.0f, T1 = 0.0f, U0 = 0.0f, U1 = 0.0f;          // this lane's rows
+#pragma unroll
+            for (int i = 0; i < CR; ++i) {
+                const float d = (lane_on && r0 + i < nfr) ? own[i] - piv : 0.0f;
+                if (i & 1) { T1 += d; U1 = __fmaf_rn(d, d, U1); } else { T0 += d; U0 = __fmaf_rn(d, d, U0); }
+            }
+            float T = T0 + T1, U = U0 + U1;
+            float Tt = T, Ut = U;
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {                               // the other row groups' share of the column
+                const int src = (cl + CG * ((cgrp + g) % NG)) << 2;
+                Tt += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(T)));
+                Ut += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(U)));
+            }
+            S0 = m0 * Tt; Q0 = m0 * Ut;
+#pragma unroll
+            for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) {
+                const float d = xe[e] - piv, wd = we[e] * d;
+                S1 += wd;
+                Q1 = __fmaf_rn(wd, d, Q1);
+            }
+        } else
         for (int j0 = 0; j0 < nfr8; j0 += 8) {
             float x[8];
 #pragma unroll
@@ -282,9 +324,8 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
                 Q0 = __fmaf_rn(wd0, d0, Q0); Q1 = __fmaf_rn(wd1, d1, Q1);
             }
         }
-        float dl[CR - 1], da[CR - 1];
 #pragma unroll
-        for (int i = 0; i < CR - 1; ++i) { dl[i] = col[u[i] & 0xffff] - piv; da[i] = col[(unsigned)u[i] >> 16] - piv; }
+        for (int i = 0; i < CR - 1; ++i) { dl[i] -= piv; da[i] -= piv; }
         float S = S0 + S1, Q = Q0 + Q1;
         float o[CR];
 #pragma unroll
@@ -363,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const int frame_stride = P.frame_stride, n_samples = P.n_samples;
     const float *cnt_tab = shared + FP.cnt_off;
     const int *upd_tab = (const int *)(shared + FP.upd_off);
+    const float *ext_tab = FP.ext_off >= 0 ? shared + FP.ext_off : nullptr;
     const float inv_win = FP.inv_win, guard = FP.guard, stale_scale = FP.stale_scale;
     const int cr = FP.cr, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
     long long ph[KWS_FAST_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
@@ -437,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         };
         fast_i2 nxt[2][8];
         fetch(0, nxt);
-        int touched = n_pass > 1 ? touch(1) : 0;
+        int touched = touch(1);
         for (int q = 0; q < n_pass; ++q) {
             const int fbase = KWS_FAST_MEL_CHUNK * q;
             const int f = fbase + fg;
@@ -455,9 +497,11 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                     v.x = wrap_prev << 16;
                     z[0][0] = fast_point(v, pre_cof);
                 }
-                if (q + 1 < n_pass) fetch(q + 1, nxt);
+                // unconditional (the frame index is clamped): a conditional request makes the compiler copy all sixteen register
+                // pairs around the branch
+                fetch(q + 1, nxt);
                 asm volatile("" : : "v"(touched));
-                if (q + 2 < n_pass) touched = touch(q + 2);
+                touched = touch(q + 2);
                 FPH(0);
                 // kf_bfly2 (m = 1, twiddle 1) on the (i4 = 0, 1) pairs, then kf_bfly4 (m = 2) on the sums (k = 0) and the
                 // differences (k = 1): outputs 8 j + k + 2 i
@@ -678,8 +722,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         bool bad;
         int lane_m = lane;
         asm volatile("" : "+v"(lane_m));
-        if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit);
-        else bad = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit);
+        if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab);
+        else bad = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab);
         if (__any(bad)) {
             if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
         }

@@ -107,6 +107,36 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
         if (r0 >= nfr) continue;
         for (int p = r0; p < r0 + win; p++) shared[(size_t)F.cnt_off + (size_t)g * nfr8 + pmap[p]] += 1.0f;
     }
+    // Usual shapes (win_size > 2 n_frames): a first window counts every row m0 times and a handful of rows more -- the kernel then
+    // needs the column's plain sums (every lane has its own rows in registers) and those few rows instead of a walk over all rows.
+    {
+        std::vector<float> ext((size_t)ng * (1 + 2 * KWS_FAST_CMVN_EXT), 0.0f);
+        bool sparse = true;
+        for (int g = 0; g < ng && sparse; g++) {
+            const int r0 = g * F.cr;
+            if (r0 >= nfr) continue;
+            const float *cn = &shared[(size_t)F.cnt_off + (size_t)g * nfr8];
+            float m0 = cn[0];
+            for (int j = 1; j < nfr; j++) m0 = std::min(m0, cn[j]);
+            float *e = &ext[(size_t)g * (1 + 2 * KWS_FAST_CMVN_EXT)];
+            e[0] = m0;
+            int n = 0;
+            for (int j = 0; j < nfr; j++)
+                if (cn[j] > m0) {
+                    if (n == KWS_FAST_CMVN_EXT) { sparse = false; break; }
+                    const int row = j;                      // multiplied by the image's row stride in finish_fast_plan
+                    memcpy(&e[1 + 2 * n], &row, sizeof(int));
+                    e[2 + 2 * n] = cn[j] - m0;
+                    n++;
+                }
+        }
+        F.ext_off = -1;
+        if (sparse) {
+            while (shared.size() & 3) shared.push_back(0.0f);
+            F.ext_off = (int)shared.size();
+            shared.insert(shared.end(), ext.begin(), ext.end());
+        }
+    }
     F.upd_off = (int)shared.size();
     shared.resize(shared.size() + (size_t)nfr, 0.0f);
     // filled once the image's row stride is known (offsets are in floats): see finish_fast_plan
@@ -129,6 +159,15 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
         const int packed = (pmap[r] * F.fs) | ((pmap[r + P.win_size] * F.fs) << 16);       // both < 65536
         memcpy(&shared[(size_t)F.upd_off + r], &packed, sizeof(int));
     }
+    if (F.ext_off >= 0)
+        for (int g = 0; g < KWS_FAST_WAVE / F.cg; g++)
+            for (int n = 0; n < KWS_FAST_CMVN_EXT; n++) {
+                int row;
+                float *slot = &shared[(size_t)F.ext_off + (size_t)g * (1 + 2 * KWS_FAST_CMVN_EXT) + 1 + 2 * n];
+                memcpy(&row, slot, sizeof(int));
+                row *= F.fs;
+                memcpy(slot, &row, sizeof(int));
+            }
     while (shared.size() & 3) shared.push_back(0.0f);
     F.shared_floats = (int)shared.size();
     F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4);
