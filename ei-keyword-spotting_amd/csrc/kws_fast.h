@@ -34,6 +34,8 @@ struct KwsFastBlock {
     int in_stride;                // floats per activation row of the block's input image in LDS (in_w rows: SAME padding is
                                   // applied to the operand registers, not stored)
     int m_tiles, n_tiles;         // 16-row / 16-channel output tiles (<= 4 x 2: every accumulator stays in registers)
+    int vrows;                    // output rows beyond the tiles (out_w = 16 m_tiles + vrows, vrows <= 2) computed on the vector ALU: the
+                                  // 49-frame window would otherwise pay a fourth row tile for one row
     int stage_stride;             // row stride of the un-pooled staging image (odd)
     int w_off, bias_off, addc_off;   // float offsets into the workgroup's shared LDS block
     int has_add;

@@ -123,6 +123,34 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
             v[mt].y = in_img ? v[mt].y : 0.0f;
         }
     };
+    // ---- the rows beyond the tiles (k.vrows <= 2) on the vector ALU, before anything is written over the input image: lane =
+    //      output channel x half of every tap's channel pairs; the input row is read as a broadcast, taps that fall into the
+    //      SAME padding are skipped
+    float vout[2] = { 0.0f, 0.0f };
+    for (int vr = 0; vr < k.vrows; ++vr) {
+        const int row = 16 * MT + vr, n = min(lane & 31, out_c - 1), hf = lane >> 5;
+        const int npair = k.in_cp >> 2;                               // channel pairs per tap and half
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int tap = 0; tap < k.taps; ++tap) {
+            const int r = row + tap - k.pad_left;
+            if ((unsigned)r >= (unsigned)in_w) continue;
+            const float *ap = in + r * in_stride + 2 * hf * npair;
+            const float *wp = shared + k.w_off + 2 * ((tap * (k.in_cp >> 1) + hf * npair) * out_c + n);
+            int p = 0;
+            for (; p + 1 < npair; p += 2) {
+                const float4 av = *(const float4 *)(ap + 2 * p);
+                const float2 w0 = *(const float2 *)(wp + 2 * p * out_c), w1 = *(const float2 *)(wp + 2 * (p + 1) * out_c);
+                s0 = __fmaf_rn(av.x, w0.x, s0); s1 = __fmaf_rn(av.y, w0.y, s1);
+                s0 = __fmaf_rn(av.z, w1.x, s0); s1 = __fmaf_rn(av.w, w1.y, s1);
+            }
+            if (p < npair) {
+                const float2 av = *(const float2 *)(ap + 2 * p), w0 = *(const float2 *)(wp + 2 * p * out_c);
+                s0 = __fmaf_rn(av.x, w0.x, s0); s1 = __fmaf_rn(av.y, w0.y, s1);
+            }
+        }
+        const float part = s0 + s1;
+        vout[vr] = part + __shfl_xor(part, 32, KWS_WAVE);
+    }
     float2 a[MT], b[NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a[mt] = *(const float2 *)(abase + mt * mstep);
@@ -188,6 +216,13 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
                 if (row < out_w && n < out_c) sp[row * sstride] = v;
             }
         }
+    }
+    for (int vr = 0; vr < k.vrows; ++vr) {
+        const int n = lane & 31, nc = min(n, out_c - 1);
+        float v = vout[vr] + shared[k.bias_off + nc];
+        v = fminf(fmaxf(v, cmin), cmax);
+        if (has_add) { v = v + shared[k.addc_off + nc]; v = fminf(fmaxf(v, amin), amax); }
+        if (lane < 32 && n < out_c) stage[(16 * MT + vr) * sstride + n] = v;
     }
 }
 
@@ -747,6 +782,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             switch (k.m_tiles * 4 + k.n_tiles) {
             case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n, tl, tp); break;
             case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n); break;
+            case 3 * 4 + 2: fast_conv_tiles<3, 2>(k, cur, stage, sstride, shared, lane_n, tl, tp); break;
+            case 3 * 4 + 1: fast_conv_tiles<3, 1>(k, cur, stage, sstride, shared, lane_n); break;
             case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shared, lane_n); break;
             case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shared, lane_n); break;
             case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shared, lane_n); break;

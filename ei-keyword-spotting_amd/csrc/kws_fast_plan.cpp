@@ -224,7 +224,8 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         k.pool = s.pool; k.pool_stride = s.pool_stride; k.pool_w = s.pool_w;
         k.in_stride = b == 0 ? F.fs : k.in_cp + 4;
         k.m_tiles = (s.out_w + 15) / 16; k.n_tiles = (s.out_c + 15) / 16;
-        if (k.m_tiles == 3) k.m_tiles = 4;       // tile shapes the kernel instantiates: {1, 2, 4} x {1, 2}
+        k.vrows = 0;
+        if (s.out_w >= 16 && s.out_w % 16 <= 2 && s.out_w % 16 != 0 && (k.in_cp % 4) == 0) { k.m_tiles = s.out_w / 16; k.vrows = s.out_w % 16; }
         if (k.m_tiles > 4 || k.n_tiles > 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: conv block %d is %d x %d outputs (at most 64 x 32)", b, s.out_w, s.out_c);
         if (b == 0 && (k.in_cp > h->dsp.n_filters || s.in_w != h->dsp.n_frames || s.in_c != h->dsp.n_cepstral))
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: first conv block does not read the feature matrix");
