@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     // scratch to index its blocks
     const KwsFastPlan &FP = *FPp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
     float *shared = lds;
     float *F = lds + FP.shared_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
     float *R1 = F + FP.f_floats;                                      // FFT buffers + power rows; later block 1's input image

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
     constexpr int CHF = 2 * CHP + (LW ? 2 : 0);          // frame slots per power-spectrum row (stride)
     constexpr int MELS = NF + 1, NCEPT = NF / 2 + 1;     // DCT only produces outputs 0..NF/2 (fast-dct-fft.cpp:71)
     __shared__ typename MfccSmemSel<CHP, NF, LW>::type sm;
-    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = LW ? (int)(threadIdx.x >> 6) : 0;
+    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = LW ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int half = lane >> 5, t = lane & 31;
     // this wave's view of the LDS block (one wave per workgroup unless LW > 0)
     float *zw, *sm_p, *sm_dcny, *sm_mel, *sm_energy;

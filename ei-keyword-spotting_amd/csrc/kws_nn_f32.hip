@@ -277,7 +277,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
     // scratch as soon as a block is indexed dynamically
     const KwsNnPlanF32 &N = *Np;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
     // development aid: shader-clock totals per phase of wave 0 of workgroup 0 (input, each block, head)
     const bool profiling = prof != nullptr && blockIdx.x == 0 && wave == 0;
     long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;

@@ -151,29 +151,52 @@ __device__ __forceinline__ void nn_head(const KwsNnPlan &N, const NnHeadTab &H, 
     WAVE_SYNC();
 }
 
+// per-channel requantisation constants (MultiplyByQuantizedMultiplier, common.h:138-162), staged in LDS once per workgroup
+struct NnRq { int bias, mult, ls, rs, mask, half; };
+__device__ __forceinline__ NnRq nn_rq_of(const int4 *tab, int oc)
+{
+    const int4 v = tab[oc];                                   // bias_eff, multiplier, shift, -
+    NnRq q;
+    q.bias = v.x; q.mult = v.y;
+    q.ls = max(v.z, 0); q.rs = max(-v.z, 0);
+    q.mask = (int)((1ll << q.rs) - 1); q.half = q.mask >> 1;
+    return q;
+}
+// bias + requantise + output offset + activation clamp of one accumulator (integer_ops/conv.h:111-116).  srdhm() without its
+// overflow branch: that needs a == b == INT_MIN, and the plan refuses negative multipliers.
+__device__ __forceinline__ int nn_requant(int m, const NnRq &q, int out_zp, int act_min, int act_max)
+{
+    m += q.bias;
+    const int x = (int)((unsigned)m << q.ls);
+    const long long p = (long long)x * (long long)q.mult + (1ll << 30);
+    const int hi = (int)(p >> 31);
+    const int rem = hi & q.mask, thr = q.half + (hi < 0 ? 1 : 0);
+    const int r = (hi >> q.rs) + (rem > thr ? 1 : 0) + out_zp;
+    return min(max(r, act_min), act_max);
+}
+
 __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                          float *__restrict__ scores, NnTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
 
-    // ---- shared: weights + ADD tables of every block ---------------------------------------------------------
+    // ---- shared: weights, ADD tables and requantisation constants of every block, in block order ---------------
     const int fcw_bytes = nn_head_fcw_bytes(N), fcx_bytes = nn_fcx_bytes(N);
     const NnHeadTab head = nn_head_stage(N, smem_raw, fcw_bytes);
-    unsigned char *sp = smem_raw + fcw_bytes + ((KWS_HEAD_REST + 15) & ~15);
-    const int8_t *s_w[KWS_MAX_BLOCKS];
-    const int8_t *s_lut[KWS_MAX_BLOCKS];
+    unsigned char *const blocks_base = smem_raw + fcw_bytes + ((KWS_HEAD_REST + 15) & ~15);
+    unsigned char *sp = blocks_base;
     int act_bytes = 0;
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlock &k = N.blk[b];
         const int wbytes = k.w_bytes;
         for (int i = threadIdx.x * 4; i < wbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.w + i);
-        s_w[b] = (const int8_t *)sp;
         sp += (wbytes + 15) & ~15;
         const int lbytes = k.has_lut ? k.out_c * 256 : 0;
         for (int i = threadIdx.x * 4; i < lbytes; i += blockDim.x * 4) *(int *)(sp + i) = *(const int *)(k.add_lut + i);
-        s_lut[b] = (const int8_t *)sp;
         sp += lbytes;
+        for (int i = threadIdx.x; i < k.out_c; i += blockDim.x) ((int4 *)sp)[i] = make_int4(k.bias_eff[i], k.mult[i], k.shift[i], 0);
+        sp += k.out_c * 16;
         const int ab = nn_rows(k) * k.in_cpad;
         act_bytes = max(act_bytes, ab);
     }
@@ -182,7 +205,8 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
     int8_t *actA = (int8_t *)(sp + wave * (2 * act_bytes + fcx_bytes + 64 * 4));
     int8_t *actB = actA + act_bytes;
     int8_t *fcx = actB + act_bytes;                    // the FULLY_CONNECTED input vector (last block's pooled output)
-    int *lgv = (int *)(fcx + fcx_bytes);               // logits
+    int *lgv = (int *)(fcx + fcx_bytes);               // logits; until the head runs, the sink of stores that fall outside the image
+    int8_t *const sink = (int8_t *)lgv + 4 * lane;
     __syncthreads();
 
     const int F = N.n_features;
@@ -218,8 +242,17 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
         mark(0);
         int8_t *cur = actA, *nxt = actB;
         int pooled_off = 0;
+        const unsigned char *bp = blocks_base;
         for (int b = 0; b < N.n_blocks; ++b) {
             const KwsConvBlock &k = N.blk[b];
+            // this block's share of the workgroup's LDS block (kept as running pointers: an array of them would be indexed
+            // through the scalar unit per access)
+            const int8_t *wb = (const int8_t *)bp;
+            bp += (k.w_bytes + 15) & ~15;
+            const int8_t *lutb = (const int8_t *)bp;
+            bp += k.has_lut ? k.out_c * 256 : 0;
+            const int4 *rqt = (const int4 *)bp;
+            bp += k.out_c * 16;
             const bool last = (b + 1 == N.n_blocks);
             const int nrows = last ? 0 : nn_rows(N.blk[b + 1]);
             const int ncp = last ? k.out_c : N.blk[b + 1].in_cpad;
@@ -229,29 +262,30 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                 for (int i = lane * 16; i < nrows * ncp; i += 64 * 16) *(int4 *)(nxt + i) = make_int4(zp4, zp4, zp4, zp4);
                 WAVE_SYNC();
             }
-            const int n_out = k.pool_w * k.out_c;
-            // requantise + folded ADD/ReLU of one pooled accumulator, store (integer_ops/conv.h:111-116, add.h)
-            struct Rq { int bias, mult, shift; };                // per-channel requantisation constants, fetched once per item
-            auto rq_of = [&](int oc) { Rq q = { k.bias_eff[oc], k.mult[oc], k.shift[oc] }; return q; };
-            auto finish = [&](int m, int pw, int oc, const Rq &q) {
-                m += q.bias;
-                int r = mbqm(m, q.mult, q.shift) + k.out_zp;
-                r = min(max(r, k.act_min), k.act_max);
-                const int8_t o = k.has_lut ? s_lut[b][oc * 256 + (r + 128)] : (int8_t)r;
-                const int idx = pw * k.out_c + oc;
-                if (last) fcx[idx] = o;
-                else nxt[(npl + pw) * ncp + oc] = o;
-                if (taps.pooled) taps.pooled[(size_t)clip * taps.pooled_stride + pooled_off + idx] = o;
+            const int out_c = k.out_c, out_w = k.out_w, n_out = k.pool_w * out_c;
+            const int out_zp = k.out_zp, act_min = k.act_min, act_max = k.act_max;
+            const bool has_lut = k.has_lut != 0;
+            // output (pooled row pw, channel oc) lands at dbase + pw * dstride + oc; the optional debug tap mirrors it in HBM
+            int8_t *const dbase = last ? fcx : nxt + npl * ncp;
+            const int dstride = last ? out_c : ncp;
+            int8_t *const tp = taps.pooled ? taps.pooled + (size_t)clip * taps.pooled_stride + pooled_off : nullptr;
+            // one accumulator at a time (the paths below that are not worth batching)
+            auto finish = [&](int m, int pw, int oc, const NnRq &q) {
+                const int r = nn_requant(m, q, out_zp, act_min, act_max);
+                const int8_t o = has_lut ? lutb[oc * 256 + (r + 128)] : (int8_t)r;
+                dbase[pw * dstride + oc] = o;
+                if (tp) tp[pw * out_c + oc] = o;
             };
-            if (k.depthwise && k.depth_mult == 1 && (k.out_c & 3) == 0 && k.taps <= 8) {
+            if (k.depthwise && k.depth_mult == 1 && (out_c & 3) == 0 && k.taps <= 8) {
                 // integer_ops/depthwise_conv.h:64-103, one input channel per output.  A lane owns 4 consecutive channels of
                 // one pooling window (or of 8 time steps when the block is not pooled): the tb + taps - 1 activation rows
                 // it needs are read ONCE as 32-bit words (4 channels each), the 4 x taps weights as 8 words, everything
-                // else is register arithmetic -- one pass over the block instead of one LDS round trip per multiply
+                // else is register arithmetic.  Outputs are requantised as a batch, looked up as a batch and stored four
+                // channels per word.
                 const bool pooled = k.pool > 1;
                 const int tb = pooled ? k.pool : KWS_POOL_MAX, tstride = pooled ? k.pool_stride : KWS_POOL_MAX;
-                const int n_tb = pooled ? k.pool_w : (k.out_w + KWS_POOL_MAX - 1) / KWS_POOL_MAX;
-                const int n_cg = k.out_c >> 2, tp4 = (k.taps + 3) & ~3, nrow = tb + k.taps - 1;
+                const int n_tb = pooled ? k.pool_w : (out_w + KWS_POOL_MAX - 1) / KWS_POOL_MAX;
+                const int n_cg = out_c >> 2, tp4 = (k.taps + 3) & ~3, nrow = tb + k.taps - 1;
                 for (int item = lane; item < n_tb * n_cg; item += 64) {
                     const int pw = item / n_cg, oc0 = (item - pw * n_cg) * 4;
                     const int t0 = pw * tstride;
@@ -261,10 +295,13 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                         xw[r] = r < nrow ? *(const int *)(cur + (t0 + r) * k.in_cpad + oc0) : 0;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const int *wr = (const int *)(s_w[b] + (oc0 + c) * tp4);
+                        const int *wr = (const int *)(wb + (oc0 + c) * tp4);
                         ww[c][0] = wr[0];
                         ww[c][1] = tp4 > 4 ? wr[1] : 0;
                     }
+                    NnRq rq[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rq[c] = nn_rq_of(rqt, oc0 + c);
                     int acc[KWS_POOL_MAX][4];
 #pragma unroll
                     for (int i = 0; i < KWS_POOL_MAX; ++i)
@@ -282,33 +319,55 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                             }
                         }
                     }
-                    Rq rq[4];
+                    if (pooled) {
+                        int o[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) rq[c] = rq_of(oc0 + c);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (pooled) {
+                        for (int c = 0; c < 4; ++c) {
                             int m = (int)0x80000000;
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i)
-                                if (i < tb && t0 + i < k.out_w) m = max(m, acc[i][c]);
-                            finish(m, pw, oc0 + c, rq[c]);
-                        } else {
+                                if (i < tb && t0 + i < out_w) m = max(m, acc[i][c]);
+                            o[c] = nn_requant(m, rq[c], out_zp, act_min, act_max);
+                        }
+                        if (has_lut)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = lutb[(oc0 + c) * 256 + (o[c] + 128)];
+                        const int word = (o[0] & 0xff) | ((o[1] & 0xff) << 8) | ((o[2] & 0xff) << 16) | ((int)((unsigned)o[3] << 24));
+                        *(int *)(dbase + pw * dstride + oc0) = word;
+                        if (tp)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) tp[pw * out_c + oc0 + c] = (int8_t)o[c];
+                    } else {
+                        int o[KWS_POOL_MAX][4];
+#pragma unroll
+                        for (int i = 0; i < KWS_POOL_MAX; ++i)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[i][c] = nn_requant(acc[i][c], rq[c], out_zp, act_min, act_max);
+                        if (has_lut)
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i)
-                                if (t0 + i < k.out_w) finish(acc[i][c], t0 + i, oc0 + c, rq[c]);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o[i][c] = lutb[(oc0 + c) * 256 + (o[i][c] + 128)];
+#pragma unroll
+                        for (int i = 0; i < KWS_POOL_MAX; ++i) {
+                            const int word = (o[i][0] & 0xff) | ((o[i][1] & 0xff) << 8) | ((o[i][2] & 0xff) << 16) | ((int)((unsigned)o[i][3] << 24));
+                            const bool ok = t0 + i < out_w;
+                            *(int *)(ok ? dbase + (t0 + i) * dstride + oc0 : sink) = word;
+                            if (tp && ok)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) tp[(t0 + i) * out_c + oc0 + c] = (int8_t)o[i][c];
                         }
                     }
                 }
             } else if (k.depthwise) {                    // any depth multiplier / channel count: one output per lane and pass
                 const int tp4 = (k.taps + 3) & ~3;
                 for (int idx = lane; idx < n_out; idx += 64) {
-                    const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                    const int pw = idx / out_c, oc = idx - pw * out_c;
                     const int t0 = pw * k.pool_stride;
                     int acc[KWS_POOL_MAX];
 #pragma unroll
                     for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i] = 0;
-                    const int8_t *wrow = s_w[b] + oc * tp4;
+                    const int8_t *wrow = wb + oc * tp4;
                     const int8_t *xcol = cur + t0 * k.in_cpad + oc / k.depth_mult;
                     for (int tap = 0; tap < k.taps; ++tap) {
                         const int wv = wrow[tap];
@@ -319,8 +378,8 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                     int m = (int)0x80000000;
 #pragma unroll
                     for (int i = 0; i < KWS_POOL_MAX; ++i)
-                        if (i < k.pool && t0 + i < k.out_w) m = max(m, acc[i]);
-                    finish(m, pw, oc, rq_of(oc));
+                        if (i < k.pool && t0 + i < out_w) m = max(m, acc[i]);
+                    finish(m, pw, oc, nn_rq_of(rqt, oc));
                 }
             } else if (k.mfma) {
                 // CONV_2D without pooling on v_mfma_i32_32x32x32_i8: [time x (taps * in_cpad)] x [(taps * in_cpad) x out_c], one or
@@ -328,9 +387,11 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                 // the same slot -> (tap, channel) map; int32 accumulation is exact, so the sums equal the reference's scalar loops
                 const int cp = k.in_cpad, n = lane & 31, hh = lane >> 5;
                 const int ks = cp == 16 ? (k.taps + 1) >> 1 : cp == 32 ? k.taps : 2 * k.taps;
-                const bool two = k.out_w > 32;
+                const bool two = out_w > 32;
+                const int nc = min(n, out_c - 1);                                              // columns >= out_c: never stored
                 v16i acc0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, acc1 = acc0;
-                const int8_t *wrow = s_w[b] + (size_t)min(n, k.out_c - 1) * k.taps * cp;      // columns >= out_c: never stored
+                const int8_t *wrow = wb + (size_t)nc * k.taps * cp;
+                const NnRq rq = nn_rq_of(rqt, nc);
                 for (int s_ = 0; s_ < ks; ++s_) {
                     const int tap = cp == 16 ? 2 * s_ + hh : cp == 32 ? s_ : s_ >> 1;
                     const int ch = cp == 16 ? 0 : cp == 32 ? 16 * hh : 32 * (s_ & 1) + 16 * hh;
@@ -343,14 +404,26 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, wv, acc1, 0, 0, 0);
                     }
                 }
-                // accumulator register r of a tile holds row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column lane & 31
-                if (n < k.out_c) {
-                    const Rq rq = rq_of(n);
+                // accumulator register r of a tile holds row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column lane & 31: the lane
+                // requantises its column's 16 (32) values as a batch, looks them up as a batch, then stores (rows / columns
+                // outside the image go to the sink: no branch per value)
+                const int8_t *lp = lutb + nc * 256 + 128;
+                int8_t *const dcol = dbase + n;
+                const bool col_ok = n < out_c;
+                for (int tile = 0; tile < (two ? 2 : 1); ++tile) {
+                    const v16i &acc = tile ? acc1 : acc0;
+                    int o[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = nn_requant(acc[r], rq, out_zp, act_min, act_max);
+                    if (has_lut)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[r] = lp[o[r]];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (row < k.out_w) finish(acc0[r], row, n, rq);
-                        if (two && 32 + row < k.out_w) finish(acc1[r], 32 + row, n, rq);
+                        const int row = 32 * tile + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const bool ok = col_ok && row < out_w;
+                        *(ok ? dcol + row * dstride : sink) = (int8_t)o[r];
+                        if (tp && ok) tp[row * out_c + n] = (int8_t)o[r];
                     }
                 }
             } else {
@@ -359,9 +432,9 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                 // (an un-pooled block is walked in groups of KWS_POOL_MAX time steps, each stored on its own)
                 const bool pooled = k.pool > 1;
                 const int tb = pooled ? k.pool : KWS_POOL_MAX, tstride = pooled ? k.pool_stride : KWS_POOL_MAX;
-                const int n_tb = pooled ? k.pool_w : (k.out_w + KWS_POOL_MAX - 1) / KWS_POOL_MAX;
-                const int ob = (n_tb * k.out_c > 64 && (k.out_c & 1) == 0) ? 2 : 1;
-                const int n_ocb = k.out_c / ob;
+                const int n_tb = pooled ? k.pool_w : (out_w + KWS_POOL_MAX - 1) / KWS_POOL_MAX;
+                const int ob = (n_tb * out_c > 64 && (out_c & 1) == 0) ? 2 : 1;
+                const int n_ocb = out_c / ob;
                 const int c16n = k.in_cpad >> 4;
                 for (int item = lane; item < n_tb * n_ocb; item += 64) {
                     const int pw = item / n_ocb, oc0 = (item - pw * n_ocb) * ob;
@@ -369,13 +442,13 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                     int acc[KWS_POOL_MAX][2];
 #pragma unroll
                     for (int i = 0; i < KWS_POOL_MAX; ++i) acc[i][0] = acc[i][1] = 0;
-                    const int8_t *w0 = s_w[b] + (size_t)oc0 * k.taps * k.in_cpad;
+                    const int8_t *w0 = wb + (size_t)oc0 * k.taps * k.in_cpad;
                     const int8_t *w1 = w0 + (ob == 2 ? k.taps * k.in_cpad : 0);
                     for (int tap = 0; tap < k.taps; ++tap) {
                         const int8_t *xrow = cur + (t0 + tap) * k.in_cpad;
                         for (int c16 = 0; c16 < c16n; ++c16) {
                             const int4 wa = *(const int4 *)(w0 + tap * k.in_cpad + 16 * c16);
-                            const int4 wb = *(const int4 *)(w1 + tap * k.in_cpad + 16 * c16);
+                            const int4 wb4 = *(const int4 *)(w1 + tap * k.in_cpad + 16 * c16);
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i) {
                                 if (i < tb) {
@@ -386,10 +459,10 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                                     a = __builtin_amdgcn_sdot4(wa.z, xv.z, a, false);
                                     a = __builtin_amdgcn_sdot4(wa.w, xv.w, a, false);
                                     if (ob == 2) {
-                                        c = __builtin_amdgcn_sdot4(wb.x, xv.x, c, false);
-                                        c = __builtin_amdgcn_sdot4(wb.y, xv.y, c, false);
-                                        c = __builtin_amdgcn_sdot4(wb.z, xv.z, c, false);
-                                        c = __builtin_amdgcn_sdot4(wb.w, xv.w, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb4.x, xv.x, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb4.y, xv.y, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb4.z, xv.z, c, false);
+                                        c = __builtin_amdgcn_sdot4(wb4.w, xv.w, c, false);
                                     }
                                     acc[i][0] = a; acc[i][1] = c;
                                 }
@@ -397,17 +470,17 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                         }
                     }
                     for (int o = 0; o < ob; ++o) {
-                        const Rq rq = rq_of(oc0 + o);
+                        const NnRq rq = nn_rq_of(rqt, oc0 + o);
                         if (pooled) {
                             int m = (int)0x80000000;
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i)
-                                if (i < tb && t0 + i < k.out_w) m = max(m, acc[i][o]);
+                                if (i < tb && t0 + i < out_w) m = max(m, acc[i][o]);
                             finish(m, pw, oc0 + o, rq);
                         } else {
 #pragma unroll
                             for (int i = 0; i < KWS_POOL_MAX; ++i)
-                                if (t0 + i < k.out_w) finish(acc[i][o], t0 + i, oc0 + o, rq);
+                                if (t0 + i < out_w) finish(acc[i][o], t0 + i, oc0 + o, rq);
                         }
                     }
                 }
@@ -572,7 +645,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES) void kws_nn_mfma_kernel(Kw
     __shared__ __attribute__((aligned(16))) int8_t s_act2[KWS_NN_WAVES][KWS_A2_ROWS * 32];
     __shared__ int s_vec[KWS_NN_WAVES][64];
     __shared__ __attribute__((aligned(16))) unsigned char s_head[KWS_HEAD_BYTES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
     const KwsConvBlock &k1 = N.blk[0], &k2 = N.blk[1];
     const NnHeadTab head = nn_head_stage(N, s_head);
     for (int i = threadIdx.x * 4; i < k1.out_c * 256; i += blockDim.x * 4) *(int *)(s_lut1 + i) = *(const int *)(k1.add_lut + i);
@@ -626,7 +699,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES, 2) void kws_cmvn_nn_kernel
     __shared__ int s_vec[KWS_NN_WAVES][FUSE ? 64 : 1];
     __shared__ __attribute__((aligned(16))) unsigned char s_head[FUSE ? KWS_HEAD_BYTES : 16];
     NnHeadTab head = { nullptr, nullptr, nullptr, nullptr };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
     const int nfr = P.n_frames, ncep = P.n_cepstral, nfeat = nfr * ncep;
     const int prow = nfr + 2 * P.pad;
     for (int i = threadIdx.x; i < prow; i += blockDim.x) s_map[i] = P.pad_map[i];
@@ -722,6 +795,7 @@ size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves)
         const KwsConvBlock &k = N.blk[b];
         s += ((size_t)k.w_bytes + 15) & ~(size_t)15;
         s += k.has_lut ? (size_t)k.out_c * 256 : 0;
+        s += (size_t)k.out_c * 16;                      // requantisation constants
         const int ab = nn_rows(k) * k.in_cpad;
         act = ab > act ? ab : act;
     }
@@ -749,7 +823,7 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
     int nw = KWS_NN_WAVES_MAX;
     while (nw > KWS_NN_WAVES && kws_nn_smem_bytes(N, nw) > 158 * 1024) --nw;
     const size_t smem = kws_nn_smem_bytes(N, nw);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / smem, (size_t)(8 / nw)));           // 171 VGPRs: two waves per SIMD
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / smem, (size_t)(8 / nw)));           // 232 VGPRs: two waves per SIMD
     grid = (n_clips + nw - 1) / nw;
     if (grid > (grid_cap / 4) * per_cu) grid = (grid_cap / 4) * per_cu;          // grid_cap = 4 workgroups per CU
     if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
