@@ -3,6 +3,8 @@
 // kws_cmvn_nn_kernel (cmvnw + quantise [+ network] for the stage API / continuous mode).  Replaces the EON-compiled
 // TFLite-Micro graph (MODEL/tflite-model/trained_model_compiled.cpp:312-328).
 #include "kws_device.h"
+#include <cstdio>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------
 //  gemmlowp / TFLite fixed-point helpers (fixedpoint.h:329-368, TFL/kernels/internal/common.h:138-162)
@@ -59,7 +61,7 @@ __device__ __forceinline__ int one_over_one_plus_x(int a)     // fixedpoint.h:84
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int KWS_NN_WAVES = 4;
-constexpr int KWS_NN_WAVES_MAX = 8;      // generic kernel: as many waves per workgroup as the LDS allows (they share weights and tables)
+constexpr int KWS_NN_WAVES_MAX = 12;     // generic kernel: as many waves per workgroup as the LDS allows (they share weights and tables)
 constexpr int KWS_POOL_MAX = 8;
 // rows of a block's padded int8 input image in the generic kernel: un-pooled blocks are walked KWS_POOL_MAX time steps at
 // a time, so reads reach up to ceil(out_w / 8) * 8 + taps - 1
@@ -101,6 +103,21 @@ __device__ __forceinline__ NnHeadTab nn_head_stage(const KwsNnPlan &N, unsigned 
     return t;                                                                                // caller: __syncthreads()
 }
 
+// whole-wave reductions: four DPP steps inside a row of 16 lanes, then lane ^ 16 and lane ^ 32 through the LDS crossbar
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op)
+{
+    v = op(v, (T)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+    v = op(v, (T)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+    v = op(v, (T)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));    // row_half_mirror
+    v = op(v, (T)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));    // row_mirror
+    v = op(v, (T)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));                      // lane ^ 16
+    v = op(v, (T)__shfl_xor((int)v, 32, KWS_WAVE));
+    return v;
+}
+__device__ __forceinline__ int wave_reduce_max(int v) { return wave_reduce<int>(v, [](int a, int b) { return max(a, b); }); }
+__device__ __forceinline__ unsigned wave_reduce_add(unsigned v) { return wave_reduce<unsigned>(v, [](unsigned a, unsigned b) { return a + b; }); }
+
 __device__ __forceinline__ void nn_head(const KwsNnPlan &N, const NnHeadTab &H, const int8_t *xin, int *lg, int lane, int clip,
                                         float *__restrict__ scores, const NnTaps &taps)
 {
@@ -125,24 +142,23 @@ __device__ __forceinline__ void nn_head(const KwsNnPlan &N, const NnHeadTab &H, 
         if (taps.fc) taps.fc[(size_t)clip * N.fc_out + out] = (int8_t)lgt;
     }
     WAVE_SYNC();
-    const int logit = lane < N.fc_out ? lg[lane] : 0;
-    // ---- SOFTMAX int8 -> int8 (reference/softmax.h:66-144), every lane < n_labels redundantly ---------------
-    if (lane < N.fc_out) {
-        int mx = -128;
-        for (int c = 0; c < N.fc_out; ++c) mx = max(mx, lg[c]);
-        int sum = 0;
-        for (int c = 0; c < N.fc_out; ++c) {
-            const int d = mx - lg[c];
-            if (H.sm_valid[d]) sum = (int)((unsigned)sum + (unsigned)rdivpot(H.sm_exp[d], 12));
-        }
+    const bool on = lane < N.fc_out;
+    const int logit = on ? lg[lane] : 0;
+    // ---- SOFTMAX int8 -> int8 (reference/softmax.h:66-144): lane = class; the maximum and the sum of exponentials are wave
+    //      reductions (the reference's unsigned wrap-around additions commute) ----------------------------------------------
+    const int mx = wave_reduce_max(on ? logit : -128);
+    const int d = on ? mx - logit : 0;
+    const bool valid = on && H.sm_valid[d] != 0;
+    const int ex = H.sm_exp[d];
+    const int sum = (int)wave_reduce_add(valid ? (unsigned)rdivpot(ex, 12) : 0u);
+    if (on) {
         const int hp1 = sum ? __clz(sum) : 32;                                  // GetReciprocal, common.h:530-546
         const int nbits = 12 - hp1;
         const int ssm1 = (int)(((unsigned)sum << hp1) - (1u << 31));
         const int scale = one_over_one_plus_x(ssm1);
-        const int d = mx - logit;
         int o = -128;
-        if (H.sm_valid[d]) {
-            const int unsat = rdivpot(srdhm(scale, H.sm_exp[d]), nbits + 31 - 8);
+        if (valid) {
+            const int unsat = rdivpot(srdhm(scale, ex), nbits + 31 - 8);
             o = min(max(unsat - 128, -128), 127);
         }
         if (taps.out_q) taps.out_q[(size_t)clip * N.fc_out + lane] = (int8_t)o;
@@ -175,7 +191,7 @@ __device__ __forceinline__ int nn_requant(int m, const NnRq &q, int out_zp, int 
     return min(max(r, act_min), act_max);
 }
 
-__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX, 3) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                          float *__restrict__ scores, NnTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -338,24 +354,20 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
 #pragma unroll
                             for (int c = 0; c < 4; ++c) tp[pw * out_c + oc0 + c] = (int8_t)o[c];
                     } else {
-                        int o[KWS_POOL_MAX][4];
 #pragma unroll
-                        for (int i = 0; i < KWS_POOL_MAX; ++i)
+                        for (int i = 0; i < KWS_POOL_MAX; ++i) {               // a time step's four channels: one word
+                            int o[4];
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) o[i][c] = nn_requant(acc[i][c], rq[c], out_zp, act_min, act_max);
-                        if (has_lut)
+                            for (int c = 0; c < 4; ++c) o[c] = nn_requant(acc[i][c], rq[c], out_zp, act_min, act_max);
+                            if (has_lut)
 #pragma unroll
-                            for (int i = 0; i < KWS_POOL_MAX; ++i)
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) o[i][c] = lutb[(oc0 + c) * 256 + (o[i][c] + 128)];
-#pragma unroll
-                        for (int i = 0; i < KWS_POOL_MAX; ++i) {
-                            const int word = (o[i][0] & 0xff) | ((o[i][1] & 0xff) << 8) | ((o[i][2] & 0xff) << 16) | ((int)((unsigned)o[i][3] << 24));
+                                for (int c = 0; c < 4; ++c) o[c] = lutb[(oc0 + c) * 256 + (o[c] + 128)];
+                            const int word = (o[0] & 0xff) | ((o[1] & 0xff) << 8) | ((o[2] & 0xff) << 16) | ((int)((unsigned)o[3] << 24));
                             const bool ok = t0 + i < out_w;
                             *(int *)(ok ? dbase + (t0 + i) * dstride + oc0 : sink) = word;
                             if (tp && ok)
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) tp[(t0 + i) * out_c + oc0 + c] = (int8_t)o[i][c];
+                                for (int c = 0; c < 4; ++c) tp[(t0 + i) * out_c + oc0 + c] = (int8_t)o[c];
                         }
                     }
                 }
@@ -412,18 +424,23 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX) void kws_nn_kernel(Kws
                 const bool col_ok = n < out_c;
                 for (int tile = 0; tile < (two ? 2 : 1); ++tile) {
                     const v16i &acc = tile ? acc1 : acc0;
-                    int o[16];
+                    // registers 4 g .. 4 g + 3 hold rows 32 tile + 8 g + 4 hh + 0 .. 3: a group past the image is skipped whole
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[r] = nn_requant(acc[r], rq, out_zp, act_min, act_max);
-                    if (has_lut)
+                    for (int g = 0; g < 4; ++g) {
+                        if (32 * tile + 8 * g >= out_w) break;
+                        int o[4];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[r] = lp[o[r]];
+                        for (int i = 0; i < 4; ++i) o[i] = nn_requant(acc[4 * g + i], rq, out_zp, act_min, act_max);
+                        if (has_lut)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * tile + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        const bool ok = col_ok && row < out_w;
-                        *(ok ? dcol + row * dstride : sink) = (int8_t)o[r];
-                        if (tp && ok) tp[row * out_c + n] = (int8_t)o[r];
+                            for (int i = 0; i < 4; ++i) o[i] = lp[o[i]];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = 32 * tile + 8 * g + 4 * hh + i;
+                            const bool ok = col_ok && row < out_w;
+                            *(ok ? dcol + row * dstride : sink) = (int8_t)o[i];
+                            if (tp && ok) tp[row * out_c + n] = (int8_t)o[i];
+                        }
                     }
                 }
             } else {
@@ -818,12 +835,12 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
             hipLaunchKernelGGL(kws_nn_mfma_kernel<64>, dim3(grid), dim3(KWS_WAVE * KWS_NN_WAVES), 0, stream, N, q_in, n_clips, scores, taps);
         return (int)hipGetLastError();
     }
-    // generic kernel: 8 waves per workgroup when the CU's LDS holds them (2 per SIMD instead of 1 for wide models whose
-    // tables allow a single workgroup per CU), one round of persistent workgroups
-    int nw = KWS_NN_WAVES_MAX;
+    // generic kernel (168 VGPRs: three waves per SIMD): one persistent workgroup per CU with as many waves as the LDS holds (they
+    // share the weights and tables), up to twelve
+    int nw = KWS_NN_WAVES_MAX, per_cu = 1;
     while (nw > KWS_NN_WAVES && kws_nn_smem_bytes(N, nw) > 158 * 1024) --nw;
+    if (const char *ev = getenv("KWS_DEV_NN_WAVES")) { int a = 0, b2 = 0; if (sscanf(ev, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= KWS_NN_WAVES_MAX && b2 >= 1) { nw = a; per_cu = b2; } }   // development aid (occupancy experiments)
     const size_t smem = kws_nn_smem_bytes(N, nw);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / smem, (size_t)(8 / nw)));           // 232 VGPRs: two waves per SIMD
     grid = (n_clips + nw - 1) / nw;
     if (grid > (grid_cap / 4) * per_cu) grid = (grid_cap / 4) * per_cu;          // grid_cap = 4 workgroups per CU
     if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
