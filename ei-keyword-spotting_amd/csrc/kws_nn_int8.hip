@@ -61,7 +61,7 @@ __device__ __forceinline__ int one_over_one_plus_x(int a)     // fixedpoint.h:84
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int KWS_NN_WAVES = 4;
-constexpr int KWS_NN_WAVES_MAX = 12;     // generic kernel: as many waves per workgroup as the LDS allows (they share weights and tables)
+constexpr int KWS_NN_WAVES_MAX = 16;     // generic kernel: as many waves per workgroup as the LDS allows (they share weights and tables)
 constexpr int KWS_POOL_MAX = 8;
 // rows of a block's padded int8 input image in the generic kernel: un-pooled blocks are walked KWS_POOL_MAX time steps at
 // a time, so reads reach up to ceil(out_w / 8) * 8 + taps - 1
@@ -191,7 +191,7 @@ __device__ __forceinline__ int nn_requant(int m, const NnRq &q, int out_zp, int 
     return min(max(r, act_min), act_max);
 }
 
-__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX, 3) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX, 4) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                          float *__restrict__ scores, NnTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX, 3) void kws_nn_kernel(
     const NnHeadTab head = nn_head_stage(N, smem_raw, fcw_bytes);
     unsigned char *const blocks_base = smem_raw + fcw_bytes + ((KWS_HEAD_REST + 15) & ~15);
     unsigned char *sp = blocks_base;
-    int act_bytes = 0;
+    int act_b[2] = { 0, 0 };                           // block b reads buffer b & 1: each is sized for its own blocks
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlock &k = N.blk[b];
         const int wbytes = k.w_bytes;
@@ -214,13 +214,13 @@ __global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX, 3) void kws_nn_kernel(
         for (int i = threadIdx.x; i < k.out_c; i += blockDim.x) ((int4 *)sp)[i] = make_int4(k.bias_eff[i], k.mult[i], k.shift[i], 0);
         sp += k.out_c * 16;
         const int ab = nn_rows(k) * k.in_cpad;
-        act_bytes = max(act_bytes, ab);
+        act_b[b & 1] = max(act_b[b & 1], ab);
     }
-    act_bytes = (act_bytes + 15) & ~15;
+    act_b[0] = (act_b[0] + 15) & ~15; act_b[1] = (act_b[1] + 15) & ~15;
     // per wave: two activation buffers (ping-pong) + a small vector for FC/softmax
-    int8_t *actA = (int8_t *)(sp + wave * (2 * act_bytes + fcx_bytes + 64 * 4));
-    int8_t *actB = actA + act_bytes;
-    int8_t *fcx = actB + act_bytes;                    // the FULLY_CONNECTED input vector (last block's pooled output)
+    int8_t *actA = (int8_t *)(sp + wave * (act_b[0] + act_b[1] + fcx_bytes + 64 * 4));
+    int8_t *actB = actA + act_b[0];
+    int8_t *fcx = actB + act_b[1];                    // the FULLY_CONNECTED input vector (last block's pooled output)
     int *lgv = (int *)(fcx + fcx_bytes);               // logits; until the head runs, the sink of stores that fall outside the image
     int8_t *const sink = (int8_t *)lgv + 4 * lane;
     __syncthreads();
@@ -807,17 +807,16 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
 size_t kws_nn_smem_bytes(const KwsNnPlan &N, int n_waves)
 {
     size_t s = (size_t)nn_head_fcw_bytes(N) + ((KWS_HEAD_REST + 15) & ~15);
-    int act = 0;
+    int act[2] = { 0, 0 };
     for (int b = 0; b < N.n_blocks; ++b) {
         const KwsConvBlock &k = N.blk[b];
         s += ((size_t)k.w_bytes + 15) & ~(size_t)15;
         s += k.has_lut ? (size_t)k.out_c * 256 : 0;
         s += (size_t)k.out_c * 16;                      // requantisation constants
         const int ab = nn_rows(k) * k.in_cpad;
-        act = ab > act ? ab : act;
+        act[b & 1] = ab > act[b & 1] ? ab : act[b & 1];
     }
-    act = (act + 15) & ~15;
-    return s + (size_t)n_waves * (2 * act + nn_fcx_bytes(N) + 64 * 4);
+    return s + (size_t)n_waves * (((act[0] + 15) & ~15) + ((act[1] + 15) & ~15) + nn_fcx_bytes(N) + 64 * 4);
 }
 
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
