@@ -60,6 +60,7 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     // a lane reads F.nz (resp. KWS_FAST_NZ2) consecutive bins from its filter's first one: the power rows are padded so that the
     // reads of the last filters stay inside the chunk buffer
     F.pstride = (F.nbins + std::max(F.nz, KWS_FAST_NZ2)) | 1;
+    if (F.pstride <= 136) F.pstride = 136;           // = 8 mod 64: the eight frames' stores of one bin (8 lanes each) cover the 64 banks
     auto tap_table = [&](auto filter_of_lane, int width, std::vector<int> &start, std::vector<float> &w) {
         start.assign(KWS_FAST_WAVE, 0);
         w.assign((size_t)KWS_FAST_WAVE * width, 0.0f);
@@ -192,7 +193,9 @@ static EI_IMPULSE_ERROR build_fast_plain(kws_handle *h)
     std::vector<float> shared;
     EI_IMPULSE_ERROR e = build_fast_dsp(h, F, shared);
     if (e) return e;
-    F.fs = h->dsp.n_filters;
+    // row stride of the image: 4 x odd floats, so that the 16 rows x 8-byte reads of an MFMA operand fetch (DCT, first convolution)
+    // and the 4-row x 16-column writes of the DCT tiles fall into distinct LDS banks
+    F.fs = h->dsp.n_filters + 4;
     F.fuse = 0;
     F.n_labels = (int)h->model.labels.size();
     return finish_fast_plan(h, F, shared, 0, 0);
@@ -213,7 +216,9 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
     F.fuse = 1;
     F.n_blocks = N.n_blocks;
     F.n_labels = N.n_labels;
-    F.fs = h->dsp.n_filters;
+    // row stride of the image: 4 x odd floats, so that the 16 rows x 8-byte reads of an MFMA operand fetch (DCT, first convolution)
+    // and the 4-row x 16-column writes of the DCT tiles fall into distinct LDS banks
+    F.fs = h->dsp.n_filters + 4;
     int need[2] = { 0, 0 };                     // floats each image region must hold beyond its first use
     for (int b = 0; b < N.n_blocks; b++) {
         const KwsConvBlockF32 &s = N.blk[b];
