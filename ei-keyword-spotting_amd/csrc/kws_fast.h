@@ -54,7 +54,7 @@ struct KwsFastPlan {
     const float *tap_w2;          // [64][KWS_FAST_NZ2]
     // ---- DCT on the matrix cores
     int dct_groups, dct_nt;       // NF / 8 k-groups, ceil((NF/2+1) / 16) output tiles
-    const float *dct_frag;        // [dct_groups][2][dct_nt][64] B fragments: 2 cos(pi n (2k+1) / 2NF) * ortho scale
+    int dct_off;                  // shared LDS: [dct_groups][2][dct_nt][64] B fragments: 2 cos(pi n (2k+1) / 2NF) * ortho scale
     float stale_scale;            // sqrtf(1/(2NF)): coefficients above NF/2 keep the log-mel input x 2 x this (fast-dct-fft.cpp:71)
     // ---- cmvnw
     int cr, cg;                   // rows per lane, columns per pass (13 x 16 or 17 x 20)

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     float *img = F;                                                   // [n_frames][fs]
     float *elog = F + nfr * fs;                                       // log frame energies, parked until the DCT has run
     constexpr int NZ2 = DG > 4 ? KWS_FAST_NZ2 : 1;
-    const float *dct_frag = FP.dct_frag;
+    const float *dct_frag = shared + FP.dct_off;
     const int pstride = FP.pstride;
     const int n_waves = blockDim.x >> 6;
     // 1 / fft_length, the int16 scale 2^-15 squared and the split's two halvings: powers of two (the plan checks fft_length)

@@ -146,7 +146,9 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     if ((e = h->upload(tw1, &F.tap_w1))) return e;
     if ((e = h->upload(s2, &F.tap_start2))) return e;
     if ((e = h->upload(tw2, &F.tap_w2))) return e;
-    if ((e = h->upload(frag, &F.dct_frag))) return e;
+    while (shared.size() & 3) shared.push_back(0.0f);
+    F.dct_off = (int)shared.size();                  // the workgroup's LDS copy (a clip's 4 DG reads per lane: not worth an L2 round trip)
+    shared.insert(shared.end(), frag.begin(), frag.end());
     return EI_IMPULSE_OK;
 }
 
