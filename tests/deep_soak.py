@@ -6,6 +6,8 @@ features compared bit for bit, int8 input tensors and int8-model scores exactly,
 Then 3 000 windows per model go through run_classifier() one by one (the latency-mode kernel) and must equal the batch path's
 scores bit for bit, and 4 096 continuous-mode streams advance 14 slices with every 16th stream followed by the restated
 run_classifier_continuous().  Writes one summary line per model and check; exit status 1 on any difference.
+
+  python tests/deep_soak.py [rounds] [clips] fast   -- the same sweep for KWS_MODE_FAST against its tolerance (fast_sweep below)
 """
 import multiprocessing as mp
 import os
@@ -32,9 +34,75 @@ def _worker(args):
     return first, s, f, q
 
 
+def fast_sweep(rounds, B):
+    """KWS_MODE_FAST over `rounds` full batches per model, every clip against the oracle: float32 graphs -- the maximum score
+    difference (bar: 1e-4); int8 graphs -- clips whose scores changed, all of which must be explained by a flipped int8 input
+    value (same tensor => same scores, bit for bit)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    cores = len(os.sched_getaffinity(0))
+    chunk, bad = 512, 0
+    with mp.get_context("spawn").Pool(cores) as pool:
+        for name in ("cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "l476_no_yes.kwsm", "cfg2_mfcc40_int8.kwsm"):
+            path = os.path.join(MODELS, name)
+            gm = pkg.Model(path, device=0)
+            gm.set_mode(pkg.MODE_FAST)
+            F, C = gm.n_features, gm.n_labels
+            t0 = time.time()
+            n_clips = n_over = n_changed = n_unexplained = n_flips = n_back = 0
+            max_score = max_feat = 0.0
+            for r in range(rounds):
+                seed, base = 2000 + r, 11 * r * B
+                pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+                pkg.synth_clips_device(seed, base, B, 16000, pcm.data_ptr())
+                feats = torch.empty((B, F), dtype=torch.float32, device="cuda:0")
+                scores = torch.empty((B, C), dtype=torch.float32, device="cuda:0")
+                q = None if gm.is_float else torch.empty((B, F), dtype=torch.int8, device="cuda:0")
+                gm.run_classifier_batch_device(pcm.data_ptr(), B, scores.data_ptr(), None, None)           # the timed form: scores only
+                torch.cuda.synchronize()
+                gs = scores.cpu().numpy()
+                n_back += gm.fast_fallback_count()
+                gm.run_classifier_batch_device(pcm.data_ptr(), B, scores.data_ptr(), feats.data_ptr(), None if q is None else q.data_ptr())
+                torch.cuda.synchronize()
+                gf = feats.cpu().numpy()
+                gq = None if q is None else q.cpu().numpy()
+                jobs = [(path, seed, base + i, min(chunk, B - i)) for i in range(0, B, chunk)]
+                for first, so, fo, qo in pool.imap_unordered(_worker, jobs):
+                    i = first - base
+                    n = len(so)
+                    d = np.abs(gs[i:i + n] - so).max(axis=1)
+                    max_feat = max(max_feat, float(np.abs(gf[i:i + n] - fo).max()))
+                    if gm.is_float:
+                        max_score = max(max_score, float(d.max()))
+                        n_over += int((d > 1e-4).sum())
+                    else:
+                        flips = (gq[i:i + n] != qo).sum(axis=1)
+                        n_flips += int(flips.sum())
+                        n_changed += int((d > 0).sum())
+                        n_unexplained += int(((d > 0) & (flips == 0)).sum())
+                    n_clips += n
+            ok = (n_over == 0) if gm.is_float else (n_unexplained == 0 and n_changed <= 0.02 * n_clips)
+            bad += 0 if ok else 1
+            if gm.is_float:
+                print("%s KWS_MODE_FAST (fused network: %s): %d clips, max |score - oracle| = %.3g, %d clips over 1e-4, max |feature - oracle| = %.3g, "
+                      "%d clips handed back to the exact kernels; %s (%.0f s)" % (name, gm.fast_is_fused, n_clips, max_score, n_over, max_feat, n_back,
+                                                                                "OK" if ok else "MISMATCH", time.time() - t0), flush=True)
+            else:
+                print("%s KWS_MODE_FAST: %d clips, %.4f int8 input values per clip on the other side of a rounding boundary, %d clips with a changed "
+                      "score (%d of them with an identical input tensor), max |feature - oracle| = %.3g, %d clips handed back; %s (%.0f s)"
+                      % (name, n_clips, n_flips / max(1, n_clips), n_changed, n_unexplained, max_feat, n_back, "OK" if ok else "MISMATCH",
+                         time.time() - t0), flush=True)
+            gm.close()
+    sys.exit(1 if bad else 0)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    if len(sys.argv) > 3 and sys.argv[3] == "fast":
+        return fast_sweep(rounds, B)
     sys.path.insert(0, ROOT)
     import torch
     from __graft_entry__ import load_package
