@@ -159,6 +159,9 @@ def test_run_classifier_drop_in(pkg, gpu476, l476, oracle):
     rc = pkg.lib().run_classifier(ctypes.byref(sig), ctypes.byref(res), False)
     assert rc == 0
     assert sig.total_length == 16000                              # caller's struct untouched
+    # the documented deviation: the window is gathered with four get_data calls of 4 000 samples, in
+    # order, instead of the reference's 98 small ones
+    assert calls == [(0, 4000), (4000, 4000), (8000, 4000), (12000, 4000)]
     got = np.float32([res.classification[i].value for i in range(4)])
     assert [res.classification[i].label.decode() for i in range(4)] == ["no", "noise", "unknown", "yes"]
     assert (bits(got) == bits(l476.run_batch(clip)[0])).all()
