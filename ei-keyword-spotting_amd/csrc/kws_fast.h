@@ -1,10 +1,12 @@
 // kws_fast.h -- execution plan of KWS_MODE_FAST (internal to libkws_mi355x.so): the tolerance-mode form of the hot path.
 //
 // The exact kernels (kws_mfcc.hip, kws_nn_f32.hip) replay the reference's floating-point operation order and are bound by the
-// instruction stream that order forces (DESIGN.md 4.4).  BASELINE.json's north_star grants 1e-4 on fp32 scores; this mode
+// instruction stream that order forces (DESIGN.md 4.1, 4.6).  BASELINE.json's north_star grants 1e-4 on fp32 scores; this mode
 // spends that tolerance where the reference's order is expensive and keeps it where a different order would be visible:
-//   * the 256-point FFT is still KissFFT's radix-4,4,4,2 order, bit for bit: FFT round-off is relative to the loudest bin, so
-//     any other factorisation moves the weak bins' log-mel energies by ~1e-4 (tools/fast_mode_study.py) -- not affordable;
+//   * the 256-point FFT still performs KissFFT's radix-4,4,4,2 butterflies with the reference's operation order (only their lane
+//     changes; multiplications by a unit twiddle are skipped and power-of-two scales are folded, both exact): FFT round-off is
+//     relative to the loudest bin, so any other factorisation moves the weak bins' log-mel energies by ~1e-4
+//     (tools/fast_mode_study.py) -- not affordable;
 //   * power spectrum re*re + im*im in fp32 (no fp64 sqrt-then-square), frame energy by a lane reduction, mel gather in any order;
 //   * DCT-II as a [frames x NF] x [NF x NF/2+1] product on v_mfma_f32_16x16x4_f32 (true fp32);
 //   * cmvnw with O(1) running sums per (row, column) on pivot-shifted data instead of two 101-term walks;
@@ -20,12 +22,12 @@
 #define KWS_FAST_MAX_BLOCKS 4
 #define KWS_FAST_NZ_MAX 12        // longest mel filter (filters 0..31) kept in registers
 #define KWS_FAST_NZ2 8            // longest of filters 32..39
-#define KWS_FAST_DCT_GROUPS 5     // NF / 8 <= 5: DCT operand fragments kept in registers
-#define KWS_FAST_MEL_CHUNK 8      /* frames per pass of the spectral loop: eight lanes per frame */
-#define KWS_FAST_CMVN_EXT 8
-#define KWS_FAST_XS 144           /* floats per frame of the FFT exchange buffer: 64 positions + 2 floats of padding per 8; = 16 mod 64 */      // frames transformed per pass of the spectral loop (their power rows feed one mel pass)
+#define KWS_FAST_DCT_GROUPS 5     // NF / 8 <= 5 k-groups of the DCT's operand fragments
+#define KWS_FAST_MEL_CHUNK 8      // frames per pass of the spectral loop: eight lanes per frame; their power rows feed one mel pass
+#define KWS_FAST_CMVN_EXT 8       // rows a cmvnw first window may count more often than the others (sparse form, see ext_off)
+#define KWS_FAST_XS 144           // floats per frame of the FFT exchange buffer: 64 positions + 2 floats of padding per 8; = 16 mod 64
 #define KWS_FAST_WAVE 64
-#define KWS_FAST_ZF 320           // floats per in-place FFT buffer (kws_device.h KWS_ZF)
+#define KWS_FAST_ZF 320           // floats per in-place FFT buffer of the exact kernel (kws_device.h KWS_ZF)
 
 struct KwsFastBlock {
     int in_w, in_c, in_cp;        // time steps, channels, channels padded to a multiple of 8 (the contraction's k-groups)
@@ -65,7 +67,7 @@ struct KwsFastPlan {
     float inv_win;
     float guard;                  // a window with std < guard * max(1, |mean|) sends the clip to the exact kernels
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
-    //      R1 = four FFT buffers + four power rows, later the other activation image
+    //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;
     const float *shared_init;     // global image of the workgroup's shared LDS block (weights, biases, cmvnw tables)
     // ---- float32 network fused behind the features (fuse = 0: features / int8 tensor go to HBM instead)

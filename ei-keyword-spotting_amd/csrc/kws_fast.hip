@@ -5,9 +5,10 @@
 // add.h:179-215, pooling.h:189-237, fully_connected.h:26-60, softmax.h:31-63) with the convolutions on v_mfma_f32_16x16x4_f32.
 // Eight waves of a workgroup share the weights in LDS; nothing but the PCM and the scores crosses HBM.
 //
-// With 14 KB of LDS per wave only two waves fit a SIMD, so every phase is written to keep its own memory operations in
-// flight: loads of a phase are issued as one batch before the arithmetic that consumes them, tile counts are template
-// parameters (no predicated code inside the contraction loops), and the convolution loops fetch one k-step ahead.
+// With 13 KB of LDS per wave next to the shared weights, and ~208 VGPRs, only two waves fit a SIMD, so every phase is written to
+// keep its own memory operations in flight: loads of a phase are issued as one batch before the arithmetic that consumes them,
+// tile counts are template parameters (no predicated code inside the contraction loops), and the convolution loops fetch one
+// k-step ahead.  DESIGN.md 4.4 has the phase table, the counters and what was tried and rejected.
 #include "kws_device.h"
 #include "kws_fast.h"
 
