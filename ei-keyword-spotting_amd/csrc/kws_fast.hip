@@ -104,7 +104,7 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{ 0.f, 0.f, 0.f, 0.f };
     const int in_stride = k.in_stride, out_c = k.out_c, in_w = k.in_w;
-    const int ncg = k.in_cp >> 3, n_it = k.taps * ncg;
+    const int n_it = k.taps * (k.in_cp >> 3);
     // operand addresses as offsets from one LDS pointer each (pointers kept in an array lose their address space and every
     // weight read becomes a flat_load): a lane part in a VGPR + a step part the scalar unit advances
     const float *abase = in + (lm - k.pad_left) * in_stride + 2 * lq;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
     int bl[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bl[nt] = 2 * min(16 * nt + lm, out_c - 1);
-    const int mstep = 16 * in_stride, bstep = 8 * out_c, wrap = in_stride - 8 * (ncg - 1);
+    const int mstep = 16 * in_stride;
     const int row0 = lm - k.pad_left;                       // image row of this lane's operand for tile 0, tap 0
     // the zeroing is applied when a fetched operand is handed to the MFMAs, not at the load: the loads of a step then go out
     // back to back and are only waited for after the previous step's MFMAs have been issued
@@ -158,16 +158,17 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
     clip_rows(0, a);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b[nt] = *(const float2 *)(wbase + bl[nt]);
-    int cg = 0, tap = 0, aoff = 0, boff = 0;
+    // Where a k-step's operands sit -- (image offset, tap, weight offset) -- comes from a table in the workgroup's LDS block (one
+    // broadcast 16-byte read per step, requested a step before it is needed): advanced on the scalar unit, the same bookkeeping
+    // was two dozen dependent scalar instructions per step, and a wave pays issue time for every one of them.
+    const int4 *steps = (const int4 *)(shared + k.st_off);
+    int4 dn = steps[1];
     if (t_pre) *t_pre = clock64();
     for (int it = 0; it < n_it; ++it) {
         // operands of the next step, requested before this step's MFMAs are issued (the last step re-reads its own)
-        const bool more = it + 1 < n_it;
-        const bool wr = cg + 1 == ncg;
-        aoff += more ? (wr ? wrap : 8) : 0;
-        boff += more ? bstep : 0;
-        tap += (more && wr) ? 1 : 0;
-        cg = wr ? 0 : cg + 1;
+        const int4 d1 = dn;
+        dn = steps[it + 2];                                              // n_it + 2 entries: the last step is repeated
+        const int aoff = d1.x, tap = d1.y, boff = d1.z;
         float2 an[MT], bn[NT];
 #pragma unroll
 #ifdef KWS_EXP_NOLOAD

@@ -249,6 +249,16 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
                 for (int n = 0; n < k.out_c; n++)
                     shared[(size_t)k.w_off + (((size_t)tap * (k.in_cp / 2) + ch / 2) * k.out_c + n) * 2 + (ch & 1)] =
                         w[((size_t)n * k.taps + tap) * k.in_c + ch];
+        {   // k-step table: step it = tap * (in_cp / 8) + cg reads the image at tap * in_stride + 8 cg and the weights at it * 8 out_c
+            while (shared.size() & 3) shared.push_back(0.0f);
+            k.st_off = (int)shared.size();
+            const int ncg = k.in_cp / 8, n_it = k.taps * ncg;
+            for (int it = 0; it < n_it + 2; it++) {
+                const int i = std::min(it, n_it - 1), tap = i / ncg, cg = i % ncg;
+                const int e[4] = { tap * k.in_stride + 8 * cg, tap, i * 8 * k.out_c, 0 };
+                for (int j = 0; j < 4; j++) { float f; memcpy(&f, &e[j], sizeof f); shared.push_back(f); }
+            }
+        }
         k.bias_off = (int)shared.size();
         shared.insert(shared.end(), h->hostf.bias[b].begin(), h->hostf.bias[b].end());
         k.addc_off = (int)shared.size();
