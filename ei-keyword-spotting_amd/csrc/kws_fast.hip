@@ -171,15 +171,9 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         const int aoff = d1.x, tap = d1.y, boff = d1.z;
         float2 an[MT], bn[NT];
 #pragma unroll
-#ifdef KWS_EXP_NOLOAD
-        for (int mt = 0; mt < MT; ++mt) { an[mt] = a[mt]; asm volatile("" : "+v"(an[mt].x), "+v"(an[mt].y)); }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { bn[nt] = b[nt]; asm volatile("" : "+v"(bn[nt].x), "+v"(bn[nt].y)); }
-#else
         for (int mt = 0; mt < MT; ++mt) an[mt] = *(const float2 *)(abase + aoff + mt * mstep);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const float2 *)(wbase + boff + bl[nt]);
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
