@@ -313,7 +313,7 @@ def pmc_for(kernel, model, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=600, help="timed steps (default: > 1 s of GPU time in the timed region)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 65536; 131072 at 8 GPUs = 1 M clips)")
     ap.add_argument("--model", default=DEFAULT_MODEL)
@@ -387,7 +387,7 @@ def main():
     r = measure(backend, a.model, a.mode, a.steps, a.warmup, barrier, max_over_ranks)
     others, also = [], []
     if world == 1 and not a.no_also and not a.dry_run_cpu:
-        side_steps = max(20, a.steps // 4)
+        side_steps = max(20, a.steps // 8)
         others.append(measure(backend, a.model, "exact" if a.mode == "fast" else "fast", side_steps, a.warmup, barrier, max_over_ranks))
         for mp_ in ALSO_MODELS:
             if not os.path.samefile(mp_, a.model):
@@ -458,9 +458,9 @@ def main():
                 "network_kernel": "fused into kws_fast_kernel" if x["fused"] else x["nn_kernel"],
                 "hbm_frac": round((CLIP_LEN * 2 + x["labels"] * 4) * B / (x["ms_path"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     if others:
-        out["modes"] = [line(r, a.steps)] + [line(x, max(20, a.steps // 4)) for x in others]
+        out["modes"] = [line(r, a.steps)] + [line(x, side_steps) for x in others]
     if also:
-        out["also"] = [line(x, max(20, a.steps // 4)) for x in also]
+        out["also"] = [line(x, side_steps) for x in also]
     if cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out))
