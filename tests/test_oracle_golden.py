@@ -259,3 +259,38 @@ def test_mfe_model_golden(oracle, tmp_path):
         assert rc == 0 and produced == bool(g["cont_produced"][k]), k
         if produced:
             assert (bits(sc) == bits(g["cont_scores"][k])).all(), k
+
+
+def test_eon_import_reads_an_mfe_block_configuration():
+    """tools/eon_import.py: a model_metadata.h that instantiates ei_dsp_config_mfe_t (the MFE block of the newer SDK copy, field
+    order of L432 model-parameters/model_metadata.h:103-112) yields a version-2 blob whose DSP block is MFE."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import eon_import
+    meta_h = '''
+#define EI_CLASSIFIER_RAW_SAMPLE_COUNT           16000
+#define EI_CLASSIFIER_FREQUENCY                  16000
+#define EI_CLASSIFIER_NN_INPUT_FRAME_SIZE        1960
+const char* ei_classifier_inferencing_categories[] = { "a", "b" };
+ei_dsp_config_mfe_t ei_dsp_config_3 = {
+    1,
+    0.02f,
+    0.02f,
+    40,
+    256,
+    300,
+    0,
+    101
+};
+'''
+    m = eon_import.parse_metadata(meta_h)
+    d = m["dsp"]
+    assert d["block"] == 1 and d["num_filters"] == 40 and d["num_cepstral"] == 40 and d["fft_length"] == 256
+    assert d["win_size"] == 101 and d["low_frequency"] == 300 and d["high_frequency"] == 0 and d["pre_cof"] == 0.0
+    assert abs(d["frame_length"] - 0.02) < 1e-9 and m["labels"] == ["a", "b"]
+    # the shipped exports stay MFCC blocks, byte for byte
+    for name, sub in (("l476_no_yes.kwsm", "nucleo-l476-keyword-spotting/ei-keyword-spotting"),):
+        ref_dir = "/root/reference/embedded-demos/stm32cubeide/" + sub
+        if os.path.isdir(ref_dir):
+            blob, _ = eon_import.import_export(ref_dir)
+            assert blob == open(os.path.join(ROOT, "models", name), "rb").read()

@@ -109,15 +109,25 @@ def parse_compiled_model(src):
     return tensors, nodes, int(m_in.group(1)), int(m_out.group(1))
 
 
-def parse_metadata(src):
+def parse_metadata(src, dsp_block="auto"):
     def define(name, cast=int):
         return cast(re.search(r"#define\s+%s\s+([^\s]+)" % name, src).group(1))
     labels = re.findall(r'"([^"]*)"', re.search(r"ei_classifier_inferencing_categories\[\]\s*=\s*\{([^}]*)\}", src).group(1))
-    body = re.search(r"ei_dsp_config_mfcc_t\s+ei_dsp_config_\d+\s*=\s*\{(.*?)\};", src, re.S).group(1)
-    v = [x.rstrip("f") for x in _numlist(body)]
-    dsp = {"axes": int(v[0]), "num_cepstral": int(v[1]), "frame_length": float(v[2]), "frame_stride": float(v[3]),
-           "num_filters": int(v[4]), "fft_length": int(v[5]), "win_size": int(v[6]), "low_frequency": int(v[7]),
-           "high_frequency": int(v[8]), "pre_cof": float(v[9]), "pre_shift": int(v[10])}
+    mfcc = re.search(r"ei_dsp_config_mfcc_t\s+ei_dsp_config_\d+\s*=\s*\{(.*?)\};", src, re.S)
+    mfe = re.search(r"ei_dsp_config_mfe_t\s+ei_dsp_config_\d+\s*=\s*\{(.*?)\};", src, re.S)
+    if dsp_block == "mfe" or (dsp_block == "auto" and mfe and not mfcc):
+        # the MFE block of the newer SDK copy (L432 model-parameters/model_metadata.h:103-112: axes, frame_length, frame_stride,
+        # num_filters, fft_length, low_frequency, high_frequency, win_size); extract_mfe_features applies no pre-emphasis and its
+        # feature matrix is [frames][filters] (classifier/ei_run_dsp.h:369-418)
+        v = [x.rstrip("f") for x in _numlist(mfe.group(1))]
+        dsp = {"axes": int(v[0]), "num_cepstral": int(v[3]), "frame_length": float(v[1]), "frame_stride": float(v[2]),
+               "num_filters": int(v[3]), "fft_length": int(v[4]), "win_size": int(v[7]), "low_frequency": int(v[5]),
+               "high_frequency": int(v[6]), "pre_cof": 0.0, "pre_shift": 1, "block": 1}
+    else:
+        v = [x.rstrip("f") for x in _numlist(mfcc.group(1))]
+        dsp = {"axes": int(v[0]), "num_cepstral": int(v[1]), "frame_length": float(v[2]), "frame_stride": float(v[3]),
+               "num_filters": int(v[4]), "fft_length": int(v[5]), "win_size": int(v[6]), "low_frequency": int(v[7]),
+               "high_frequency": int(v[8]), "pre_cof": float(v[9]), "pre_shift": int(v[10])}
     return {"labels": labels, "dsp": dsp,
             "raw_sample_count": define("EI_CLASSIFIER_RAW_SAMPLE_COUNT"),
             "frequency": define("EI_CLASSIFIER_FREQUENCY"),
@@ -208,11 +218,12 @@ def parse_blob(blob):
     return tensors, nodes, t_in, t_out, meta
 
 
-def import_export(export_dir):
+def import_export(export_dir, dsp_block="auto"):
+    """dsp_block: "auto" (MFE only if the metadata instantiates ei_dsp_config_mfe_t and no MFCC block), "mfcc" or "mfe" """
     with open(f"{export_dir}/tflite-model/trained_model_compiled.cpp") as f:
         tensors, nodes, t_in, t_out = parse_compiled_model(f.read())
     with open(f"{export_dir}/model-parameters/model_metadata.h") as f:
-        meta = parse_metadata(f.read())
+        meta = parse_metadata(f.read(), dsp_block)
     return serialise(tensors, nodes, t_in, t_out, meta), (tensors, nodes, meta)
 
 
@@ -220,8 +231,10 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("export_dir", help="directory holding tflite-model/ and model-parameters/")
     ap.add_argument("out", help="output .kwsm path")
+    ap.add_argument("--dsp-block", choices=("auto", "mfcc", "mfe"), default="auto",
+                    help="which DSP block the impulse uses (auto: the one model_metadata.h instantiates)")
     a = ap.parse_args()
-    blob, (tensors, nodes, meta) = import_export(a.export_dir)
+    blob, (tensors, nodes, meta) = import_export(a.export_dir, a.dsp_block)
     with open(a.out, "wb") as f:
         f.write(blob)
     print(f"{a.out}: {len(blob)} bytes, {len(tensors)} tensors, {len(nodes)} nodes, labels={meta['labels']}",
