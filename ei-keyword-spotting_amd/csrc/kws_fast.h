@@ -40,7 +40,7 @@ struct KwsFastBlock {
                                   // 49-frame window would otherwise pay a fourth row tile for one row
     int stage_stride;             // row stride of the un-pooled staging image (odd)
     int w_off, bias_off, addc_off;   // float offsets into the workgroup's shared LDS block
-    int st_off;                   // k-step table [taps * in_cp / 8 + 2] x int4 { image offset (floats), tap, weight offset (floats), - }
+    int st_off;                   // k-step table [taps * in_cp / 8 + 3] x int4 { image offset (floats), tap, weight offset (floats), - }
     int has_add;
     float conv_min, conv_max, add_min, add_max, pool_min, pool_max;
 };

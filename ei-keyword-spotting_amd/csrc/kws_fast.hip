@@ -152,43 +152,47 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         const float part = s0 + s1;
         vout[vr] = part + __shfl_xor(part, 32, KWS_WAVE);
     }
-    float2 a[MT], b[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const float2 *)(abase + mt * mstep);
-    clip_rows(0, a);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *(const float2 *)(wbase + bl[nt]);
     // Where a k-step's operands sit -- (image offset, tap, weight offset) -- comes from a table in the workgroup's LDS block (one
     // broadcast 16-byte read per step, requested a step before it is needed): advanced on the scalar unit, the same bookkeeping
     // was two dozen dependent scalar instructions per step, and a wave pays issue time for every one of them.
+    // The loop is unrolled by two over two operand sets (no register moves between steps); a set's operands are requested
+    // before the other set's MFMAs are issued.
     const int4 *steps = (const int4 *)(shared + k.st_off);
-    int4 dn = steps[1];
+    auto fetch = [&](const int4 &d, float2 (&aa)[MT], float2 (&bb)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aa[mt] = *(const float2 *)(abase + d.x + mt * mstep);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bb[nt] = *(const float2 *)(wbase + d.z + bl[nt]);
+    };
+    auto mfmas = [&](const float2 (&aa)[MT], const float2 (&bb)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[mt].x, bb[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[mt].y, bb[nt].y, acc[mt][nt], 0, 0, 0);
+    };
+    float2 a0[MT], b0[NT], a1[MT], b1[NT];
+    int4 d0 = steps[0], d1 = steps[1];
+    fetch(d0, a0, b0);
+    clip_rows(d0.y, a0);
     if (t_pre) *t_pre = clock64();
-    for (int it = 0; it < n_it; ++it) {
-        // operands of the next step, requested before this step's MFMAs are issued (the last step re-reads its own)
-        const int4 d1 = dn;
-        dn = steps[it + 2];                                              // n_it + 2 entries: the last step is repeated
-        const int aoff = d1.x, tap = d1.y, boff = d1.z;
-        float2 an[MT], bn[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) an[mt] = *(const float2 *)(abase + aoff + mt * mstep);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const float2 *)(wbase + boff + bl[nt]);
+    for (int it = 0; it < n_it; it += 2) {
+        const int4 d2 = steps[it + 2];                                   // n_it + 3 entries: the last step is repeated
+        fetch(d1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+        mfmas(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        clip_rows(tap, an);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+        clip_rows(d1.y, a1);
+        if (it + 1 >= n_it) break;                                        // odd step count
+        d1 = steps[it + 3];
+        fetch(d2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        clip_rows(d2.y, a0);
     }
     if (t_loop) *t_loop = clock64();
     // ---- epilogue: bias, fused activation, ADD(constant) + activation (conv.h:88-93, add.h:200-212) ---------------------

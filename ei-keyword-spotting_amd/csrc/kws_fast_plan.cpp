@@ -253,7 +253,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
             while (shared.size() & 3) shared.push_back(0.0f);
             k.st_off = (int)shared.size();
             const int ncg = k.in_cp / 8, n_it = k.taps * ncg;
-            for (int it = 0; it < n_it + 2; it++) {
+            for (int it = 0; it < n_it + 3; it++) {
                 const int i = std::min(it, n_it - 1), tap = i / ncg, cg = i % ncg;
                 const int e[4] = { tap * k.in_stride + 8 * cg, tap, i * 8 * k.out_c, 0 };
                 for (int j = 0; j < 4; j++) { float f; memcpy(&f, &e[j], sizeof f); shared.push_back(f); }
