@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const float *cnt_tab = shared + FP.cnt_off;
     const int *upd_tab = (const int *)(shared + FP.upd_off);
     const float *ext_tab = FP.ext_off >= 0 ? shared + FP.ext_off : nullptr;
-    const float inv_win = FP.inv_win, guard = FP.guard, stale_scale = FP.stale_scale;
+    const float inv_win = FP.inv_win, guard = FP.guard;
     const int cr = FP.cr, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
     long long ph[KWS_FAST_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
@@ -710,34 +710,23 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                 }
             }
             WAVE_SYNC();                                     // every operand of the transform is in a register
-            // coefficients above NF/2 are never written by the reference's transform: they keep the log-mel input, doubled and
-            // scaled (fast-dct-fft.cpp:71-74, numpy.hpp:392-397); c0 <- log(frame energy) (feature.hpp:425-429)
-            const int nst = ncep - (NF / 2 + 1);
-            if (nst > 0) {
-                constexpr int NSTQ = ((NF / 2 - 1) * 52 + KWS_WAVE - 1) / KWS_WAVE;
-                const unsigned inv = (1u << 20) / (unsigned)nst + 1u;           // i / nst for i < 52 * 19
-                float stale[NSTQ];
-                int sidx[NSTQ];
-#pragma unroll
-                for (int q = 0; q < NSTQ; ++q) {
-                    const int i = min(lane_l + q * KWS_WAVE, nfr * nst - 1);
-                    const int r = (int)(((unsigned)i * inv) >> 20);
-                    sidx[q] = r * fs + NF / 2 + 1 + (i - r * nst);
-                    stale[q] = img[sidx[q]];
-                }
-#pragma unroll
-                for (int q = 0; q < NSTQ; ++q)
-                    if (lane_l + q * KWS_WAVE < nfr * nst) img[sidx[q]] = (stale[q] * 2.0f) * stale_scale;
-            }
+            // Coefficients above NF/2 are never written by the reference's transform: they keep the log-mel input, doubled and
+            // scaled (fast-dct-fft.cpp:71-74, numpy.hpp:392-397).  cmvnw normalises every column by its own mean and deviation,
+            // so a constant factor on a column does not reach the features (it only rescales the epsilon added to the
+            // deviation, 1.2e-7): those columns are left as they are.  c0 <- log(frame energy) (feature.hpp:425-429).
+            // Stores without a branch per value: rows past the last frame and coefficients that are not this tile's go to a
+            // per-lane sink (the log-energy slots, read above).
+            float *const sink = elog + lane_l;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int n = 16 * nt + lm;
+                    const bool col_ok = n <= NF / 2 && n > 0;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * lq + i;
-                        if (r < nfr && n <= NF / 2 && n > 0) img[r * fs + n] = acc[mt][nt][i];
+                        *((col_ok && r < nfr) ? img + r * fs + n : sink) = acc[mt][nt][i];
                     }
                 }
             if (lane_l < nfr) img[lane_l * fs] = e0;
