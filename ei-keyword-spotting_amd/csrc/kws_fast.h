@@ -70,6 +70,7 @@ struct KwsFastPlan {
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;
+    int sink_off;                 // F + sink_off + lane: where a lane's stores that fall outside an image go (no branch per value)
     const float *shared_init;     // global image of the workgroup's shared LDS block (weights, biases, cmvnw tables)
     // ---- float32 network fused behind the features (fuse = 0: features / int8 tensor go to HBM instead)
     int fuse, n_blocks;

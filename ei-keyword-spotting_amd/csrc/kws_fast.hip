@@ -95,7 +95,8 @@ __device__ __forceinline__ float oct_sum(float v)
 // ---------------------------------------------------------------------------------------------------------
 template <int MT, int NT>
 __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ stage,
-                                                int sstride, const float *__restrict__ shared, int lane, long long *t_loop = nullptr, long long *t_pre = nullptr)
+                                                int sstride, const float *__restrict__ shared, int lane, float *__restrict__ sink,
+                                                long long *t_loop = nullptr, long long *t_pre = nullptr)
 {
     const int lm = lane & 15, lq = lane >> 4;
     v4f acc[MT][NT];
@@ -213,7 +214,7 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
                 float v = acc[mt][nt][i] + bias;
                 v = fminf(fmaxf(v, cmin), cmax);
                 if (has_add) { v = v + addc; v = fminf(fmaxf(v, amin), amax); }
-                if (row < out_w && n < out_c) sp[row * sstride] = v;
+                *((row < out_w && n < out_c) ? sp + row * sstride : sink) = v;
             }
         }
     }
@@ -715,8 +716,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             // so a constant factor on a column does not reach the features (it only rescales the epsilon added to the
             // deviation, 1.2e-7): those columns are left as they are.  c0 <- log(frame energy) (feature.hpp:425-429).
             // Stores without a branch per value: rows past the last frame and coefficients that are not this tile's go to a
-            // per-lane sink (the log-energy slots, read above).
-            float *const sink = elog + lane_l;
+            // per-lane sink.
+            float *const sink = F + FP.sink_off + lane_l;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -756,6 +757,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 
         // ---- the float32 graph: CONV_2D blocks ping-pong between the two images, then FULLY_CONNECTED and SOFTMAX ----------
         float *cur = F, *oth = R1;
+        float *const wsink = F + FP.sink_off + lane;
         int lane_n = lane;
         asm volatile("" : "+v"(lane_n));
         for (int b = 0; b < n_blocks; ++b) {
@@ -769,14 +771,14 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             const int sstride = pooled ? k.stage_stride : o_stride;
             long long t_loop = 0, t_pre = 0, *tl = (PROF && b == 0) ? &t_loop : nullptr, *tp = (PROF && b == 0) ? &t_pre : nullptr;
             switch (k.m_tiles * 4 + k.n_tiles) {
-            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n, tl, tp); break;
-            case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n); break;
-            case 3 * 4 + 2: fast_conv_tiles<3, 2>(k, cur, stage, sstride, shared, lane_n, tl, tp); break;
-            case 3 * 4 + 1: fast_conv_tiles<3, 1>(k, cur, stage, sstride, shared, lane_n); break;
-            case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shared, lane_n); break;
-            case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shared, lane_n); break;
-            case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shared, lane_n); break;
-            default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shared, lane_n); break;
+            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n, wsink, tl, tp); break;
+            case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
+            case 3 * 4 + 2: fast_conv_tiles<3, 2>(k, cur, stage, sstride, shared, lane_n, wsink, tl, tp); break;
+            case 3 * 4 + 1: fast_conv_tiles<3, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
+            case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shared, lane_n, wsink); break;
+            case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
+            case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shared, lane_n, wsink); break;
+            default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
             }
             WAVE_SYNC();
             if (PROF && b == 0) { ph[9] += t_loop - t_pre; ph[10] += clock64() - t_loop; ph[11] += t_pre - tlast; }
