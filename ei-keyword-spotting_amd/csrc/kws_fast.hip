@@ -427,7 +427,10 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     __syncthreads();
 
     const int nfr = P.n_frames, ncep = P.n_cepstral, NF = 8 * DG;
-    const int n_pass = (nfr + KWS_FAST_MEL_CHUNK - 1) / KWS_FAST_MEL_CHUNK;
+    // a remainder of one or two frames (the 49th of the standard window) would cost a whole eight-frame pass: it gets a tail pass
+    // with 32 lanes per frame instead (four points per lane, three exchanges -- round 1's layout of the same butterflies)
+    const int n_tail = (nfr >= KWS_FAST_MEL_CHUNK && (nfr & 7) != 0 && (nfr & 7) <= 2) ? (nfr & 7) : 0;
+    const int n_pass = n_tail ? nfr / KWS_FAST_MEL_CHUNK : (nfr + KWS_FAST_MEL_CHUNK - 1) / KWS_FAST_MEL_CHUNK;
     const int fs = FP.fs, fuse = FP.fuse;
     float *img = F;                                                   // [n_frames][fs]
     float *elog = F + nfr * fs;                                       // log frame energies, parked until the DCT has run
@@ -512,6 +515,48 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         auto touch = [&](int q) {
             const int f = min(KWS_FAST_MEL_CHUNK * q + fg, nfr - 1);
             return *(const int *)(xbase + (f * frame_stride + 32 * fl));
+        };
+        // ---- mel filterbank for the frames of a pass: dot_by_row as a register-tap gather, zero handling, log.  pairs = pairs of
+        //      frame slots a lane half walks (2: slots 4 h .. 4 h + 3 of an eight-frame pass; 1: the tail pass, slots 0, 1)
+        auto mel_phase = [&](int fbase, int nfc, int pairs) {
+            WAVE_SYNC();
+            // filters 0..31: lane half h takes frame slots 4 h .. 4 h + 3; filters 32..39 (40 filters only): one frame slot each
+            const int j2 = 32 + (lane_c & 7), sl2 = lane_c >> 3;
+            const float *p1 = pw + 4 * half * pstride + start1, *p2 = pw + sl2 * pstride + start2;
+            float macc[5] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2 += 2) {
+                if (s2 >= 2 * pairs) break;
+                float xv[2][NZ];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int n = 0; n < NZ; ++n) xv[s][n] = p1[(s2 + s) * pstride + n];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int n = 0; n < NZ; ++n) acc = __fmaf_rn(xv[s][n], w1[n], acc);
+                    macc[s2 + s] = acc;
+                }
+            }
+            float acc2 = 0.0f;
+            if (DG > 4) {
+                float xv2[NZ2];
+#pragma unroll
+                for (int n = 0; n < NZ2; ++n) xv2[n] = p2[n];
+#pragma unroll
+                for (int n = 0; n < NZ2; ++n) acc2 = __fmaf_rn(xv2[n], w2[n], acc2);
+            }
+            macc[4] = acc2;
+#pragma unroll
+            for (int s = 0; s < 5; ++s) macc[s] = fast_log(macc[s] == 0.0f ? FLT_EPSILON : macc[s]);   // functions.hpp:63-69
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int slot = 4 * half + s;
+                if (slot < nfc && t < NF) img[(fbase + slot) * fs + t] = macc[s];
+            }
+            if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2] = macc[4];
         };
         fast_i2 nxt[2][8];
         fetch(0, nxt);
@@ -624,49 +669,111 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             }
             FPH(2);
 
-            // ---- mel filterbank for the eight frames: dot_by_row as a register-tap gather, zero handling, log ----------
-            WAVE_SYNC();
-            const int nfc = min(KWS_FAST_MEL_CHUNK, nfr - fbase);
-            {
-                // filters 0..31: lane half h takes frame slots 4 h .. 4 h + 3; filters 32..39 (40 filters only): one frame slot each
-                const int j2 = 32 + (lane_c & 7), sl2 = lane_c >> 3;
-                const float *p1 = pw + 4 * half * pstride + start1, *p2 = pw + sl2 * pstride + start2;
-                float macc[5];
-#pragma unroll
-                for (int s2 = 0; s2 < 4; s2 += 2) {
-                    float xv[2][NZ];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int n = 0; n < NZ; ++n) xv[s][n] = p1[(s2 + s) * pstride + n];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int n = 0; n < NZ; ++n) acc = __fmaf_rn(xv[s][n], w1[n], acc);
-                        macc[s2 + s] = acc;
-                    }
-                }
-                float acc2 = 0.0f;
-                if (DG > 4) {
-                    float xv2[NZ2];
-#pragma unroll
-                    for (int n = 0; n < NZ2; ++n) xv2[n] = p2[n];
-#pragma unroll
-                    for (int n = 0; n < NZ2; ++n) acc2 = __fmaf_rn(xv2[n], w2[n], acc2);
-                }
-                macc[4] = acc2;
-#pragma unroll
-                for (int s = 0; s < 5; ++s) macc[s] = fast_log(macc[s] == 0.0f ? FLT_EPSILON : macc[s]);   // functions.hpp:63-69
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int slot = 4 * half + s;
-                    if (slot < nfc && t < NF) img[(fbase + slot) * fs + t] = macc[s];
-                }
-                if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2] = macc[4];
-            }
+            mel_phase(fbase, min(KWS_FAST_MEL_CHUNK, nfr - fbase), 2);
             WAVE_SYNC();
             FPH(3);
+        }
+
+        if (n_tail) {
+            // ---- tail pass: frames 8 n_pass + h on lane half h, a lane transforms four of its frame's 128 points per stage:
+            //      kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32, each through an in-place, padded
+            //      buffer behind the two power rows it feeds
+            const int ft = KWS_FAST_MEL_CHUNK * n_pass + half;
+            const bool live_t = ft < nfr;
+            const int s0 = min(ft, nfr - 1) * frame_stride + 8 * t;
+            const int4 rawv = *(const int4 *)(xbase + s0);
+            const int rawp = s0 == 0 ? wrap_prev : (int)xbase[s0 - 1];
+            const int k01 = t & 1, g01 = t >> 1, n0 = (g01 >> 2) + 4 * (g01 & 3), K2 = t & 7, G2 = t >> 3;
+            const cf ta1 = to_cf(P.tw[16 * k01]), ta2 = to_cf(P.tw[32 * k01]), ta3 = to_cf(P.tw[48 * k01]);
+            const cf tb1 = to_cf(P.tw[4 * K2]), tb2 = to_cf(P.tw[8 * K2]), tb3 = to_cf(P.tw[12 * K2]);
+            const cf tc1 = to_cf(P.tw[t]), tc2 = to_cf(P.tw[2 * t]), tc3 = to_cf(P.tw[3 * t]);
+            float *zb = R1 + 2 * pstride + half * KWS_ZF;
+            {
+                float y[8];
+                float prev = (float)rawp;                              // unscaled, like the eight-frame passes (see pscale)
+                const int w[4] = { rawv.x, rawv.y, rawv.z, rawv.w };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = (float)(short)(w[i] & 0xffff), hi = (float)(w[i] >> 16);
+                    const float pl = pre_cof * prev;
+                    y[2 * i] = lo - pl;
+                    const float ph_ = pre_cof * lo;
+                    y[2 * i + 1] = hi - ph_;
+                    prev = hi;
+                }
+                *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);
+                *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
+            }
+            WAVE_SYNC();
+            cf v[4];
+            {
+                cf la[4], lb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { la[i] = ld_cf(zb, n0 + 16 * i); lb[i] = ld_cf(zb, n0 + 16 * i + 64); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = k01 ? csub(la[i], lb[i]) : cadd(la[i], lb[i]);
+            }
+            bfly4(v[0], v[1], v[2], v[3], ta1, ta2, ta3);
+            WAVE_SYNC();                                              // every lane has read its inputs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_cf(zb, 8 * g01 + k01 + 2 * i, v[i]);
+            WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
+            bfly4(v[0], v[1], v[2], v[3], tb1, tb2, tb3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, v[i]);
+            WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ld_cf(zb, t + 32 * i);
+            bfly4(v[0], v[1], v[2], v[3], tc1, tc2, tc3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, v[i]);
+            WAVE_SYNC();
+            {
+                const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
+                cf fpk[2], fq[2];
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;
+                    fpk[rep] = ld_cf(zb, k);
+                    fq[rep] = ld_cf(zb, KWS_NC - k);
+                }
+                const float2 d0 = *(const float2 *)zb;                // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
+                float *prow = pw + half * pstride;
+                float esum = 0.0f;
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;
+                    const cf stw_ = rep ? st2 : st1;
+                    cf fpnk; fpnk.r = fq[rep].r; fpnk.i = -fq[rep].i;
+                    const cf f1k = cadd(fpk[rep], fpnk), f2k = csub(fpk[rep], fpnk);
+                    const cf twv = cmul(f2k, stw_);
+                    cf lo, hi;                                       // twice the reference's: the halving is part of pscale
+                    lo.r = f1k.r + twv.r;
+                    lo.i = f1k.i + twv.i;
+                    hi.r = f1k.r - twv.r;
+                    hi.i = twv.i - f1k.i;
+                    const float plo = __fmaf_rn(lo.r, lo.r, lo.i * lo.i) * pscale;
+                    const float phi = __fmaf_rn(hi.r, hi.r, hi.i * hi.i) * pscale;
+                    if (k != KWS_NC / 2) {                           // bin 64 is written twice by the reference: the second store wins
+                        esum += plo;
+                        prow[k] = plo;
+                    }
+                    esum += phi;
+                    prow[KWS_NC - k] = phi;
+                }
+                if (t == 0) {
+                    const float dc = d0.x + d0.y, ny = d0.x - d0.y;
+                    const float pdc = (dc * dc) * (4.0f * pscale), pny = (ny * ny) * (4.0f * pscale);
+                    esum += pdc + pny;
+                    prow[0] = pdc;
+                }
+                esum = half_wave_sum(esum);
+                if (t == 0 && live_t) elog[ft] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
+            }
+            mel_phase(KWS_FAST_MEL_CHUNK * n_pass, n_tail, 1);
+            WAVE_SYNC();
         }
 
         // ---- DCT-II (numpy.hpp:378-401) as [frames x NF] x [NF x NF/2+1] on the matrix cores, in place: two rounds of two
