@@ -39,6 +39,8 @@ struct KwsFastBlock {
     int vrows;                    // output rows beyond the tiles (out_w = 16 m_tiles + vrows, vrows <= 2) computed on the vector ALU: the
                                   // 49-frame window would otherwise pay a fourth row tile for one row
     int stage_stride;             // row stride of the un-pooled staging image (odd)
+    int fpool;                    // 1: MAX_POOL_2D with non-overlapping windows of >= 4 rows is taken on the raw accumulators (register
+                                  // maxima + LDS float-max atomics into [pool_w][32]); the epilogue then runs on the pooled values only
     int w_off, bias_off, addc_off;   // float offsets into the workgroup's shared LDS block
     int st_off;                   // k-step table [taps * in_cp / 8 + 3] x int4 { image offset (floats), tap, weight offset (floats), - }
     int has_add;

@@ -196,10 +196,51 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         clip_rows(d2.y, a0);
     }
     if (t_loop) *t_loop = clock64();
+    const int out_w = k.out_w;
+    if (k.fpool) {
+        // ---- MAX_POOL_2D with non-overlapping windows, taken on the raw accumulators: bias, the activation clamps and the ADD are
+        //      non-decreasing in the accumulator, so max and epilogue commute (same values, bit for bit) and only pool_w x out_c
+        //      values go through the epilogue (fast_pool_finish).  A lane folds its four rows of a tile into at most two window
+        //      maxima in registers and merges them into pm[window][32] (the dead input image) with LDS float-max atomics.
+        float *pm = stage;
+        WAVE_SYNC();                                                  // every lane has read its last operands from the image
+        for (int i = lane; i < k.pool_w * 32; i += KWS_WAVE) pm[i] = -FLT_MAX;
+        WAVE_SYNC();
+        const unsigned pinv = (1u << 16) / (unsigned)k.pool + 1u;      // r / pool for r < 64
+        const int pool_w = k.pool_w;
+        float *const psink = pm + pool_w * 32 + lane;                  // windows past the last one (VALID pooling), channels past out_c
+        auto merge = [&](int p, int n, float m, bool ok) {
+            __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)((ok && p < pool_w && n < out_c) ? pm + p * 32 + n : psink), m, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);
+        };
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = 16 * nt + lm;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r0 = 16 * mt + 4 * lq;
+                int pw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[i] = (int)(((unsigned)(r0 + i) * pinv) >> 16);
+                float mlo = acc[mt][nt][0], mhi = acc[mt][nt][3];      // pool >= 4: the four rows touch at most two windows
+#pragma unroll
+                for (int i = 1; i < 4; ++i) {
+                    const bool row_ok = r0 + i < out_w;
+                    mlo = (row_ok && pw[i] == pw[0]) ? fmaxf(mlo, acc[mt][nt][i]) : mlo;
+                    if (i < 3) mhi = (row_ok && pw[i] == pw[3]) ? fmaxf(mhi, acc[mt][nt][i]) : mhi;
+                }
+                merge(pw[0], n, mlo, r0 < out_w);
+                merge(pw[3], n, mhi, r0 + 3 < out_w && pw[3] != pw[0]);
+            }
+        }
+        for (int vr = 0; vr < k.vrows; ++vr) {
+            const int r = 16 * MT + vr;
+            merge((int)(((unsigned)r * pinv) >> 16), lane & 31, vout[vr], lane < 32);
+        }
+        return;
+    }
     // ---- epilogue: bias, fused activation, ADD(constant) + activation (conv.h:88-93, add.h:200-212) ---------------------
     const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max;
     const bool has_add = k.has_add != 0;
-    const int out_w = k.out_w;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = 16 * nt + lm;
@@ -224,6 +265,26 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         v = fminf(fmaxf(v, cmin), cmax);
         if (has_add) { v = v + shared[k.addc_off + nc]; v = fminf(fmaxf(v, amin), amax); }
         if (lane < 32 && n < out_c) stage[(16 * MT + vr) * sstride + n] = v;
+    }
+}
+
+// Pooled-in-flight blocks (KwsFastBlock::fpool): the window maxima of the raw accumulators sit in pm[pool_w][32]; bias, activation,
+// ADD + activation, pooling clamp -- the reference's order per value (conv.h:88-93, add.h:200-212, pooling.h:231-233) -- and the
+// zeroed k-padding channels of the next image.
+__device__ __forceinline__ void fast_pool_finish(const KwsFastBlock &k, const float *__restrict__ pm, float *__restrict__ img,
+                                                 const float *__restrict__ shared, int lane, int out_stride, int out_cp)
+{
+    const int items = k.pool_w * out_cp, out_c = k.out_c;
+    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;
+    const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max, pmin = k.pool_min, pmax = k.pool_max;
+    const bool has_add = k.has_add != 0;
+    for (int i = lane; i < items; i += KWS_WAVE) {
+        const int p = (int)(((unsigned)i * inv) >> 20), c = i - p * out_cp, cc = min(c, out_c - 1);
+        float v = pm[p * 32 + cc] + shared[k.bias_off + cc];
+        v = fminf(fmaxf(v, cmin), cmax);
+        if (has_add) { v = v + shared[k.addc_off + cc]; v = fminf(fmaxf(v, amin), amax); }
+        v = fminf(fmaxf(v, pmin), pmax);
+        img[p * out_stride + c] = c < out_c ? v : 0.0f;
     }
 }
 
@@ -889,7 +950,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             }
             WAVE_SYNC();
             if (PROF && b == 0) { ph[9] += t_loop - t_pre; ph[10] += clock64() - t_loop; ph[11] += t_pre - tlast; }
-            fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
+            if (k.fpool) fast_pool_finish(k, stage, oth, shared, lane_n, o_stride, o_cp);
+            else fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
             WAVE_SYNC();
             float *tmp = cur; cur = oth; oth = tmp;
             FPH(6 + (b > 0));

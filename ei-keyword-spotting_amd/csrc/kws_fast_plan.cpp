@@ -239,6 +239,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         if (b == 0 && (k.in_cp > h->dsp.n_filters || s.in_w != h->dsp.n_frames || s.in_c != h->dsp.n_cepstral))
             return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: first conv block does not read the feature matrix");
         k.stage_stride = s.out_c | 1;
+        k.fpool = (s.pool > 1 && s.pool == s.pool_stride && s.pool >= 4 && s.out_c <= 32 && s.pool_w * 32 + KWS_FAST_WAVE <= s.in_w * k.in_stride) ? 1 : 0;
         k.has_add = s.has_add;
         k.conv_min = s.conv_min; k.conv_max = s.conv_max; k.add_min = s.add_min; k.add_max = s.add_max;
         k.pool_min = s.pool_min; k.pool_max = s.pool_max;
