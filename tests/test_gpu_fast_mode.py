@@ -353,3 +353,44 @@ def test_fast_mode_streams_follow_the_continuous_oracle(name, pkg, oracle):
     assert gm.fast_fallback_count() >= 1                                  # last step: at least the silent stream
     sb.close()
     gm.close()
+
+
+FUSED_POOL_GRAPHS = {
+    # (out_channels, taps, pool): positive pool = SAME (a ragged last window is clipped), negative = VALID (the tail is dropped)
+    "pool7_7": dict(seed=61, ncep=13, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4),                  # the shipped shape
+    "pool5_valid_one_block": dict(seed=62, ncep=13, blocks=((24, 5, -5),), n_labels=5),                # 49 -> 9 (rows 45..48 dropped), Dense over 216
+    "pool4_valid": dict(seed=63, ncep=16, blocks=((16, 3, -4), (8, 3, -4)), n_labels=3),               # 49 -> 12 (row 48 dropped) -> 3
+    "pool6_valid_40ch": dict(seed=64, num_filters=40, ncep=40, low=300, high=0, blocks=((32, 3, -6), (16, 3, 1)), n_labels=6),   # 49 -> 8
+    "pool2_small_windows": dict(seed=65, ncep=13, blocks=((8, 3, 2), (16, 3, 2)), n_labels=4),         # windows < 4 rows: staging path
+    "pool8_valid_then_none": dict(seed=66, ncep=20, blocks=((12, 4, -8), (12, 2, 1)), n_labels=4),     # 49 -> 6 (row 48 dropped), then an un-pooled block
+}
+
+
+@pytest.mark.parametrize("key", sorted(FUSED_POOL_GRAPHS))
+def test_fast_mode_fused_graphs_with_other_pooling_shapes(key, pkg, oracle, tmp_path):
+    """The fused float network of kws_fast_kernel over pooling shapes other than the shipped 7 / 7: windows taken on the raw
+    accumulators (non-overlapping, >= 4 rows: SAME with a ragged last window, VALID with a dropped tail) and the staging path
+    (windows of 2 or 3 rows), each against the restated float kernels within the fast mode's score tolerance."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dequantize_model import dequantize
+    from kws_testlib import synth_model_blob
+    blob = dequantize(synth_model_blob(**FUSED_POOL_GRAPHS[key]))
+    p = tmp_path / ("%s.kwsm" % key)
+    p.write_bytes(blob)
+    om = OracleModel(oracle, str(p))
+    try:
+        gm = pkg.Model(blob=blob)
+    except pkg.KwsError as e:                       # a draw outside the documented limits of the plan builder
+        assert e.code == -18
+        pytest.skip("graph outside the kernels' limits: %s" % e)
+    gm.set_mode(pkg.MODE_FAST)
+    assert gm.fast_is_fused, key
+    B = 700
+    host = np.concatenate([oracle.synth(300 + len(key), 5, B - 6), np.stack(list(special_clips().values()))[:6]])
+    pcm = torch.from_numpy(np.ascontiguousarray(host)).to("cuda:0")
+    s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+    so, fo, _ = om.run_batch(host, want_features=True)
+    assert np.abs(s - so).max() <= FAST_SCORE_TOL, (key, float(np.abs(s - so).max()))
+    gm.close()
