@@ -474,9 +474,18 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
     if (e) return e;
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
     const bool fused = scores && h->is_float && h->fast_fused_ok;
+    int rc = 0;
+    if (fused && want_f) {
+        // the fused kernel keeps the feature matrix on chip: a caller who also wants it gets it from the feature-emitting form first
+        // (both launches list the same ill-conditioned clips: the list is restarted in between)
+        rc = kws_launch_fast(h->dsp, h->fast_plain, h->d_fast_plain, pcm, (int)B, nullptr, fx, nullptr, h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1,
+                             h->n_cu, s);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
+        HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+    }
     const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
-    int rc = kws_launch_fast(h->dsp, FP, fused ? h->d_fast_fused : h->d_fast_plain, pcm, (int)B, scores, (fused && !want_f) ? nullptr : fx, q, h->nn.in_scale, h->nn.in_zp,
-                             h->d_flags, h->d_flags + 1, h->n_cu, s);
+    rc = kws_launch_fast(h->dsp, FP, fused ? h->d_fast_fused : h->d_fast_plain, pcm, (int)B, scores, fused ? nullptr : fx, fused ? nullptr : q, h->nn.in_scale,
+                         h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
     if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
     if (scores && !fused) {
         if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, nullptr, s))) return e; }

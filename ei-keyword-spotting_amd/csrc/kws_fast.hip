@@ -343,10 +343,10 @@ __device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__
 //  ext_tab != NULL (win_size > 2 n_frames, the usual shapes): the first window counts every row m0 times and at most
 //  KWS_FAST_CMVN_EXT rows more, so it is m0 x (the column's plain sums, gathered from the row groups' own rows with
 //  ds_bpermute) + those few rows, instead of a walk over every row.
-template <int CR, int CG, typename Emit>
+template <int CR, int CG, bool HAS_OUT, typename Emit>
 __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
                                           float inv_win, float guard, int lane, int nfr, int ncep, Emit emit,
-                                          const float *__restrict__ ext_tab)
+                                          const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
     const int cgrp = min(lane / CG, NG - 1), cl = lane - (lane / CG) * CG;
@@ -444,9 +444,13 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 #pragma unroll
         for (int i = 0; i < CR; ++i) {
             const int r = r0 + i;
-            if (act && r < nfr) {
-                col[r * fs] = o[i];
-                emit(r, c, o[i]);
+            if constexpr (HAS_OUT) {                  // features / the int8 tensor leave for HBM with each value
+                if (act && r < nfr) {
+                    col[r * fs] = o[i];
+                    emit(r, c, o[i]);
+                }
+            } else {                                  // LDS only: no branch per value, rows / columns outside the matrix go to the sink
+                *((act && r < nfr) ? col + r * fs : sink) = o[i];
             }
         }
     }
@@ -462,7 +466,10 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 // NZ: taps of mel filters 0..31 kept in registers (filters 32..39, when there are 40, keep KWS_FAST_NZ2); DG: DCT k-groups = filters / 8
 // FROM_CEP: the windows arrive as cepstra before cmvnw [n_frames][n_cepstral] (continuous mode: the rolling buffers of kws_streams_*,
 // ring-indexed per KwsDspPlan::ring_*) instead of PCM: the kernel starts at cmvnw.
-template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false>
+// NET: the float32 network follows in the same launch (no feature / int8 outputs); !NET: the features / the int8 tensor leave for
+// HBM and no network code is compiled in.  Two instantiations instead of run-time flags: each form's cmvnw stores are written
+// for what it does (with a branch per value only where a global store hangs on it).
+template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false, bool NET = true>
 __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const KwsFastPlan *__restrict__ FPp, const int16_t *__restrict__ pcm, int n_clips,
                                                           float *__restrict__ scores, float *__restrict__ features,
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     // with 32 lanes per frame instead (four points per lane, three exchanges -- round 1's layout of the same butterflies)
     const int n_tail = (nfr >= KWS_FAST_MEL_CHUNK && (nfr & 7) != 0 && (nfr & 7) <= 2) ? (nfr & 7) : 0;
     const int n_pass = n_tail ? nfr / KWS_FAST_MEL_CHUNK : (nfr + KWS_FAST_MEL_CHUNK - 1) / KWS_FAST_MEL_CHUNK;
-    const int fs = FP.fs, fuse = FP.fuse;
+    const int fs = FP.fs;
     float *img = F;                                                   // [n_frames][fs]
     float *elog = F + nfr * fs;                                       // log frame energies, parked until the DCT has run
     constexpr int NZ2 = DG > 4 ? KWS_FAST_NZ2 : 1;
@@ -915,13 +922,15 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         bool bad;
         int lane_m = lane;
         asm volatile("" : "+v"(lane_m));
-        if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab);
-        else bad = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab);
+        float *const csink = F + FP.sink_off + lane_m;
+        if (cr == 13) bad = fast_cmvn<13, 16, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab, csink);
+        else bad = fast_cmvn<17, 20, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab, csink);
         if (__any(bad)) {
             if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
         }
         FPH(5);
-        if (!fuse) continue;
+        if constexpr (!NET) continue;
+        else {
 
         // ---- the float32 graph: CONV_2D blocks ping-pong between the two images, then FULLY_CONNECTED and SOFTMAX ----------
         float *cur = F, *oth = R1;
@@ -974,6 +983,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         }
         WAVE_SYNC();
         FPH(8);
+        }   // NET
     }
     if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
         for (int i = 0; i < KWS_FAST_NPHASE; ++i) prof_out[i] = ph[i];
@@ -982,7 +992,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 // ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
-template <int NZ, int DG, bool PROF, bool FROM_CEP = false>
+template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true>
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
                          long long *prof_out, hipStream_t stream, const float *cep = nullptr)
@@ -990,14 +1000,14 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     const size_t smem = ((size_t)FP.shared_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_done = true;
     }
     const int per_wg = FP.n_waves;
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
-    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
+    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
                        features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep);
     return (int)hipGetLastError();
 }
@@ -1009,11 +1019,15 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
     if (n_clips <= 0) return 0;
 #define KWS_FAST_ARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream
     if (FP.dct_groups == 4)
-        return FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_ARGS)
-                                                                                    : launch_fast_t<KWS_FAST_NZ_MAX, 4, false>(KWS_FAST_ARGS);
+        return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_ARGS)
+                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 4, false>(KWS_FAST_ARGS))
+                       : (FP.nz <= 4 ? launch_fast_t<4, 4, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false, false, false>(KWS_FAST_ARGS)
+                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 4, false, false, false>(KWS_FAST_ARGS));
     if (FP.dct_groups == 5)
-        return FP.nz <= 4 ? launch_fast_t<4, 5, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false>(KWS_FAST_ARGS)
-                                                                                    : launch_fast_t<KWS_FAST_NZ_MAX, 5, false>(KWS_FAST_ARGS);
+        return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 5, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false>(KWS_FAST_ARGS)
+                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 5, false>(KWS_FAST_ARGS))
+                       : (FP.nz <= 4 ? launch_fast_t<4, 5, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false, false, false>(KWS_FAST_ARGS)
+                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false>(KWS_FAST_ARGS));
     return (int)hipErrorInvalidValue;
 }
 
@@ -1024,8 +1038,10 @@ int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, con
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
     // mel taps / DCT are not part of this variant: one instantiation serves every model
-    return launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu,
-                                            nullptr, stream, cep);
+    return FP.fuse ? launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list,
+                                                      n_cu, nullptr, stream, cep)
+                   : launch_fast_t<4, 4, false, true, false>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count,
+                                                             flag_list, n_cu, nullptr, stream, cep);
 }
 
 // development aid: phase clocks (<= 4-tap builds only)
