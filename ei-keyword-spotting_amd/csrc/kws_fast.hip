@@ -178,22 +178,25 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
     float2 a0[MT], b0[NT], a1[MT], b1[NT];
     int4 d0 = steps[0], d1 = steps[1];
     fetch(d0, a0, b0);
-    clip_rows(d0.y, a0);
     if (t_pre) *t_pre = clock64();
+    // per half: request the other set's operands, zero this set's out-of-image rows (they were requested a half earlier: no wait),
+    // issue this set's MFMAs
     for (int it = 0; it < n_it; it += 2) {
         const int4 d2 = steps[it + 2];                                   // n_it + 3 entries: the last step is repeated
         fetch(d1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        clip_rows(d0.y, a0);
         mfmas(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        clip_rows(d1.y, a1);
         if (it + 1 >= n_it) break;                                        // odd step count
+        const int tap1 = d1.y;
         d1 = steps[it + 3];
         fetch(d2, a0, b0);
+        d0 = d2;
         __builtin_amdgcn_sched_barrier(0);
+        clip_rows(tap1, a1);
         mfmas(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        clip_rows(d2.y, a0);
     }
     if (t_loop) *t_loop = clock64();
     const int out_w = k.out_w;
