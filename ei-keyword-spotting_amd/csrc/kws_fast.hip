@@ -139,6 +139,21 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
             const float *ap = in + r * in_stride + 2 * hf * npair;
             const float *wp = shared + k.w_off + 2 * ((tap * (k.in_cp >> 1) + hf * npair) * out_c + n);
             int p = 0;
+            // five double pairs at a time (a 40-channel image: a whole tap of this lane's half): fifteen requests go out before the
+            // first product is formed, so the tap pays one LDS round trip instead of five
+            for (; p + 9 < npair; p += 10) {
+                float4 av[5];
+                float2 wv[10];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) av[i] = *(const float4 *)(ap + 2 * p + 4 * i);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) wv[i] = *(const float2 *)(wp + 2 * (p + i) * out_c);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    s0 = __fmaf_rn(av[i].x, wv[2 * i].x, s0); s1 = __fmaf_rn(av[i].y, wv[2 * i].y, s1);
+                    s0 = __fmaf_rn(av[i].z, wv[2 * i + 1].x, s0); s1 = __fmaf_rn(av[i].w, wv[2 * i + 1].y, s1);
+                }
+            }
             for (; p + 1 < npair; p += 2) {
                 const float4 av = *(const float4 *)(ap + 2 * p);
                 const float2 w0 = *(const float2 *)(wp + 2 * p * out_c), w1 = *(const float2 *)(wp + 2 * (p + 1) * out_c);

@@ -282,6 +282,10 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
     const bool profiling = prof != nullptr && blockIdx.x == 0 && wave == 0;
     long long ph[KWS_MAX_BLOCKS + 2] = { 0 }, tlast = profiling ? clock64() : 0;
     auto mark = [&](int i) { if (profiling) { const long long now = clock64(); ph[i] += now - tlast; tlast = now; } };
+    // a workgroup none of whose waves has a clip (the empty re-run list of a KWS_MODE_FAST call, a short list) leaves before
+    // the weights are staged: 16.5 us -> launch overhead for the empty list
+    const int n_sel = sel_count(sel, n_clips);
+    if ((int)blockIdx.x * n_waves >= n_sel) return;
     float *sp = (float *)smem_raw;
     int s_w_off[KWS_MAX_BLOCKS];     // float offsets into the LDS block: pointers kept in an array lose their address space (flat loads)
     for (int b = 0; b < N.n_blocks; ++b) {
@@ -316,7 +320,6 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
         const int lo = k.pad_left * k.in_c, hi = lo + k.in_w * k.in_c, tot = nnf_rows(k) * k.in_c;
         return ((lo | hi | N.n_features) & 3) == 0 && ((tot + 3) >> 2) <= 64 * NNF_PF && N.n_blocks > 1;
     }();
-    const int n_sel = sel_count(sel, n_clips);
     for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci += gridDim.x * n_waves) {
         const int clip = sel_clip(sel, ci);
         {
