@@ -29,16 +29,31 @@ __device__ __forceinline__ float half_wave_sum(float v)
     v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // lane ^ 16
     return v;
 }
+// whole-wave reductions, every lane receives the result: four DPP steps inside a row of 16 (no LDS round trip), then lane ^ 16
+// and lane ^ 32 through the LDS crossbar
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, KWS_WAVE));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)));
+    return fmaxf(v, __shfl_xor(v, 32, KWS_WAVE));
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, KWS_WAVE);
+    v = half_wave_sum(v);
+    return v + __shfl_xor(v, 32, KWS_WAVE);
+}
+// sum over aligned groups of S lanes (S a power of two, wave-uniform); every lane of a group receives it
+__device__ __forceinline__ float group_sum(float v, int S)
+{
+    if (S > 1) v += dpp_mov<0xB1>(v);
+    if (S > 2) v += dpp_mov<0x4E>(v);
+    if (S > 4) v += dpp_mov<0x141>(v);
+    if (S > 8) v += dpp_mov<0x140>(v);
+    if (S > 16) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+    if (S > 32) v += __shfl_xor(v, 32, KWS_WAVE);
     return v;
 }
 
@@ -984,20 +999,24 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             FPH(6 + (b > 0));
         }
         {
-            // FULLY_CONNECTED (fully_connected.h:26-60): lane = output unit; SOFTMAX (softmax.h:31-63)
+            // FULLY_CONNECTED (fully_connected.h:26-60): an output unit is served by an aligned group of S = 64 / 2^ceil(log2 fc_out)
+            // lanes, each summing every S-th product (a lane per unit walked fc_in dependent LDS round trips with four lanes busy);
+            // SOFTMAX (softmax.h:31-63)
             const int fc_in = FP.fc_in, fc_out = FP.fc_out;
-            const float *wfc = shared + FP.fc_w_off + min(lane_n, fc_out - 1) * fc_in;
+            const int sh = fc_out > 1 ? 32 - __builtin_clz(fc_out - 1) : 0;
+            const int S = KWS_WAVE >> sh, unit = lane_n >> (6 - sh), sl = lane_n & (S - 1), uc = min(unit, fc_out - 1);
+            const float *wfc = shared + FP.fc_w_off + uc * fc_in;
             float tot = 0.0f, tot1 = 0.0f;
-            int i = 0;
-            for (; i + 1 < fc_in; i += 2) { tot = __fmaf_rn(cur[i], wfc[i], tot); tot1 = __fmaf_rn(cur[i + 1], wfc[i + 1], tot1); }
+            int i = sl;
+            for (; i + S < fc_in; i += 2 * S) { tot = __fmaf_rn(cur[i], wfc[i], tot); tot1 = __fmaf_rn(cur[i + S], wfc[i + S], tot1); }
             if (i < fc_in) tot = __fmaf_rn(cur[i], wfc[i], tot);
-            tot = (tot + tot1) + shared[FP.fc_b_off + min(lane_n, fc_out - 1)];
+            tot = group_sum(tot + tot1, S) + shared[FP.fc_b_off + uc];
             tot = fminf(fmaxf(tot, FP.fc_min), FP.fc_max);
-            const bool on = lane_n < fc_out;
+            const bool on = unit < fc_out;
             const float mx = wave_max(on ? tot : -FLT_MAX);
-            const float e = on ? expf((tot - mx) * FP.beta) : 0.0f;
-            const float sum = wave_sum(e);
-            if (on) scores[(size_t)clip * n_labels + lane_n] = e / sum;
+            const float e = expf((tot - mx) * FP.beta);
+            const float sum = wave_sum(on && sl == 0 ? e : 0.0f);
+            if (on && sl == 0) scores[(size_t)clip * n_labels + unit] = e / sum;
         }
         WAVE_SYNC();
         FPH(8);
