@@ -8,7 +8,9 @@ reference's own code path for that configuration.
 
 Two arithmetic modes of the same library are timed (include/kws/kws.h):
   * KWS_MODE_FAST  -- the headline `value`: scores within 1e-4 of the reference's (the tolerance BASELINE.json's north_star
-    states; tests/test_gpu_fast_mode.py holds every one of 65 536 clips to it), MFCC + network in ONE kernel launch;
+    states; tests/test_gpu_fast_mode.py holds every one of 65 536 clips to it, tests/test_gpu_fast_families.py nine adversarial
+    input families), MFCC + network in ONE kernel launch; clips whose cmvnw would amplify the re-ordering past that are re-run by
+    the exact kernels inside the same call (their share is reported as config.fast_fallback_rate);
   * KWS_MODE_EXACT -- MFCC features bit-identical to the reference's, scores within 1e-6; reported under "modes".
 At N = 1 the same run also times the model the reference DOES ship (49x13 MFCC, int8) and the other BASELINE configurations;
 they are reported under "also".
@@ -205,6 +207,10 @@ class GpuBackend:
     def checksum(self):
         return float(self.gathered.double().sum().item())
 
+    def checksum_class0(self):
+        # the probability mass of class 0 over every clip: unlike the plain sum (= the number of softmax rows) it depends on the scores
+        return float(self.gathered[:, 0].double().sum().item())
+
     def fallback(self):
         return self.model.fast_fallback_count()
 
@@ -263,6 +269,9 @@ class CpuOracleBackend:
     def checksum(self):
         return float(self.gathered.double().sum().item())
 
+    def checksum_class0(self):
+        return float(self.gathered[:, 0].double().sum().item())
+
     def fallback(self):
         return 0
 
@@ -287,7 +296,7 @@ def measure(backend, model_path, mode, steps, warmup, barrier, max_over_ranks):
     info = backend.load(model_path, mode)
     dt = timed_steps(backend, steps, warmup, barrier, max_over_ranks)
     ms_path, ms_gather = backend.phase_ms(steps)
-    res = dict(info, model=os.path.basename(model_path), mode=mode, dt=dt, ms_path=ms_path, ms_gather=ms_gather, checksum=backend.checksum(),
+    res = dict(info, model=os.path.basename(model_path), mode=mode, dt=dt, ms_path=ms_path, ms_gather=ms_gather, checksum=backend.checksum(), checksum0=backend.checksum_class0(),
                fallback=backend.fallback() if mode == "fast" else 0)
     backend.close_model()
     return res
@@ -414,7 +423,7 @@ def main():
         if x["mode"] == "fast":
             return ("scores within 1e-4 of the reference's (KWS_MODE_FAST; ill-conditioned clips re-run exactly)" if x["is_float"] else
                     "KWS_MODE_FAST: MFCC within tolerance, network bit-exact from the int8 tensor on (an input value may move one step at a "
-                    "rounding boundary)") + " -- tests/test_gpu_fast_mode.py"
+                    "rounding boundary)") + " -- tests/test_gpu_fast_mode.py, tests/test_gpu_fast_families.py"
         return ("MFCC features + logits bit-exact, scores <= 1e-6 vs the reference's float kernels" if x["is_float"]
                 else "bit-exact vs reference") + " -- tests/test_gpu_parity.py"
 
@@ -445,15 +454,20 @@ def main():
         "data": "synthetic" + (" (DRY RUN ON CPU: oracle + gloo stand in for the GPU library + RCCL; not a measurement)" if a.dry_run_cpu else ""),
         "config": {"workload": workload(r["model"]), "mode": r["mode"], "clips_per_gpu": B, "global_batch": world * B, "kwsm_file": r["model"],
                    "parity": parity(r), "network_fused_into_mfcc_kernel": r["fused"], "clips_rerun_by_exact_kernels_last_step": r["fallback"],
+                   "fast_fallback_rate": round(r["fallback"] / float(B), 6),
+                   "fast_fallback_note": "share of this workload's clips the fast kernel handed back to the exact kernels (cmvnw guard, DESIGN.md 4.4); "
+                                         "other input families: profiles/r03_fast_families.txt (tests/test_gpu_fast_families.py)",
                    "collective": ("all_gather(scores) over RCCL (kws_allgather_scores, %d ranks)" % world) if use_comm else "none",
                    "lib_sha256": lib_sha256()},
         "collective": {"allgather_ms_per_step": round(r["ms_gather"], 4), "inside_timed_region": True, "ranks": world} if use_comm else None,
         "roofline": roof,
         "checksum": r["checksum"],
+        "checksum_class0": r["checksum0"],
     }
 
     def line(x, steps):
         return {"kwsm_file": x["model"], "mode": x["mode"], "workload": workload(x["model"]), "value": round(B * steps / x["dt"], 1),
+                "fast_fallback_rate": round(x["fallback"] / float(B), 6),
                 "unit": "clips/s", "ms_per_step": round(x["dt"] / steps * 1e3, 4), "steps": steps, "dtype": dtype(x), "parity": parity(x),
                 "network_kernel": "fused into kws_fast_kernel" if x["fused"] else x["nn_kernel"],
                 "hbm_frac": round((CLIP_LEN * 2 + x["labels"] * 4) * B / (x["ms_path"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}

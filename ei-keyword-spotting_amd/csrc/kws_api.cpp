@@ -55,7 +55,7 @@ void kws_destroy(kws_handle *h)
     if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
     if (h->d_flags) (void)hipFree(h->d_flags);
-    for (void *p : { (void *)h->g_ws, (void *)h->g_mfcc, (void *)h->g_feat }) if (p) (void)hipFree(p);
+    for (auto &g : h->g_sets) for (void *p : { (void *)g.ws, (void *)g.mfcc, (void *)g.feat }) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         for (void *p : { (void *)h->pipe.pcm[k], (void *)h->pipe.s[k], (void *)h->pipe.f[k], (void *)h->pipe.q[k] }) if (p) (void)hipFree(p);
         if (h->pipe.st[k]) (void)hipStreamDestroy(h->pipe.st[k]);
@@ -103,18 +103,31 @@ EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode)
     h->mode = mode;
     return EI_IMPULSE_OK;
 }
-int kws_get_mode(const kws_handle *h) { return h->mode; }
+int kws_get_mode(const kws_handle *h)
+{
+    std::lock_guard<std::mutex> lk(const_cast<kws_handle *>(h)->mu);
+    return h->mode;
+}
 int kws_fast_is_fused(const kws_handle *h) { return h->fast_fused_ok ? 1 : 0; }
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count)
 {
     if (!h || !count) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     *count = 0;
+    std::lock_guard<std::mutex> lk(h->mu);
     if (!h->d_flags) return EI_IMPULSE_OK;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     int n = 0;
     HIP_TRY(hipMemcpy(&n, h->d_flags, sizeof(int), hipMemcpyDeviceToHost));
     *count = (size_t)n;
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, float *abs_thr, float *rel_thr)
+{
+    if (!h || !abs_thr || !rel_thr) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (!h->fast_plain_ok) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%s", h->fast_why.c_str());
+    for (size_t c = 0; c < h->fast_guard_abs.size(); c++) { abs_thr[c] = h->fast_guard_abs[c]; rel_thr[c] = h->fast_guard_rel[c]; }
     return EI_IMPULSE_OK;
 }
 
@@ -133,25 +146,36 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
 int grid_cap_mfcc(const kws_handle *h) { return h->n_cu * 8; }
 int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 
-// buffers of the general MFCC kernels for a batch of B windows
-EI_IMPULSE_ERROR ensure_generic(kws_handle *h, size_t B)
+// Buffers of the general MFCC kernels for a batch of B windows on stream s (B = 0: the transform scratch only).  A stream keeps
+// its set; when more than kGenericSets streams have been seen, the oldest set is handed on after the device has drained.
+EI_IMPULSE_ERROR generic_for(kws_handle *h, hipStream_t s, size_t B, kws_handle::GenericBuf **out)
 {
     std::lock_guard<std::mutex> lk(h->g_mu);
+    kws_handle::GenericBuf *g = nullptr;
+    for (auto &c : h->g_sets) if (c.used && c.s == s) { g = &c; break; }
+    if (!g) for (auto &c : h->g_sets) if (!c.used) { g = &c; break; }
+    if (!g) {
+        g = &h->g_sets[h->g_next];
+        h->g_next = (h->g_next + 1) % kws_handle::kGenericSets;
+        HIP_TRY(hipDeviceSynchronize());          // its stream may be gone by now: wait for everything
+    }
+    g->used = true; g->s = s;
     const size_t need_ws = kws_generic_ws_bytes(h->dsp, grid_cap_mfcc(h));
-    if (need_ws > h->g_ws_bytes) {
-        if (h->g_ws) (void)hipFree(h->g_ws);
-        h->g_ws = nullptr; h->g_ws_bytes = 0;
-        HIP_TRY(hipMalloc((void **)&h->g_ws, need_ws));
-        h->g_ws_bytes = need_ws;
+    if (need_ws > g->ws_bytes) {
+        if (g->ws) (void)hipFree(g->ws);
+        g->ws = nullptr; g->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&g->ws, need_ws));
+        g->ws_bytes = need_ws;
     }
-    if (B > h->g_cap) {
-        for (void *p : { (void *)h->g_mfcc, (void *)h->g_feat }) if (p) (void)hipFree(p);
-        h->g_mfcc = h->g_feat = nullptr; h->g_cap = 0;
+    if (B > g->cap) {
+        for (void *p : { (void *)g->mfcc, (void *)g->feat }) if (p) (void)hipFree(p);
+        g->mfcc = g->feat = nullptr; g->cap = 0;
         const size_t F = h->model.nn_input_frame_size;
-        HIP_TRY(hipMalloc((void **)&h->g_mfcc, std::max<size_t>(B * F, 1) * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&h->g_feat, std::max<size_t>(B * F, 1) * sizeof(float)));
-        h->g_cap = B;
+        HIP_TRY(hipMalloc((void **)&g->mfcc, std::max<size_t>(B * F, 1) * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&g->feat, std::max<size_t>(B * F, 1) * sizeof(float)));
+        g->cap = B;
     }
+    *out = g;
     return EI_IMPULSE_OK;
 }
 
@@ -168,9 +192,10 @@ EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void 
         return EI_IMPULSE_OK;
     }
     if (h->dsp.generic) {
-        EI_IMPULSE_ERROR e = ensure_generic(h, 0);
+        kws_handle::GenericBuf *g = nullptr;
+        EI_IMPULSE_ERROR e = generic_for(h, s, 0, &g);
         if (e) return e;
-        int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, h->g_ws, grid_cap_mfcc(h), s);
+        int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, g->ws, grid_cap_mfcc(h), s);
         if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
     }
@@ -198,10 +223,11 @@ EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float,
     }
     if (h->dsp.generic) {
         // cepstra -> g_mfcc, then cmvnw + quantisation (the general kernels are two launches; the cepstra go through HBM)
-        EI_IMPULSE_ERROR e = ensure_generic(h, B);
+        kws_handle::GenericBuf *g = nullptr;
+        EI_IMPULSE_ERROR e = generic_for(h, s, B, &g);
         if (e) return e;
-        int rc = kws_launch_spectral_generic(h->dsp, pcm, is_float, (int)B, h->g_mfcc, nullptr, 0, h->g_ws, grid_cap_mfcc(h), s);
-        if (!rc) rc = kws_launch_cmvn_generic(h->dsp, h->g_mfcc, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, s);
+        int rc = kws_launch_spectral_generic(h->dsp, pcm, is_float, (int)B, g->mfcc, nullptr, 0, g->ws, grid_cap_mfcc(h), s);
+        if (!rc) rc = kws_launch_cmvn_generic(h->dsp, g->mfcc, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
     }
@@ -251,14 +277,15 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
     }
     if (h->dsp.generic) {
         if (h->is_float && (q || tap_pooled || tap_fc || tap_out)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 outputs requested from a float32 model");
-        EI_IMPULSE_ERROR e = ensure_generic(h, B);
+        kws_handle::GenericBuf *g = nullptr;
+        EI_IMPULSE_ERROR e = generic_for(h, s, B, &g);
         if (e) return e;
-        float *f = features ? features : (h->is_float ? h->g_feat : nullptr);
+        float *f = features ? features : (h->is_float ? g->feat : nullptr);
         int8_t *qq = h->is_float ? nullptr : (q ? q : h->s_q);
         int rc = 0;
         if (ring_rows) {
-            rc = kws_launch_unring(mfcc, h->g_mfcc, (int)B, h->dsp.n_frames, h->dsp.n_cepstral, ring_rows, ring_head, s);
-            mfcc = h->g_mfcc;
+            rc = kws_launch_unring(mfcc, g->mfcc, (int)B, h->dsp.n_frames, h->dsp.n_cepstral, ring_rows, ring_head, s);
+            mfcc = g->mfcc;
         }
         if (!rc) rc = kws_launch_cmvn_generic(h->dsp, mfcc, (int)B, f, qq, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -289,7 +316,8 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
 
 // KWS_MODE_FAST for windows that arrive as cepstra (continuous mode): O(1) cmvnw + the network (fused for float graphs), then the
 // exact kernels over the windows the fast kernel listed as ill-conditioned.  Uses the handle's scratch (h->mu held by the caller).
-EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B, float *scores, hipStream_t s, int ring_rows, int ring_head)
+EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B, float *scores, hipStream_t s, int ring_rows, int ring_head,
+                                     float *features, int8_t *q_out)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     EI_IMPULSE_ERROR e = ensure_flags(h, B);
@@ -298,11 +326,19 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
     KwsDspPlan PR = h->dsp;
     PR.ring_rows = ring_rows; PR.ring_head = ring_head;
     const bool fused = h->is_float && h->fast_fused_ok;
+    float *fx = features ? features : h->s_mfcc;
+    int8_t *q = h->is_float ? nullptr : (q_out ? q_out : h->s_q);
+    int rc = 0;
+    if (fused && features) {
+        // the fused form keeps the feature matrix on chip: a caller who also wants it gets it from the feature-emitting form first
+        rc = kws_launch_fast_from_cepstra(PR, h->fast_plain, h->d_fast_plain, mfcc, (int)B, nullptr, fx, nullptr, h->nn.in_scale, h->nn.in_zp, h->d_flags,
+                                          h->d_flags + 1, h->n_cu, s);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+    }
     const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
-    float *fx = h->s_mfcc;
-    int8_t *q = h->is_float ? nullptr : h->s_q;
-    int rc = kws_launch_fast_from_cepstra(PR, FP, fused ? h->d_fast_fused : h->d_fast_plain, mfcc, (int)B, scores, fused ? nullptr : fx, q,
-                                          h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
+    rc = kws_launch_fast_from_cepstra(PR, FP, fused ? h->d_fast_fused : h->d_fast_plain, mfcc, (int)B, scores, fused ? nullptr : fx, q,
+                                      h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
     if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (!fused) {
         if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, nullptr, s))) return e; }
@@ -313,8 +349,8 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
     }
     // exact re-run of the listed windows (indexed by their own numbers)
     int ran_nn = 0;
-    rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, h->is_float ? fx : nullptr, q, h->is_float ? nullptr : scores, nullptr, h->pooled_tap_bytes, nullptr,
-                            nullptr, grid_cap_nn(h), &ran_nn, s, h->d_flags);
+    rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, (h->is_float || features) ? fx : nullptr, q, h->is_float ? nullptr : scores, nullptr, h->pooled_tap_bytes,
+                            nullptr, nullptr, grid_cap_nn(h), &ran_nn, s, h->d_flags);
     if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags);
     else if (!ran_nn) rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
@@ -376,6 +412,10 @@ EI_IMPULSE_ERROR kws_cmvn_inference_batch_device(kws_handle *h, const float *mfc
     EI_IMPULSE_ERROR e = ensure_scratch(h, B);
     if (e) return e;
     ScratchUse use(h, (hipStream_t)stream);
+    if (h->mode == KWS_MODE_FAST) {
+        if (h->is_float && q_in) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "int8 input tensor requested from a float32 model");
+        return cmvn_nn_fast_device(h, mfcc, B, scores, (hipStream_t)stream, 0, 0, features, q_in);
+    }
     return cmvn_nn_device(h, mfcc, B, features, q_in, scores, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 

@@ -68,7 +68,11 @@ struct KwsFastPlan {
     int ext_off;                  // shared LDS, or -1: per row group [1 + 2 * KWS_FAST_CMVN_EXT] = base multiplicity m0 of its first window,
                                   // then (row offset as int bits, extra multiplicity) for the rows counted more than m0 times
     float inv_win;
-    float guard;                  // a window with std < guard * max(1, |mean|) sends the clip to the exact kernels
+    // A window of column c whose deviation is below guard[c].abs + guard[c].rel * |mean| sends the clip to the exact kernels: what the
+    // fp32 re-ordering moved in a cepstral coefficient (absolute) or in the window's mean (relative to |mean|) comes out of cmvnw
+    // divided by the deviation, and the threshold is where that quotient reaches the feature tolerance (kws_fast_plan.cpp)
+    int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x { abs, rel }
+    int pad_off;                  // shared LDS: [n_frames + 2 pad] ints, numpy::pad_1d_symmetric's row order (column 0's exact window means)
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;

@@ -9,6 +9,8 @@
 // keep its own memory operations in flight: loads of a phase are issued as one batch before the arithmetic that consumes them,
 // tile counts are template parameters (no predicated code inside the contraction loops), and the convolution loops fetch one
 // k-step ahead.  DESIGN.md 4.4 has the phase table, the counters and what was tried and rejected.
+#include <atomic>
+
 #include "kws_device.h"
 #include "kws_fast.h"
 
@@ -378,7 +380,7 @@ __device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__
 //  ds_bpermute) + those few rows, instead of a walk over every row.
 template <int CR, int CG, bool HAS_OUT, typename Emit>
 __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                          float inv_win, float guard, int lane, int nfr, int ncep, Emit emit,
+                                          float inv_win, const float *__restrict__ guard_tab, const float *__restrict__ mref, int lane, int nfr, int ncep, Emit emit,
                                           const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
@@ -406,6 +408,12 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
         float *col = img + min(c, ncep - 1);
         // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name
         const float piv = col[0];
+        const float2 gcol = ((const float2 *)guard_tab)[cb + cl];   // (absolute, per |mean|); padded to a multiple of CG columns
+        // column 0 (the log frame energy, |mean| ~ 10): its window means were summed in the reference's own order (fast_c0_means)
+        const bool is_c0 = cb + cl == 0;
+        float mr[CR];
+#pragma unroll
+        for (int i = 0; i < CR; ++i) mr[i] = cb == 0 ? mref[min(r0 + i, nfr - 1)] : 0.0f;
         float own[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) own[i] = col[min(r0 + i, nfr - 1) * fs];
@@ -465,8 +473,8 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
             var = fmaxf(var, 0.0f);
             const float sd = __builtin_amdgcn_sqrtf(var);
             const float rstd = __builtin_amdgcn_rcpf(sd + FLT_EPSILON);
-            if (act && r0 + i < nfr) bad |= sd < guard * fmaxf(1.0f, fabsf(m + piv));
-            o[i] = ((own[i] - piv) - m) * rstd;
+            if (act && r0 + i < nfr) bad |= sd < __fmaf_rn(gcol.y, fabsf(m + piv), gcol.x);
+            o[i] = (is_c0 ? own[i] - mr[i] : (own[i] - piv) - m) * rstd;
             if (i + 1 < CR) {
                 S = (S + da[i]) - dl[i];
                 Q = __fmaf_rn(da[i], da[i], Q);
@@ -545,7 +553,10 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const float *cnt_tab = shared + FP.cnt_off;
     const int *upd_tab = (const int *)(shared + FP.upd_off);
     const float *ext_tab = FP.ext_off >= 0 ? shared + FP.ext_off : nullptr;
-    const float inv_win = FP.inv_win, guard = FP.guard;
+    const float inv_win = FP.inv_win;
+    const float *guard_tab = shared + FP.guard_off;
+    const int *pad_idx = (const int *)(shared + FP.pad_off);
+    const int win_size = P.win_size, prow = nfr + 2 * P.pad;
     const int cr = FP.cr, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
     long long ph[KWS_FAST_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
@@ -956,8 +967,32 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         int lane_m = lane;
         asm volatile("" : "+v"(lane_m));
         float *const csink = F + FP.sink_off + lane_m;
-        if (cr == 13) bad = fast_cmvn<13, 16, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab, csink);
-        else bad = fast_cmvn<17, 20, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard, lane_m, nfr, ncep, emit, ext_tab, csink);
+        // ---- column 0's window means in the reference's own order (processing.hpp:326-389 over numpy::mean_axis0, numpy.hpp:746-784:
+        //      a sequential fp32 sum of win_size padded rows, then a division).  The log frame energy sits near -10 for quiet audio, so
+        //      that sum rounds at ~6e-5 per step and the mean carries ~1e-6 |mean| of rounding noise of the reference's own making:
+        //      for a stationary background (deviation of the log energy ~0.05) that would be the largest error of the whole feature
+        //      matrix -- unless the sum is simply replayed.  One column only: a lane per row, win_size additions over a padded copy of
+        //      the column in the dead exchange buffer (conflict-free: consecutive lanes read consecutive words).
+        {
+            float *padv = R1;
+            for (int p = lane_m; p < prow; p += KWS_WAVE) padv[p] = img[pad_idx[p] * fs];
+            WAVE_SYNC();
+            const float *pv = padv + min(lane_m, nfr - 1);
+            float s = 0.0f;
+            int i = 0;
+            for (; i + 8 <= win_size; i += 8) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = pv[i + e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[e];
+            }
+            for (; i < win_size; ++i) s += pv[i];
+            if (lane_m < nfr) elog[lane_m] = __fdiv_rn(s, (float)win_size);
+            WAVE_SYNC();
+        }
+        if (cr == 13) bad = fast_cmvn<13, 16, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, lane_m, nfr, ncep, emit, ext_tab, csink);
+        else bad = fast_cmvn<17, 20, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, lane_m, nfr, ncep, emit, ext_tab, csink);
         if (__any(bad)) {
             if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
         }
@@ -1035,11 +1070,15 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
                          long long *prof_out, hipStream_t stream, const float *cep = nullptr)
 {
     const size_t smem = ((size_t)FP.shared_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the opt-in for more than 64 KB of dynamic LDS is per device (and this instantiation): one bit per device, set once
+    static std::atomic<unsigned long long> attr_done{ 0 };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
-        attr_done = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int per_wg = FP.n_waves;
     int grid = (n_clips + per_wg - 1) / per_wg;

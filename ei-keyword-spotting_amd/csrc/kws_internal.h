@@ -157,8 +157,18 @@ struct kws_handle {
     // the scratch (and the fast mode's clip list) is shared by every call on this handle: a call on another stream than the
     // previous one first waits for it (see ScratchUse)
     // general MFCC kernels (KwsDspPlan::generic): per-workgroup transform scratch, cepstra and feature buffers, grown on demand
-    float *g_ws = nullptr, *g_mfcc = nullptr, *g_feat = nullptr;
-    size_t g_ws_bytes = 0, g_cap = 0;
+    // One set PER STREAM: the transform scratch is indexed by workgroup, so two launches that run concurrently (the two streams of
+    // kws_run_classifier_batch, or callers of the stage API on streams of their own) must not share it; launches on one stream are
+    // ordered.  generic_for() hands out the set of a stream.
+    struct GenericBuf {
+        hipStream_t s = nullptr;
+        bool used = false;
+        float *ws = nullptr, *mfcc = nullptr, *feat = nullptr;
+        size_t ws_bytes = 0, cap = 0;
+    };
+    static const int kGenericSets = 8;
+    GenericBuf g_sets[kGenericSets];
+    int g_next = 0;
     std::mutex g_mu;
     hipEvent_t scratch_ev = nullptr;
     hipStream_t scratch_stream = nullptr;
@@ -197,6 +207,7 @@ struct kws_handle {
     const KwsFastPlan *d_fast_plain = nullptr, *d_fast_fused = nullptr;     // the same plans in device memory
     bool fast_plain_ok = false, fast_fused_ok = false;
     std::string fast_why;
+    std::vector<float> fast_guard_abs, fast_guard_rel;    // host copy of the cmvnw guard's per-column thresholds (kws_fast_guard)
     int mode = KWS_MODE_EXACT;
     int *d_flags = nullptr;       // [0] = count, [1 + i] = clip index
     size_t flags_cap = 0;
@@ -240,8 +251,9 @@ extern "C" {
 KWS_INTERNAL EI_IMPULSE_ERROR ensure_scratch(kws_handle *h, size_t B);
 KWS_INTERNAL void kws_sdk_forget_default(kws_handle *h);      // kws_sdk.cpp: kws_destroy() of the installed default model
 KWS_INTERNAL int grid_cap_mfcc(const kws_handle *h);
-KWS_INTERNAL EI_IMPULSE_ERROR ensure_generic(kws_handle *h, size_t B);
-KWS_INTERNAL EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B, float *scores, hipStream_t s, int ring_rows, int ring_head);
+KWS_INTERNAL EI_IMPULSE_ERROR generic_for(kws_handle *h, hipStream_t s, size_t B, kws_handle::GenericBuf **out);
+KWS_INTERNAL EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B, float *scores, hipStream_t s, int ring_rows, int ring_head,
+                                                  float *features = nullptr, int8_t *q_out = nullptr);
 KWS_INTERNAL int grid_cap_nn(const kws_handle *h);
 KWS_INTERNAL EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
                                  const float *wrap, hipStream_t s, int out_stride = 0);

@@ -41,6 +41,9 @@ EI_IMPULSE_ERROR kws_streams_init(kws_stream_batch *sb)          // run_classifi
         // linearly again
         const KwsDspPlan &P = sb->h->dsp;
         const int rows = (int)(sb->h->model.nn_input_frame_size / (size_t)P.n_cepstral);
+        // the last step may still be writing feat[0] on the caller's stream (a hipStreamNonBlocking stream is not ordered with the
+        // default stream the copy goes to)
+        HIP_TRY(hipDeviceSynchronize());
         int rc = kws_launch_unring(sb->feat[0], sb->feat[1], (int)sb->S, rows, P.n_cepstral, sb->ring_rows, sb->head, nullptr);
         if (rc) return fail(KWS_ERROR_HIP, "copy kernel launch failed");
         HIP_TRY(hipDeviceSynchronize());
@@ -213,17 +216,26 @@ EI_IMPULSE_ERROR kws_set_default_model(kws_handle *h)
 
 kws_handle *kws_default_model(void)
 {
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    if (!g_default) {
-        const char *path = getenv("KWS_MODEL");
-        if (!path) { fail(KWS_ERROR_NO_MODEL, "no model: call kws_set_default_model() or set KWS_MODEL"); return nullptr; }
-        const char *dev = getenv("KWS_DEVICE");
-        kws_handle *h = nullptr;
-        if (kws_create_from_file(path, dev ? atoi(dev) : 0, &h) != EI_IMPULSE_OK) return nullptr;
-        g_default = h;
-        g_default_owned = true;
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);
+        if (g_default) return g_default;
     }
-    return g_default;
+    // The model is created OUTSIDE the lock: when a plan builder refuses the file, kws_create() tears the handle down with
+    // kws_destroy(), which asks kws_sdk_forget_default() -- under g_default_mu -- whether it is destroying the default.
+    const char *path = getenv("KWS_MODEL");
+    if (!path) { fail(KWS_ERROR_NO_MODEL, "no model: call kws_set_default_model() or set KWS_MODEL"); return nullptr; }
+    const char *dev = getenv("KWS_DEVICE");
+    kws_handle *h = nullptr;
+    if (kws_create_from_file(path, dev ? atoi(dev) : 0, &h) != EI_IMPULSE_OK) return nullptr;
+    kws_handle *loser = nullptr, *winner = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_default_mu);
+        if (g_default) loser = h;                  // another thread installed a model in the meantime: keep that one
+        else { g_default = h; g_default_owned = true; }
+        winner = g_default;
+    }
+    if (loser) kws_destroy(loser);
+    return winner;
 }
 
 // The label count of the loaded model decides where `anomaly` and `timing` sit behind the classification array

@@ -48,7 +48,9 @@ const char *kws_nn_kernel_name(const kws_handle *h);    /* which network kernel 
 const char *kws_mfcc_kernel_name(const kws_handle *h);  /* "kws_mfcc_kernel" (tuned shapes) or "kws_spectral_generic_kernel" */
 int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI_CLASSIFIER_TFLITE_INPUT_QUANTIZED == 0) */
 
-/* ---- arithmetic mode of the batch hot path (kws_run_classifier_batch*, kws_extract_mfcc_batch_device) --------------------
+/* ---- arithmetic mode of the device-resident batch hot path (kws_run_classifier_batch_device, kws_extract_mfcc_batch_device,
+ * kws_cmvn_inference_batch_device, kws_streams_step_device).  The host-buffer entry point kws_run_classifier_batch always runs the exact kernels: it is bound by
+ * PCIe, the mode would buy nothing there.
  * KWS_MODE_EXACT (default): every floating-point operation replays the reference's order: MFCC features bit-identical, int8 graphs
  *   bit-identical end to end, float32 scores within 1e-6.
  * KWS_MODE_FAST: the tolerance BASELINE.json grants (1e-4 on float32 scores) is spent where the reference's operation order is
@@ -58,7 +60,7 @@ int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI
  *   kernels inside the same call, so their results are the exact mode's.  int8 graphs: fast MFCC + the exact int8 network;
  *   an int8 input value may then differ by one step where a feature sits on a rounding boundary.
  * kws_streams_step_device follows the mode too (the slice's MFCC stays exact; the whole-window cmvnw + network take the fast
- * kernel).  The SDK entry points (run_classifier ...) and the stage API always run the exact kernels. */
+ * kernel).  The SDK entry points (run_classifier ...) and the other stage entry points always run the exact kernels. */
 #define KWS_MODE_EXACT 0
 #define KWS_MODE_FAST 1
 EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode);   /* KWS_ERROR_UNSUPPORTED_MODEL if the model's DSP block is outside the fast kernel */
@@ -67,6 +69,11 @@ int kws_get_mode(const kws_handle *h);
 int kws_fast_is_fused(const kws_handle *h);
 /* clips the last KWS_MODE_FAST call on this handle handed back to the exact kernels (synchronises the device) */
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
+/* When a clip is handed back: a cmvnw window of cepstral column c whose deviation is below abs_thr[c] + rel_thr[c] * |window mean|
+ * (the fp32 re-ordering moves a coefficient, and the reference's own summation order its window mean, by bounded amounts that cmvnw
+ * divides by the deviation).  Both arrays hold one value per cepstral coefficient of a frame;
+ * KWS_ERROR_UNSUPPORTED_MODEL if the model has no fast mode. */
+EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, float *abs_thr, float *rel_thr);
 
 /* The model used by the SDK-style entry points run_classifier()/run_inference().  If none was set,
  * the first call loads the file named by the environment variable KWS_MODEL on device KWS_DEVICE (0). */

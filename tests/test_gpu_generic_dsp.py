@@ -109,3 +109,42 @@ def test_general_kernels_float_model_and_drop_in_entry_points(pkg, oracle, tmp_p
         got = np.float32([res.classification[i].value for i in range(gm.n_labels)])
         assert np.abs(got - so[ci]).max() <= 1e-6
     gm.close()
+
+
+def test_general_kernels_host_batch_over_two_streams(pkg, oracle, tmp_path):
+    """kws_run_classifier_batch cuts a host batch into chunks of 8 192 clips that alternate between two streams.  The general
+    kernels' transform scratch is indexed by workgroup: each stream has to own its set (one shared set was a race
+    that corrupted features for B > 8 192 on a general-configuration model).  Three chunks here, so both streams carry kernels at
+    the same time; every clip must equal the single-stream device path, and a strided sample the oracle."""
+    import torch
+    blob = synth_model_blob(seed=3, **dict(BLOCKS, fft_length=512))
+    path = str(tmp_path / "m.kwsm")
+    open(path, "wb").write(blob)
+    gm = pkg.Model(blob=blob)
+    assert gm.mfcc_kernel == "kws_spectral_generic_kernel"
+    om = OracleModel(oracle, path)
+    n = 2 * 8192 + 700
+    clips = oracle.synth(21, 0, n)
+    for _ in range(2):                                                  # twice: the second pass finds every buffer allocated
+        s, f, q = gm.run_classifier_batch(clips, want_features=True)
+    d = torch.from_numpy(clips).to("cuda:0")
+    s1 = torch.zeros((n, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    f1 = torch.zeros((n, gm.n_features), dtype=torch.float32, device="cuda:0")
+    q1 = torch.zeros((n, gm.n_features), dtype=torch.int8, device="cuda:0")
+    gm.run_classifier_batch_device(d.data_ptr(), n, s1.data_ptr(), f1.data_ptr(), q1.data_ptr())
+    torch.cuda.synchronize()
+    assert (bits(f) == bits(f1.cpu().numpy())).all() and (q == q1.cpu().numpy()).all() and (bits(s) == bits(s1.cpu().numpy())).all()
+    idx = np.arange(0, n, 61)
+    so, fo, qo = om.run_batch(clips[idx], want_features=True)
+    assert (bits(f[idx]) == bits(fo)).all() and (q[idx] == qo).all() and (bits(s[idx]) == bits(so)).all()
+    # two caller-owned streams on the stage API at the same time
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = [torch.zeros((4096, gm.n_features), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    for rep in range(3):
+        for k in range(2):
+            gm.mfcc_batch_device(d[k * 4096:].data_ptr(), 4096, out[k].data_ptr(), st[k].cuda_stream)
+    torch.cuda.synchronize()
+    want = np.stack([oracle.mfcc_nocmvn(clips[i], om.cfg).reshape(-1) for i in (0, 4095, 4096, 8191)])
+    got = np.stack([out[0][0].cpu().numpy(), out[0][4095].cpu().numpy(), out[1][0].cpu().numpy(), out[1][4095].cpu().numpy()])
+    assert (bits(got) == bits(want)).all()
+    gm.close()

@@ -884,3 +884,30 @@ def test_random_mfcc_configurations_on_gpu(pkg, oracle):
         gm.close()
         n_ok += 1
     assert n_ok >= 25, (n_ok, n_refused)
+
+
+def test_default_model_from_an_unsupported_file_returns_the_error(pkg, tmp_path):
+    """KWS_MODEL names a file that parses but that a plan builder refuses: run_classifier() must come back with the error.  (It used
+    to dead-lock: kws_default_model() held its mutex while kws_create()'s failure path asked kws_destroy() -> kws_sdk_forget_default()
+    for the same mutex.)  Run in a child process with a time limit so that a regression is a failure, not a hung suite."""
+    import subprocess
+    import sys
+    from kws_testlib import ROOT, synth_model_blob
+    bad = tmp_path / "unsupported.kwsm"
+    bad.write_bytes(synth_model_blob(seed=3, blocks=((64, 3, 1),), n_labels=6))      # FULLY_CONNECTED input beyond the kernel's limit
+    code = (
+        "import sys, ctypes\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from __graft_entry__ import load_package\n"
+        "pkg = load_package(); L = pkg.lib()\n"
+        "assert L.kws_default_model() is None\n"
+        "res = pkg.result_struct(6)()\n"
+        "s = pkg.Signal(pkg.GET_DATA_FN(lambda off, n, out: 0), 16000)\n"
+        "rc = L.run_classifier(ctypes.byref(s), ctypes.byref(res), False)\n"
+        "assert rc != 0 and len(L.kws_last_error()) > 0, rc\n"
+        "print('rc', rc)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KWS_MODEL=str(bad)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr[-2000:]
+    assert "rc -" in out.stdout
