@@ -64,6 +64,7 @@ void kws_destroy(kws_handle *h)
         if (p) (void)hipFree(p);
     for (void *p : { (void *)h->ws.h_x, (void *)h->ws.h_s, (void *)h->ws.h_f })
         if (p) (void)hipHostFree(p);
+    for (hipEvent_t ev : h->ws.ev) if (ev) (void)hipEventDestroy(ev);
     if (h->ws.st) (void)hipStreamDestroy(h->ws.st);
     delete h;
 }

@@ -192,6 +192,7 @@ struct kws_handle {
         int8_t *d_q = nullptr;
         float *h_s = nullptr, *h_f = nullptr;     // pinned: scores, features
         hipStream_t st = nullptr;
+        hipEvent_t ev[3] = { nullptr, nullptr, nullptr };   // before the DSP block / between the stages / after the network (timing fields)
     } ws;
     std::mutex sdk_mu;            // the SDK entry points are serialised (the reference is non-reentrant)
     // continuous-mode state (ei_run_classifier.h:115-121, 187)

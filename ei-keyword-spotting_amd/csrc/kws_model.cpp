@@ -93,6 +93,10 @@ bool parse_model(const void *blob, size_t nbytes, Model &m)
         uint32_t nq = r.u32();
         if (r.bad || nq > 65536) return false;
         for (uint32_t k = 0; k < nq; k++) t.scale.push_back(r.f32());
+        // a quantisation scale is a positive, finite, normal number (TFLite's converter never writes anything else); the plan
+        // builders divide by it and feed the quotients to frexp / round (found by the UBSan run of tests/test_sanitizers.py: a NaN
+        // scale reached the double -> int64 conversion of h_quantize_multiplier)
+        for (float sc : t.scale) if (!(sc >= 1e-30f && sc <= 1e30f)) return false;
         for (uint32_t k = 0; k < nq; k++) t.zero.push_back(r.i32());
         t.qdim = r.i32();
         t.nbytes = r.u32();
@@ -277,7 +281,7 @@ int32_t h_rdivpot(int32_t x, int e)
 }
 void h_quantize_multiplier(double m, int32_t *q, int *shift)
 {
-    if (m == 0.) { *q = 0; *shift = 0; return; }
+    if (m == 0. || !std::isfinite(m)) { *q = 0; *shift = 0; return; }
     const double f = frexp(m, shift);
     int64_t qf = (int64_t)round(f * (double)(1ll << 31));
     if (qf == (1ll << 31)) { qf /= 2; ++*shift; }

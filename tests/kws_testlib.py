@@ -11,7 +11,8 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "libkws_oracle.so")
+# KWS_ORACLE_SO: another build of oracle/kws_oracle.c (tests/test_sanitizers.py points it at the ASan + UBSan build)
+ORACLE_SO = os.environ.get("KWS_ORACLE_SO") or os.path.join(ROOT, "oracle", "libkws_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libei_ref_l476.so")
 MODELS = os.path.join(ROOT, "models")
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -1,0 +1,94 @@
+// host_driver.cpp -- TEST INFRASTRUCTURE ONLY (tests/test_sanitizers.py): feeds .kwsm blobs (the shipped ones and mutated /
+// truncated copies written by the test) to the HOST code of the library, built with -fsanitize=address,undefined against
+// hip_stub.cpp.  A blob the parser and the plan builders accept is then walked through the C ABI's host logic (argument checks,
+// scratch growth, the two-stream host pipeline, the continuous-mode bookkeeping, the SDK entry points); kernels do not run (see
+// hip_stub.cpp), so no output value means anything -- the run is about memory safety and undefined behaviour only.
+// One line per blob: "<path> rc <kws_create's return code>".  Exit status 0 unless a sanitizer aborts the process.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/kws/kws.h"
+
+static std::vector<float> g_audio;
+static int get_data(size_t off, size_t len, float *out)
+{
+    if (off + len > g_audio.size()) return -1;
+    memcpy(out, g_audio.data() + off, len * sizeof(float));
+    return 0;
+}
+
+static void walk(kws_handle *h)
+{
+    const size_t n = (size_t)kws_clip_samples(h), F = (size_t)kws_feature_count(h), C = (size_t)kws_label_count(h);
+    for (int i = 0; i < (int)C; i++) (void)kws_label(h, i);
+    (void)kws_nn_kernel_name(h); (void)kws_mfcc_kernel_name(h); (void)kws_frame_count(h); (void)kws_filter_count(h);
+    const size_t B = 5;
+    std::vector<int16_t> pcm(B * n + 8, 1);
+    std::vector<float> scores(B * C + 1), feats(B * F + 1), thr(256), rel(256);
+    std::vector<int8_t> q(B * F + 1);
+    const bool is_float = kws_model_is_float(h) != 0;
+    for (int mode = 0; mode < 2; mode++) {
+        if (kws_set_mode(h, mode) != EI_IMPULSE_OK) continue;
+        (void)kws_fast_guard(h, thr.data(), rel.data());
+        // "device" pointers are host heap under the stub: the entry points' host logic runs, launches are no-ops
+        (void)kws_run_classifier_batch_device(h, pcm.data(), B, scores.data(), feats.data(), is_float ? nullptr : q.data(), nullptr);
+        (void)kws_run_classifier_batch_device(h, pcm.data(), B, scores.data(), nullptr, nullptr, nullptr);
+        (void)kws_run_classifier_batch_device(h, pcm.data(), 0, scores.data(), nullptr, nullptr, nullptr);
+        (void)kws_extract_mfcc_batch_device(h, pcm.data(), B, feats.data(), is_float ? nullptr : q.data(), nullptr);
+        (void)kws_mfcc_batch_device(h, pcm.data(), B, feats.data(), nullptr);
+        (void)kws_cmvn_inference_batch_device(h, feats.data(), B, scores.data(), feats.data(), nullptr, nullptr);
+        (void)kws_run_inference_batch_device(h, feats.data(), B, scores.data(), nullptr);
+        size_t nfb = 0;
+        (void)kws_fast_fallback_count(h, &nfb);
+    }
+    (void)kws_set_mode(h, KWS_MODE_EXACT);
+    (void)kws_run_classifier_batch(h, pcm.data(), B, scores.data(), feats.data(), is_float ? nullptr : q.data());
+    (void)kws_nn_batch(h, q.data(), 2, scores.data(), nullptr, nullptr, nullptr);
+    (void)kws_nn_f32_batch_device(h, feats.data(), 2, scores.data(), nullptr, nullptr);
+    (void)kws_mfe_batch_device(h, pcm.data(), 2, feats.data(), nullptr, nullptr);
+    kws_stream_batch *sb = nullptr;
+    if (kws_streams_create(h, 3, &sb) == EI_IMPULSE_OK) {
+        std::vector<int16_t> slice(3 * (n / 4) + 8, 2);
+        int produced = 0;
+        for (int k = 0; k < 6; k++) (void)kws_streams_step_device(sb, slice.data(), n / 4, nullptr, scores.data(), &produced, nullptr);
+        (void)kws_streams_init(sb);
+        (void)kws_streams_step_device(sb, slice.data(), n / 4, nullptr, scores.data(), &produced, nullptr);
+        (void)kws_streams_step_device(sb, slice.data(), n / 4 + 1, nullptr, scores.data(), &produced, nullptr);      // wrong slice length
+        kws_streams_destroy(sb);
+    }
+    // the SDK entry points on this model: ei_compat.h publishes this program's EI_CLASSIFIER_LABEL_COUNT (4): a model with another
+    // label count must be refused before anything is written into the 4-label result struct
+    (void)kws_set_default_model(h);
+    g_audio.assign(n, 0.25f);
+    signal_t sig;
+    sig.get_data = &get_data;
+    sig.total_length = n;
+    ei_impulse_result_t res;
+    memset(&res, 0, sizeof res);
+    (void)run_classifier(&sig, &res, false);
+    run_classifier_init();
+    sig.total_length = n / 4;
+    (void)run_classifier_continuous(&sig, &res, false);
+}
+
+int main(int argc, char **argv)
+{
+    for (int i = 1; i < argc; i++) {
+        FILE *f = fopen(argv[i], "rb");
+        if (!f) { printf("%s rc open-failed\n", argv[i]); continue; }
+        std::vector<unsigned char> blob;
+        unsigned char tmp[4096];
+        size_t k;
+        while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) blob.insert(blob.end(), tmp, tmp + k);
+        fclose(f);
+        kws_handle *h = nullptr;
+        const EI_IMPULSE_ERROR rc = kws_create(blob.data(), blob.size(), 0, &h);
+        printf("%s rc %d\n", argv[i], (int)rc);
+        fflush(stdout);
+        if (rc == EI_IMPULSE_OK) { walk(h); kws_destroy(h); }
+    }
+    return 0;
+}
