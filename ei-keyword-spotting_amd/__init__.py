@@ -16,7 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libkws_mi355x.so")
+# KWS_LIB: another build of the same library (development aid: same-box A/B runs of tools/ab_rate.py)
+LIB_PATH = os.environ.get("KWS_LIB") or os.path.join(_HERE, "libkws_mi355x.so")
 MODELS_DIR = os.path.join(ROOT, "models")
 DEFAULT_MODEL = os.path.join(MODELS_DIR, "l476_no_yes.kwsm")
 
@@ -96,7 +97,8 @@ def lib():
         L.kws_get_mode.argtypes = [vp]
         L.kws_fast_is_fused.argtypes = [vp]
         L.kws_fast_fallback_count.argtypes = [vp, C.POINTER(sz)]
-        L.kws_fast_guard.argtypes = [vp, vp, vp]
+        if hasattr(L, "kws_fast_guard"):                 # absent from older builds compared in tools/ab_rate.py
+            L.kws_fast_guard.argtypes = [vp, vp, vp]
         L.kws_nn_kernel_name.restype = C.c_char_p
         L.kws_nn_kernel_name.argtypes = [vp]
         L.kws_mfcc_kernel_name.restype = C.c_char_p

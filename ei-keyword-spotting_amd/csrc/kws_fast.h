@@ -10,7 +10,8 @@
 //   * power spectrum re*re + im*im in fp32 (no fp64 sqrt-then-square), frame energy by a lane reduction, mel gather in any order;
 //   * DCT-II as a [frames x NF] x [NF x NF/2+1] product on v_mfma_f32_16x16x4_f32 (true fp32);
 //   * cmvnw with O(1) running sums per (row, column) on pivot-shifted data instead of two 101-term walks;
-//   * float32 graphs: CONV_2D blocks as [time x taps*C] x [taps*C x out_c] on v_mfma_f32_16x16x4_f32 in the SAME launch: the
+//   * float32 graphs: CONV_2D blocks -- the pointwise 1x1 halves of a depthwise-separable CNN included -- as
+//     [time x taps*C] x [taps*C x out_c] on v_mfma_f32_16x16x4_f32 in the SAME launch, DEPTHWISE_CONV_2D taps on the vector ALU: the
 //     feature matrix never leaves LDS (one wave = one clip from PCM to scores).
 // Clips whose cmvnw is ill-conditioned (a near-constant column: the reference's answer there is decided by its own rounding
 // sequence, SURVEY section 4 "silence canary") are detected, listed, and re-run by the exact kernels in the same call.
@@ -19,7 +20,7 @@
 
 #include "kws_plan.h"
 
-#define KWS_FAST_MAX_BLOCKS 4
+#define KWS_FAST_MAX_BLOCKS 8        // conv / depthwise / pointwise blocks of a fused float32 graph (= KWS_MAX_BLOCKS)
 #define KWS_FAST_NZ_MAX 12        // longest mel filter (filters 0..31) kept in registers
 #define KWS_FAST_NZ2 8            // longest of filters 32..39
 #define KWS_FAST_DCT_GROUPS 5     // NF / 8 <= 5 k-groups of the DCT's operand fragments
@@ -44,6 +45,8 @@ struct KwsFastBlock {
     int w_off, bias_off, addc_off;   // float offsets into the workgroup's shared LDS block
     int st_off;                   // k-step table [taps * in_cp / 8 + 3] x int4 { image offset (floats), tap, weight offset (floats), - }
     int has_add;
+    int dw, mult;                 // DEPTHWISE_CONV_2D (reference/depthwiseconv_float.h:25): output channel n reads input channel n / mult; its taps run on
+                                  // the vector ALU from the LDS image (fast_dwconv), weights [tap][out_c] at w_off
     float conv_min, conv_max, add_min, add_max, pool_min, pool_max;
 };
 
@@ -71,7 +74,10 @@ struct KwsFastPlan {
     // A window of column c whose deviation is below guard[c].abs + guard[c].rel * |mean| sends the clip to the exact kernels: what the
     // fp32 re-ordering moved in a cepstral coefficient (absolute) or in the window's mean (relative to |mean|) comes out of cmvnw
     // divided by the deviation, and the threshold is where that quotient reaches the feature tolerance (kws_fast_plan.cpp)
-    int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x { abs, rel }
+    int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x { abs, per |window mean| }
+    float c0_factor, c0_abs, c0_rel, c0_inv_rows;   // column 0: the exact window means are only computed when c0_factor x (plain deviation of
+                                  // the column) < c0_abs + c0_rel x (its largest magnitude); c0_factor = sqrt(c0_mult n_frames / win_size),
+                                  // c0_mult = how often every window holds every row at least (0: always compute them)
     int pad_off;                  // shared LDS: [n_frames + 2 pad] ints, numpy::pad_1d_symmetric's row order (column 0's exact window means)
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image

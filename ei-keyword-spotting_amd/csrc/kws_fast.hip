@@ -334,9 +334,13 @@ __device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__
     const int sstride = k.stage_stride, out_w = k.out_w, out_c = k.out_c, pool = k.pool, pstr = k.pool_stride;
     const float pmin = k.pool_min, pmax = k.pool_max;
     if (!pooled) {
-        for (int i = lane; i < items; i += KWS_WAVE) {
-            const int p = (int)(((unsigned)i * inv) >> 20), c = i - p * out_cp;
-            if (c >= out_c) img[p * out_stride + c] = 0.0f;
+        // the tiles were written straight into the next image: only its k-padding channels (at most seven per row) are left
+        const int npad = out_cp - out_c;
+        if (npad == 0) return;
+        const unsigned pinv = (1u << 20) / (unsigned)npad + 1u;
+        for (int i = lane; i < k.pool_w * npad; i += KWS_WAVE) {
+            const int p = (int)(((unsigned)i * pinv) >> 20), c = out_c + (i - p * npad);
+            img[p * out_stride + c] = 0.0f;
         }
         return;
     }
@@ -368,6 +372,115 @@ __device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+//  One DEPTHWISE_CONV_2D block (reference/depthwiseconv_float.h:25: out[t][n] = sum_tap in[t + tap - pad_left][n / mult] * w[tap][n],
+//  taps that fall into the SAME padding skipped) + bias + activation [+ ADD + activation] + MAX_POOL_2D over time (pooling.h:189-237:
+//  windows clipped to the image) on the vector ALU, straight from the input image in LDS into the next block's image.  A few taps per
+//  output: nothing to contract -- the pointwise 1x1 convolution that follows a depthwise block is the GEMM, and runs on the matrix cores
+//  (fast_conv_tiles with taps = 1).  Items = (pooled row, channel incl. the next image's k-padding channels, which receive zeros);
+//  consecutive lanes take consecutive channels of a row: every LDS access of a step is a contiguous run of words.
+// ---------------------------------------------------------------------------------------------------------
+//  fast_dw_t<TAPS>: a lane owns a SEGMENT of consecutive output rows of one channel -- a pooling window, or (no pooling) one of
+//  64 / out_cp chunks of the time axis -- and slides a TAPS-deep register window along it: per row one LDS read (requested a row
+//  ahead), TAPS multiply-adds on weights held in registers, the clamps, and a store or a running maximum.
+template <int TAPS>
+__device__ __forceinline__ void fast_dw_t(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ img,
+                                          const float *__restrict__ shared, int lane, int out_stride, int out_cp)
+{
+    const int out_c = k.out_c, in_w = k.in_w, out_w = k.out_w, pad_left = k.pad_left, in_stride = k.in_stride, mult = k.mult;
+    const bool pooled = k.pool > 1 || k.pool_stride > 1;
+    const int n_seg = pooled ? k.pool_w : max(1, KWS_WAVE / out_cp);
+    const int seg_rows = pooled ? k.pool : (out_w + n_seg - 1) / n_seg, seg_step = pooled ? k.pool_stride : seg_rows;
+    const int items = n_seg * out_cp;
+    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;        // i / out_cp for i < 4096, out_cp <= 64
+    const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max, pmin = k.pool_min, pmax = k.pool_max;
+    const bool has_add = k.has_add != 0;
+    const float *wt = shared + k.w_off;
+    for (int i = lane; i < items; i += KWS_WAVE) {
+        const int seg = (int)(((unsigned)i * inv) >> 20), c = i - seg * out_cp, cc = min(c, out_c - 1);
+        const float *col = in + (mult == 1 ? cc : cc / mult);
+        float w[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) w[t] = wt[t * out_c + cc];
+        const float bias = shared[k.bias_off + cc], addc = shared[k.addc_off + cc];
+        const int r0 = seg * seg_step, r1 = min(r0 + seg_rows, out_w);
+        auto fetch = [&](int row) { const float v = col[min(max(row, 0), in_w - 1) * in_stride]; return (unsigned)row < (unsigned)in_w ? v : 0.0f; };   // SAME padding
+        // the window x[0 .. TAPS + 2]: TAPS - 1 rows of history + four new rows per trip, requested together (one LDS round trip per
+        // four outputs; indices are compile-time constants after unrolling, so sliding the window costs no moves)
+        float x[TAPS + 3];
+#pragma unroll
+        for (int t = 0; t + 1 < TAPS; ++t) x[t] = fetch(r0 + t - pad_left);
+        float m = -FLT_MAX;
+        float *dst = img + c;
+        for (int r = r0; r < r1; r += 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[TAPS - 1 + e] = fetch(r + e + TAPS - 1 - pad_left);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) acc = __fmaf_rn(x[e + t], w[t], acc);
+                float v = fminf(fmaxf(acc + bias, cmin), cmax);
+                if (has_add) v = fminf(fmaxf(v + addc, amin), amax);
+                const bool live = r + e < r1;
+                if (pooled) m = live ? fmaxf(m, v) : m;
+                else if (live) dst[(r + e) * out_stride] = c < out_c ? v : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t + 1 < TAPS; ++t) x[t] = x[t + 4];
+        }
+        if (pooled) dst[seg * out_stride] = c < out_c ? fminf(fmaxf(m, pmin), pmax) : 0.0f;
+    }
+}
+
+// any tap count (more than eight taps: the general, unblocked form)
+__device__ __forceinline__ void fast_dwconv_any(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ img,
+                                                const float *__restrict__ shared, int lane, int out_stride, int out_cp)
+{
+    const int items = k.pool_w * out_cp, out_c = k.out_c, in_w = k.in_w, out_w = k.out_w, taps = k.taps, pad_left = k.pad_left;
+    const int in_stride = k.in_stride, pool = k.pool, pstr = k.pool_stride, mult = k.mult;
+    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;        // i / out_cp for i < 4096, out_cp <= 64
+    const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max, pmin = k.pool_min, pmax = k.pool_max;
+    const bool has_add = k.has_add != 0;
+    const float *wt = shared + k.w_off;
+    for (int i = lane; i < items; i += KWS_WAVE) {
+        const int p = (int)(((unsigned)i * inv) >> 20), c = i - p * out_cp, cc = min(c, out_c - 1);
+        const float *col = in + (mult == 1 ? cc : cc / mult);
+        const float bias = shared[k.bias_off + cc], addc = shared[k.addc_off + cc];
+        float m = -FLT_MAX;
+        for (int j = 0; j < pool; ++j) {
+            const int r = p * pstr + j;
+            if (r >= out_w) break;                                  // ragged last window (SAME pooling): clipped as pooling.h clips it
+            float acc = 0.0f;
+            for (int tap = 0; tap < taps; ++tap) {
+                const int row = r + tap - pad_left;
+                if ((unsigned)row < (unsigned)in_w) acc = __fmaf_rn(col[row * in_stride], wt[tap * out_c + cc], acc);
+            }
+            float v = fminf(fmaxf(acc + bias, cmin), cmax);
+            if (has_add) v = fminf(fmaxf(v + addc, amin), amax);
+            m = fmaxf(m, v);
+        }
+        m = fminf(fmaxf(m, pmin), pmax);
+        img[p * out_stride + c] = c < out_c ? m : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ img,
+                                            const float *__restrict__ shared, int lane, int out_stride, int out_cp)
+{
+    switch (k.taps) {
+    case 1: fast_dw_t<1>(k, in, img, shared, lane, out_stride, out_cp); break;
+    case 2: fast_dw_t<2>(k, in, img, shared, lane, out_stride, out_cp); break;
+    case 3: fast_dw_t<3>(k, in, img, shared, lane, out_stride, out_cp); break;
+    case 4: fast_dw_t<4>(k, in, img, shared, lane, out_stride, out_cp); break;
+    case 5: fast_dw_t<5>(k, in, img, shared, lane, out_stride, out_cp); break;
+    case 6: fast_dw_t<6>(k, in, img, shared, lane, out_stride, out_cp); break;
+    case 7: fast_dw_t<7>(k, in, img, shared, lane, out_stride, out_cp); break;
+    case 8: fast_dw_t<8>(k, in, img, shared, lane, out_stride, out_cp); break;
+    default: fast_dwconv_any(k, in, img, shared, lane, out_stride, out_cp); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 //  cmvnw (processing.hpp:326-389) in place over the cepstra image, O(1) per (row, column): the window of padded row r + 1 is
 //  the window of r minus padded row r plus padded row r + win, so running sums of d = x - pivot and d * d (pivot = the column's
 //  first row: the sums stay small, var = Q/n - (S/n)^2 does not cancel) replace two win-term walks.  A lane owns one column and
@@ -380,7 +493,7 @@ __device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__
 //  ds_bpermute) + those few rows, instead of a walk over every row.
 template <int CR, int CG, bool HAS_OUT, typename Emit>
 __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                          float inv_win, const float *__restrict__ guard_tab, const float *__restrict__ mref, int lane, int nfr, int ncep, Emit emit,
+                                          float inv_win, const float *__restrict__ guard_tab, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep, Emit emit,
                                           const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
@@ -408,12 +521,14 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
         float *col = img + min(c, ncep - 1);
         // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name
         const float piv = col[0];
-        const float2 gcol = ((const float2 *)guard_tab)[cb + cl];   // (absolute, per |mean|); padded to a multiple of CG columns
-        // column 0 (the log frame energy, |mean| ~ 10): its window means were summed in the reference's own order (fast_c0_means)
-        const bool is_c0 = cb + cl == 0;
+        float2 gcol = ((const float2 *)guard_tab)[cb + cl];         // (absolute, per |window mean|); padded to a multiple of CG columns
+        // column 0 (the log frame energy, |mean| ~ 10): when its deviation is small against its level, its window means have been summed
+        // in the reference's own order (c0_exact) and the relative part of its guard does not apply
+        const bool is_c0 = c0_exact && cb + cl == 0;
+        gcol.y = is_c0 ? 0.0f : gcol.y;
         float mr[CR];
 #pragma unroll
-        for (int i = 0; i < CR; ++i) mr[i] = cb == 0 ? mref[min(r0 + i, nfr - 1)] : 0.0f;
+        for (int i = 0; i < CR; ++i) mr[i] = (c0_exact && cb == 0) ? mref[min(r0 + i, nfr - 1)] : 0.0f;
         float own[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) own[i] = col[min(r0 + i, nfr - 1) * fs];
@@ -500,7 +615,7 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 }
 
 // PROF: development aid -- shader-clock totals per phase of wave 0 of workgroup 0 (tools/gpu_fast_phase_profile.py)
-#define KWS_FAST_NPHASE 12
+#define KWS_FAST_NPHASE 20       // 0..8 phases, 9..11 detail of block 0, 12 + b: block b >= 1 on its own
 #define FPH(i) do { if (PROF) { const long long now_ = clock64(); ph[i] += now_ - tlast; tlast = now_; } } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
@@ -973,26 +1088,63 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         //      for a stationary background (deviation of the log energy ~0.05) that would be the largest error of the whole feature
         //      matrix -- unless the sum is simply replayed.  One column only: a lane per row, win_size additions over a padded copy of
         //      the column in the dead exchange buffer (conflict-free: consecutive lanes read consecutive words).
+        // Only when it matters: every window holds every row at least c0_mult times (plan), so a window's deviation is at least
+        // sqrt(c0_mult n_frames / win_size) x the column's plain deviation over the n_frames rows; if that already clears the relative
+        // guard at the column's largest magnitude, the running-sum mean is good enough for every window (error kappa |mean| / deviation
+        // below the feature tolerance) and the pass is skipped -- the usual case for audio whose loudness changes over the second.
+        bool c0_exact;
         {
-            float *padv = R1;
-            for (int p = lane_m; p < prow; p += KWS_WAVE) padv[p] = img[pad_idx[p] * fs];
-            WAVE_SYNC();
-            const float *pv = padv + min(lane_m, nfr - 1);
-            float s = 0.0f;
-            int i = 0;
-            for (; i + 8 <= win_size; i += 8) {
-                float v[8];
+            const bool on = lane_m < nfr;
+            const float x0 = img[min(lane_m, nfr - 1) * fs];
+            const float mu = wave_sum(on ? x0 : 0.0f) * FP.c0_inv_rows;
+            const float d0 = on ? x0 - mu : 0.0f;
+            const float sd0 = __builtin_amdgcn_sqrtf(wave_sum(d0 * d0) * FP.c0_inv_rows);
+            const float top = wave_max(on ? fabsf(x0) : 0.0f);
+            c0_exact = !(FP.c0_factor * sd0 >= __fmaf_rn(FP.c0_rel, top, FP.c0_abs));
+        }
+        if (c0_exact) {
+            // four copies of the padded column, copy s shifted by s rows: lane r's window pad[r ..] then starts at a 16-byte aligned slot
+            // of copy r & 3 and arrives as ds_read_b128s, four of them (16 terms) requested before the first addition of a trip.  No
+            // predicate per term: whole trips, then whole 16-byte groups, then the last win_size % 4 terms.
+            constexpr int PS = 260;                                          // floats per copy: up to 4 x 64 slots + the reads past the window
+            float *pc = R1;
+            for (int p = lane_m; p < prow; p += KWS_WAVE) {                  // a rare path: kept small rather than batched (registers)
+                int prw[4];
+                float pvv[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = pv[i + e];
+                for (int sft = 0; sft < 4; ++sft) prw[sft] = pad_idx[min(p + sft, prow - 1)];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[e];
+                for (int sft = 0; sft < 4; ++sft) pvv[sft] = img[prw[sft] * fs];
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft) pc[sft * PS + p] = pvv[sft];
             }
-            for (; i < win_size; ++i) s += pv[i];
-            if (lane_m < nfr) elog[lane_m] = __fdiv_rn(s, (float)win_size);
+            WAVE_SYNC();
+            const int r = min(lane_m, nfr - 1);
+            const float4 *pv = (const float4 *)(pc + (r & 3) * PS + (r & ~3));
+            float sum = 0.0f;
+            int q = 0;
+            const int nq = win_size >> 2;
+            for (; q + 4 <= nq; q += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pv[q + e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sum += v[e].x; sum += v[e].y; sum += v[e].z; sum += v[e].w; }
+            }
+            for (; q < nq; ++q) { const float4 v = pv[q]; sum += v.x; sum += v.y; sum += v.z; sum += v.w; }
+            {
+                const float4 v = pv[q];                                      // the slots past the window hold later rows (finite), not used
+                const int rem = win_size & 3;
+                if (rem > 0) sum += v.x;
+                if (rem > 1) sum += v.y;
+                if (rem > 2) sum += v.z;
+            }
+            if (lane_m < nfr) elog[lane_m] = __fdiv_rn(sum, (float)win_size);
             WAVE_SYNC();
         }
-        if (cr == 13) bad = fast_cmvn<13, 16, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, lane_m, nfr, ncep, emit, ext_tab, csink);
-        else bad = fast_cmvn<17, 20, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, lane_m, nfr, ncep, emit, ext_tab, csink);
+        if (PROF) { const long long now_ = clock64(); ph[19] += now_ - tlast; }
+        if (cr == 13) bad = fast_cmvn<13, 16, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, emit, ext_tab, csink);
+        else bad = fast_cmvn<17, 20, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, emit, ext_tab, csink);
         if (__any(bad)) {
             if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
         }
@@ -1015,6 +1167,14 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             float *stage = pooled ? cur : oth;
             const int sstride = pooled ? k.stage_stride : o_stride;
             long long t_loop = 0, t_pre = 0, *tl = (PROF && b == 0) ? &t_loop : nullptr, *tp = (PROF && b == 0) ? &t_pre : nullptr;
+            if (k.dw) {
+                fast_dwconv(k, cur, oth, shared, lane_n, o_stride, o_cp);
+                WAVE_SYNC();
+                float *tmp = cur; cur = oth; oth = tmp;
+                if (PROF && b > 0) { const long long now_ = clock64(); ph[12 + b] += now_ - tlast; }
+                FPH(6 + (b > 0));
+                continue;
+            }
             switch (k.m_tiles * 4 + k.n_tiles) {
             case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n, wsink, tl, tp); break;
             case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
@@ -1031,6 +1191,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             else fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
             WAVE_SYNC();
             float *tmp = cur; cur = oth; oth = tmp;
+            if (PROF && b > 0) { const long long now_ = clock64(); ph[12 + b] += now_ - tlast; }
             FPH(6 + (b > 0));
         }
         {

@@ -86,7 +86,7 @@ def run_device(pkg, gm, mode, pcm_t):
 
 
 def guard_margin(gm, sdw, mw):
-    """per clip: min over cmvnw windows of deviation / (abs_thr[c] + rel |mean|) -- below 1 the clip is handed back"""
+    """per clip: min over cmvnw windows of deviation / (abs_thr[c] + rel_thr[c] |mean|) -- below 1 the clip is handed back"""
     a, rel = gm.fast_guard()
     thr = a[None, None, :] + rel[None, None, :] * np.abs(mw)
     return (sdw / thr).reshape(len(sdw), -1).min(axis=1)
@@ -126,7 +126,7 @@ def test_fast_mode_on_adversarial_input_families(name, pkg, pool):
         assert not np.isnan(s1).any(), fam
         # the guard does what it says: well inside it -> handed back (results are the exact mode's); well outside -> kept
         assert handed_back[margin < 0.9].all(), fam
-        assert (~handed_back[margin > 1.1]).mean() > 0.99 or nfb == n, fam
+        assert nfb == n or not (margin > 1.1).any() or (~handed_back[margin > 1.1]).mean() > 0.99, fam
         assert (bits(s1[handed_back]) == bits(s0[handed_back])).all(), fam
         if gm.is_float:
             assert ds.max() <= FAST_SCORE_TOL, line

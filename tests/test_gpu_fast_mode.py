@@ -199,24 +199,67 @@ def test_fast_mode_edge_batches_and_mode_switch(pkg, oracle):
     gm.close()
 
 
-def test_fast_mode_unfused_float_graph_and_extract_mfcc(pkg, oracle):
-    """A float graph with DEPTHWISE_CONV_2D blocks keeps its exact network kernel behind the fast MFCC kernel; the
-    extract_mfcc_features entry point follows the mode too."""
+def test_fast_mode_depthwise_separable_graph_is_fused_and_extract_mfcc(pkg, oracle):
+    """BASELINE configs[4]'s float graph (49x40 MFCC + 7-block depthwise-separable CNN): since round 3 the fast kernel runs it fused
+    -- pointwise 1x1 CONV_2D blocks on the matrix cores, DEPTHWISE_CONV_2D taps on the vector ALU, more than four blocks -- so the
+    feature matrix never leaves the chip; the extract_mfcc_features entry point follows the mode too."""
     import torch
     path = os.path.join(MODELS, "cfg5_dscnn_mfcc40_f32.kwsm")
     gm = pkg.Model(path, device=0)
     om = OracleModel(oracle, path)
-    assert not gm.fast_is_fused
-    B = 1024
+    assert gm.fast_is_fused
+    B = 4096
     host = oracle.synth(77, 0, B)
     pcm = torch.from_numpy(host).to("cuda:0")
     s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+    s2, _, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm, want_f=False)              # one launch: PCM -> scores
     so, fo, _ = om.run_batch(host, want_features=True)
+    print("\ncfg5 fp32 fused in fast mode, %d clips: max |score - oracle| = %.3g" % (B, np.abs(s2 - so).max()))
     assert np.abs(s - so).max() <= FAST_SCORE_TOL and np.abs(f - fo).max() <= FAST_FEATURE_TOL
+    assert (s2 == s).all()
     f2 = torch.zeros((B, gm.n_features), dtype=torch.float32, device="cuda:0")
     gm.extract_mfcc_batch_device(pcm.data_ptr(), B, f2.data_ptr())
     torch.cuda.synchronize()
     assert (bits(f2.cpu().numpy()) == bits(f)).all()
+    gm.close()
+
+
+FUSED_DW_GRAPHS = {
+    # ("dw", depth_mult, taps, pool, act) / ("pw", out_channels, act) / (out_channels, taps, pool); act 0 none, 1 relu, 3 relu6
+    "dscnn_a": dict(seed=21, blocks=((16, 5, 1), ("dw", 1, 3, 1, 1), ("pw", 24, 1), ("dw", 1, 5, 7, 0), ("pw", 8, 3), (8, 3, 7)), n_labels=5),
+    "dscnn_b_dw_first_mult2": dict(seed=22, ncep=10, blocks=(("dw", 2, 7, 7, 3), ("pw", 12, 1), ("dw", 1, 3, 7, 1)), n_labels=3),
+    "dw_valid_pool_mult2": dict(seed=71, ncep=13, blocks=((12, 3, 1), ("dw", 1, 4, -4, 1), ("pw", 20, 0), ("dw", 2, 2, 4, 3), ("pw", 6, 1)), n_labels=4),
+    "dw_same_pool_ragged": dict(seed=74, ncep=13, blocks=((12, 3, 1), ("dw", 1, 3, 2, 1), ("pw", 10, 1), ("dw", 1, 9, 1, 0), ("pw", 6, 1)), n_labels=4),   # 49 -> 25 (ragged), nine taps
+    "dw40": dict(seed=72, num_filters=40, ncep=40, low=300, high=0, blocks=(("dw", 1, 5, 1, 1), ("pw", 32, 1), ("dw", 1, 3, 7, 1), ("pw", 16, 3), (8, 3, 7)), n_labels=6),
+    "eight_blocks": dict(seed=73, ncep=13, blocks=((16, 3, 1), ("dw", 1, 3, 1, 1), ("pw", 16, 1), ("dw", 1, 3, 2, 1), ("pw", 16, 1), ("dw", 1, 3, 2, 1), ("pw", 16, 1), ("dw", 1, 3, 7, 0)), n_labels=4),
+}
+
+
+@pytest.mark.parametrize("key", sorted(FUSED_DW_GRAPHS))
+def test_fast_mode_fused_depthwise_separable_graphs(key, pkg, oracle, tmp_path):
+    """Depthwise-separable float graphs in the fused fast kernel: depthwise first block, depth multiplier 2, VALID pooling with a
+    dropped tail, ragged SAME windows, 40-channel inputs, eight blocks -- each against the restated float kernels
+    (reference/depthwiseconv_float.h:25, reference/conv.h:28-99) within the fast mode's score tolerance, incl. the special clips."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dequantize_model import dequantize
+    from kws_testlib import synth_model_blob
+    blob = dequantize(synth_model_blob(**FUSED_DW_GRAPHS[key]))
+    p = tmp_path / ("%s.kwsm" % key)
+    p.write_bytes(blob)
+    om = OracleModel(oracle, str(p))
+    gm = pkg.Model(blob=blob)
+    gm.set_mode(pkg.MODE_FAST)
+    assert gm.fast_is_fused, key
+    B = 700
+    host = np.concatenate([oracle.synth(400 + len(key), 5, B - 6), np.stack(list(special_clips().values()))[:6]])
+    pcm = torch.from_numpy(np.ascontiguousarray(host)).to("cuda:0")
+    s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+    so, fo, _ = om.run_batch(host, want_features=True)
+    assert np.abs(s - so).max() <= FAST_SCORE_TOL, (key, float(np.abs(s - so).max()))
+    se, _, _ = run_device(pkg, gm, pkg.MODE_EXACT, pcm)
+    assert np.abs(se - so).max() <= EXACT_SCORE_TOL, key
     gm.close()
 
 

@@ -33,13 +33,14 @@ def _oracle_worker(args):
     cep = np.stack([o.mfcc_nocmvn(p, om.cfg) for p in pcm])
     sdw, mw = column_conditioning(cep, om.cfg.win_size, full=True)
     rel = (sdw / np.maximum(1.0, np.abs(mw))).reshape(len(pcm), -1).min(axis=1)
-    return s, f, q, rel, sdw.reshape(len(pcm), -1).min(axis=1), sdw.astype(np.float32), mw.astype(np.float32)
+    level = np.float32([np.abs(np.log(o.mfe(p, om.cfg)[0].astype(np.float64))).max() for p in pcm])     # the guard's level: largest |log-mel energy|
+    return s, f, q, rel, sdw.reshape(len(pcm), -1).min(axis=1), sdw.astype(np.float32), mw.astype(np.float32), level
 
 
 def oracle_clips(pool, path, pcm, chunk=128):
     jobs = [(path, pcm[i:i + chunk]) for i in range(0, len(pcm), chunk)]
     parts = pool.map(_oracle_worker, jobs)
-    return [np.concatenate([p[k] for p in parts]) for k in range(7)]
+    return [np.concatenate([p[k] for p in parts]) for k in range(8)]
 
 
 def main():
@@ -74,7 +75,7 @@ def main():
             s1, f1, q1 = run(pkg.MODE_FAST)
             nfb = gm.fast_fallback_count()
             s0, f0, q0 = run(pkg.MODE_EXACT)
-            so, fo, qo, rel, sd, sdw, mw = oracle_clips(pool, path, host)
+            so, fo, qo, rel, sd, sdw, mw, level = oracle_clips(pool, path, host)
             exact_ok = bool((f0.view(np.uint32) == fo.view(np.uint32)).all())
             kept = (f1.view(np.uint32) != f0.view(np.uint32)).any(axis=1)          # a re-run clip has the exact kernels' bits
             ds = np.abs(s1 - so).max(axis=1)
@@ -93,6 +94,8 @@ def main():
                                  max_dscore=float(ds[mk].max()) if mk.any() else 0.0, max_dfeature=float(df[mk].max()) if mk.any() else 0.0))
             row["by_conditioning"] = bins
             report[name][fam] = row
+            row["level_quantiles"] = [float(v) for v in np.quantile(level, [0, 0.5, 1])]
+            print("  %-14s level min / median / max %.1f / %.1f / %.1f" % ((fam,) + tuple(row["level_quantiles"])))
             print("  %-14s fallback %5d/%d  max|ds| %.3g  max|df| %.3g  >1e-4: %d  exact==oracle: %s  (%.1fs)"
                   % (fam, nfb, n, ds.max(), df.max(), row["clips_over_1e4"], exact_ok, time.time() - t0))
             print("      " + "  ".join("[%g,%g): %d kept %d ds %.2g df %.2g" % (b["lo"], b["hi"], b["clips"], b["kept"], b["max_dscore"], b["max_dfeature"])
@@ -109,12 +112,14 @@ def main():
             NFh = gm.n_filters // 2
             ea = np.abs(f1 - fo).reshape(n, nr, nc) * sdw
             sel = (sdw > 1e-3) & (sdw < 0.05) & kept[:, None, None] & np.isfinite(ea)
-            def cls(lo, hi, rel_to_mean=False):
+            def cls(lo, hi, rel_to_mean=False, per_level=False):
                 e = ea[:, :, lo:hi][sel[:, :, lo:hi]]
                 if rel_to_mean:
                     e = e / np.maximum(1.0, np.abs(mw[:, :, lo:hi][sel[:, :, lo:hi]]))
+                if per_level:
+                    e = e / np.broadcast_to(level[:, None, None], ea[:, :, lo:hi].shape)[sel[:, :, lo:hi]]
                 return (float(e.max()), float(np.quantile(e, 0.999)), int(e.size)) if e.size else (0.0, 0.0, 0)
-            row["eabs"] = dict(c0=cls(0, 1), c0_per_mean=cls(0, 1, True), dct=cls(1, min(nc, NFh + 1)), stale=cls(NFh + 1, nc), stale_per_mean=cls(NFh + 1, nc, True))
+            row["eabs"] = dict(c0=cls(0, 1), c0_per_mean=cls(0, 1, True), dct=cls(1, min(nc, NFh + 1)), dct_per_level=cls(1, min(nc, NFh + 1), per_level=True), stale=cls(NFh + 1, nc), stale_per_mean=cls(NFh + 1, nc, True))
             print("      E_abs (windows with 1e-3 < deviation < 0.05) max / 99.9%% / count:  " + "  ".join("%s %.2g / %.2g / %d" % ((k,) + v) for k, v in row["eabs"].items()))
             # second tier candidate: the exact kernels' cepstra (bit-identical to the reference) through the fast cmvnw + network
             gm.set_mode(pkg.MODE_EXACT)

@@ -11,16 +11,22 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda")
 pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
 s = torch.empty((B, m.n_labels), dtype=torch.float32, device="cuda")
-prof = torch.zeros(16, dtype=torch.int64, device="cuda")
+prof = torch.zeros(24, dtype=torch.int64, device="cuda")
 L = pkg.lib()
 L.kws_dev_fast_phase_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
 for _ in range(2):
     rc = L.kws_dev_fast_phase_profile(m.h, pcm.data_ptr(), B, s.data_ptr(), prof.data_ptr())
     torch.cuda.synchronize()
-p = prof.cpu().numpy()[:12]
+pa = prof.cpu().numpy()
+p = pa[:12]
 names = ["load+preemph", "fft", "split+power+energy", "mel+log", "dct", "cmvn", "conv block 0", "conv blocks 1+", "fc+softmax", "(block 0: k loop)", "(block 0: epilogue)", "(block 0: preamble)"]
 tot = p[:9].sum()
 nclips = max(1, B // (256 * int(os.environ.get("KWS_DEV_FAST_WAVES", "8"))))
 print(os.path.basename(path), "rc", rc, "clips by wave 0 ~", nclips, "total cycles", tot, "per clip", tot / nclips)
 for n, v in zip(names, p):
     print("%-20s %12d  %5.1f%%  %8.0f cycles/clip" % (n, v, 100.0 * v / tot, v / nclips))
+for b in range(1, 8):
+    if pa[12 + b]:
+        print("  block %d              %12d  %5.1f%%  %8.0f cycles/clip" % (b, pa[12 + b], 100.0 * pa[12 + b] / tot, pa[12 + b] / nclips))
+if pa[19]:
+    print("  (cmvn: column-0 means) %9d  %5.1f%%  %8.0f cycles/clip" % (pa[19], 100.0 * pa[19] / tot, pa[19] / nclips))
