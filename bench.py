@@ -181,7 +181,7 @@ class GpuBackend:
         m.set_mode(self.pkg.MODE_FAST if mode == "fast" else self.pkg.MODE_EXACT)
         self.scores = torch.empty((self.B, m.n_labels), dtype=torch.float32, device=self.dev)
         self.gathered = torch.empty((self.world * self.B, m.n_labels), dtype=torch.float32, device=self.dev) if self.use_comm else self.scores
-        return {"labels": m.n_labels, "is_float": m.is_float, "nn_kernel": m.nn_kernel, "fused": bool(m.fast_is_fused and m.is_float and mode == "fast")}
+        return {"labels": m.n_labels, "is_float": m.is_float, "nn_kernel": m.nn_kernel, "fused": bool(m.fast_is_fused and mode == "fast")}
 
     def events(self, steps):
         self.ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]

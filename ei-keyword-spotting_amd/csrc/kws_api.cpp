@@ -109,7 +109,7 @@ int kws_get_mode(const kws_handle *h)
     std::lock_guard<std::mutex> lk(const_cast<kws_handle *>(h)->mu);
     return h->mode;
 }
-int kws_fast_is_fused(const kws_handle *h) { return h->fast_fused_ok ? 1 : 0; }
+int kws_fast_is_fused(const kws_handle *h) { return (h->fast_fused_ok || h->fast_q_ok) ? 1 : 0; }
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count)
 {
     if (!h || !count) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
@@ -516,6 +516,19 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
     const bool fused = scores && h->is_float && h->fast_fused_ok;
     int rc = 0;
+    if (scores && !h->is_float && h->fast_q_ok) {
+        // int8 graph of the matrix-core shape: the network runs in the same launch on the quantised tensor it has just produced in LDS;
+        // the feature matrix / the tensor only go to HBM when the caller asked for them (q is the caller's buffer or the scratch the
+        // exact re-run below needs anyway -- the fast kernel writes it only in the first case)
+        rc = kws_launch_fast(h->dsp, h->fast_q, h->d_fast_q, pcm, (int)B, scores, want_f ? fx : nullptr, q != h->s_q ? q : nullptr, h->nn.in_scale, h->nn.in_zp,
+                             h->d_flags, h->d_flags + 1, h->n_cu, s, h->d_nn);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
+        rc = kws_launch_mfcc_fused(h->dsp, pcm, 0, (int)B, want_f ? fx : nullptr, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s, h->d_flags);
+        if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
+        if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (fused && want_f) {
         // the fused kernel keeps the feature matrix on chip: a caller who also wants it gets it from the feature-emitting form first
         // (both launches list the same ill-conditioned clips: the list is restarted in between)

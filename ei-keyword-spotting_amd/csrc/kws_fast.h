@@ -84,6 +84,9 @@ struct KwsFastPlan {
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;
     int sink_off;                 // F + sink_off + lane: where a lane's stores that fall outside an image go (no branch per value)
     const float *shared_init;     // global image of the workgroup's shared LDS block (weights, biases, cmvnw tables)
+    // ---- int8 two-block graph fused behind the features (kws_nn_int8_dev.h: nn_mfma_clip): qnet = bytes per activation row of its first
+    //      block (16 / 64), 0 = none; q_floats = floats of the workgroup's shared LDS block its tables take, behind shared_floats
+    int qnet, q_floats;
     // ---- float32 network fused behind the features (fuse = 0: features / int8 tensor go to HBM instead)
     int fuse, n_blocks;
     KwsFastBlock blk[KWS_FAST_MAX_BLOCKS];

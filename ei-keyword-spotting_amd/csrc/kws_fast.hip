@@ -13,6 +13,7 @@
 
 #include "kws_device.h"
 #include "kws_fast.h"
+#include "kws_nn_int8_dev.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 static_assert(KWS_FAST_ZF == KWS_ZF && KWS_FAST_WAVE == KWS_WAVE, "kws_fast.h mirrors kws_device.h");
@@ -486,14 +487,15 @@ __device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *
 //  first row: the sums stay small, var = Q/n - (S/n)^2 does not cancel) replace two win-term walks.  A lane owns one column and
 //  CR consecutive rows; the first window of a row group is sum_j cnt[g][j] d_j with the multiplicities tabulated by the host.
 //  Three batches of loads per column block (the column, the update table, the rows the updates name); statistics and results
-//  stay in registers until every lane has read what it needs, only then are the rows overwritten.
+//  stay in registers until every lane has read what it needs, only then are the rows overwritten.  The features stay in the LDS
+//  image: what has to leave the chip (feature matrix, int8 tensor) is written by the caller in one coalesced pass.
 // ---------------------------------------------------------------------------------------------------------
 //  ext_tab != NULL (win_size > 2 n_frames, the usual shapes): the first window counts every row m0 times and at most
 //  KWS_FAST_CMVN_EXT rows more, so it is m0 x (the column's plain sums, gathered from the row groups' own rows with
 //  ds_bpermute) + those few rows, instead of a walk over every row.
-template <int CR, int CG, bool HAS_OUT, typename Emit>
+template <int CR, int CG>
 __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                          float inv_win, const float *__restrict__ guard_tab, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep, Emit emit,
+                                          float inv_win, const float *__restrict__ guard_tab, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
                                           const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
@@ -600,14 +602,7 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 #pragma unroll
         for (int i = 0; i < CR; ++i) {
             const int r = r0 + i;
-            if constexpr (HAS_OUT) {                  // features / the int8 tensor leave for HBM with each value
-                if (act && r < nfr) {
-                    col[r * fs] = o[i];
-                    emit(r, c, o[i]);
-                }
-            } else {                                  // LDS only: no branch per value, rows / columns outside the matrix go to the sink
-                *((act && r < nfr) ? col + r * fs : sink) = o[i];
-            }
+            *((act && r < nfr) ? col + r * fs : sink) = o[i];      // no branch per value: rows / columns outside the matrix go to the sink
         }
     }
     WAVE_SYNC();
@@ -625,26 +620,45 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 // NET: the float32 network follows in the same launch (no feature / int8 outputs); !NET: the features / the int8 tensor leave for
 // HBM and no network code is compiled in.  Two instantiations instead of run-time flags: each form's cmvnw stores are written
 // for what it does (with a branch per value only where a global store hangs on it).
-template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false, bool NET = true>
+// QCP: 16 / 64 = the int8 two-block network on the matrix cores follows in the same launch (with !NET): the quantised input tensor is
+// written as the 16- / 64-byte activation rows of nn_mfma_clip (kws_nn_int8_dev.h) instead of -- or besides -- going to HBM, and the
+// network is bit-exact from that tensor on, as in kws_nn_mfma_kernel; 0: no int8 network code.
+template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false, bool NET = true, int QCP = 0>
 __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const KwsFastPlan *__restrict__ FPp, const int16_t *__restrict__ pcm, int n_clips,
                                                           float *__restrict__ scores, float *__restrict__ features,
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,
-                                                          long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr)
+                                                          long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr,
+                                                          const KwsNnPlan *__restrict__ QNp = nullptr)
 {
+    static_assert(QCP == 0 || !NET, "the int8 network follows the feature-emitting form");
     // the plan is read from memory (scalar loads, any block index); by value in the kernel arguments the compiler copies it to
     // scratch to index its blocks
     const KwsFastPlan &FP = *FPp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (KWS_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
     float *shared = lds;
-    float *F = lds + FP.shared_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
+    float *F = lds + FP.shared_floats + FP.q_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
     float *R1 = F + FP.f_floats;                                      // FFT buffers + power rows; later block 1's input image
     float *xw = R1, *pw = R1;                                         // the FFT's exchange buffer; the power rows reuse it
     for (int i = threadIdx.x; i < FP.shared_floats; i += blockDim.x) shared[i] = FP.shared_init[i];
     // the power rows are padded so that every filter can read its full tap count: the padding is only ever multiplied by zero
     // weights, but it must be finite (LDS is not cleared between kernels)
     for (int i = lane; i < FP.r1_floats; i += KWS_WAVE) R1[i] = 0.0f;
+    // the int8 network's tables, shared by the workgroup, behind the float block: ADD + ReLU look-up tables, FULLY_CONNECTED weights and
+    // softmax tables (nn_head_stage), weight fragments and requantisation words (nn_mfma_stage_lds)
+    // (layout of that block: 32 x 256 + 16 x 256 table bytes, the head's tables, 16-byte weight fragments [KS1 + 4][64], 6 x 64 words;
+    // its addresses are re-derived where they are used -- kept across the clip loop they would cost registers in every phase)
+    constexpr int Q_HEAD = 48 * 256, Q_WB1 = Q_HEAD + ((KWS_HEAD_BYTES + 15) & ~15), Q_WB2 = Q_WB1 + (QCP == 16 ? 4 : 16) * KWS_WAVE * 16,
+                  Q_RQ = Q_WB2 + 4 * KWS_WAVE * 16;
+    if constexpr (QCP != 0) {
+        unsigned char *const qs = (unsigned char *)(lds + FP.shared_floats);
+        const KwsNnPlan &QN = *QNp;
+        for (int i = threadIdx.x * 4; i < QN.blk[0].out_c * 256; i += blockDim.x * 4) *(int *)(qs + i) = *(const int *)(QN.blk[0].add_lut + i);
+        for (int i = threadIdx.x * 4; i < QN.blk[1].out_c * 256; i += blockDim.x * 4) *(int *)(qs + 32 * 256 + i) = *(const int *)(QN.blk[1].add_lut + i);
+        (void)nn_head_stage(QN, qs + Q_HEAD);
+        nn_mfma_stage_lds<QCP == 0 ? 16 : QCP>(QN, (v4i *)(qs + Q_WB1), (v4i *)(qs + Q_WB2), (int *)(qs + Q_RQ));
+    }
     // from cepstra nothing fills the images' channel padding before the first convolution reads it (times zero weights)
     if constexpr (FROM_CEP)
         for (int i = lane; i < FP.wave_floats; i += KWS_WAVE) F[i] = 0.0f;
@@ -1073,11 +1087,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // ---- cmvnw + optional outputs (extract_mfcc_features' matrix, the int8 input tensor) --------------------------------
         float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
         int8_t *qclip = q_out ? q_out + (size_t)clip * (nfr * ncep) : nullptr;
-        auto emit = [&](int row, int c, float o) {
-            const int idx = row * ncep + c;
-            if (fout) fout[idx] = o;
-            if (qclip) qclip[idx] = quantize_feature(o, in_scale, in_zp);
-        };
+        int8_t *const act1 = (int8_t *)R1;                              // [KWS_A1_ROWS][QCP]: row = time + tap, padding = the input zero point
         bool bad;
         int lane_m = lane;
         asm volatile("" : "+v"(lane_m));
@@ -1143,12 +1153,51 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             WAVE_SYNC();
         }
         if (PROF) { const long long now_ = clock64(); ph[19] += now_ - tlast; }
-        if (cr == 13) bad = fast_cmvn<13, 16, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, emit, ext_tab, csink);
-        else bad = fast_cmvn<17, 20, !NET>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, emit, ext_tab, csink);
+        if constexpr (QCP != 0) {
+            // the exchange buffer is dead from here to the next clip: it becomes the network's first activation image
+            const int z1 = (int)((unsigned)(QNp->blk[0].in_zp & 0xff) * 0x01010101u);
+            for (int i = lane_m; i < KWS_A1_ROWS * (QCP / 4); i += KWS_WAVE) ((int *)act1)[i] = z1;
+            WAVE_SYNC();
+        }
+        if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+        else bad = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
         if (__any(bad)) {
             if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
         }
+        if constexpr (!NET) {
+            // ---- what leaves the chip, and the network's quantised input: one pass over the feature image, consecutive lanes take
+            //      consecutive values of extract_mfcc_features' [frame][coefficient] order (coalesced stores)
+            const unsigned inv = (1u << 20) / (unsigned)ncep + 1u;           // i / ncep for i < 4096
+            const int q_pad = QCP != 0 ? QNp->blk[0].pad_left : 0;
+            for (int i = lane; i < nfr * ncep; i += KWS_WAVE) {
+                const int r = (int)(((unsigned)i * inv) >> 20), c = i - r * ncep;
+                const float o = img[r * fs + c];
+                if (fout) fout[i] = o;
+                if (QCP != 0 || qclip) {
+                    const int8_t qb = quantize_feature(o, in_scale, in_zp);
+                    if (qclip) qclip[i] = qb;
+                    if constexpr (QCP != 0) act1[(r + q_pad) * QCP + c] = qb;
+                }
+            }
+            WAVE_SYNC();
+        }
         FPH(5);
+        if constexpr (QCP != 0) {
+            // ---- the int8 graph (two CONV_2D blocks on v_mfma_i32_*_i8, FULLY_CONNECTED, SOFTMAX): the image is dead, its first words
+            //      hold the second activation image and the head's vectors
+            const KwsNnPlan &QN = *QNp;
+            int8_t *const act2 = (int8_t *)F;                           // [KWS_A2_ROWS][32]
+            int *const vec = (int *)(F + KWS_A2_ROWS * 8);              // 64 + 16 ints: FULLY_CONNECTED input and logits
+            const int z2 = (int)((unsigned)(QN.blk[1].in_zp & 0xff) * 0x01010101u);
+            for (int i = lane; i < KWS_A2_ROWS * 8; i += KWS_WAVE) ((int *)act2)[i] = z2;
+            WAVE_SYNC();
+            unsigned char *const qs = (unsigned char *)(lds + FP.shared_floats);
+            const NnMfmaLds<QCP> qctx = nn_mfma_lds_ctx<QCP>(QN, (const v4i *)(qs + Q_WB1), (const v4i *)(qs + Q_WB2), (const int *)(qs + Q_RQ), lane);
+            const NnHeadTab q_head = nn_head_tab(qs + Q_HEAD);
+            const NnTaps no_taps = { nullptr, 0, nullptr, nullptr, nullptr, nullptr };
+            nn_mfma_clip<QCP>(qctx, QN, q_head, act1, act2, vec, (const int8_t *)qs, (const int8_t *)qs + 32 * 256, lane, clip, scores, no_taps);
+            WAVE_SYNC();
+        }
         if constexpr (!NET) continue;
         else {
 
@@ -1225,35 +1274,47 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 // ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
-template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true>
+template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true, int QCP = 0>
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
-                         long long *prof_out, hipStream_t stream, const float *cep = nullptr)
+                         long long *prof_out, hipStream_t stream, const float *cep = nullptr, const KwsNnPlan *d_nn = nullptr)
 {
-    const size_t smem = ((size_t)FP.shared_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
+    const size_t smem = ((size_t)FP.shared_floats + FP.q_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
     // the opt-in for more than 64 KB of dynamic LDS is per device (and this instantiation): one bit per device, set once
     static std::atomic<unsigned long long> attr_done{ 0 };
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int per_wg = FP.n_waves;
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
-    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
-                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep);
+    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
+                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn);
     return (int)hipGetLastError();
 }
 
 int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
-                    float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream)
+                    float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
+                    const KwsNnPlan *d_nn)
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
+    if (FP.qnet) {
+        // int8 graph fused: 16-byte activation rows go with the 32-filter front end, 64-byte rows with the 40-filter one (the plan checks)
+#define KWS_FAST_QARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream, nullptr, d_nn
+        if (FP.qnet == 16 && FP.dct_groups == 4)
+            return FP.nz <= 4 ? launch_fast_t<4, 4, false, false, false, 16>(KWS_FAST_QARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false, false, false, 16>(KWS_FAST_QARGS)
+                                                                                                          : launch_fast_t<KWS_FAST_NZ_MAX, 4, false, false, false, 16>(KWS_FAST_QARGS);
+        if (FP.qnet == 64 && FP.dct_groups == 5)
+            return FP.nz <= 4 ? launch_fast_t<4, 5, false, false, false, 64>(KWS_FAST_QARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false, false, false, 64>(KWS_FAST_QARGS)
+                                                                                                          : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false, 64>(KWS_FAST_QARGS);
+        return (int)hipErrorInvalidValue;
+    }
 #define KWS_FAST_ARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream
     if (FP.dct_groups == 4)
         return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_ARGS)
@@ -1266,6 +1327,12 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
                        : (FP.nz <= 4 ? launch_fast_t<4, 5, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false, false, false>(KWS_FAST_ARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false>(KWS_FAST_ARGS));
     return (int)hipErrorInvalidValue;
+}
+
+// bytes of the workgroup's shared LDS block the fused int8 network's tables take (the layout of the kernel's prologue)
+size_t kws_fast_qnet_bytes(int qcp)
+{
+    return (size_t)48 * 256 + ((KWS_HEAD_BYTES + 15) & ~15) + (size_t)((qcp == 16 ? 4 : 16) + 4) * KWS_WAVE * 16 + 6 * KWS_WAVE * 4;
 }
 
 // cmvnw + (fused float network | features / int8 tensor) from cepstra in HBM, ring-indexed per P.ring_* (continuous mode)

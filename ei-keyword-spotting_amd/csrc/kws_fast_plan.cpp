@@ -245,7 +245,7 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     F.sink_off = F.f_floats - KWS_FAST_WAVE;
     F.r1_floats = round_up(std::max(std::max(KWS_FAST_MEL_CHUNK * KWS_FAST_XS, KWS_FAST_MEL_CHUNK * F.pstride), need_r1), 4);
     F.wave_floats = F.f_floats + F.r1_floats;
-    const int avail = kLdsBytes / 4 - F.shared_floats;
+    const int avail = kLdsBytes / 4 - F.shared_floats - F.q_floats;
     F.n_waves = std::min(8, avail / F.wave_floats);
     if (const char *ev = getenv("KWS_DEV_FAST_WAVES")) F.n_waves = std::max(1, std::min(F.n_waves, atoi(ev)));   // development aid (occupancy experiments)
     if (F.n_waves < 4 && !getenv("KWS_DEV_FAST_WAVES")) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
@@ -253,7 +253,7 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     EI_IMPULSE_ERROR e = h->upload(shared, &F.shared_init);
     if (e) return e;
     std::vector<KwsFastPlan> one(1, F);
-    return h->upload(one, &F == &h->fast_fused ? &h->d_fast_fused : &h->d_fast_plain);
+    return h->upload(one, &F == &h->fast_fused ? &h->d_fast_fused : &F == &h->fast_q ? &h->d_fast_q : &h->d_fast_plain);
 }
 
 // plain form: extract_mfcc_features only; the feature matrix and / or the int8 input tensor go to HBM
@@ -270,6 +270,32 @@ static EI_IMPULSE_ERROR build_fast_plain(kws_handle *h)
     F.fuse = 0;
     F.n_labels = (int)h->model.labels.size();
     return finish_fast_plan(h, F, shared, 0, 0);
+}
+
+// int8 graphs of the two-block matrix-core shape (kws_nn_mfma_kernel's): the same network fused behind the features
+static EI_IMPULSE_ERROR build_fast_q(kws_handle *h)
+{
+    KwsFastPlan &F = h->fast_q;
+    memset(&F, 0, sizeof(F));
+    if (h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the fused int8 network needs an int8 graph");
+    if (!kws_nn_uses_mfma(h->nn)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the int8 graph is outside the two-block matrix-core shape; it keeps its own kernel");
+    const int qcp = h->nn.blk[0].in_cpad == 16 ? 16 : 64;
+    if ((qcp == 16) != (h->dsp.n_filters == 32))
+        return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d-byte activation rows with %d mel filters is not an instantiated pairing", qcp, h->dsp.n_filters);
+    std::vector<float> shared;
+    EI_IMPULSE_ERROR e = build_fast_dsp(h, F, shared);
+    if (e) return e;
+    F.fs = h->dsp.n_filters + 4;
+    F.fuse = 0;
+    F.n_labels = (int)h->model.labels.size();
+    F.qnet = qcp;
+    F.q_floats = (int)((kws_fast_qnet_bytes(qcp) + 15) / 16 * 4);
+    if (!h->d_nn) {
+        std::vector<KwsNnPlan> one(1, h->nn);
+        if ((e = h->upload(one, &h->d_nn))) return e;
+    }
+    // the exchange buffer doubles as the first activation image (72 rows), the feature image as the second one + the head's vectors
+    return finish_fast_plan(h, F, shared, 24 * 8 + 96, 72 * qcp / 4);
 }
 
 // fused form: float32 graphs made of CONV_2D blocks only
@@ -363,5 +389,7 @@ EI_IMPULSE_ERROR build_fast_plans(kws_handle *h)
     if (!h->fast_plain_ok) h->fast_why = kws_last_error();
     h->fast_fused_ok = h->fast_plain_ok && build_fast_fused(h) == EI_IMPULSE_OK;
     if (h->fast_plain_ok && !h->fast_fused_ok) h->fast_why = kws_last_error();
+    h->fast_q_ok = h->fast_plain_ok && !h->is_float && build_fast_q(h) == EI_IMPULSE_OK;
+    if (h->fast_plain_ok && !h->is_float && !h->fast_q_ok) h->fast_why = kws_last_error();
     return EI_IMPULSE_OK;
 }

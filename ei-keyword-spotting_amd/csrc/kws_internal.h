@@ -42,7 +42,8 @@ void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
-                    int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream);
+                    int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream, const KwsNnPlan *d_nn = nullptr);
+size_t kws_fast_qnet_bytes(int qcp);     // LDS bytes of the fused int8 network's shared tables (kws_fast.hip)
 int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream);
 int kws_launch_mix_audio(const float *words, const int *word_len, size_t word_stride, const float *noise, const int *start, float word_vol,
@@ -204,9 +205,10 @@ struct kws_handle {
     // KWS_MODE_FAST (kws_fast.h): host copies of a float graph's constants (the fused plan re-lays them out), the two plans,
     // and the list of clips the fast kernel hands back to the exact kernels
     struct HostF32 { std::vector<float> w[KWS_MAX_BLOCKS], bias[KWS_MAX_BLOCKS], addc[KWS_MAX_BLOCKS], fc_w, fc_b; } hostf;
-    KwsFastPlan fast_plain{}, fast_fused{};
-    const KwsFastPlan *d_fast_plain = nullptr, *d_fast_fused = nullptr;     // the same plans in device memory
-    bool fast_plain_ok = false, fast_fused_ok = false;
+    KwsFastPlan fast_plain{}, fast_fused{}, fast_q{};   // features / int8 tensor to HBM; float32 graph fused; int8 two-block graph fused
+    const KwsFastPlan *d_fast_plain = nullptr, *d_fast_fused = nullptr, *d_fast_q = nullptr;     // the same plans in device memory
+    const KwsNnPlan *d_nn = nullptr;                    // the int8 plan in device memory (the fused form reads it from there)
+    bool fast_plain_ok = false, fast_fused_ok = false, fast_q_ok = false;
     std::string fast_why;
     std::vector<float> fast_guard_abs, fast_guard_rel;    // host copy of the cmvnw guard's per-column thresholds (kws_fast_guard)
     int mode = KWS_MODE_EXACT;
