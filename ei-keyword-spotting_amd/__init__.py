@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = [
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
     "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count", "kws_fast_guard",
     "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_allgather_scores", "kws_comm_destroy",
+    "kws_wav_info_from_memory", "kws_wav_decode_mono", "kws_resample_length", "kws_resample_device",
     "kws_synth_clips_device", "kws_mix_audio_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
@@ -119,6 +120,12 @@ def lib():
         L.kws_extract_mfe_batch_device.argtypes = [vp, vp, sz, vp, vp]
         L.kws_synth_clips_device.argtypes = [u32, u32, u32, u32, vp, vp]
         L.kws_mix_audio_device.argtypes = [vp, vp, sz, vp, sz, vp, C.c_float, C.c_float, sz, sz, vp, vp]
+        if hasattr(L, "kws_wav_decode_mono"):
+            L.kws_wav_info_from_memory.argtypes = [vp, sz, vp]
+            L.kws_wav_decode_mono.argtypes = [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(i32)]
+            L.kws_resample_length.restype = sz
+            L.kws_resample_length.argtypes = [sz, i32, i32]
+            L.kws_resample_device.argtypes = [vp, sz, i32, vp, sz, i32, vp]
         L.kws_streams_create.argtypes = [vp, sz, C.POINTER(vp)]
         L.kws_streams_destroy.argtypes = [vp]
         L.kws_streams_init.argtypes = [vp]
@@ -332,6 +339,36 @@ class Comm:
 def mix_audio_device(words_ptr, word_len_ptr, word_stride, noise_ptr, noise_len, start_ptr, word_vol, bg_vol, n_clips, n, out_ptr, stream=None):
     _check(lib().kws_mix_audio_device(words_ptr, word_len_ptr, word_stride, noise_ptr, noise_len, start_ptr, word_vol, bg_vol, n_clips, n,
                                       out_ptr, stream))
+
+
+class WavInfo(C.Structure):                      # kws_wav_info
+    _fields_ = [("channels", C.c_int), ("sample_rate", C.c_int), ("bits_per_sample", C.c_int), ("is_float", C.c_int),
+                ("frames", C.c_size_t), ("data_offset", C.c_size_t)]
+
+
+def wav_info(data):
+    """container facts of a RIFF/WAVE image (bytes)"""
+    w = WavInfo()
+    _check(lib().kws_wav_info_from_memory(data, len(data), C.byref(w)))
+    return w
+
+
+def wav_decode_mono(data):
+    """(float32 mono samples, sample rate) of a WAV image, as librosa.load(sr = None, mono = True) would return them"""
+    import numpy as np
+    n, sr = C.c_size_t(), C.c_int()
+    _check(lib().kws_wav_decode_mono(data, len(data), None, 0, C.byref(n), C.byref(sr)))
+    out = np.zeros(n.value, np.float32)
+    _check(lib().kws_wav_decode_mono(data, len(data), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n), C.byref(sr)))
+    return out, sr.value
+
+
+def resample_length(n_in, sr_in, sr_out):
+    return lib().kws_resample_length(n_in, sr_in, sr_out)
+
+
+def resample_device(in_ptr, n_in, sr_in, out_ptr, n_out, sr_out, stream=None):
+    _check(lib().kws_resample_device(in_ptr, n_in, sr_in, out_ptr, n_out, sr_out, stream))
 
 
 def synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream=None):

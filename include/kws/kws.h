@@ -175,6 +175,25 @@ void kws_comm_destroy(kws_comm *c);
 EI_IMPULSE_ERROR kws_mix_audio_device(const float *words, const int *word_len, size_t word_stride, const float *noise, size_t noise_len,
                                       const int *start, float word_vol, float bg_vol, size_t n_clips, size_t n, int16_t *out, void *stream);
 
+/* ---- the rest of that step: what librosa.load(path, sr = 16000, mono = True) (dataset-curation.py:111,126) does with a WAV file before
+ * mix_audio sees it -- decode, mix down to mono, resample.  PARITY UNPINNED like kws_mix_audio_device (no librosa / soundfile / resampy in
+ * reach): the decoder follows libsndfile's published conversion rules (integer PCM / 2^(bits - 1); 8-bit WAV is unsigned), the mono mix-down
+ * NumPy's mean over the channels, the resampler the published design of resampy's "kaiser_best" filter (Kaiser-windowed sinc, 64 zero
+ * crossings); tests hold them to Python's `wave` / scipy.io.wavfile and to scipy.signal.resample_poly within a stated tolerance.
+ *   kws_wav_info_from_memory  container facts of a RIFF/WAVE image in memory (PCM 8 / 16 / 24 / 32 bit, IEEE float 32, also as
+ *                             WAVE_FORMAT_EXTENSIBLE; unknown chunks are skipped)
+ *   kws_wav_decode_mono       host: samples -> float32 in [-1, 1), channels averaged; out == NULL only reports *frames / *sample_rate
+ *   kws_resample_length       ceil(n_in * sr_out / sr_in), librosa's output length
+ *   kws_resample_device       device -> device; sr_in == sr_out copies (librosa.load leaves such a file alone) */
+typedef struct {
+    int channels, sample_rate, bits_per_sample, is_float;
+    size_t frames, data_offset;
+} kws_wav_info;
+EI_IMPULSE_ERROR kws_wav_info_from_memory(const void *bytes, size_t nbytes, kws_wav_info *info);
+EI_IMPULSE_ERROR kws_wav_decode_mono(const void *bytes, size_t nbytes, float *out, size_t out_cap, size_t *frames, int *sample_rate);
+size_t kws_resample_length(size_t n_in, int sr_in, int sr_out);
+EI_IMPULSE_ERROR kws_resample_device(const float *in, size_t n_in, int sr_in, float *out, size_t n_out, int sr_out, void *stream);
+
 /* deterministic synthetic clips generated directly in HBM (include/kws/kws_synth.h) */
 EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len,
                                         int16_t *out, void *stream);
