@@ -1598,10 +1598,13 @@ void kwso_mix_audio(const float *word, int word_len, const float *noise_window, 
             float b = (float)(0.5 * (double)bg_vol) * noise_window[i];   /* 0.5 * bg_vol * ndarray(float32): the scalar takes the array's dtype */
             x = a + (double)b;                              /* list + ndarray -> float64 */
         }
-        double r = rint(x * 32767.0);                       /* sf.write(subtype PCM_16) of doubles: lrint(x * 0x7FFF); saturated here */
-        if (r < -32768.0) r = -32768.0;
-        if (r > 32767.0) r = 32767.0;
-        out[i] = (int16_t)r;
+        /* sf.write(subtype PCM_16) of doubles: libsndfile's d2les_array, lrint(x * 0x7FFF) and the low 16 bits of it -- clipping
+           (SFC_SET_CLIPPING) is off by default and python-soundfile does not switch it on, so a value beyond full scale WRAPS.  The
+           reference's own parameters cannot get there (|0.5 word + 0.5 bg| <= 1 for volumes <= 1); assumed from libsndfile's published
+           source, not checked against it here (PARITY UNPINNED). */
+        double r = rint(x * 32767.0);
+        if (!(r > -9.0e18 && r < 9.0e18)) r = 0.0;           /* outside long long (or NaN): lrint's result is unspecified; zero here */
+        out[i] = (int16_t)(uint16_t)((unsigned long long)(long long)r & 0xffffull);
     }
 }
 

@@ -8,7 +8,7 @@ from kws_testlib import ROOT
 
 
 def script_expression(word, noise_window, word_vol, bg_vol, n):
-    """lines 107-135 of the script evaluated by NumPy itself (minus librosa.load), then PCM16 as libsndfile stores doubles"""
+    """lines 107-135 of the script evaluated by NumPy itself (minus librosa.load), then PCM16 as libsndfile stores doubles (no clipping)"""
     if word is None:
         waveform = [0] * n
     else:
@@ -21,7 +21,7 @@ def script_expression(word, noise_window, word_vol, bg_vol, n):
         # python_float * float32_scalar to float64 (value-based casting); NumPy 2 would keep float32.  float(i) spells the former.
         waveform = [0.5 * word_vol * float(i) for i in waveform] + (0.5 * bg_vol * noise_window)
     x = np.asarray(waveform, np.float64)
-    return np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.int16)
+    return (np.rint(x * 32767.0).astype(np.int64) & 0xffff).astype(np.uint16).view(np.int16)     # libsndfile without clipping: the low 16 bits
 
 
 def cases():
@@ -33,7 +33,7 @@ def cases():
         noise = (rng.standard_normal(n) * 0.1).astype(np.float32)
         out.append((word, noise, 1.0, 0.3))
         out.append((word, None, 1.0, 1.0))
-    out.append(((rng.standard_normal(n) * 3).astype(np.float32), (rng.standard_normal(n) * 3).astype(np.float32), 1.0, 1.0))   # saturation
+    out.append(((rng.standard_normal(n) * 3).astype(np.float32), (rng.standard_normal(n) * 3).astype(np.float32), 1.0, 1.0))   # beyond full scale: wraps
     return out
 
 
