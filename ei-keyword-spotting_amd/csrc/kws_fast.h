@@ -83,6 +83,7 @@ struct KwsFastPlan {
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;
     int sink_off;                 // F + sink_off + lane: where a lane's stores that fall outside an image go (no branch per value)
+    int stash_off;                // F + stash_off: 48 floats that survive from one clip of a wave to its next (the paired tail pass)
     const float *shared_init;     // global image of the workgroup's shared LDS block (weights, biases, cmvnw tables)
     // ---- int8 two-block graph fused behind the features (kws_nn_int8_dev.h: nn_mfma_clip): qnet = bytes per activation row of its first
     //      block (16 / 64), 0 = none; q_floats = floats of the workgroup's shared LDS block its tables take, behind shared_floats

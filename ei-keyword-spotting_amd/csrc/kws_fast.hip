@@ -689,7 +689,12 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const int cr = FP.cr, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
     long long ph[KWS_FAST_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
 
-    for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += gridDim.x * n_waves) {
+    // A window of 8 k + 1 frames leaves one frame for the tail pass, which has room for two: the tail pass of every other clip also
+    // transforms the last frame of the wave's NEXT clip and parks its log-mel row and log energy in the stash (per wave, behind the sink).
+    const int clip_stride = gridDim.x * n_waves;
+    float *const stash = F + FP.stash_off;                             // [0 .. NF): log-mel row, [47]: log frame energy
+    bool have_stash = false;
+    for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += clip_stride) {
         // ---- per-lane constants of the spectral phase (the FFT is kws_mfcc_kernel's: KissFFT's order, bit for bit).  They are
         //      re-derived per clip from a lane index the compiler cannot see through: hoisted out of the clip loop, the FFT's
         //      twiddles and the three dozen LDS addresses of the pair loop stay live through the DCT, cmvnw and convolution phases
@@ -759,7 +764,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         };
         // ---- mel filterbank for the frames of a pass: dot_by_row as a register-tap gather, zero handling, log.  pairs = pairs of
         //      frame slots a lane half walks (2: slots 4 h .. 4 h + 3 of an eight-frame pass; 1: the tail pass, slots 0, 1)
-        auto mel_phase = [&](int fbase, int nfc, int pairs) {
+        // adj1: added to the image offset of frame slot 1's stores (the tail pass parks the NEXT clip's last frame in the stash)
+        auto mel_phase = [&](int fbase, int nfc, int pairs, int adj1) {
             WAVE_SYNC();
             // filters 0..31: lane half h takes frame slots 4 h .. 4 h + 3; filters 32..39 (40 filters only): one frame slot each
             const int j2 = 32 + (lane_c & 7), sl2 = lane_c >> 3;
@@ -795,13 +801,17 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int slot = 4 * half + s;
-                if (slot < nfc && t < NF) img[(fbase + slot) * fs + t] = macc[s];
+                if (slot < nfc && t < NF) img[(fbase + slot) * fs + t + (slot == 1 ? adj1 : 0)] = macc[s];
             }
-            if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2] = macc[4];
+            if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2 + (sl2 == 1 ? adj1 : 0)] = macc[4];
         };
         fast_i2 nxt[2][8];
         fetch(0, nxt);
         int touched = touch(1);
+        const bool pair_tail = n_tail == 1 && !have_stash && clip + clip_stride < n_clips;
+        // the next clip's last frame: 256 samples = 512 bytes, warmed now so that the tail pass finds them in the cache
+        int touched_tail = 0;
+        if (pair_tail && lane_c < 8) touched_tail = *(const int *)(xbase + (size_t)clip_stride * n_samples + (nfr - 1) * frame_stride + 32 * lane_c);
         for (int q = 0; q < n_pass; ++q) {
             const int fbase = KWS_FAST_MEL_CHUNK * q;
             const int f = fbase + fg;
@@ -910,20 +920,29 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             }
             FPH(2);
 
-            mel_phase(fbase, min(KWS_FAST_MEL_CHUNK, nfr - fbase), 2);
+            mel_phase(fbase, min(KWS_FAST_MEL_CHUNK, nfr - fbase), 2, 0);
             WAVE_SYNC();
             FPH(3);
         }
 
-        if (n_tail) {
-            // ---- tail pass: frames 8 n_pass + h on lane half h, a lane transforms four of its frame's 128 points per stage:
-            //      kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32, each through an in-place, padded
-            //      buffer behind the two power rows it feeds
-            const int ft = KWS_FAST_MEL_CHUNK * n_pass + half;
+        asm volatile("" : : "v"(touched_tail));
+        if (n_tail == 1 && have_stash) {
+            // this clip's last frame was transformed by the previous clip's tail pass
+            if (lane_c < NF) img[(nfr - 1) * fs + lane_c] = stash[lane_c];
+            if (lane_c == 47) elog[nfr - 1] = stash[47];
+            have_stash = false;
+            WAVE_SYNC();
+        } else if (n_tail) {
+            // ---- tail pass: frames 8 n_pass + h on lane half h -- or, when one frame is left and the wave has another clip to come, this
+            //      clip's last frame on half 0 and the next clip's on half 1 --, a lane transforms four of its frame's 128 points per
+            //      stage: kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32, each through an in-place,
+            //      padded buffer behind the two power rows it feeds
+            const int16_t *const xb_t = (pair_tail && half == 1) ? xbase + (size_t)clip_stride * n_samples : xbase;
+            const int ft = pair_tail ? nfr - 1 : KWS_FAST_MEL_CHUNK * n_pass + half;
             const bool live_t = ft < nfr;
             const int s0 = min(ft, nfr - 1) * frame_stride + 8 * t;
-            const int4 rawv = *(const int4 *)(xbase + s0);
-            const int rawp = s0 == 0 ? wrap_prev : (int)xbase[s0 - 1];
+            const int4 rawv = *(const int4 *)(xb_t + s0);
+            const int rawp = s0 == 0 ? wrap_prev : (int)xb_t[s0 - 1];       // (s0 = 0 needs a window of one frame: no tail pass then)
             const int k01 = t & 1, g01 = t >> 1, n0 = (g01 >> 2) + 4 * (g01 & 3), K2 = t & 7, G2 = t >> 3;
             const cf ta1 = to_cf(P.tw[16 * k01]), ta2 = to_cf(P.tw[32 * k01]), ta3 = to_cf(P.tw[48 * k01]);
             const cf tb1 = to_cf(P.tw[4 * K2]), tb2 = to_cf(P.tw[8 * K2]), tb3 = to_cf(P.tw[12 * K2]);
@@ -1011,9 +1030,11 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                     prow[0] = pdc;
                 }
                 esum = half_wave_sum(esum);
-                if (t == 0 && live_t) elog[ft] = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
+                if (t == 0 && live_t) *((pair_tail && half == 1) ? stash + 47 : elog + ft) = fast_log(esum == 0.0f ? FLT_EPSILON : esum);
             }
-            mel_phase(KWS_FAST_MEL_CHUNK * n_pass, n_tail, 1);
+            // frame slot 1 of a paired pass belongs to the next clip: its row goes to the stash instead of image row n_frames
+            mel_phase(KWS_FAST_MEL_CHUNK * n_pass, pair_tail ? 2 : n_tail, 1, pair_tail ? (int)(stash - img) - nfr * fs : 0);
+            have_stash = pair_tail;
             WAVE_SYNC();
         }
 

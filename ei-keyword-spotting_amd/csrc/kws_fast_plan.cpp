@@ -241,8 +241,9 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     while (shared.size() & 3) shared.push_back(0.0f);
     F.shared_floats = (int)shared.size();
     // image + log energies (or a later block's image), then one slot per lane: the sink of stores that fall outside an image
-    F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4) + KWS_FAST_WAVE;
-    F.sink_off = F.f_floats - KWS_FAST_WAVE;
+    F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4) + KWS_FAST_WAVE + 48;
+    F.sink_off = F.f_floats - KWS_FAST_WAVE - 48;
+    F.stash_off = F.f_floats - 48;
     F.r1_floats = round_up(std::max(std::max(KWS_FAST_MEL_CHUNK * KWS_FAST_XS, KWS_FAST_MEL_CHUNK * F.pstride), need_r1), 4);
     F.wave_floats = F.f_floats + F.r1_floats;
     const int avail = kLdsBytes / 4 - F.shared_floats - F.q_floats;

@@ -9,7 +9,10 @@
 #include "kws_nn_int8_dev.h"
 
 
-__global__ __launch_bounds__(KWS_WAVE * KWS_NN_WAVES_MAX, 4) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
+// MAXW: waves per workgroup the build allows.  16 (four per SIMD) caps the kernel at 128 VGPRs, which it overruns by 20 (176 B of
+// scratch per lane); 12 (three per SIMD) gives it 168 and no scratch -- the launcher picks by measurement (below).
+template <int MAXW>
+__global__ __launch_bounds__(KWS_WAVE * MAXW) void kws_nn_kernel(KwsNnPlan N, const int8_t *__restrict__ q_in, int n_clips,
                                                                          float *__restrict__ scores, NnTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -510,11 +513,19 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
     const size_t smem = kws_nn_smem_bytes(N, nw);
     grid = (n_clips + nw - 1) / nw;
     if (grid > (grid_cap / 4) * per_cu) grid = (grid_cap / 4) * per_cu;          // grid_cap = 4 workgroups per CU
-    if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute((const void *)kws_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (nw <= 12) {
+        if (smem > 64 * 1024) {                    // wide models: opt in to more than the default 64 KB of dynamic LDS
+            hipError_t e = hipFuncSetAttribute((const void *)kws_nn_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kws_nn_kernel<12>, dim3(grid), dim3(KWS_WAVE * nw), smem, stream, N, q_in, n_clips, scores, taps);
+        return (int)hipGetLastError();
+    }
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kws_nn_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kws_nn_kernel, dim3(grid), dim3(KWS_WAVE * nw), smem, stream, N, q_in, n_clips, scores, taps);
+    hipLaunchKernelGGL(kws_nn_kernel<16>, dim3(grid), dim3(KWS_WAVE * nw), smem, stream, N, q_in, n_clips, scores, taps);
     return (int)hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ def fast_sweep(rounds, B):
     cores = len(os.sched_getaffinity(0))
     chunk, bad = 512, 0
     with mp.get_context("spawn").Pool(cores) as pool:
-        for name in ("cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "l476_no_yes.kwsm", "cfg2_mfcc40_int8.kwsm"):
+        for name in ("cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "cfg5_dscnn_mfcc40_f32.kwsm", "l476_no_yes.kwsm", "cfg2_mfcc40_int8.kwsm"):
             path = os.path.join(MODELS, name)
             gm = pkg.Model(path, device=0)
             gm.set_mode(pkg.MODE_FAST)

@@ -15,12 +15,16 @@ re-ordering moved in the cepstra is amplified by 1 / deviation.  The synthetic b
   near_constant  a frame-periodic signal (every frame the same samples: constant cepstral columns) plus a perturbation whose
                  size is swept over five decades: walks every cmvnw column's deviation THROUGH the guard of the fast kernel
   detuned_tone   a tone a few millihertz .. hertz away from a multiple of the frame rate (50 Hz): nearly identical frames
+  word_background  the reference's OWN data shape, for scale: dataset-curation.py mixes every word with a window of a background
+                 recording at its default volumes (word 1.0, background 0.1: 0.5 word + 0.05 background, lines 134-135, 167-181) --
+                 a word shorter than the window over white / pink / amplitude-modulated noise (the test mixes it with
+                 kws_mix_audio_device)
 """
 import numpy as np
 
 CLIP_LEN = 16000
 FS = 16000.0
-FAMILIES = ("amp_sweep", "word_silence", "dc_tone", "clipped", "pure_tone", "bursts", "quiet_noise", "near_constant", "detuned_tone")
+FAMILIES = ("amp_sweep", "word_silence", "dc_tone", "clipped", "pure_tone", "bursts", "quiet_noise", "near_constant", "detuned_tone", "word_background")
 
 
 def _to_pcm(x):
@@ -60,6 +64,20 @@ def word_waveforms(n, seed):
     return x.astype(np.float32), length.astype(np.int32)
 
 
+def background_track(seed, seconds=30):
+    """float32 background recording in -1 .. 1: thirds of white noise, pink noise and slowly amplitude-modulated noise"""
+    rng = np.random.default_rng([seed, 99])
+    m = int(seconds * FS) // 3
+    white = rng.standard_normal(m) * 0.15
+    spec = np.fft.rfft(rng.standard_normal(m))
+    spec[1:] /= np.sqrt(np.arange(1, spec.size))
+    spec[0] = 0
+    pink = np.fft.irfft(spec, m)
+    pink *= 0.2 / pink.std()
+    mod = rng.standard_normal(m) * 0.2 * (0.55 + 0.45 * np.sin(2 * np.pi * 0.7 * np.arange(m) / FS + 1.0))
+    return np.clip(np.concatenate([white, pink, mod]), -1, 1).astype(np.float32)
+
+
 def family(name, n, seed=0):
     rng = np.random.default_rng([seed, FAMILIES.index(name)])
     t = np.arange(CLIP_LEN, dtype=np.float64)
@@ -70,6 +88,12 @@ def family(name, n, seed=0):
         # host twin of what the GPU test makes with kws_mix_audio_device (word_vol 1, no background): 0.5 * word, then PCM16
         w, _ = word_waveforms(n, seed)
         return _to_pcm(0.5 * w.astype(np.float64) * 32767.0)
+    if name == "word_background":
+        w, _ = word_waveforms(n, seed)
+        track = background_track(seed)
+        start = rng.integers(0, track.size - CLIP_LEN + 1, n)
+        noise = np.stack([track[st:st + CLIP_LEN] for st in start])
+        return _to_pcm((0.5 * w.astype(np.float64) + (np.float32(0.05) * noise).astype(np.float64)) * 32767.0)
     if name == "dc_tone":
         dc = rng.choice([-1.0, 1.0], (n, 1)) * np.exp(rng.uniform(np.log(50.0), np.log(20000.0), (n, 1)))
         amp = np.exp(rng.uniform(np.log(20.0), np.log(10000.0), (n, 1)))

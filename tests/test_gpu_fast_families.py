@@ -1,5 +1,6 @@
 """-m gpu: KWS_MODE_FAST off the friendly distribution.  Nine input families that put cmvnw columns
-anywhere between "constant" and "lively" (tests/kws_families.py) x 8 192 clips go through the fast kernel AND the C oracle, clip
+anywhere between "constant" and "lively", plus the reference's own data shape (word + background recording at dataset-curation.py's
+default volumes) for scale (tests/kws_families.py), x 8 192 clips go through the fast kernel AND the C oracle, clip
 by clip.  Bar: float32 scores within 1e-4 (north_star); int8 graphs: the network is exact from the GPU's own int8 tensor on, flip
 rate reported.  Per family the test prints max |score - oracle|, max |feature - oracle| and the fallback rate.
 
@@ -12,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from kws_families import FAMILIES, column_conditioning, family, word_waveforms
+from kws_families import FAMILIES, background_track, column_conditioning, family, word_waveforms
 from kws_testlib import MODELS, ROOT, Oracle, OracleModel, bits
 
 pytestmark = pytest.mark.gpu
@@ -60,16 +61,24 @@ def family_pcm(pkg, name, n, seed):
     """host int16 [n][16000]; word_silence is made on the GPU by kws_mix_audio_device (word shorter than the window, no background:
     the zero padding of dataset-curation.py:114-116)"""
     import torch
-    if name != "word_silence":
+    if name not in ("word_silence", "word_background"):
         return family(name, n, seed)
     w, ln = word_waveforms(n, seed)
     words = torch.from_numpy(w).to("cuda:0")
     lens = torch.from_numpy(ln).to("cuda:0")
     out = torch.zeros((n, 16000), dtype=torch.int16, device="cuda:0")
-    pkg.mix_audio_device(words.data_ptr(), lens.data_ptr(), 16000, None, 0, None, 1.0, 0.0, n, 16000, out.data_ptr())
+    if name == "word_silence":
+        pkg.mix_audio_device(words.data_ptr(), lens.data_ptr(), 16000, None, 0, None, 1.0, 0.0, n, 16000, out.data_ptr())
+    else:                                            # the reference's defaults: word_vol 1.0, bg_vol 0.1 (dataset-curation.py:167-181)
+        track = torch.from_numpy(background_track(seed)).to("cuda:0")
+        start = torch.from_numpy(np.random.default_rng([seed, 5]).integers(0, track.numel() - 16000 + 1, n).astype(np.int32)).to("cuda:0")
+        pkg.mix_audio_device(words.data_ptr(), lens.data_ptr(), 16000, track.data_ptr(), track.numel(), start.data_ptr(), 1.0, 0.1, n, 16000, out.data_ptr())
     torch.cuda.synchronize()
     host = out.cpu().numpy()
-    assert (np.abs(host).max(axis=1) > 0).mean() > 0.9 and all((host[i, ln[i]:] == 0).all() for i in range(0, n, 97))   # word, then digital silence
+    if name == "word_silence":
+        assert (np.abs(host).max(axis=1) > 0).mean() > 0.9 and all((host[i, ln[i]:] == 0).all() for i in range(0, n, 97))   # word, then digital silence
+    else:
+        assert all(np.abs(host[i, ln[i]:].astype(np.int32)).max() > 20 for i in range(0, n, 97))                          # word, then the background
     return host
 
 
