@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "kws_extract_mfcc_batch_device", "kws_run_inference_batch_device", "kws_mfcc_batch_device",
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
-    "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count", "kws_fast_guard",
+    "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count", "kws_fast_exact_count", "kws_fast_guard",
     "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_allgather_scores", "kws_comm_destroy",
     "kws_wav_info_from_memory", "kws_wav_decode_mono", "kws_resample_length", "kws_resample_device",
     "kws_synth_clips_device", "kws_mix_audio_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
@@ -99,7 +99,9 @@ def lib():
         L.kws_fast_is_fused.argtypes = [vp]
         L.kws_fast_fallback_count.argtypes = [vp, C.POINTER(sz)]
         if hasattr(L, "kws_fast_guard"):                 # absent from older builds compared in tools/ab_rate.py
-            L.kws_fast_guard.argtypes = [vp, vp, vp]
+            L.kws_fast_guard.argtypes = [vp, i32, vp, vp]
+        if hasattr(L, "kws_fast_exact_count"):
+            L.kws_fast_exact_count.argtypes = [vp, C.POINTER(sz)]
         L.kws_nn_kernel_name.restype = C.c_char_p
         L.kws_nn_kernel_name.argtypes = [vp]
         L.kws_mfcc_kernel_name.restype = C.c_char_p
@@ -218,13 +220,20 @@ class Model:
         _check(self.L.kws_fast_fallback_count(self.h, C.byref(n)))
         return n.value
 
-    def fast_guard(self):
+    def fast_exact_count(self):
+        """clips of the last fast-mode batch call that ended in the exact kernels (the second tier handed them back)"""
+        n = C.c_size_t()
+        _check(self.L.kws_fast_exact_count(self.h, C.byref(n)))
+        return n.value
+
+    def fast_guard(self, tier=1):
         """(abs_thr, rel_thr), one value per cepstral coefficient: a cmvnw window of column c with deviation below
-        abs_thr[c] + rel_thr[c] * |mean| hands its clip back to the exact kernels"""
+        abs_thr[c] + rel_thr[c] * |mean| makes that tier hand its clip back (tier 1: the fast kernel; tier 2: fast cmvnw + network on
+        exact cepstra)"""
         import numpy as np
         n = self.n_features // self.n_frames
         a, r = np.zeros(n, np.float32), np.zeros(n, np.float32)
-        _check(self.L.kws_fast_guard(self.h, a.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)))
+        _check(self.L.kws_fast_guard(self.h, tier, a.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)))
         return a, r
 
     def set_default(self):

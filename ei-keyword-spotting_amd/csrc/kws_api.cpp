@@ -55,6 +55,8 @@ void kws_destroy(kws_handle *h)
     if (h->s_mfcc) (void)hipFree(h->s_mfcc);
     if (h->s_q) (void)hipFree(h->s_q);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->d_flags2) (void)hipFree(h->d_flags2);
+    if (h->s_cep) (void)hipFree(h->s_cep);
     for (auto &g : h->g_sets) for (void *p : { (void *)g.ws, (void *)g.mfcc, (void *)g.feat }) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         for (void *p : { (void *)h->pipe.pcm[k], (void *)h->pipe.s[k], (void *)h->pipe.f[k], (void *)h->pipe.q[k] }) if (p) (void)hipFree(p);
@@ -124,11 +126,26 @@ EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count)
     return EI_IMPULSE_OK;
 }
 
-EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, float *abs_thr, float *rel_thr)
+EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, int tier, float *abs_thr, float *rel_thr)
 {
-    if (!h || !abs_thr || !rel_thr) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (!h || !abs_thr || !rel_thr || (tier != 1 && tier != 2)) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_fast_guard: bad argument");
     if (!h->fast_plain_ok) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%s", h->fast_why.c_str());
-    for (size_t c = 0; c < h->fast_guard_abs.size(); c++) { abs_thr[c] = h->fast_guard_abs[c]; rel_thr[c] = h->fast_guard_rel[c]; }
+    const std::vector<float> &a = tier == 1 ? h->fast_guard_abs : h->fast_guard2_abs, &r = tier == 1 ? h->fast_guard_rel : h->fast_guard2_rel;
+    for (size_t c = 0; c < a.size(); c++) { abs_thr[c] = a[c]; rel_thr[c] = r[c]; }
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count)
+{
+    if (!h || !count) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    *count = 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->d_flags2) return EI_IMPULSE_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, h->d_flags2, sizeof(int), hipMemcpyDeviceToHost));
+    *count = (size_t)n;
     return EI_IMPULSE_OK;
 }
 
@@ -136,8 +153,11 @@ static EI_IMPULSE_ERROR ensure_flags(kws_handle *h, size_t B)
 {
     if (B + 1 <= h->flags_cap) return EI_IMPULSE_OK;
     if (h->d_flags) (void)hipFree(h->d_flags);
-    h->d_flags = nullptr; h->flags_cap = 0;
+    if (h->d_flags2) (void)hipFree(h->d_flags2);
+    h->d_flags = h->d_flags2 = nullptr; h->flags_cap = 0;
     HIP_TRY(hipMalloc((void **)&h->d_flags, (B + 1) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&h->d_flags2, (B + 1) * sizeof(int)));
+    HIP_TRY(hipMemset(h->d_flags2, 0, sizeof(int)));
     h->flags_cap = B + 1;
     return EI_IMPULSE_OK;
 }
@@ -506,6 +526,52 @@ EI_IMPULSE_ERROR kws_run_inference_batch_device(kws_handle *h, const float *feat
 // KWS_MODE_FAST: the fast kernel over every clip, then the exact kernels over the clips it listed as ill-conditioned (the list and
 // its length stay in HBM: nothing synchronises).  fx: feature scratch / output [B][n_features] (exact re-runs of float graphs and
 // un-fused graphs read it), q: int8 tensor [B][n_features] for int8 graphs; want_f: the caller asked for the feature matrix.
+// What follows the fast kernel of a batch call, on the clips it handed back (list d_flags; list and count stay in HBM, nothing
+// synchronises).  Second tier: their cepstra from the exact kernels -- bit-identical to the reference's, so the DCT term of the guard is
+// gone -- then the fast cmvnw + network from those cepstra (kws_fast_kernel<FROM_CEP> over the list), with the guard that is left
+// (window mean and near-constant columns, KwsFastPlan::guard_cep_off).  Third tier: what that hands back (list d_flags2) goes through
+// the exact cmvnw + network and comes out with the exact mode's bits.  A clip costs its tiers: ~0.4 x the exact path for the second.
+static EI_IMPULSE_ERROR rerun_flagged_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *fx, bool want_f, int8_t *q, hipStream_t s)
+{
+    const size_t F = h->model.nn_input_frame_size;
+    if (B > h->cep_cap) {
+        if (h->s_cep) (void)hipFree(h->s_cep);
+        h->s_cep = nullptr; h->cep_cap = 0;
+        HIP_TRY(hipMalloc((void **)&h->s_cep, B * F * sizeof(float)));
+        h->cep_cap = B;
+    }
+    HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));
+    int rc = kws_launch_spectral(h->dsp, pcm, 0, (int)B, h->s_cep, nullptr, 0, grid_cap_mfcc(h), s, h->d_flags);
+    if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    const bool fused = scores && h->is_float && h->fast_fused_ok;
+    if (!scores || (fused && want_f) || !fused) {
+        // the feature-emitting form: features (float graphs: the network's input; or the caller's wish) and the int8 tensor
+        rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_plain, h->d_fast_plain, h->s_cep, (int)B, nullptr, (h->is_float || want_f) ? fx : nullptr, q,
+                                          h->nn.in_scale, h->nn.in_zp, h->d_flags2, h->d_flags2 + 1, h->n_cu, s, h->d_flags);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (fused) HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));      // the fused form lists the same windows again
+    }
+    if (fused) {
+        rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, h->s_cep, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
+                                          h->d_flags2, h->d_flags2 + 1, h->n_cu, s, h->d_flags);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    } else if (scores) {
+        if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags);
+        else rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
+        if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    // third tier: exact cmvnw (+ the int8 matrix-core network when it is fused there) from the same cepstra, then the exact network
+    int ran_nn = 0;
+    rc = kws_launch_cmvn_nn(h->dsp, h->nn, h->s_cep, (int)B, (h->is_float || want_f) ? fx : nullptr, q, (scores && !h->is_float) ? scores : nullptr, nullptr,
+                            h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), &ran_nn, s, h->d_flags2);
+    if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (!scores) return EI_IMPULSE_OK;
+    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags2);
+    else if (!ran_nn) rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags2);
+    if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EI_IMPULSE_OK;
+}
+
 static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *fx, bool want_f, int8_t *q,
                                              hipStream_t s)
 {
@@ -523,11 +589,7 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
         rc = kws_launch_fast(h->dsp, h->fast_q, h->d_fast_q, pcm, (int)B, scores, want_f ? fx : nullptr, q != h->s_q ? q : nullptr, h->nn.in_scale, h->nn.in_zp,
                              h->d_flags, h->d_flags + 1, h->n_cu, s, h->d_nn);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
-        rc = kws_launch_mfcc_fused(h->dsp, pcm, 0, (int)B, want_f ? fx : nullptr, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s, h->d_flags);
-        if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
-        if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        return EI_IMPULSE_OK;
+        return rerun_flagged_device(h, pcm, B, scores, fx, want_f, q, s);
     }
     if (fused && want_f) {
         // the fused kernel keeps the feature matrix on chip: a caller who also wants it gets it from the feature-emitting form first
@@ -548,14 +610,7 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
             if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         }
     }
-    // exact re-run of the listed clips, indexed by their own clip numbers
-    rc = kws_launch_mfcc_fused(h->dsp, pcm, 0, (int)B, fx, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s, h->d_flags);
-    if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (!scores) return EI_IMPULSE_OK;
-    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags);
-    else rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
-    if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    return EI_IMPULSE_OK;
+    return rerun_flagged_device(h, pcm, B, scores, fx, want_f, q, s);
 }
 
 static EI_IMPULSE_ERROR classify_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *f, int8_t *q, hipStream_t s)

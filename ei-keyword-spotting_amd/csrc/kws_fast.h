@@ -75,6 +75,7 @@ struct KwsFastPlan {
     // fp32 re-ordering moved in a cepstral coefficient (absolute) or in the window's mean (relative to |mean|) comes out of cmvnw
     // divided by the deviation, and the threshold is where that quotient reaches the feature tolerance (kws_fast_plan.cpp)
     int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x { abs, per |window mean| }
+    int guard_cep_off;            // the same for windows that arrive as the exact kernels' cepstra (no DCT term): continuous mode, second tier
     float c0_factor, c0_abs, c0_rel, c0_inv_rows;   // column 0: the exact window means are only computed when c0_factor x (plain deviation of
                                   // the column) < c0_abs + c0_rel x (its largest magnitude); c0_factor = sqrt(c0_mult n_frames / win_size),
                                   // c0_mult = how often every window holds every row at least (0: always compute them)

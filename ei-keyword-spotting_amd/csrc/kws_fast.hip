@@ -629,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,
                                                           long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr,
-                                                          const KwsNnPlan *__restrict__ QNp = nullptr)
+                                                          const KwsNnPlan *__restrict__ QNp = nullptr, const int *__restrict__ sel = nullptr)
 {
     static_assert(QCP == 0 || !NET, "the int8 network follows the feature-emitting form");
     // the plan is read from memory (scalar loads, any block index); by value in the kernel arguments the compiler copies it to
@@ -637,6 +637,9 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const KwsFastPlan &FP = *FPp;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (KWS_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
+    // a workgroup none of whose waves has a clip (the usually empty list of the second tier, a short list) leaves before it stages
+    // its 50 KB of tables
+    if ((int)blockIdx.x * (int)(blockDim.x >> 6) >= sel_count(sel, n_clips)) return;
     float *shared = lds;
     float *F = lds + FP.shared_floats + FP.q_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
     float *R1 = F + FP.f_floats;                                      // FFT buffers + power rows; later block 1's input image
@@ -683,7 +686,9 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const int *upd_tab = (const int *)(shared + FP.upd_off);
     const float *ext_tab = FP.ext_off >= 0 ? shared + FP.ext_off : nullptr;
     const float inv_win = FP.inv_win;
-    const float *guard_tab = shared + FP.guard_off;
+    // cepstra that arrive from HBM are the exact kernels' (continuous mode's slices, the second tier of a batch call): the DCT term
+    // of the guard does not apply to them (KwsFastPlan::guard_cep_off)
+    const float *guard_tab = shared + (FROM_CEP ? FP.guard_cep_off : FP.guard_off);
     const int *pad_idx = (const int *)(shared + FP.pad_off);
     const int win_size = P.win_size, prow = nfr + 2 * P.pad;
     const int cr = FP.cr, n_blocks = FP.n_blocks, n_labels = FP.n_labels;
@@ -694,7 +699,11 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const int clip_stride = gridDim.x * n_waves;
     float *const stash = F + FP.stash_off;                             // [0 .. NF): log-mel row, [47]: log frame energy
     bool have_stash = false;
-    for (int clip = blockIdx.x * n_waves + wave; clip < n_clips; clip += clip_stride) {
+    // sel: optional clip-selection list (sel[0] = count, sel[1 + i] = clip) -- the clips an earlier launch handed back
+    const int n_sel = sel_count(sel, n_clips);
+    for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci += clip_stride) {
+        const int clip = sel_clip(sel, ci);
+        const int next_clip = ci + clip_stride < n_sel ? sel_clip(sel, ci + clip_stride) : -1;        // the wave's next clip (paired tail pass)
         // ---- per-lane constants of the spectral phase (the FFT is kws_mfcc_kernel's: KissFFT's order, bit for bit).  They are
         //      re-derived per clip from a lane index the compiler cannot see through: hoisted out of the clip loop, the FFT's
         //      twiddles and the three dozen LDS addresses of the pair loop stay live through the DCT, cmvnw and convolution phases
@@ -808,10 +817,11 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         fast_i2 nxt[2][8];
         fetch(0, nxt);
         int touched = touch(1);
-        const bool pair_tail = n_tail == 1 && !have_stash && clip + clip_stride < n_clips;
+        const bool pair_tail = n_tail == 1 && !have_stash && next_clip >= 0;
         // the next clip's last frame: 256 samples = 512 bytes, warmed now so that the tail pass finds them in the cache
         int touched_tail = 0;
-        if (pair_tail && lane_c < 8) touched_tail = *(const int *)(xbase + (size_t)clip_stride * n_samples + (nfr - 1) * frame_stride + 32 * lane_c);
+        const int16_t *const xnext = pcm + (size_t)max(next_clip, 0) * n_samples;
+        if (pair_tail && lane_c < 8) touched_tail = *(const int *)(xnext + (nfr - 1) * frame_stride + 32 * lane_c);
         for (int q = 0; q < n_pass; ++q) {
             const int fbase = KWS_FAST_MEL_CHUNK * q;
             const int f = fbase + fg;
@@ -937,7 +947,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             //      clip's last frame on half 0 and the next clip's on half 1 --, a lane transforms four of its frame's 128 points per
             //      stage: kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32, each through an in-place,
             //      padded buffer behind the two power rows it feeds
-            const int16_t *const xb_t = (pair_tail && half == 1) ? xbase + (size_t)clip_stride * n_samples : xbase;
+            const int16_t *const xb_t = (pair_tail && half == 1) ? xnext : xbase;
             const int ft = pair_tail ? nfr - 1 : KWS_FAST_MEL_CHUNK * n_pass + half;
             const bool live_t = ft < nfr;
             const int s0 = min(ft, nfr - 1) * frame_stride + 8 * t;
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true, int QCP = 0>
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
-                         long long *prof_out, hipStream_t stream, const float *cep = nullptr, const KwsNnPlan *d_nn = nullptr)
+                         long long *prof_out, hipStream_t stream, const float *cep = nullptr, const KwsNnPlan *d_nn = nullptr, const int *sel = nullptr)
 {
     const size_t smem = ((size_t)FP.shared_floats + FP.q_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
     // the opt-in for more than 64 KB of dynamic LDS is per device (and this instantiation): one bit per device, set once
@@ -1315,7 +1325,7 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
     hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
-                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn);
+                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel);
     return (int)hipGetLastError();
 }
 
@@ -1358,15 +1368,16 @@ size_t kws_fast_qnet_bytes(int qcp)
 
 // cmvnw + (fused float network | features / int8 tensor) from cepstra in HBM, ring-indexed per P.ring_* (continuous mode)
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
-                                 float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream)
+                                 float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
+                                 const int *sel)
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
     // mel taps / DCT are not part of this variant: one instantiation serves every model
     return FP.fuse ? launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list,
-                                                      n_cu, nullptr, stream, cep)
+                                                      n_cu, nullptr, stream, cep, nullptr, sel)
                    : launch_fast_t<4, 4, false, true, false>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count,
-                                                             flag_list, n_cu, nullptr, stream, cep);
+                                                             flag_list, n_cu, nullptr, stream, cep, nullptr, sel);
 }
 
 // development aid: phase clocks (<= 4-tap builds only)

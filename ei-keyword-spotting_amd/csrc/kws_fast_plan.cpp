@@ -35,7 +35,11 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &shared)
 {
     const int ncep = h->model.dsp.num_cepstral, NF = h->model.dsp.num_filters;
-    const float kFeatureTol = 1.0e-4f;
+    // the score tolerance divided by the largest measured ratio score error / largest feature error of a clip (1.28: one clip of the
+    // "bursts" family through the 49x40 graph, found when the second tier first ran with 1e-4) -- for the terms whose constant is the
+    // largest value seen.  The DCT term uses the 99.9 % value of its error and the plain 1e-4 (see above): its tail is thin, and at the
+    // stricter tolerance a few hundredths of a percent of the bench's own clips would take the second tier for nothing
+    const float kFeatureTol = 1.0e-4f / 1.3f, kDctTol = 1.0e-4f;
     float e0 = 2.0e-6f, ek = 3.8e-7f * (float)NF, es = 1.0e-6f, kappa = 2.2e-6f, scale = 1.0f;
     if (const char *ev = getenv("KWS_DEV_FAST_GUARD_SCALE")) scale = (float)atof(ev);      // development aid: 0 switches the guard off (tools/gpu_fast_families.py)
     if (const char *ev = getenv("KWS_DEV_FAST_GUARD")) (void)sscanf(ev, "%f,%f,%f,%f", &e0, &ek, &es, &kappa);   // development aid: E[0], E[k], E[stale], kappa
@@ -45,13 +49,24 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
     for (int c = 0; c < round_up(ncep, F.cg); c++) {
         // column 0: the kernel drops the relative part whenever it has computed the exact window means, and it computes them whenever
         // the relative part could flag a window -- so towards the caller (kws_fast_guard) column 0 has none
-        const float a = scale * (c == 0 ? e0 : c <= NF / 2 ? ek : es) / kFeatureTol, r = scale * kappa / kFeatureTol;
+        const float a = scale * (c == 0 ? e0 / kFeatureTol : c <= NF / 2 ? ek / kDctTol : es / kFeatureTol), r = scale * kappa / kFeatureTol;
         // the kernel leaves the columns above NF/2 unscaled (the reference's carry 2 sqrt(1/2NF): cmvnw's output does not see a
         // per-column factor), so their deviations and means are 1 / unit times the reference's there
         const float unit = c > NF / 2 ? 2.0f * h->dsp.dct_s1 : 1.0f;
         shared.push_back(a / unit);
         shared.push_back(r);
         if (c < ncep) { h->fast_guard_abs.push_back(a); h->fast_guard_rel.push_back(c == 0 ? 0.0f : r); }
+    }
+    // Second table: the windows whose cepstra are the exact kernels' (bit-identical to the reference's): E[c] is gone, what remains is the
+    // window mean's kappa |mean| and a floor below which the reference's own rounding decides a near-constant column (its mean's noise
+    // scales with the magnitude of the summed values, which |mean| under-states for a column that changes sign: 2e-7 / kFeatureTol)
+    F.guard_cep_off = (int)shared.size();
+    h->fast_guard2_abs.clear(); h->fast_guard2_rel.clear();
+    for (int c = 0; c < round_up(ncep, F.cg); c++) {
+        const float a = scale * 2.0e-7f / kFeatureTol, r = scale * kappa / kFeatureTol;
+        shared.push_back(a);                       // FROM_CEP images hold the reference's values in every column: no unit change
+        shared.push_back(r);
+        if (c < ncep) { h->fast_guard2_abs.push_back(a); h->fast_guard2_rel.push_back(c == 0 ? 0.0f : r); }
     }
     // numpy::pad_1d_symmetric's row order, for the replayed window means of column 0
     std::vector<int> pmap;

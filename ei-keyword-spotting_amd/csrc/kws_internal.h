@@ -20,7 +20,7 @@
 
 // launchers in kws_mfcc.hip, kws_nn_int8.hip, kws_nn_f32.hip, kws_misc.hip
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
-                        int out_stride, int grid_cap, hipStream_t stream);
+                        int out_stride, int grid_cap, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_maf(float *scores, float *running_sum, float *maf_buf, int n, int buf_idx, int taps, hipStream_t stream);
 int kws_launch_unring(const float *src, float *dst, int n_streams, int rows, int cols, int ring_rows, int head, hipStream_t stream);
 int kws_launch_mfe(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mel_out, float *energy_out, const float *wrap,
@@ -34,7 +34,8 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
                        float *scores, int8_t *tap_pooled, int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap,
                        int *ran_nn, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
-                                 float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream);
+                                 float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
+                                 const int *sel = nullptr);
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
                       float *tap_logits, int n_cu, hipStream_t stream, const int *sel = nullptr);
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);
@@ -212,10 +213,13 @@ struct kws_handle {
     const KwsNnPlan *d_nn = nullptr;                    // the int8 plan in device memory (the fused form reads it from there)
     bool fast_plain_ok = false, fast_fused_ok = false, fast_q_ok = false;
     std::string fast_why;
+    std::vector<float> fast_guard2_abs, fast_guard2_rel;   // second tier (exact cepstra -> fast cmvnw + network)
     std::vector<float> fast_guard_abs, fast_guard_rel;    // host copy of the cmvnw guard's per-column thresholds (kws_fast_guard)
     int mode = KWS_MODE_EXACT;
-    int *d_flags = nullptr;       // [0] = count, [1 + i] = clip index
-    size_t flags_cap = 0;
+    int *d_flags = nullptr;       // [0] = count, [1 + i] = clip index: the clips the fast kernel handed back (first tier)
+    int *d_flags2 = nullptr;      // the same for the second tier: the clips that go to the exact cmvnw + network
+    float *s_cep = nullptr;       // [B][n_features] exact cepstra of the first tier's clips (indexed by clip)
+    size_t flags_cap = 0, cep_cap = 0;
 
     template <typename T> EI_IMPULSE_ERROR upload(const std::vector<T> &v, const T **out)
     {

@@ -644,12 +644,12 @@ int kws_launch_mfcc_fused_prof(const KwsDspPlan &P, const void *pcm, int n_clips
 // speechpy::feature::mfcc for n_clips windows -> mfcc_out[n_clips][n_frames*n_cepstral] (cepstra before cmvnw)
 // out_stride: floats between consecutive windows' outputs (0 = packed, n_frames*n_cepstral)
 int kws_launch_spectral(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
-                        int out_stride, int grid_cap, hipStream_t stream)
+                        int out_stride, int grid_cap, hipStream_t stream, const int *sel)
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (out_stride == 0) out_stride = P.n_frames * P.n_cepstral;
-    return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream)
-                        : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream);
+    return pcm_is_float ? launch_mfcc_t<true, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream, sel)
+                        : launch_mfcc_t<false, false, false>(P, pcm, n_clips, mfcc_out, nullptr, 0.f, 0, wrap, out_stride, grid_cap, nullptr, stream, sel);
 }
 
 // speechpy::feature::mfe (feature.hpp:193-318) for n_clips windows: mel energies + frame energies.  out_stride: floats between

@@ -67,13 +67,19 @@ EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode);   /* KWS_ERROR_UNSUPPORT
 int kws_get_mode(const kws_handle *h);
 /* 1: KWS_MODE_FAST runs this model's network fused behind the MFCC block (float32 CONV_2D graphs); 0: features go through HBM */
 int kws_fast_is_fused(const kws_handle *h);
-/* clips the last KWS_MODE_FAST call on this handle handed back to the exact kernels (synchronises the device) */
+/* What the last KWS_MODE_FAST batch call on this handle did with its clips (both synchronise the device):
+ *   kws_fast_fallback_count  clips the fast kernel (first tier) handed back.  They went to the SECOND tier: cepstra from the exact kernels
+ *                            (bit-identical to the reference's), then the fast cmvnw + network from those -- about 0.4 x the exact path;
+ *   kws_fast_exact_count     clips the second tier handed back in turn: they were finished by the exact kernels and carry the exact
+ *                            mode's bits.
+ * When a tier hands a clip back: a cmvnw window of cepstral column c whose deviation is below abs_thr[c] + rel_thr[c] * |window mean|
+ * (kws_fast_guard; tier 1: the fp32 re-ordering moves a coefficient by a bounded amount -- the DCT's outputs above all --, tier 2: only
+ * the reference's own summation order moves its window mean; both are divided by the deviation).  The arrays hold one
+ * value per cepstral coefficient of a frame; KWS_ERROR_UNSUPPORTED_MODEL if the model has no fast mode.
+ * kws_streams_step_device and kws_cmvn_inference_batch_device start from exact cepstra: their one fast tier is tier 2. */
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
-/* When a clip is handed back: a cmvnw window of cepstral column c whose deviation is below abs_thr[c] + rel_thr[c] * |window mean|
- * (the fp32 re-ordering moves a coefficient, and the reference's own summation order its window mean, by bounded amounts that cmvnw
- * divides by the deviation).  Both arrays hold one value per cepstral coefficient of a frame;
- * KWS_ERROR_UNSUPPORTED_MODEL if the model has no fast mode. */
-EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, float *abs_thr, float *rel_thr);
+EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);
+EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, int tier, float *abs_thr, float *rel_thr);
 
 /* The model used by the SDK-style entry points run_classifier()/run_inference().  If none was set,
  * the first call loads the file named by the environment variable KWS_MODEL on device KWS_DEVICE (0). */

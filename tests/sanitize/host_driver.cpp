@@ -32,7 +32,8 @@ static void walk(kws_handle *h)
     const bool is_float = kws_model_is_float(h) != 0;
     for (int mode = 0; mode < 2; mode++) {
         if (kws_set_mode(h, mode) != EI_IMPULSE_OK) continue;
-        (void)kws_fast_guard(h, thr.data(), rel.data());
+        (void)kws_fast_guard(h, 1, thr.data(), rel.data());
+        (void)kws_fast_guard(h, 2, thr.data(), rel.data());
         // "device" pointers are host heap under the stub: the entry points' host logic runs, launches are no-ops
         (void)kws_run_classifier_batch_device(h, pcm.data(), B, scores.data(), feats.data(), is_float ? nullptr : q.data(), nullptr);
         (void)kws_run_classifier_batch_device(h, pcm.data(), B, scores.data(), nullptr, nullptr, nullptr);
@@ -43,6 +44,7 @@ static void walk(kws_handle *h)
         (void)kws_run_inference_batch_device(h, feats.data(), B, scores.data(), nullptr);
         size_t nfb = 0;
         (void)kws_fast_fallback_count(h, &nfb);
+        (void)kws_fast_exact_count(h, &nfb);
     }
     (void)kws_set_mode(h, KWS_MODE_EXACT);
     (void)kws_run_classifier_batch(h, pcm.data(), B, scores.data(), feats.data(), is_float ? nullptr : q.data());
