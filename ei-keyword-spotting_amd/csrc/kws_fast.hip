@@ -639,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     const int lane = threadIdx.x & (KWS_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
     // a workgroup none of whose waves has a clip (the usually empty list of the second tier, a short list) leaves before it stages
     // its 50 KB of tables
-    if ((int)blockIdx.x * (int)(blockDim.x >> 6) >= sel_count(sel, n_clips)) return;
+    if (FROM_CEP && (int)blockIdx.x * (int)(blockDim.x >> 6) >= sel_count(sel, n_clips)) return;
     float *shared = lds;
     float *F = lds + FP.shared_floats + FP.q_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
     float *R1 = F + FP.f_floats;                                      // FFT buffers + power rows; later block 1's input image
@@ -700,10 +700,12 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
     float *const stash = F + FP.stash_off;                             // [0 .. NF): log-mel row, [47]: log frame energy
     bool have_stash = false;
     // sel: optional clip-selection list (sel[0] = count, sel[1 + i] = clip) -- the clips an earlier launch handed back
-    const int n_sel = sel_count(sel, n_clips);
+    // (only the forms that start from cepstra are launched over a list: the PCM forms see every clip, and their paired tail pass needs
+    // no list look-ups)
+    const int n_sel = FROM_CEP ? sel_count(sel, n_clips) : n_clips;
     for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci += clip_stride) {
-        const int clip = sel_clip(sel, ci);
-        const int next_clip = ci + clip_stride < n_sel ? sel_clip(sel, ci + clip_stride) : -1;        // the wave's next clip (paired tail pass)
+        const int clip = FROM_CEP ? sel_clip(sel, ci) : ci;
+        const int next_clip = ci + clip_stride < n_sel ? ci + clip_stride : -1;        // the wave's next clip (paired tail pass; PCM forms only)
         // ---- per-lane constants of the spectral phase (the FFT is kws_mfcc_kernel's: KissFFT's order, bit for bit).  They are
         //      re-derived per clip from a lane index the compiler cannot see through: hoisted out of the clip loop, the FFT's
         //      twiddles and the three dozen LDS addresses of the pair loop stay live through the DCT, cmvnw and convolution phases
