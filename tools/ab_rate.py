@@ -47,7 +47,11 @@ def main():
     res = {}
     for _ in range(rounds):
         for v in variants:
-            env = dict(os.environ, KWS_LIB=os.path.join(ROOT, "ab_tmp", "libkws_%s.so" % v))
+            # a variant "name+VAR" runs libkws_name.so with the environment variable VAR=1 (development switches of the library)
+            name, _, var = v.partition("+")
+            env = dict(os.environ, KWS_LIB=os.path.join(ROOT, "ab_tmp", "libkws_%s.so" % name))
+            if var:
+                env[var] = "1"
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", models, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if out.returncode != 0:
                 print(v, "FAILED", out.stderr[-800:])
