@@ -16,20 +16,27 @@ import sys
 
 
 def per_kernel(path, counter):
+    """average counter value per launch, per INSTANTIATION (a step launches several instantiations of a kernel template -- the hot one and
+    the usually empty re-run forms -- which must not be averaged together); reported under the template's name: the instantiation that
+    moves the most"""
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"]
-        short = name.split("(")[0].split("<")[0].replace("void ", "").strip()
-        acc[short].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+        full = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        acc[full].append(float(r["Counter_Value"]))
+    best = {}
+    for full, v in acc.items():
+        short, mean = full.split("<")[0].strip(), sum(v) / len(v)
+        if short not in best or mean > best[short][0]:
+            best[short] = (mean, full)
+    return {k: m for k, (m, _) in best.items()}, {k: f for k, (_, f) in best.items()}
 
 
 def main():
     fetch, write, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     model = sys.argv[5] if len(sys.argv) > 5 else "cfg2_mfcc40_f32.kwsm"
-    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    (f, f_inst), (w, _) = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ei-keyword-spotting_amd", "libkws_mi355x.so")
     res = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
            "command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
@@ -42,13 +49,13 @@ def main():
         if not k.startswith("kws"):
             continue
         rd, wr = int(f.get(k, 0.0) * 1024 * 2), int(w.get(k, 0.0) * 1024)
-        res["kernels"][k] = {"FETCH_SIZE_KiB_avg": f.get(k, 0.0), "WRITE_SIZE_KiB_avg": w.get(k, 0.0),
+        res["kernels"][k] = {"instantiation": f_inst.get(k, k), "FETCH_SIZE_KiB_avg": f.get(k, 0.0), "WRITE_SIZE_KiB_avg": w.get(k, 0.0),
                              "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic_bytes": rd + wr}
     # SQ counters of the same library, if tools/pmc_sets.sh wrote a summary next to the output
     sq = os.path.join(os.path.dirname(os.path.abspath(out)), "summary.json")
     if os.path.exists(sq):
         res["sq"] = {}
-        for name, cs in json.load(open(sq)).items():
+        for name, cs in sorted(json.load(open(sq)).items(), key=lambda kv: kv[1].get("SQ_INSTS_VALU", 0.0)):      # the busiest instantiation last: it wins
             short = name.split("<")[0].strip()
             if "SQ_INSTS_VALU" in cs and "SQ_WAVE_CYCLES" in cs:
                 res["sq"][short] = {"VALU_instructions_per_clip": round(cs["SQ_INSTS_VALU"] / batch, 1),
