@@ -428,7 +428,7 @@ def main():
                 else "bit-exact vs reference") + " -- tests/test_gpu_parity.py"
 
     def dominant(x):
-        return "kws_fast_kernel" if x["mode"] == "fast" else "kws_mfcc_kernel"
+        return "kws_fast_kernel" if x["mode"] == "fast" else "kws_mfcc8_kernel"
 
     def dtype(x):
         return ("f32 (MFCC, KissFFT-order FFT) / %s (CNN)" if x["mode"] == "fast" else "f32+f64 (MFCC) / %s (CNN)") % ("f32" if x["is_float"] else "i8")
@@ -444,7 +444,7 @@ def main():
             "algorithmic_bytes_per_launch": algo_bytes * B, "algorithmic_bytes_per_clip": algo_bytes,
             "hot_path_ms": round(r["ms_path"], 4),
             "hot_path_ms_note": "HIP events on the launch stream around the hot-path call of every timed step (fast mode, fused graph: one "
-                                "kws_fast_kernel launch + three empty-list launches of the exact kernels; exact mode: kws_mfcc_kernel + the network kernel)",
+                                "kws_fast_kernel launch + three empty-list launches of the exact kernels; exact mode: kws_mfcc8_kernel + the network kernel)",
             "note": "not HBM-bound: two waves per SIMD (14 KB of LDS per wave), VALU / LDS / MFMA issue and LDS round trips bound the kernel; see valu",
             "valu": pmc[2] if pmc else None}
     out = {

@@ -67,6 +67,40 @@ __device__ __forceinline__ void bfly4(cf &f0, cf &f1, cf &f2, cf &f3, cf t1, cf 
     f3.i = s5.i + s4.r;
 }
 
+// kf_bfly4 with unit twiddles (k = 0): the three products by (1, 0) are exact up to the sign of a zero
+__device__ __forceinline__ void bfly4_unit(cf &f0, cf &f1, cf &f2, cf &f3)
+{
+    const cf s0 = f1, s1 = f2, s2 = f3;
+    cf s5 = csub(f0, s1);
+    f0 = cadd(f0, s1);
+    cf s3 = cadd(s0, s2), s4 = csub(s0, s2);
+    f2 = csub(f0, s3);
+    f0 = cadd(f0, s3);
+    f1.r = s5.r + s4.i;
+    f1.i = s5.i - s4.r;
+    f3.r = s5.r - s4.i;
+    f3.i = s5.i + s4.r;
+}
+
+// Four consecutive samples x[e - 2 .. e + 1] (e even) as two dwords: complex FFT input n of a frame is (y[2n], y[2n + 1]) with
+// y[s] = x[s] - cof x[s - 1] (processing.hpp:104-106), so a point needs three of them.  4-byte aligned, not 8.
+typedef int fast_i2 __attribute__((ext_vector_type(2), aligned(4)));
+
+// the point of fast_i2 v in the reference's own arithmetic: numpy::int16_to_float (numpy.hpp:1289), then processing::preemphasis
+// (processing.hpp:104-106): y[s] = x[s] - (cof * x[s - 1]), product and difference rounded separately
+__device__ __forceinline__ cf exact_point(fast_i2 v, float pre_cof)
+{
+    const float prev = (float)(v.x >> 16) * (1.0f / 32768.0f);
+    const float lo = (float)(short)(v.y & 0xffff) * (1.0f / 32768.0f);
+    const float hi = (float)(v.y >> 16) * (1.0f / 32768.0f);
+    cf z;
+    const float pl = pre_cof * prev;
+    z.r = lo - pl;
+    const float ph_ = pre_cof * lo;
+    z.i = hi - ph_;
+    return z;
+}
+
 __device__ __forceinline__ cf ld_cf(const float *b, int n) { n += 8 * (n >> 5); float2 v = *(const float2 *)(b + 2 * n); cf c; c.r = v.x; c.i = v.y; return c; }
 __device__ __forceinline__ void st_cf(float *b, int n, cf c) { n += 8 * (n >> 5); *(float2 *)(b + 2 * n) = make_float2(c.r, c.i); }
 __device__ __forceinline__ cf to_cf(float2 v) { cf c; c.r = v.x; c.i = v.y; return c; }

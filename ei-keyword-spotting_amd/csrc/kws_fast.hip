@@ -60,9 +60,6 @@ __device__ __forceinline__ float group_sum(float v, int S)
     return v;
 }
 
-// Four consecutive samples x[e - 2 .. e + 1] (e even) as two dwords: complex FFT input n of a frame is (y[2n], y[2n + 1]) with
-// y[s] = x[s] - cof x[s - 1] (processing.hpp:104-106), so a point needs three of them.  4-byte aligned, not 8.
-typedef int fast_i2 __attribute__((ext_vector_type(2), aligned(4)));
 // The int16 -> float scale 2^-15 (numpy.hpp:1289) is not applied here: pre-emphasis, the FFT and the split are linear and every
 // one of their roundings commutes with a power of two, so the factor is folded -- exactly -- into the power spectrum's scale.
 __device__ __forceinline__ cf fast_point(fast_i2 v, float pre_cof)
@@ -76,20 +73,6 @@ __device__ __forceinline__ cf fast_point(fast_i2 v, float pre_cof)
     const float ph_ = pre_cof * lo;
     z.i = hi - ph_;
     return z;
-}
-// kf_bfly4 with unit twiddles (k = 0): the three products by (1, 0) are exact up to the sign of a zero
-__device__ __forceinline__ void bfly4_unit(cf &f0, cf &f1, cf &f2, cf &f3)
-{
-    const cf s0 = f1, s1 = f2, s2 = f3;
-    cf s5 = csub(f0, s1);
-    f0 = cadd(f0, s1);
-    cf s3 = cadd(s0, s2), s4 = csub(s0, s2);
-    f2 = csub(f0, s3);
-    f0 = cadd(f0, s3);
-    f1.r = s5.r + s4.i;
-    f1.i = s5.i - s4.r;
-    f3.r = s5.r - s4.i;
-    f3.i = s5.i + s4.r;
 }
 // sum over the eight lanes of a frame group; every lane of the group receives it
 __device__ __forceinline__ float oct_sum(float v)

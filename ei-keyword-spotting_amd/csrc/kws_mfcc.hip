@@ -5,6 +5,12 @@
 // Two shapes of the same code: the throughput shape (one wave per clip, persistent grid) and, for calls with a handful of
 // windows, the latency shape (LW waves per clip: frames and cmvnw tasks dealt out over a workgroup).  Built without the SLP
 // vectoriser (see the Makefile); the DCT constants are literals (kws_dct_tables.h).
+// kws_mfcc8_kernel (further down) is the throughput shape for int16 PCM on the spectral layout of kws_fast_kernel -- eight lanes
+// per frame, one LDS exchange per FFT instead of three -- with the same arithmetic, operation by operation; kws_mfcc_kernel keeps
+// the float-sample calls (the SDK's signal_t callback), the latency shape, and stays selectable for int16 PCM through the
+// development switch KWS_DEV_MFCC_OLD_LAYOUT (tools/gpu_mfcc_layout_check.py compares the two bit for bit, stage by stage).
+#include <stdlib.h>
+
 #include "kws_device.h"
 #include "kws_dct_tables.h"
 
@@ -549,6 +555,481 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
 }
 
 // ---------------------------------------------------------------------------------------------------------
+//  Kernel 1b: the same function -- same arithmetic, operation by operation -- on the spectral layout kws_fast_kernel introduced
+//  (round 3): eight lanes own a frame and sixteen of its 128 complex points each, eight frames per pass, so that kf_bfly2 (m = 1),
+//  kf_bfly4 (m = 2) and, after ONE exchange through LDS, kf_bfly4 m = 8 and m = 32 all run in registers (kiss_fft.cpp:15-84,
+//  232-296); kws_mfcc_kernel's layout (32 lanes per frame, four points per lane) takes three exchanges per frame pair.  The lanes
+//  of a frame swap the upper halves of their points for kiss_fftr's split (kiss_fftr.cpp:84-119); the power spectrum goes through
+//  fp64 as in the reference (bin_power); a pass's eight power rows feed the frame energies (129 ordered additions, one lane per
+//  frame) and the mel stage (lane = filter, the taps in registers).  DCT and cmvnw are kws_mfcc_kernel's.  int16 PCM only, one
+//  wave per window; float samples and the latency shape stay with kws_mfcc_kernel.
+//  13 KB of LDS per wave (the exchange buffer, the power rows, the tail pass's buffers and cmvnw's tables share one region) + the mel taps.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KWS_M8_CHUNK = 8;      // frames per pass
+constexpr int KWS_M8_XS = 144;       // floats per frame of the exchange buffer: 64 positions + 2 floats of padding per 8
+constexpr int KWS_M8_PS = 136;       // floats per power row (129 bins): = 8 mod 64, the eight frames' stores of one bin cover the banks
+constexpr int KWS_M8_MAP = 640;      // cmvnw's pad map sits behind its offset table (kws_mfcc_max_win: at most 640 offsets)
+template <int NF, int NZ>
+struct alignas(16) Mfcc8Smem {
+    static constexpr int MELS = NF + 1;
+    float r1[KWS_M8_CHUNK * KWS_M8_XS];
+    float mel[kws_mel_rows(NF) * MELS];
+    float energy[kws_mel_rows(NF)];
+    // the mel filters' ascending-bin taps [tap][filter]: weight and bin (as an offset into a power row); taps beyond a filter's end have
+    // weight 0 and read bin 0.  In registers they would stay live through the FFT (2 x 2 NZ values per lane) and be spilled.
+    float tap_w[NZ * NF];
+    int tap_b[NZ * NF];
+};
+static_assert(KWS_M8_CHUNK * KWS_M8_PS <= KWS_M8_CHUNK * KWS_M8_XS && 2 * KWS_M8_PS + 2 * KWS_ZF <= KWS_M8_CHUNK * KWS_M8_XS &&
+              KWS_M8_MAP + KWS_MAXPROW <= KWS_M8_CHUNK * KWS_M8_XS, "everything that shares Mfcc8Smem::r1 fits");
+static_assert(sizeof(Mfcc8Smem<32, KWS_MAXNZ>) <= 20 * 1024 && sizeof(Mfcc8Smem<40, KWS_MAXNZ>) <= 20 * 1024, "8 waves per CU need <= 20 KB LDS each");
+
+template <bool WITH_CMVN, int NZ, int NF, bool PROF, bool WIDE, int OCC>
+__global__ __launch_bounds__(KWS_WAVE, OCC) void kws_mfcc8_kernel(KwsDspPlan P, const int16_t *__restrict__ pcm, int n_clips,
+                                                                  float *__restrict__ features, int8_t *__restrict__ q_out,
+                                                                  float in_scale, int in_zp, const float *__restrict__ wrap, int out_stride,
+                                                                  long long *prof_out = nullptr, const int *__restrict__ sel = nullptr)
+{
+    constexpr int MELS = NF + 1, NCEPT = NF / 2 + 1, PS = KWS_M8_PS, XS = KWS_M8_XS;
+    __shared__ Mfcc8Smem<NF, NZ> sm;
+    const int lane = threadIdx.x;
+    float *const xw = sm.r1, *const pw = sm.r1;                        // the FFT's exchange buffer; the power rows reuse it
+    int *const offt = (int *)sm.r1, *const sm_map = (int *)sm.r1 + KWS_M8_MAP;   // cmvnw's tables: the spectral buffers are dead by then
+    const int nfr = P.n_frames, ncep = P.n_cepstral, prow = nfr + 2 * P.pad;
+    // a remainder of one or two frames (the 49th of the standard window) would cost a whole eight-frame pass: it gets a tail pass
+    // with 32 lanes per frame (kws_mfcc_kernel's layout)
+    const int n_tail = (nfr >= KWS_M8_CHUNK && (nfr & 7) != 0 && (nfr & 7) <= 2) ? (nfr & 7) : 0;
+    const int n_pass = n_tail ? nfr / KWS_M8_CHUNK : (nfr + KWS_M8_CHUNK - 1) / KWS_M8_CHUNK;
+    const float pre_cof = P.pre_cof, inv_fft = P.inv_fft;
+    const int frame_stride = P.frame_stride, n_samples = P.n_samples;
+    long long ph[KWS_NPHASE] = { 0 }, tlast = PROF ? clock64() : 0;
+    if (lane < NF) {
+        const int s0 = P.filt_start[lane], e0 = P.filt_start[lane + 1];
+#pragma unroll
+        for (int n = 0; n < NZ; ++n) {
+            const bool on = s0 + n < e0;
+            sm.tap_b[n * NF + lane] = on ? P.filt_bin[s0 + n] : 0;
+            sm.tap_w[n * NF + lane] = on ? P.filt_w[s0 + n] : 0.0f;
+        }
+    }
+    WAVE_SYNC();
+
+    const int n_sel = sel_count(sel, n_clips);
+    int touched_next = 0;
+    for (int ci = blockIdx.x; ci < n_sel; ci += gridDim.x) {
+        const int clip = sel_clip(sel, ci);
+        // per-lane constants of the spectral phase, re-derived per clip from a lane index the compiler cannot see through: hoisted out
+        // of the clip loop they would stay live through cmvnw (three dozen registers) for ~100 L2-resident loads per clip
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+        const int fl = lane_c & 7, fg = lane_c >> 3;
+        // blocks fl (output positions 8 fl ..) and fl + 8: block j = 4 i1 + i2 reads input points i1 + 4 i2 + 16 i3 + 64 i4
+        const int nbA = (fl >> 2) + 4 * (fl & 3);
+        const cf a1 = to_cf(P.tw[16]), a2 = to_cf(P.tw[32]), a3 = to_cf(P.tw[48]);
+        const cf b1 = to_cf(P.tw[4 * fl]), b2 = to_cf(P.tw[8 * fl]), b3 = to_cf(P.tw[12 * fl]);
+        cf c1[4], c2[4], c3[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { c1[a] = to_cf(P.tw[fl + 8 * a]); c2[a] = to_cf(P.tw[2 * (fl + 8 * a)]); c3[a] = to_cf(P.tw[3 * (fl + 8 * a)]); }
+        // split twiddles of this lane's eight bin pairs (k, 128 - k), k = fl + 8 a + 32 b for b < 2; lane 0's first pair is (64, 64)
+        cf stw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = fl + 8 * (q & 3) + 32 * (q >> 2);
+            stw[q] = to_cf(P.stw[(k == 0 ? KWS_NC / 2 : k) - 1]);
+        }
+        const int xwr = fg * XS + 18 * fl;                              // exchange buffer: position p of a frame at 2 p + 2 (p / 8)
+        const int xrd = fg * XS + 2 * fl;
+        const int partner = (lane_c & ~7) | ((8 - fl) & 7);
+        const int half = lane_c >> 5, t = lane_c & 31;
+        const int16_t *xbase = pcm + (size_t)clip * n_samples;
+        // x[-1] of the window's first sample: its last sample (processing.hpp:68, 104-106) unless the caller says otherwise (continuous mode)
+        const float wrap_prev = wrap ? wrap[clip] : (float)xbase[n_samples - 1] * (1.0f / 32768.0f);
+        // a point's four samples x[2n - 2 .. 2n + 1] of frame f, requested one pass ahead
+        auto fetch = [&](int q, fast_i2 (&raw)[2][8]) {
+            const int f = min(KWS_M8_CHUNK * q + fg, nfr - 1);
+            const int16_t *xf = xbase + (f * frame_stride + 2 * nbA - 2);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int16_t *src = xf + (4 * blk + 32 * (i >> 1) + 128 * (i & 1));
+                    if (blk == 0 && i == 0) src = src < xbase ? xbase : src;
+                    raw[blk][i] = *(const fast_i2 *)src;
+                }
+        };
+        // the frames of the pass after that: one 64-byte segment per lane, a pass before the real requests (see kws_fast_kernel)
+        auto touch = [&](int q) {
+            const int f = min(KWS_M8_CHUNK * q + fg, nfr - 1);
+            return *(const int *)(xbase + (f * frame_stride + 32 * fl));
+        };
+        // ---- frame energy (feature.hpp:289-298): sequential fp32 sum over the 129 bins of a power row (numpy.hpp:88-94) ----------
+        auto energy_of = [&](const float *pl, int f) {
+            float e = 0.0f;
+            float4 cur[8], nxt4[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = *(const float4 *)(pl + 4 * u);
+#pragma unroll
+            for (int k0 = 0; k0 < KWS_NBINS - 1; k0 += 32) {
+                if (k0 + 32 < KWS_NBINS - 1) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) nxt4[u] = *(const float4 *)(pl + k0 + 32 + 4 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { e += cur[u].x; e += cur[u].y; e += cur[u].z; e += cur[u].w; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cur[u] = nxt4[u];
+            }
+            e += pl[KWS_NBINS - 1];
+            if (e == 0.0f) e = FLT_EPSILON;                                           // feature.hpp:296-298
+            sm.energy[f] = e;
+            if constexpr (!WITH_CMVN)
+                if (P.mfe_energy) P.mfe_energy[(size_t)clip * nfr + f] = e;
+        };
+        // ---- mel filterbank for the frames of a pass: dot_by_row (numpy.hpp:183-211) as an ascending-bin gather, zero handling, log.
+        //      pairs = pairs of frame slots a lane half walks (2: slots 4 h .. 4 h + 3 of an eight-frame pass; 1: the tail pass, slots 0, 1)
+        auto mel_phase = [&](int fbase, int nfc, int pairs) {
+            const float *p1 = pw + 4 * half * PS, *p2 = pw + fg * PS;
+            float macc[5] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
+            {
+                // filter lane & 31 for four of the pass's frame slots
+                float w1[NZ];
+                int fb1[NZ];
+#pragma unroll
+                for (int n = 0; n < NZ; ++n) { w1[n] = sm.tap_w[n * NF + t]; fb1[n] = sm.tap_b[n * NF + t]; }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2 += 2) {
+                    if (s2 >= 2 * pairs) break;
+                    float xv[2][NZ];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int n = 0; n < NZ; ++n) xv[s][n] = p1[(s2 + s) * PS + fb1[n]];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int n = 0; n < NZ; ++n) {
+                            const float prod = xv[s][n] * w1[n];
+                            acc += prod;
+                        }
+                        macc[s2 + s] = acc;
+                    }
+                }
+            }
+            if constexpr (NF > 32) {
+                // with 40 filters also filter 32 + lane & 7 for one slot
+                float w2[NZ], xv2[NZ];
+#pragma unroll
+                for (int n = 0; n < NZ; ++n) { w2[n] = sm.tap_w[n * NF + 32 + fl]; xv2[n] = p2[sm.tap_b[n * NF + 32 + fl]]; }
+                float acc = 0.0f;
+#pragma unroll
+                for (int n = 0; n < NZ; ++n) {
+                    const float prod = xv2[n] * w2[n];
+                    acc += prod;
+                }
+                macc[4] = acc;
+            }
+            auto put = [&](int slot, int j, float a) {
+                if (a == 0.0f) a = FLT_EPSILON;                                       // functions.hpp:63-69
+                if constexpr (!WITH_CMVN)
+                    if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)ring_out_row(P, fbase + slot) * NF + j] = a;
+                sm.mel[(fbase + slot) * MELS + j] = fast_log(a);
+            };
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int slot = 4 * half + s;
+                if (s < 2 * pairs && slot < nfc && t < NF) put(slot, t, macc[s]);
+            }
+            if constexpr (NF > 32)
+                if (fg < nfc && 32 + fl < NF) put(fg, 32 + fl, macc[4]);
+        };
+
+        fast_i2 nxt[2][8];
+        fetch(0, nxt);
+        asm volatile("" : : "v"(touched_next));
+        int touched = touch(1);
+        for (int q = 0; q < n_pass; ++q) {
+            const int fbase = KWS_M8_CHUNK * q;
+            const int f = fbase + fg;
+            const bool live = f < nfr;
+            cf u[4][4];                                                  // after the exchange: u[a][b] = position fl + 8 a + 32 b
+            {
+                cf z[2][8];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) z[blk][i] = exact_point(nxt[blk][i], pre_cof);
+                if (f == 0 && fl == 0) {                                 // the clip's first sample: its predecessor wraps
+                    const fast_i2 v = nxt[0][0];                         // (the request was clamped to the window's start: v.x = x[0], x[1])
+                    const float lo = (float)(short)(v.x & 0xffff) * (1.0f / 32768.0f), hi = (float)(v.x >> 16) * (1.0f / 32768.0f);
+                    const float pl = pre_cof * wrap_prev;
+                    z[0][0].r = lo - pl;
+                    const float ph_ = pre_cof * lo;
+                    z[0][0].i = hi - ph_;
+                }
+                // unconditional (the frame index is clamped): a conditional request makes the compiler copy all sixteen register
+                // pairs around the branch
+                fetch(q + 1, nxt);
+                asm volatile("" : : "v"(touched));
+                touched = touch(q + 2);
+                PH(0);
+                // kf_bfly2 (m = 1, twiddle 1) on the (i4 = 0, 1) pairs, then kf_bfly4 (m = 2) on the sums (k = 0) and the
+                // differences (k = 1): outputs 8 j + k + 2 i
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    cf sv[4], df[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sv[i] = cadd(z[blk][2 * i], z[blk][2 * i + 1]); df[i] = csub(z[blk][2 * i], z[blk][2 * i + 1]); }
+                    bfly4_unit(sv[0], sv[1], sv[2], sv[3]);
+                    bfly4(df[0], df[1], df[2], df[3], a1, a2, a3);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { z[blk][2 * i] = sv[i]; z[blk][2 * i + 1] = df[i]; }
+                }
+                // the exchange, half a frame at a time (64 positions per frame fit the buffer): block fl feeds b = 0, 1
+#pragma unroll
+                for (int rnd = 0; rnd < 2; ++rnd) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) *(float2 *)(xw + xwr + 2 * r) = make_float2(z[rnd][r].r, z[rnd][r].i);
+                    WAVE_SYNC();
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const float2 v = *(const float2 *)(xw + xrd + 18 * a + 72 * b);
+                            u[a][2 * rnd + b].r = v.x; u[a][2 * rnd + b].i = v.y;
+                        }
+                    WAVE_SYNC();
+                }
+            }
+            // kf_bfly4 m = 8 (k = fl) inside every block of 32, then m = 32 (k = fl + 8 a) across them
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bfly4(u[0][b], u[1][b], u[2][b], u[3][b], b1, b2, b3);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) bfly4(u[a][0], u[a][1], u[a][2], u[a][3], c1[a], c2[a], c3[a]);
+            PH(1);
+            // ---- kiss_fftr split (kiss_fftr.cpp:84-119) and the power spectrum (bin_power).  Bin pair (k, 128 - k) needs positions
+            //      k and 128 - k: the second lives in lane (8 - fl) % 8 at (3 - a, 3 - b) -- in lane 0 itself, one position further --
+            //      so the lanes swap their upper halves.
+            {
+                float *prw = pw + fg * PS;                           // (a row of a dead frame slot is written too, never used)
+                const bool lane0 = fl == 0;
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) {
+                    const int a = qq & 3, b = qq >> 2;
+                    cf other;
+                    other.r = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(u[3 - a][3 - b].r)));
+                    other.i = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(u[3 - a][3 - b].i)));
+                    cf fpk = u[a][b];
+                    int k = fl + 8 * a + 32 * b;
+                    {
+                        // lane 0: 128 - k = 8 (16 - a - 4 b) is position index 16 - qq of the lane itself; its pair 0 is (64, 64)
+                        const int o = qq == 0 ? 8 : 16 - qq;
+                        other.r = lane0 ? u[o & 3][o >> 2].r : other.r;
+                        other.i = lane0 ? u[o & 3][o >> 2].i : other.i;
+                        if (qq == 0) { fpk.r = lane0 ? u[0][2].r : fpk.r; fpk.i = lane0 ? u[0][2].i : fpk.i; k = lane0 ? KWS_NC / 2 : k; }
+                    }
+                    cf fpnk; fpnk.r = other.r; fpnk.i = -other.i;
+                    const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    const cf twv = cmul(f2k, stw[qq]);
+                    cf lo, hi;
+                    lo.r = (f1k.r + twv.r) * 0.5f;                   // HALF_OF
+                    lo.i = (f1k.i + twv.i) * 0.5f;
+                    hi.r = (f1k.r - twv.r) * 0.5f;
+                    hi.i = (twv.i - f1k.i) * 0.5f;
+                    // bin 64 is written twice by the reference and the second store (the "ncfft - k" one) wins: same order here
+                    prw[k] = bin_power(lo, inv_fft);
+                    prw[KWS_NC - k] = bin_power(hi, inv_fft);
+                }
+                if (lane0) {                                         // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
+                    cf dc, ny;
+                    dc.r = u[0][0].r + u[0][0].i; dc.i = 0.0f;
+                    ny.r = u[0][0].r - u[0][0].i; ny.i = 0.0f;
+                    prw[0] = bin_power(dc, inv_fft);
+                    prw[KWS_NC] = bin_power(ny, inv_fft);
+                }
+            }
+            WAVE_SYNC();
+            PH(2);
+            if (fl == 0 && live) energy_of(pw + fg * PS, f);
+            PH(3);
+            mel_phase(fbase, min(KWS_M8_CHUNK, nfr - fbase), 2);
+            WAVE_SYNC();                                             // the next pass's exchange overwrites the power rows
+            PH(4);
+        }
+
+        if (n_tail) {
+            // ---- tail pass: frame 8 n_pass + h on lane half h, a lane transforms four of its frame's 128 points per stage (kws_mfcc_kernel's
+            //      butterflies): kf_bfly2 (m = 1) fused with kf_bfly4 (m = 2), then kf_bfly4 m = 8 and m = 32, each through an in-place,
+            //      padded buffer behind the two power rows it feeds
+            const int ft = KWS_M8_CHUNK * n_pass + half;
+            const bool live_t = ft < nfr;
+            const int s0 = min(ft, nfr - 1) * frame_stride + 8 * t;
+            const int4 rawv = *(const int4 *)(xbase + s0);
+            // (s0 = 0 needs a window of one frame: no tail pass then)
+            const float rawp = s0 == 0 ? wrap_prev : (float)xbase[s0 - 1] * (1.0f / 32768.0f);
+            const int k01 = t & 1, g01 = t >> 1, n0 = (g01 >> 2) + 4 * (g01 & 3), K2 = t & 7, G2 = t >> 3;
+            const cf ta1 = to_cf(P.tw[16 * k01]), ta2 = to_cf(P.tw[32 * k01]), ta3 = to_cf(P.tw[48 * k01]);
+            const cf tb1 = to_cf(P.tw[4 * K2]), tb2 = to_cf(P.tw[8 * K2]), tb3 = to_cf(P.tw[12 * K2]);
+            const cf tc1 = to_cf(P.tw[t]), tc2 = to_cf(P.tw[2 * t]), tc3 = to_cf(P.tw[3 * t]);
+            float *zb = sm.r1 + 2 * PS + half * KWS_ZF;
+            {
+                float y[8];
+                float prev = rawp;
+                const int w[4] = { rawv.x, rawv.y, rawv.z, rawv.w };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = (float)(short)(w[i] & 0xffff) * (1.0f / 32768.0f);   // numpy::int16_to_float
+                    const float hi = (float)(short)(w[i] >> 16) * (1.0f / 32768.0f);
+                    const float pl = pre_cof * prev;
+                    y[2 * i] = lo - pl;
+                    const float ph_ = pre_cof * lo;
+                    y[2 * i + 1] = hi - ph_;
+                    prev = hi;
+                }
+                *(float4 *)(zb + 2 * zi(4 * t)) = make_float4(y[0], y[1], y[2], y[3]);
+                *(float4 *)(zb + 2 * zi(4 * t) + 4) = make_float4(y[4], y[5], y[6], y[7]);
+            }
+            WAVE_SYNC();
+            PH(0);
+            cf v[4];
+            {
+                cf la[4], lb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { la[i] = ld_cf(zb, n0 + 16 * i); lb[i] = ld_cf(zb, n0 + 16 * i + 64); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = k01 ? csub(la[i], lb[i]) : cadd(la[i], lb[i]);
+            }
+            bfly4(v[0], v[1], v[2], v[3], ta1, ta2, ta3);
+            WAVE_SYNC();                                              // every lane has read its inputs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_cf(zb, 8 * g01 + k01 + 2 * i, v[i]);
+            WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ld_cf(zb, 32 * G2 + K2 + 8 * i);
+            bfly4(v[0], v[1], v[2], v[3], tb1, tb2, tb3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_cf(zb, 32 * G2 + K2 + 8 * i, v[i]);
+            WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ld_cf(zb, t + 32 * i);
+            bfly4(v[0], v[1], v[2], v[3], tc1, tc2, tc3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_cf(zb, t + 32 * i, v[i]);
+            WAVE_SYNC();
+            PH(1);
+            {
+                const cf st1 = to_cf(P.stw[t]), st2 = to_cf(P.stw[t + 32]);
+                cf fpk[2], fq[2];
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;
+                    fpk[rep] = ld_cf(zb, k);
+                    fq[rep] = ld_cf(zb, KWS_NC - k);
+                }
+                const float2 d0 = *(const float2 *)zb;                // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
+                float *prw = pw + half * PS;
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep) {
+                    const int k = t + 1 + 32 * rep;
+                    const cf stw_ = rep ? st2 : st1;
+                    cf fpnk; fpnk.r = fq[rep].r; fpnk.i = -fq[rep].i;
+                    const cf f1k = cadd(fpk[rep], fpnk), f2k = csub(fpk[rep], fpnk);
+                    const cf twv = cmul(f2k, stw_);
+                    cf lo, hi;
+                    lo.r = (f1k.r + twv.r) * 0.5f;
+                    lo.i = (f1k.i + twv.i) * 0.5f;
+                    hi.r = (f1k.r - twv.r) * 0.5f;
+                    hi.i = (twv.i - f1k.i) * 0.5f;
+                    const float plo = bin_power(lo, inv_fft), phi = bin_power(hi, inv_fft);
+                    if (k != KWS_NC / 2) prw[k] = plo;                // bin 64 is written twice by the reference: the second store wins
+                    prw[KWS_NC - k] = phi;
+                }
+                if (t == 0) {
+                    cf dc, ny;
+                    dc.r = d0.x + d0.y; dc.i = 0.0f;
+                    ny.r = d0.x - d0.y; ny.i = 0.0f;
+                    prw[0] = bin_power(dc, inv_fft);
+                    prw[KWS_NC] = bin_power(ny, inv_fft);
+                }
+            }
+            WAVE_SYNC();
+            PH(2);
+            if (t == 0 && live_t) energy_of(pw + half * PS, ft);
+            PH(3);
+            mel_phase(KWS_M8_CHUNK * n_pass, n_tail, 1);
+            WAVE_SYNC();
+            PH(4);
+        }
+
+        if constexpr (!WITH_CMVN)
+            if (P.mfe_mel) { WAVE_SYNC(); continue; }                                   // MFE block: no log / DCT output
+        // ---- DCT-II via NF-point kiss_fftr, one frame per lane (numpy.hpp:378-401, fast-dct-fft.cpp:37-80): the cepstra of a frame
+        //      replace its log-mel row in place (row stride MELS); cmvnw's pad map moves into the dead spectral buffers
+        // (lane-derived constants of the DCT and of cmvnw are re-derived per clip as well: hoisted out of the clip loop they are spilled)
+        int lane_d = lane;
+        asm volatile("" : "+v"(lane_d));
+        for (int i = lane_d; i < prow; i += KWS_WAVE) sm_map[i] = P.pad_map[i];
+        // the wave's next clip: its first pass's samples are warmed in the cache while cmvnw runs
+        if (ci + (int)gridDim.x < n_sel) {
+            const int16_t *xn = pcm + (size_t)sel_clip(sel, ci + gridDim.x) * n_samples;
+            touched_next = *(const int *)(xn + (min(fg, nfr - 1) * frame_stride + 32 * fl));
+        }
+        if (lane_d < nfr) {
+            float v[NF];
+            float *mrow = sm.mel + lane_d * MELS;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) v[i] = mrow[i];
+            float *orow = WITH_CMVN ? mrow : features + (size_t)clip * out_stride + ring_out_row(P, lane_d) * ncep;
+            typedef KwsDctTab<NF> T;
+            auto put = [&](int i, cf R) {
+                if (WITH_CMVN || i < ncep) {
+                    float a = R.r * T::cs[i];
+                    float b = R.i * T::sn[i];
+                    float d = (a + b) * 2.0f;
+                    d = d * (i == 0 ? T::s0 : T::s1);
+                    orow[i] = d;
+                }
+            };
+            // coefficients above N/2 are never written by the transform: they keep the log-mel input (x2, scaled)
+            if constexpr (NF == 32) {
+                cf R[NCEPT];
+                dct_spectrum<NF>(v, [&](int i, cf r) { R[i] = r; });
+#pragma unroll
+                for (int i = 0; i < NCEPT; ++i) put(i, R[i]);
+#pragma unroll
+                for (int i = NCEPT; i < NF; ++i)
+                    if (i < ncep) orow[i] = (v[i] * 2.0f) * T::s1;
+            } else {
+                for (int i = NCEPT; i < ncep; ++i) orow[i] = (mrow[i] * 2.0f) * T::s1;
+                dct_spectrum<NF>(v, put);
+            }
+            orow[0] = fast_log(sm.energy[lane_d]);                                       // feature.hpp:425-429
+        }
+        WAVE_SYNC();
+        PH(5);
+        if constexpr (!WITH_CMVN) continue;
+
+        // ---- cmvnw (processing.hpp:326-389) + input quantisation ---------------------------------------------
+        {
+            float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
+            int8_t *qclip = q_out ? q_out + (size_t)clip * (nfr * ncep) : nullptr;
+            auto emit = [&](int row, int c, float o) {
+                const int idx = row * ncep + c;
+                if (fout) fout[idx] = o;                      // optional output (extract_mfcc_features' matrix)
+                if (qclip) qclip[idx] = quantize_feature(o, in_scale, in_zp);
+            };
+            if constexpr (WIDE) cmvn_columns<17, 20>(sm.mel, MELS, sm_map, offt, lane_d, nfr, ncep, prow, P.win_size, emit);
+            else cmvn_columns<13, 16>(sm.mel, MELS, sm_map, offt, lane_d, nfr, ncep, prow, P.win_size, emit);
+        }
+        WAVE_SYNC();
+        PH(7);
+    }
+    asm volatile("" : : "v"(touched_next));
+    if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
+        for (int i = 0; i < KWS_NPHASE; ++i) prof_out[i] = ph[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
 int kws_mfcc_max_prow(void) { return KWS_MAXPROW; }
@@ -587,6 +1068,12 @@ static void mfcc_launch(const MfccLaunchArgs &a)
     hipLaunchKernelGGL((kws_mfcc_kernel<CHP, F32IN, WITH_CMVN, NZ, NF, PROF, WIDE, LW>), a.grid, a.block, 0, a.stream, a.P, a.pcm, a.n_clips, a.out,
                        a.q_out, a.in_scale, a.in_zp, a.wrap, a.out_stride, a.prof, a.sel);
 }
+template <bool WITH_CMVN, int NZ, int NF, bool PROF, bool WIDE, int OCC>
+static void mfcc8_launch(const MfccLaunchArgs &a)
+{
+    hipLaunchKernelGGL((kws_mfcc8_kernel<WITH_CMVN, NZ, NF, PROF, WIDE, OCC>), a.grid, a.block, 0, a.stream, a.P, (const int16_t *)a.pcm, a.n_clips, a.out,
+                       a.q_out, a.in_scale, a.in_zp, a.wrap, a.out_stride, a.prof, a.sel);
+}
 struct MfccVariant {
     int n_filters, max_nz;      // mel filters; longest filter the variant keeps in registers
     int min_cepstra;            // WIDE cmvnw layout (20 columns x 3 row groups): only worth it above 16 cepstra, needs WITH_CMVN
@@ -600,13 +1087,22 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
 {
     (void)hipGetLastError();      // the status returned below is this launch's, not a stale error of an earlier call
     if (n_clips <= 0) return 0;
-    static const MfccVariant table[] = {
+    // development switch (same-box A/B of the two spectral layouts, tools/gpu_mfcc_layout_check.py): KWS_DEV_MFCC_OLD_LAYOUT keeps
+    // kws_mfcc_kernel for int16 PCM too
+    const bool old_layout = getenv("KWS_DEV_MFCC_OLD_LAYOUT") != nullptr;
+    const MfccVariant table[] = {
         // latency shape first (float samples + cmvnw only): run_classifier() and other calls of at most KWS_LAT_MAX_CLIPS windows
         { 40, 8, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, 8, 40, false, false, KWS_LAT_WAVES> : nullptr },
         { 40, KWS_MAXNZ, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, KWS_MAXNZ, 40, false, false, KWS_LAT_WAVES> : nullptr },
         { 32, 4, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, 4, 32, false, false, KWS_LAT_WAVES> : nullptr },
         { 32, KWS_MAXNZ, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, KWS_MAXNZ, 32, false, false, KWS_LAT_WAVES> : nullptr },
-        // throughput shape: one wave per clip, persistent grid
+        // throughput shape, int16 PCM: one wave per clip on the eight-lanes-per-frame spectral layout (kws_mfcc8_kernel)
+        { 40, 8, 17, false, (!F32IN && WITH_CMVN && !old_layout) ? mfcc8_launch<WITH_CMVN, 8, 40, PROF, WITH_CMVN, 2> : nullptr },
+        { 40, 8, 0, false, (!F32IN && !old_layout) ? mfcc8_launch<WITH_CMVN, 8, 40, PROF, false, 2> : nullptr },
+        { 40, KWS_MAXNZ, 0, false, (!F32IN && !old_layout) ? mfcc8_launch<WITH_CMVN, KWS_MAXNZ, 40, PROF, false, 2> : nullptr },
+        { 32, 4, 0, false, (!F32IN && !old_layout) ? mfcc8_launch<WITH_CMVN, 4, 32, PROF, false, 2> : nullptr },
+        { 32, KWS_MAXNZ, 0, false, (!F32IN && !old_layout) ? mfcc8_launch<WITH_CMVN, KWS_MAXNZ, 32, PROF, false, 2> : nullptr },
+        // throughput shape, float samples: one wave per clip, persistent grid
         { 40, 8, 17, false, WITH_CMVN ? mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, WITH_CMVN, 0> : nullptr },
         { 40, 8, 0, false, mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, 8, 40, PROF, false, 0> },
         { 40, KWS_MAXNZ, 0, false, mfcc_launch<KWS_CHP, F32IN, WITH_CMVN, KWS_MAXNZ, 40, PROF, false, 0> },
