@@ -343,6 +343,10 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
                                      float *features, int8_t *q_out)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
+    // MFE block: what arrives here are the exact kernels' mel matrices, and the block's normalisation has no fast form (nothing to gain:
+    // it divides by the matrix's range, not by a deviation): the exact path serves both modes
+    if (h->model.dsp.block == DSP_BLOCK_MFE)
+        return cmvn_nn_device(h, mfcc, B, features, h->is_float ? nullptr : q_out, scores, nullptr, nullptr, nullptr, s, ring_rows, ring_head);
     EI_IMPULSE_ERROR e = ensure_flags(h, B);
     if (e) return e;
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
@@ -586,6 +590,26 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
     const bool fused = scores && h->is_float && h->fast_fused_ok;
     int rc = 0;
+    if (h->model.dsp.block == DSP_BLOCK_MFE) {
+        // extract_mfe_features (L432 classifier/ei_run_dsp.h:369-418) with the tolerance-mode front end: kws_fast_kernel<..., MFE> writes the
+        // mel matrix (KissFFT-order FFT, fp32 power, fused mel products), then the block's own normalisation -- cmvnw(win, false, true) +
+        // numpy::normalize, the exact kernel: it divides by the matrix's range, not by a window's deviation, so nothing is ill-conditioned
+        // and no clip is handed back --, the input quantisation and the network's exact kernel
+        const KwsDspPlan &P = h->dsp;
+        const int rows = P.n_frames, cols = P.n_filters;
+        if (rows > (cols > 16 ? 51 : 52) || P.win_size < (cols > 16 ? 17 : 13))
+            return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%d frames x %d filters, window %d outside the MFE normalisation kernel's limits", rows, cols, P.win_size);
+        rc = kws_launch_fast(P, h->fast_plain, h->d_fast_plain, pcm, (int)B, nullptr, fx, nullptr, h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
+        rc = kws_launch_mfe_norm(fx, (int)B, rows, cols, P.win_size, P.pad_map, rows + 2 * P.pad, grid_cap_nn(h), s);
+        if (!rc && q) rc = kws_launch_quantize(fx, q, B * h->model.nn_input_frame_size, h->nn.in_scale, h->nn.in_zp, s);
+        if (rc) return fail(KWS_ERROR_HIP, "MFE block launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (!scores) return EI_IMPULSE_OK;
+        if (h->is_float) return nn_f32_device(h, fx, B, scores, nullptr, s);
+        rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
+        if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
     if (scores && !h->is_float && h->fast_q_ok) {
         // int8 graph of the matrix-core shape: the network runs in the same launch on the quantised tensor it has just produced in LDS;
         // the feature matrix / the tensor only go to HBM when the caller asked for them (q is the caller's buffer or the scratch the

@@ -89,6 +89,7 @@ struct KwsFastPlan {
     // ---- int8 two-block graph fused behind the features (kws_nn_int8_dev.h: nn_mfma_clip): qnet = bytes per activation row of its first
     //      block (16 / 64), 0 = none; q_floats = floats of the workgroup's shared LDS block its tables take, behind shared_floats
     int qnet, q_floats;
+    int mfe;                      // 1: the model's DSP block is MFE -- the kernel stops after the mel filterbank (kws_fast_kernel<..., MFE>)
     // ---- float32 network fused behind the features (fuse = 0: features / int8 tensor go to HBM instead)
     int fuse, n_blocks;
     KwsFastBlock blk[KWS_FAST_MAX_BLOCKS];

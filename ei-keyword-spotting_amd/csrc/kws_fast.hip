@@ -603,10 +603,13 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
 // NET: the float32 network follows in the same launch (no feature / int8 outputs); !NET: the features / the int8 tensor leave for
 // HBM and no network code is compiled in.  Two instantiations instead of run-time flags: each form's cmvnw stores are written
 // for what it does (with a branch per value only where a global store hangs on it).
+// MFE: the front end of the MFE block (extract_mfe_features of the newer SDK copy): speechpy::feature::mfe on the raw signal
+// (the plan's pre-emphasis coefficient is 0) -- the kernel stops after the mel filterbank and its zero handling (no log, no DCT, no
+// cmvnw: the block's own normalisation follows in kws_mfe_norm_kernel) and writes the [frames][filters] matrix to HBM.
 // QCP: 16 / 64 = the int8 two-block network on the matrix cores follows in the same launch (with !NET): the quantised input tensor is
 // written as the 16- / 64-byte activation rows of nn_mfma_clip (kws_nn_int8_dev.h) instead of -- or besides -- going to HBM, and the
 // network is bit-exact from that tensor on, as in kws_nn_mfma_kernel; 0: no int8 network code.
-template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false, bool NET = true, int QCP = 0>
+template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false, bool NET = true, int QCP = 0, bool MFE = false>
 __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const KwsFastPlan *__restrict__ FPp, const int16_t *__restrict__ pcm, int n_clips,
                                                           float *__restrict__ scores, float *__restrict__ features,
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                                                           const KwsNnPlan *__restrict__ QNp = nullptr, const int *__restrict__ sel = nullptr)
 {
     static_assert(QCP == 0 || !NET, "the int8 network follows the feature-emitting form");
+    static_assert(!MFE || (!NET && QCP == 0 && !FROM_CEP && !PROF), "the MFE form is the spectral prefix: mel energies to HBM");
     // the plan is read from memory (scalar loads, any block index); by value in the kernel arguments the compiler copies it to
     // scratch to index its blocks
     const KwsFastPlan &FP = *FPp;
@@ -791,7 +795,10 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             }
             macc[4] = acc2;
 #pragma unroll
-            for (int s = 0; s < 5; ++s) macc[s] = fast_log(macc[s] == 0.0f ? FLT_EPSILON : macc[s]);   // functions.hpp:63-69
+            for (int s = 0; s < 5; ++s) {
+                const float a = macc[s] == 0.0f ? FLT_EPSILON : macc[s];                               // functions.hpp:63-69
+                macc[s] = MFE ? a : fast_log(a);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int slot = 4 * half + s;
@@ -1036,7 +1043,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // ---- DCT-II (numpy.hpp:378-401) as [frames x NF] x [NF x NF/2+1] on the matrix cores, in place: two rounds of two
         //      16-frame tiles.  The transform's operand fragments are re-read per clip (L2-resident, 4 DG values per lane): kept in
         //      registers across the clip loop they push the FFT's constants into scratch.
-        {
+        if constexpr (!MFE) {
             int lane_l = lane;
             asm volatile("" : "+v"(lane_l));                 // not loop-invariant as far as the compiler can tell
             const int lm = lane_l & 15, lq = lane_l >> 4;
@@ -1118,8 +1125,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // sqrt(c0_mult n_frames / win_size) x the column's plain deviation over the n_frames rows; if that already clears the relative
         // guard at the column's largest magnitude, the running-sum mean is good enough for every window (error kappa |mean| / deviation
         // below the feature tolerance) and the pass is skipped -- the usual case for audio whose loudness changes over the second.
-        bool c0_exact;
-        {
+        bool c0_exact = false;
+        if constexpr (!MFE) {
             const bool on = lane_m < nfr;
             const float x0 = img[min(lane_m, nfr - 1) * fs];
             const float mu = wave_sum(on ? x0 : 0.0f) * FP.c0_inv_rows;
@@ -1175,7 +1182,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             for (int i = lane_m; i < KWS_A1_ROWS * (QCP / 4); i += KWS_WAVE) ((int *)act1)[i] = z1;
             WAVE_SYNC();
         }
-        if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+        if constexpr (MFE) bad = false;                   // nothing is divided by a deviation here: the mel energies leave as they are
+        else if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
         else bad = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
         if (__any(bad)) {
             if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
@@ -1290,7 +1298,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 // ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
-template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true, int QCP = 0>
+template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true, int QCP = 0, bool MFE = false>
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
                          long long *prof_out, hipStream_t stream, const float *cep = nullptr, const KwsNnPlan *d_nn = nullptr, const int *sel = nullptr)
@@ -1309,7 +1317,7 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     const int per_wg = FP.n_waves;
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
-    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
+    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
                        features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel);
     return (int)hipGetLastError();
 }
@@ -1332,6 +1340,16 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
         return (int)hipErrorInvalidValue;
     }
 #define KWS_FAST_ARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream
+    if (FP.mfe) {
+        if (scores || q_out || !features) return (int)hipErrorInvalidValue;          // the MFE form has one output: the mel matrix
+        if (FP.dct_groups == 4)
+            return FP.nz <= 4 ? launch_fast_t<4, 4, false, false, false, 0, true>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false, false, false, 0, true>(KWS_FAST_ARGS)
+                                                                                                            : launch_fast_t<KWS_FAST_NZ_MAX, 4, false, false, false, 0, true>(KWS_FAST_ARGS);
+        if (FP.dct_groups == 5)
+            return FP.nz <= 4 ? launch_fast_t<4, 5, false, false, false, 0, true>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false, false, false, 0, true>(KWS_FAST_ARGS)
+                                                                                                            : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false, 0, true>(KWS_FAST_ARGS);
+        return (int)hipErrorInvalidValue;
+    }
     if (FP.dct_groups == 4)
         return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_ARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 4, false>(KWS_FAST_ARGS))

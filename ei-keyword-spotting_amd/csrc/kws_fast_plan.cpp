@@ -34,7 +34,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // few clips; tests/test_gpu_fast_families.py holds the whole chain to 1e-4 on 9 x 8 192 clips per model.
 static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &shared)
 {
-    const int ncep = h->model.dsp.num_cepstral, NF = h->model.dsp.num_filters;
+    const int ncep = h->dsp.n_cepstral, NF = h->model.dsp.num_filters;     // (MFE block: the filters are the columns)
     // the score tolerance divided by the largest measured ratio score error / largest feature error of a clip (1.28: one clip of the
     // "bursts" family through the 49x40 graph, found when the second tier first ran with 1e-4) -- for the terms whose constant is the
     // largest value seen.  The DCT term uses the 99.9 % value of its error and the plain 1e-4 (see above): its tail is thin, and at the
@@ -95,8 +95,10 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     const Model &m = h->model;
     const DspCfg &c = m.dsp;
     const KwsDspPlan &P = h->dsp;
-    const int NF = c.num_filters, nfr = P.n_frames, ncep = c.num_cepstral;
-    if (c.block != DSP_BLOCK_MFCC) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode serves the MFCC block");
+    const int NF = c.num_filters, nfr = P.n_frames, ncep = P.n_cepstral;
+    // MFE block: the spectral prefix of the same kernel (its feature matrix is [frames][filters]: P.n_cepstral = filters); the tables of
+    // the DCT and of cmvnw are built but not read
+    F.mfe = c.block == DSP_BLOCK_MFE ? 1 : 0;
     if (P.generic) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode serves the configurations of the tuned MFCC kernel (fft 256, 32 / 40 filters, "
                                                             "up to 52 aligned frames); this model runs on the general kernels");
     if (c.fft_length != 256) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: fft_length %d (kernel is built for 256)", c.fft_length);
@@ -294,6 +296,7 @@ static EI_IMPULSE_ERROR build_fast_q(kws_handle *h)
     KwsFastPlan &F = h->fast_q;
     memset(&F, 0, sizeof(F));
     if (h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the fused int8 network needs an int8 graph");
+    if (h->fast_plain.mfe) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the MFE block's normalisation sits between the front end and the network (not fused)");
     if (!kws_nn_uses_mfma(h->nn)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the int8 graph is outside the two-block matrix-core shape; it keeps its own kernel");
     const int qcp = h->nn.blk[0].in_cpad == 16 ? 16 : 64;
     if ((qcp == 16) != (h->dsp.n_filters == 32))
@@ -320,6 +323,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
     KwsFastPlan &F = h->fast_fused;
     memset(&F, 0, sizeof(F));
     if (!h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the fused network is float32 (int8 graphs keep their exact kernels)");
+    if (h->fast_plain.mfe) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the MFE block's normalisation sits between the front end and the network (not fused)");
     const KwsNnPlanF32 &N = h->nnf;
     if (N.n_blocks > KWS_FAST_MAX_BLOCKS) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d conv blocks", N.n_blocks);
     if (N.fc_out > KWS_FAST_WAVE) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d outputs", N.fc_out);

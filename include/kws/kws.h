@@ -60,10 +60,15 @@ int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI
  *   kernels inside the same call, so their results are the exact mode's.  int8 graphs: fast MFCC + the exact int8 network;
  *   an int8 input value may then differ by one step where a feature sits on a rounding boundary.
  * kws_streams_step_device follows the mode too (the slice's MFCC stays exact; the whole-window cmvnw + network take the fast
- * kernel).  The SDK entry points (run_classifier ...) and the other stage entry points always run the exact kernels. */
+ * kernel).  The SDK entry points (run_classifier ...) and the other stage entry points always run the exact kernels.
+ * Models whose DSP block is MFE (extract_mfe_features of the newer SDK copy): KWS_MODE_FAST runs the block's front end -- FFT in
+ *   KissFFT's order, fp32 power, fused mel products -- in the fast kernel and keeps the block's normalisation (it divides by the
+ *   matrix's range, not by a deviation: nothing is ill-conditioned, no clip is handed back) and the network on their exact kernels;
+ *   kws_run_classifier_batch_device and kws_extract_mfcc_batch_device follow the mode, the entry points that start from mel matrices
+ *   (streams, kws_cmvn_inference_batch_device) have nothing left to relax. */
 #define KWS_MODE_EXACT 0
 #define KWS_MODE_FAST 1
-EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode);   /* KWS_ERROR_UNSUPPORTED_MODEL if the model's DSP block is outside the fast kernel */
+EI_IMPULSE_ERROR kws_set_mode(kws_handle *h, int mode);   /* KWS_ERROR_UNSUPPORTED_MODEL if the model's DSP configuration is outside the fast kernel (general-shape kernels) */
 int kws_get_mode(const kws_handle *h);
 /* 1: KWS_MODE_FAST runs this model's network fused behind the MFCC block (float32 CONV_2D graphs); 0: features go through HBM */
 int kws_fast_is_fused(const kws_handle *h);

@@ -47,11 +47,12 @@ def main():
     res = {}
     for _ in range(rounds):
         for v in variants:
-            # a variant "name+VAR" runs libkws_name.so with the environment variable VAR=1 (development switches of the library)
+            # a variant "name+VAR" / "name+VAR=value" runs libkws_name.so with that environment variable (development switches of the library)
             name, _, var = v.partition("+")
             env = dict(os.environ, KWS_LIB=os.path.join(ROOT, "ab_tmp", "libkws_%s.so" % name))
             if var:
-                env[var] = "1"
+                key, _, val = var.partition("=")
+                env[key] = val or "1"
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", models, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if out.returncode != 0:
                 print(v, "FAILED", out.stderr[-800:])
