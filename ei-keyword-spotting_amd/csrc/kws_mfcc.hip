@@ -1089,7 +1089,12 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
     if (n_clips <= 0) return 0;
     // development switch (same-box A/B of the two spectral layouts, tools/gpu_mfcc_layout_check.py): KWS_DEV_MFCC_OLD_LAYOUT keeps
     // kws_mfcc_kernel for int16 PCM too
-    const bool old_layout = getenv("KWS_DEV_MFCC_OLD_LAYOUT") != nullptr;
+    // Short windows (the 250 ms slices of continuous mode: 12 frames) stay with kws_mfcc_kernel: two passes cannot amortise what
+    // kws_mfcc8_kernel re-derives per window (measured: 65 536 streams advance a slice in 0.790 vs 0.814 ms); KWS_DEV_MFCC8_MIN_FRAMES moves
+    // the threshold (tests: 1 = every frame count on the new layout)
+    const char *const min_env = getenv("KWS_DEV_MFCC8_MIN_FRAMES");
+    const int min_frames8 = min_env ? atoi(min_env) : 16;
+    const bool old_layout = getenv("KWS_DEV_MFCC_OLD_LAYOUT") != nullptr || P.n_frames < min_frames8;
     const MfccVariant table[] = {
         // latency shape first (float samples + cmvnw only): run_classifier() and other calls of at most KWS_LAT_MAX_CLIPS windows
         { 40, 8, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, 8, 40, false, false, KWS_LAT_WAVES> : nullptr },

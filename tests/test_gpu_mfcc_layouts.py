@@ -41,9 +41,10 @@ def test_every_frame_count_on_both_layouts(shape, pkg, oracle, tmp_path):
         om = OracleModel(oracle, path)
         gm = pkg.Model(blob=blob)
         assert gm.n_frames == nfr and om.raw_sample_count == n
-        if gm.mfcc_kernel != "kws_mfcc8_kernel":
+        if gm.mfcc_kernel == "kws_spectral_generic_kernel":
             gm.close()
             continue                                                 # a shape the tuned kernels leave to the general ones
+        assert gm.mfcc_kernel == ("kws_mfcc8_kernel" if nfr >= 16 else "kws_mfcc_kernel")     # (short windows stay on the old layout by default)
         sp = special_clips()
         host = np.concatenate([oracle.synth(nfr, 0, 61, n), np.stack([np.resize(sp[k], n) for k in ("impulses", "zeros", "alternating_fullscale")])])
         B = len(host)
@@ -51,8 +52,9 @@ def test_every_frame_count_on_both_layouts(shape, pkg, oracle, tmp_path):
         nf, F = gm.n_filters, gm.n_features
         res = {}
         for old in (False, True):
+            os.environ["KWS_DEV_MFCC8_MIN_FRAMES"] = "1"            # the new layout for every frame count ...
             if old:
-                os.environ["KWS_DEV_MFCC_OLD_LAYOUT"] = "1"
+                os.environ["KWS_DEV_MFCC_OLD_LAYOUT"] = "1"          # ... unless the old one is forced
             try:
                 feat = torch.zeros((B, F), dtype=torch.float32, device="cuda:0")
                 q = torch.zeros((B, F), dtype=torch.int8, device="cuda:0")
@@ -65,6 +67,7 @@ def test_every_frame_count_on_both_layouts(shape, pkg, oracle, tmp_path):
                 torch.cuda.synchronize()
             finally:
                 os.environ.pop("KWS_DEV_MFCC_OLD_LAYOUT", None)
+                os.environ.pop("KWS_DEV_MFCC8_MIN_FRAMES", None)
             res[old] = [x.cpu().numpy() for x in (feat, q, cep, mel, en)]
         for a, b in zip(res[False], res[True]):
             assert (bits(a) == bits(b)).all(), (shape, nfr)
