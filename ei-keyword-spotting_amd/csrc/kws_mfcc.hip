@@ -561,8 +561,8 @@ __global__ __launch_bounds__(LW ? KWS_WAVE * LW : KWS_WAVE, LW ? 1 : 2) void kws
 //  232-296); kws_mfcc_kernel's layout (32 lanes per frame, four points per lane) takes three exchanges per frame pair.  The lanes
 //  of a frame swap the upper halves of their points for kiss_fftr's split (kiss_fftr.cpp:84-119); the power spectrum goes through
 //  fp64 as in the reference (bin_power); a pass's eight power rows feed the frame energies (129 ordered additions, one lane per
-//  frame) and the mel stage (lane = filter, the taps in registers).  DCT and cmvnw are kws_mfcc_kernel's.  int16 PCM only, one
-//  wave per window; float samples and the latency shape stay with kws_mfcc_kernel.
+//  frame) and the mel stage (lane = filter, its taps read from LDS).  DCT and cmvnw are kws_mfcc_kernel's.  int16 PCM, windows of 16
+//  frames or more, one wave per window; float samples, short windows and the latency shape stay with kws_mfcc_kernel.
 //  13 KB of LDS per wave (the exchange buffer, the power rows, the tail pass's buffers and cmvnw's tables share one region) + the mel taps.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KWS_M8_CHUNK = 8;      // frames per pass
