@@ -1310,7 +1310,7 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_done.fetch_or(bit, std::memory_order_release);
     }
