@@ -195,6 +195,10 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
     int4 d0 = steps[0], d1 = steps[1];
     fetch(d0, a0, b0);
     if (t_pre) *t_pre = clock64();
+    // The contraction runs at raised wave priority: when both waves of a SIMD have an instruction ready, the one feeding the matrix pipe
+    // goes first -- its MFMAs then execute while the other wave's vector instructions issue, instead of waiting behind them.  Measured
+    // (same-box A/B, 65 536 clips): 1.669 -> 1.637 ms for the 49x40 graph, 1.246 -> 1.228 ms for the 49x13 twin; priority 3: the same.
+    __builtin_amdgcn_s_setprio(1);
     // per half: request the other set's operands, zero this set's out-of-image rows (they were requested a half earlier: no wait),
     // issue this set's MFMAs
     for (int it = 0; it < n_it; it += 2) {
@@ -214,6 +218,7 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
         mfmas(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(0);
     if (t_loop) *t_loop = clock64();
     const int out_w = k.out_w;
     if (k.fpool) {
