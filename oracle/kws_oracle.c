@@ -1321,6 +1321,7 @@ int kwso_model_is_float(const kwso_model *m) { return m->t[m->t_in].type == TYPE
 /* float graph: input[nn_input_frame_size] -> out[label_count]; taps (optional) = every tensor, tensor-id order */
 int kwso_nn_invoke_f32(const kwso_model *m, const float *input, float *out, float *taps)
 {
+    if (!kwso_model_is_float(m)) return -3;      /* an int8 graph's tensors are not sized for float values */
     float **buf = (float **)calloc(m->n_tensors, sizeof(float *));
     float *own = (float *)calloc(m->tap_bytes / 4 + 1, sizeof(float));
     if (!buf || !own) { free(buf); free(own); return -6; }
@@ -1377,6 +1378,7 @@ void kwso_dequantize_output(const kwso_model *m, const int8_t *out_q, float *sco
 
 int kwso_nn_invoke(const kwso_model *m, const int8_t *input_q, int8_t *out_q, int8_t *taps)
 {
+    if (kwso_model_is_float(m)) return -3;
     /* every tensor gets its own buffer (the reference overlays them in a 3392-byte arena;
      * the values are the same) */
     int8_t **buf = (int8_t **)calloc(m->n_tensors, sizeof(int8_t *));

@@ -605,7 +605,8 @@ SYNTH_SPECS = {
     "ei_default40": dict(seed=31, num_filters=40, ncep=40, low=300, high=0, blocks=((16, 3, -2), (32, 3, -2), (32, 3, 1)), n_labels=12),
     "dscnn_b": dict(seed=22, ncep=10, blocks=(("dw", 2, 7, 7, 3), ("pw", 12, 1), ("dw", 1, 3, 7, 1)), n_labels=3),
     # BASELINE config 5 as worded: 49x40 MFCC, deeper depthwise-separable CNN, 10 keywords (+ noise/unknown); synthetic weights
-    "cfg5_dscnn": dict(seed=50, num_filters=40, ncep=40, low=300, high=0, n_labels=12,
+    # (logit_std: calibrated activation ranges and head, tools/synth_model.py calibrate_head -- a model whose softmax is not saturated)
+    "cfg5_dscnn": dict(seed=50, num_filters=40, ncep=40, low=300, high=0, n_labels=12, logit_std=3.5,
                        blocks=((32, 5, 1), ("dw", 1, 5, 1, 1), ("pw", 32, 1), ("dw", 1, 5, 7, 1), ("pw", 32, 1), ("dw", 1, 3, 7, 1), ("pw", 12, 0))),
 }
 

@@ -294,3 +294,20 @@ ei_dsp_config_mfe_t ei_dsp_config_3 = {
         if os.path.isdir(ref_dir):
             blob, _ = eon_import.import_export(ref_dir)
             assert blob == open(os.path.join(ROOT, "models", name), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["cfg2_mfcc40_f32.kwsm", "cfg2_mfcc40_int8.kwsm", "cfg5_dscnn_mfcc40_f32.kwsm", "cfg5_dscnn_mfcc40_int8.kwsm",
+                                  "l476_no_yes_f32.kwsm"])
+def test_synthetic_models_are_not_saturated(name):
+    """with a saturated softmax (max score > 0.999 on 90 % of the clips, p (1 - p) ~ 1e-9) a bar on the SCORES says
+    nothing about the logits.  The synthetic heads are calibrated (tools/synth_model.py calibrate_head; tools/make_models.sh): on the bench's
+    own clips the winning score's median must sit between 0.4 and 0.95 and the typical p (1 - p) of a clip near its maximum, 1/4."""
+    from kws_testlib import MODELS, Oracle, OracleModel
+    o = Oracle()
+    m = OracleModel(o, os.path.join(MODELS, name))
+    s = m.run_batch(o.synth(0, 0, 256))
+    mx = s.max(axis=1)
+    assert 0.4 <= np.median(mx) <= 0.95, np.median(mx)
+    assert (mx > 0.999).mean() < 0.05
+    assert np.median((s * (1 - s)).max(axis=1)) > 0.1
+    assert (np.bincount(s.argmax(axis=1), minlength=m.n_labels) > 0).sum() >= 3      # not one class for every clip

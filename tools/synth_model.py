@@ -18,15 +18,162 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import eon_import  # noqa: E402
 
+def dequantised_constants(tensors):
+    """float64 value of every constant tensor of an int8 graph: (q - zero_point[ch]) * scale[ch] (what tools/dequantize_model.py stores)"""
+    out = {}
+    for i, t in enumerate(tensors):
+        if not t["const"] or not t["scale"]:
+            continue
+        q = np.frombuffer(t["data"], np.int8 if t["type"] == 9 else np.int32).astype(np.float64).reshape(t["dims"])
+        scale, zero = np.float64(t["scale"]), np.float64(t["zero"])
+        if len(scale) > 1:
+            shape = [1] * len(t["dims"])
+            shape[t["qdim"]] = len(scale)
+            out[i] = (q - zero.reshape(shape)) * scale.reshape(shape)
+        else:
+            out[i] = (q - zero[0]) * scale[0]
+    return out
+
+
+def float_forward(tensors, nodes, t_in, x, stop_before_op=None, on_output=None):
+    """The graph's float32 twin evaluated in numpy for a batch x [n][features] -- the arithmetic of the reference's float kernels
+    (TFL/kernels/internal/reference/conv.h:28-99, depthwiseconv_float.h:25, add.h:179-215, pooling.h:189-237, fully_connected.h:26-60)
+    without their rounding order: used to CALIBRATE a synthetic head, never as a checker.  Activations are kept as [n][time][channel];
+    RESHAPE only renames axes in this graph family.  Returns {tensor id: value}; stops before the first node whose op is stop_before_op."""
+    act = {t_in: np.asarray(x, np.float64)}
+
+    def fused(v, a):                                    # TfLiteFusedActivation: 0 none, 1 relu, 3 relu6
+        return v if a == 0 else np.maximum(v, 0.0) if a == 1 else np.clip(v, 0.0, 6.0)
+
+    def windows(v, size, out_w, stride, pad_left):      # [n][out_w][size][c], rows outside the image = NaN (callers mask them)
+        n, w, c = v.shape
+        idx = np.arange(out_w)[:, None] * stride - pad_left + np.arange(size)[None, :]
+        ok = (idx >= 0) & (idx < w)
+        g = v[:, np.clip(idx, 0, w - 1), :]
+        return g, ok
+
+    for nd in nodes:
+        if nd["op"] == stop_before_op:
+            break
+        const = dequantised_constants(tensors)          # per node: on_output may have re-quantised a bias
+        o, p = nd["out"][0], nd["p"]
+        dims = tensors[o]["dims"]
+        a = act.get(nd["in"][0])
+        if nd["op"] == 0:                               # RESHAPE
+            n = a.shape[0]
+            act[o] = a.reshape(n, -1) if len(dims) == 2 else a.reshape(n, -1, dims[-1])
+        elif nd["op"] in (1, 6):                        # CONV_2D / DEPTHWISE_CONV_2D, 1 x K, stride 1
+            w = const[nd["in"][1]]
+            b = const[nd["in"][2]]
+            n, in_w, in_c = a.shape
+            taps = w.shape[2]
+            out_w = in_w if p[0] == 1 else in_w - taps + 1
+            pad_left = max(0, (out_w - 1) + taps - in_w) // 2
+            g, ok = windows(a, taps, out_w, 1, pad_left)
+            g = np.where(ok[None, :, :, None], g, 0.0)
+            if nd["op"] == 1:
+                v = np.einsum("nwtc,otc->nwo", g, w[:, 0]) + b
+            else:
+                mult = p[6]
+                v = np.einsum("nwto,to->nwo", np.repeat(g, mult, axis=3), w[0, 0]) + b
+            act[o] = fused(v, p[3])
+        elif nd["op"] == 2:                             # ADD of a per-channel constant
+            act[o] = fused(a + const[nd["in"][1]], p[0])
+        elif nd["op"] == 3:                             # MAX_POOL_2D over time
+            n, in_w, c = a.shape
+            size, stride = p[4], p[2]
+            out_w = dims[1]
+            pad_left = max(0, (out_w - 1) * stride + size - in_w) // 2 if p[0] == 1 else 0
+            g, ok = windows(a, size, out_w, stride, pad_left)
+            act[o] = fused(np.where(ok[None, :, :, None], g, -np.inf).max(axis=2), p[5])
+        elif nd["op"] == 4:                             # FULLY_CONNECTED
+            act[o] = fused(a @ const[nd["in"][1]].T + const[nd["in"][2]], p[0])
+        elif nd["op"] == 5:                             # SOFTMAX
+            e = np.exp((a - a.max(axis=1, keepdims=True)) * nd["beta"])
+            act[o] = e / e.sum(axis=1, keepdims=True)
+        else:
+            raise ValueError("op %d" % nd["op"])
+        if on_output:
+            on_output(nd, act[o])
+    return act
+
+
+def calibrate_ranges(tensors, nodes, t_in, x):
+    """Post-training quantisation of a synthetic graph's ACTIVATIONS: the drawn activation scales / zero points are arbitrary, so the int8
+    graph clamps most of what flows through it and has little to do with its float twin.  Here every CONV_2D / DEPTHWISE_CONV_2D / ADD /
+    FULLY_CONNECTED output gets the range its float twin shows on the calibration set x (min .. max, including 0), RESHAPE and
+    MAX_POOL_2D outputs keep their input's parameters (as TFLite requires), and every int32 bias is re-quantised at its new scale
+    input scale x filter scale[ch] (kernel_util_lite.cc:47-120 checks that product) from its old float value.  Weights and the input
+    tensor keep their drawn parameters."""
+    def on_output(nd, v):
+        o, i0 = nd["out"][0], nd["in"][0]
+        if nd["op"] in (0, 3):
+            tensors[o]["scale"], tensors[o]["zero"] = list(tensors[i0]["scale"]), list(tensors[i0]["zero"])
+            return
+        if nd["op"] == 5:
+            return
+        lo, hi = min(float(v.min()), 0.0), max(float(v.max()), 0.0)
+        sc = float(np.float32((hi - lo) / 255.0))
+        tensors[o]["scale"], tensors[o]["zero"] = [sc], [int(np.clip(round(-128 - lo / sc), -128, 127))]
+
+    def before(nd):                                     # the bias of a node whose input scale has just been settled
+        if nd["op"] not in (1, 4, 6):
+            return
+        tb, tw, i0 = nd["in"][2], nd["in"][1], nd["in"][0]
+        old = np.frombuffer(tensors[tb]["data"], np.int32).astype(np.float64) * np.float64(tensors[tb]["scale"])
+        new_scale = [float(np.float32(tensors[i0]["scale"][0]) * np.float32(s_)) for s_ in tensors[tw]["scale"]]
+        tensors[tb]["scale"] = new_scale
+        tensors[tb]["data"] = np.round(old / np.float64(new_scale)).astype(np.int32).tobytes()
+
+    act = {t_in: np.asarray(x, np.float64)}
+    for nd in nodes:
+        before(nd)
+        sub = float_forward(tensors, [nd], nd["in"][0], act[nd["in"][0]], on_output=on_output) if nd["op"] != 5 else None
+        if sub is None:
+            break
+        act[nd["out"][0]] = sub[nd["out"][0]]
+
+
+def calibrate_head(tensors, nodes, t_in, tfw, tfb, tfo, logit_std, seed, n_cal=256):
+    """Give a synthetic graph a head with a sane logit scale (synth_model_blob's logit_std).  The network's input is cmvnw's output:
+    every column standardised over its window -- so the calibration set is n_cal matrices of independent N(0, 1) values (measured: the
+    logit statistics on those equal the ones on the bench's synthetic clips to a few percent).  With z = W x the float twin's
+    bias-free logits on that set: the FULLY_CONNECTED weight scale is multiplied by logit_std / pooled deviation of (z - class mean), the
+    int32 biases become round(-class mean / bias scale) + the drawn ones, and the output tensor's scale spans +-8 logit_std."""
+    rng = np.random.default_rng(100000 + seed)
+    F = tensors[t_in]["dims"][1]
+    x = rng.standard_normal((n_cal, F))
+    fc = [nd for nd in nodes if nd["op"] == 4][0]
+    calibrate_ranges(tensors, nodes, t_in, x)
+    feat = float_forward(tensors, nodes, t_in, x, stop_before_op=4)[fc["in"][0]]
+    w = dequantised_constants(tensors)[tfw]
+    z = feat @ w.T
+    mean = z.mean(axis=0)
+    k = logit_std / float(np.sqrt(((z - mean) ** 2).mean()))
+    fw_scale = float(np.float32(tensors[tfw]["scale"][0] * k))
+    b_scale = float(np.float32(tensors[fc["in"][0]]["scale"][0]) * np.float32(fw_scale))
+    drawn = np.frombuffer(tensors[tfb]["data"], np.int32)
+    bias = np.round(-mean * k / b_scale).astype(np.int64) + drawn
+    assert np.abs(bias).max() < 2 ** 31
+    tensors[tfw]["scale"] = [fw_scale]
+    tensors[tfb]["scale"] = [b_scale]
+    tensors[tfb]["data"] = bias.astype(np.int32).tobytes()
+    tensors[tfo]["scale"] = [float(np.float32(logit_std * 8.0 / 128.0))]
+
 
 def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4,
                      conv_bias=False, add_bias=True, num_filters=32, raw_samples=16000, fft_length=256, frame_length=0.02,
-                     frame_stride=0.02, pre_cof=0.98, dsp_block="mfcc"):
+                     frame_stride=0.02, pre_cof=0.98, dsp_block="mfcc", logit_std=None):
     """blocks: sequence of
          (out_channels, taps, pool)              CONV_2D 1xK (+ optional int32 bias) -> ADD(int8 per-channel)+ReLU -> MAX_POOL
          ("dw", depth_mult, taps, pool, act)     DEPTHWISE_CONV_2D 1xK with int32 bias and fused activation -> MAX_POOL
          ("pw", out_channels, act)               CONV_2D 1x1 with int32 bias and fused activation (pointwise)
        (pool 1 = no pooling node, a negative pool = VALID padding: the ragged tail of the time axis is dropped; act: TfLiteFusedActivation 0 none, 1 relu, 3 relu6).
+       logit_std: None = the FULLY_CONNECTED layer as drawn (random weights and biases: one class usually wins every clip by tens
+       of logit units, the softmax is saturated and a score says nothing about the logits behind it); a number = the head is
+       calibrated (calibrate_head): scale and biases are set so that, over standardised random feature matrices -- which is what
+       cmvnw hands the network --, every class's logit has zero mean and the logits' pooled deviation is logit_std (the shipped
+       impulse's is 1.5).  No random draw is added or removed: every other tensor is the one the same seed gave before.
        Frame geometry defaults to the shipped one (1 s at 16 kHz, 20 ms frames and stride: 49 frames); raw_samples / frame_length /
        frame_stride / fft_length / pre_cof change the DSP block (the frame count follows speechpy's rule, processing.hpp:260-284)."""
     rng = np.random.default_rng(seed)
@@ -148,6 +295,8 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
     node(4, [tf, tfw, tfb], [tfo], [0])
     tso = T(9, [1, n_labels], scale=[0.00390625], zero=[-128])
     node(5, [tfo], [tso], beta=1.0)
+    if logit_std is not None:
+        calibrate_head(tensors, nodes, t_in, tfw, tfb, tfo, float(logit_std), seed)
     meta = {"labels": ["label%d" % i for i in range(n_labels)],
             "dsp": {"axes": 1, "num_cepstral": ncep, "frame_length": frame_length, "frame_stride": frame_stride, "num_filters": num_filters,
                     "fft_length": fft_length, "win_size": win_size, "low_frequency": low, "high_frequency": high,
@@ -167,10 +316,11 @@ def main():
     ap.add_argument("--high", type=int, default=4000)
     ap.add_argument("--labels", type=int, default=4)
     ap.add_argument("--blocks", default="30,7,7;10,7,7", help="per block: out_channels,taps,pool | dw,depth_mult,taps,pool,act | pw,out_channels,act")
+    ap.add_argument("--logit-std", type=float, default=None, help="calibrate the head: zero-mean class logits of this pooled deviation on standardised features")
     a = ap.parse_args()
     blocks = tuple(tuple(v if v in ("dw", "pw") else int(v) for v in b.split(",")) for b in a.blocks.split(";"))
     blob = synth_model_blob(a.seed, ncep=a.ncep, win_size=a.win_size, low=a.low, high=a.high, blocks=blocks,
-                            n_labels=a.labels, num_filters=a.num_filters)
+                            n_labels=a.labels, num_filters=a.num_filters, logit_std=a.logit_std)
     with open(a.out, "wb") as f:
         f.write(blob)
     print(a.out, len(blob), "bytes")
