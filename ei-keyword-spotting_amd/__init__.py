@@ -41,11 +41,18 @@ EXPORTED_SYMBOLS = [
     "kws_cmvn_inference_batch_device", "kws_nn_batch_device", "kws_nn_batch",
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
     "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count", "kws_fast_exact_count", "kws_fast_guard",
+    "kws_set_logits_tap", "kws_fast_gain", "kws_fast_tolerance_info",
     "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_allgather_scores", "kws_comm_destroy",
     "kws_wav_info_from_memory", "kws_wav_decode_mono", "kws_resample_length", "kws_resample_device",
     "kws_synth_clips_device", "kws_mix_audio_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
+
+
+class FastTolerance(C.Structure):
+    _fields_ = [("score_tol", C.c_float), ("k_sigma", C.c_float), ("lin_margin", C.c_float), ("logit_cap", C.c_float), ("g_c1", C.c_float),
+                ("g_c2", C.c_float), ("sigma_net", C.c_float), ("total_gain", C.c_float), ("uniform_feature_tol", C.c_float),
+                ("calibrated", C.c_int), ("n_columns", C.c_int), ("n_frames", C.c_int)]
 
 
 class KwsError(RuntimeError):
@@ -99,9 +106,14 @@ def lib():
         L.kws_fast_is_fused.argtypes = [vp]
         L.kws_fast_fallback_count.argtypes = [vp, C.POINTER(sz)]
         if hasattr(L, "kws_fast_guard"):                 # absent from older builds compared in tools/ab_rate.py
-            L.kws_fast_guard.argtypes = [vp, i32, vp, vp]
+            L.kws_fast_guard.argtypes = [vp, i32, vp]
+        if hasattr(L, "kws_fast_gain"):
+            L.kws_fast_gain.argtypes = [vp, vp]
+            L.kws_fast_tolerance_info.argtypes = [vp, vp]
         if hasattr(L, "kws_fast_exact_count"):
             L.kws_fast_exact_count.argtypes = [vp, C.POINTER(sz)]
+        if hasattr(L, "kws_set_logits_tap"):
+            L.kws_set_logits_tap.argtypes = [vp, vp]
         L.kws_nn_kernel_name.restype = C.c_char_p
         L.kws_nn_kernel_name.argtypes = [vp]
         L.kws_mfcc_kernel_name.restype = C.c_char_p
@@ -226,15 +238,31 @@ class Model:
         _check(self.L.kws_fast_exact_count(self.h, C.byref(n)))
         return n.value
 
+    def set_logits_tap(self, dev_ptr):
+        """float32 graphs: the batch calls also write every clip's FULLY_CONNECTED outputs to dev_ptr [B][labels] (None: off)"""
+        _check(self.L.kws_set_logits_tap(self.h, dev_ptr))
+
     def fast_guard(self, tier=1):
-        """(abs_thr, rel_thr), one value per cepstral coefficient: a cmvnw window of column c with deviation below
-        abs_thr[c] + rel_thr[c] * |mean| makes that tier hand its clip back (tier 1: the fast kernel; tier 2: fast cmvnw + network on
-        exact cepstra)"""
+        """coefficients [4][n_columns] of that tier's guard: absolute, per log-mel level, per |window mean|, per |window mean| when column 0's
+        window means were replayed (tier 1: the fast kernel; tier 2: fast cmvnw + network on exact cepstra).  See kws.h for the rule."""
         import numpy as np
         n = self.n_features // self.n_frames
-        a, r = np.zeros(n, np.float32), np.zeros(n, np.float32)
-        _check(self.L.kws_fast_guard(self.h, tier, a.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)))
-        return a, r
+        coef = np.zeros((4, n), np.float32)
+        _check(self.L.kws_fast_guard(self.h, tier, coef.ctypes.data_as(C.c_void_p)))
+        return coef
+
+    def fast_gain(self):
+        """float32 graphs: logit-difference error per unit of feature error, per cepstral column (kws_gain.cpp)"""
+        import numpy as np
+        g = np.zeros(self.n_features // self.n_frames, np.float32)
+        _check(self.L.kws_fast_gain(self.h, g.ctypes.data_as(C.c_void_p)))
+        return g
+
+    def fast_tolerance(self):
+        """kws_fast_tolerance as a dict"""
+        t = FastTolerance()
+        _check(self.L.kws_fast_tolerance_info(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in FastTolerance._fields_}
 
     def set_default(self):
         _check(self.L.kws_set_default_model(self.h))

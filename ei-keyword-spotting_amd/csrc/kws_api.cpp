@@ -128,12 +128,54 @@ EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count)
     return EI_IMPULSE_OK;
 }
 
-EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, int tier, float *abs_thr, float *rel_thr)
+EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, int tier, float *coef)
 {
-    if (!h || !abs_thr || !rel_thr || (tier != 1 && tier != 2)) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_fast_guard: bad argument");
+    if (!h || !coef || (tier != 1 && tier != 2)) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_fast_guard: bad argument");
     if (!h->fast_plain_ok) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%s", h->fast_why.c_str());
-    const std::vector<float> &a = tier == 1 ? h->fast_guard_abs : h->fast_guard2_abs, &r = tier == 1 ? h->fast_guard_rel : h->fast_guard2_rel;
-    for (size_t c = 0; c < a.size(); c++) { abs_thr[c] = a[c]; rel_thr[c] = r[c]; }
+    const size_t n = h->fast_guard_coef[tier - 1][0].size();
+    for (int k = 0; k < 4; k++)
+        for (size_t c = 0; c < n; c++) coef[(size_t)k * n + c] = h->fast_guard_coef[tier - 1][k][c];
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_fast_gain(const kws_handle *h, float *col_gain)
+{
+    if (!h || !col_gain) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_fast_gain: bad argument");
+    if (!h->is_float || !h->gain.calibrated) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "kws_fast_gain: float32 graphs of the tuned DSP shapes only");
+    for (size_t c = 0; c < h->gain.col.size(); c++) col_gain[c] = h->gain.col[c];
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_fast_tolerance_info(const kws_handle *h, kws_fast_tolerance *out)
+{
+    if (!h || !out) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_fast_tolerance_info: bad argument");
+    if (!h->fast_plain_ok) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "%s", h->fast_why.c_str());
+    const KwsFastPlan &F = h->fast_plain;
+    memset(out, 0, sizeof(*out));
+    out->score_tol = 1.0e-4f;
+    out->lin_margin = 1.1f;
+    out->k_sigma = sqrtf(F.g_c1) * out->score_tol / out->lin_margin;
+    out->logit_cap = out->k_sigma / sqrtf(F.g_c2);
+    out->g_c1 = F.g_c1; out->g_c2 = F.g_c2;
+    out->calibrated = (h->is_float && h->gain.calibrated) ? 1 : 0;
+    out->n_columns = (int)h->fast_guard_coef[0][0].size();
+    out->n_frames = h->dsp.n_frames;
+    out->sigma_net = out->calibrated ? h->gain.sigma_net : 0.0f;
+    // sum of gain^2 over every feature: a feature error of rms size t on every feature gives V = sigma_net^2 + t^2 x this
+    double g2 = 0.0;
+    for (float g : h->fast_gain_used) g2 += (double)g * (double)g * (double)h->dsp.n_frames;
+    out->total_gain = (float)sqrt(g2);
+    const double vmax = std::min(16.0 / (double)F.g_c1, 1.0 / (double)F.g_c2) - (double)out->sigma_net * (double)out->sigma_net;
+    out->uniform_feature_tol = (vmax > 0.0 && g2 > 0.0) ? (float)sqrt(vmax / g2) : 0.0f;
+    return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_set_logits_tap(kws_handle *h, float *logits)
+{
+    if (!h) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    if (logits && !h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "kws_set_logits_tap: float32 graphs only (an int8 graph's taps: kws_nn_batch_device)");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->tap_logits = logits;
     return EI_IMPULSE_OK;
 }
 
@@ -323,7 +365,7 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
         float *f = features ? features : h->s_mfcc;
         int rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, f, nullptr, nullptr, nullptr, 0, nullptr, nullptr, grid_cap_nn(h), &ran_nn, s);
         if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        return scores ? nn_f32_device(h, f, B, scores, nullptr, s) : EI_IMPULSE_OK;
+        return scores ? nn_f32_device(h, f, B, scores, h->tap_logits, s) : EI_IMPULSE_OK;
     }
     int8_t *qq = q;
     if (scores && !qq) qq = h->s_q;           // the generic NN kernel reads the quantised tensor from HBM
@@ -365,10 +407,10 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
     }
     const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
     rc = kws_launch_fast_from_cepstra(PR, FP, fused ? h->d_fast_fused : h->d_fast_plain, mfcc, (int)B, scores, fused ? nullptr : fx, q,
-                                      h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
+                                      h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s, nullptr, h->tap_logits);
     if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (!fused) {
-        if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, nullptr, s))) return e; }
+        if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, h->tap_logits, s))) return e; }
         else {
             rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
             if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -379,7 +421,7 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
     rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, (h->is_float || features) ? fx : nullptr, q, h->is_float ? nullptr : scores, nullptr, h->pooled_tap_bytes,
                             nullptr, nullptr, grid_cap_nn(h), &ran_nn, s, h->d_flags);
     if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags);
+    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, h->tap_logits, h->n_cu, s, h->d_flags);
     else if (!ran_nn) rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
     if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
@@ -561,10 +603,10 @@ static EI_IMPULSE_ERROR rerun_flagged_device(kws_handle *h, const int16_t *pcm, 
     }
     if (fused) {
         rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, h->s_cep, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
-                                          h->d_flags2, h->d_flags2 + 1, h->n_cu, s, h->d_flags);
+                                          h->d_flags2, h->d_flags2 + 1, h->n_cu, s, h->d_flags, h->tap_logits);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     } else if (scores) {
-        if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags);
+        if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, h->tap_logits, h->n_cu, s, h->d_flags);
         else rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
         if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
@@ -574,7 +616,7 @@ static EI_IMPULSE_ERROR rerun_flagged_device(kws_handle *h, const int16_t *pcm, 
                             h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), &ran_nn, s, h->d_flags2);
     if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (!scores) return EI_IMPULSE_OK;
-    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, nullptr, h->n_cu, s, h->d_flags2);
+    if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, h->tap_logits, h->n_cu, s, h->d_flags2);
     else if (!ran_nn) rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags2);
     if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
@@ -605,7 +647,7 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
         if (!rc && q) rc = kws_launch_quantize(fx, q, B * h->model.nn_input_frame_size, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "MFE block launch failed: %s", hipGetErrorString((hipError_t)rc));
         if (!scores) return EI_IMPULSE_OK;
-        if (h->is_float) return nn_f32_device(h, fx, B, scores, nullptr, s);
+        if (h->is_float) return nn_f32_device(h, fx, B, scores, h->tap_logits, s);
         rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
         if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
@@ -629,10 +671,10 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
     }
     const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
     rc = kws_launch_fast(h->dsp, FP, fused ? h->d_fast_fused : h->d_fast_plain, pcm, (int)B, scores, fused ? nullptr : fx, fused ? nullptr : q, h->nn.in_scale,
-                         h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
+                         h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s, nullptr, h->tap_logits);
     if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
     if (scores && !fused) {
-        if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, nullptr, s))) return e; }
+        if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, h->tap_logits, s))) return e; }
         else {
             rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
             if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -646,7 +688,7 @@ static EI_IMPULSE_ERROR classify_device(kws_handle *h, const int16_t *pcm, size_
     EI_IMPULSE_ERROR e;
     if (h->is_float) {
         e = mfcc_fused_device(h, pcm, 0, B, f, nullptr, s);
-        return e ? e : nn_f32_device(h, f, B, scores, nullptr, s);
+        return e ? e : nn_f32_device(h, f, B, scores, h->tap_logits, s);
     }
     e = mfcc_fused_device(h, pcm, 0, B, (f || h->model.dsp.block != DSP_BLOCK_MFE) ? f : h->s_mfcc, q, s);
     if (e) return e;

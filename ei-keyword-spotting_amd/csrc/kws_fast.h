@@ -71,11 +71,16 @@ struct KwsFastPlan {
     int ext_off;                  // shared LDS, or -1: per row group [1 + 2 * KWS_FAST_CMVN_EXT] = base multiplicity m0 of its first window,
                                   // then (row offset as int bits, extra multiplicity) for the rows counted more than m0 times
     float inv_win;
-    // A window of column c whose deviation is below guard[c].abs + guard[c].rel * |mean| sends the clip to the exact kernels: what the
-    // fp32 re-ordering moved in a cepstral coefficient (absolute) or in the window's mean (relative to |mean|) comes out of cmvnw
-    // divided by the deviation, and the threshold is where that quotient reaches the feature tolerance (kws_fast_plan.cpp)
-    int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x { abs, per |window mean| }
-    int guard_cep_off;            // the same for windows that arrive as the exact kernels' cepstra (no DCT term): continuous mode, second tier
+    // The guard (kws_fast_plan.cpp: build_guard).  What the fp32 re-ordering moved in a cepstral coefficient, or in a
+    // window's mean, comes out of cmvnw divided by the window's deviation; weighted with the graph's logit gain per column (kws_gain.cpp)
+    // and summed in quadrature over the clip's windows it estimates the variance V of a logit difference's error:
+    //     V = v_net + sum over windows (r, c) of ((g.abs + g.lev x level + g.rel x |mean|) / (deviation + eps))^2,
+    // level = the clip's rms log-mel energy (fp32 rounds relative to it).  The clip stays in the fast kernel iff
+    //     V x max(g_c1 x P^2, g_c2) <= 1,     P = the largest p (1 - p) of its scores (1/4 where the network runs in another kernel):
+    // g_c1 = (k sigma x margin / score tolerance)^2, g_c2 = (k sigma / largest logit error the linearisation is trusted for)^2.
+    int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x float4 { abs, lev, rel, rel when column 0's means were replayed }
+    int guard_cep_off;            // the same for windows that arrive as the exact kernels' cepstra (no spectral terms): continuous mode, second tier
+    float g_c1, g_c2, v_net, lvl_inv;   // lvl_inv = 1 / (n_frames x filters): level^2 = lvl_inv x sum of log-mel^2
     float c0_factor, c0_abs, c0_rel, c0_inv_rows;   // column 0: the exact window means are only computed when c0_factor x (plain deviation of
                                   // the column) < c0_abs + c0_rel x (its largest magnitude); c0_factor = sqrt(c0_mult n_frames / win_size),
                                   // c0_mult = how often every window holds every row at least (0: always compute them)

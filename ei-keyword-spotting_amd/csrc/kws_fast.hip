@@ -481,10 +481,12 @@ __device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *
 //  ext_tab != NULL (win_size > 2 n_frames, the usual shapes): the first window counts every row m0 times and at most
 //  KWS_FAST_CMVN_EXT rows more, so it is m0 x (the column's plain sums, gathered from the row groups' own rows with
 //  ds_bpermute) + those few rows, instead of a walk over every row.
+//  Returns this lane's share of the guard's variance estimate (kws_fast.h): sum over its windows of
+//  ((g.abs + g.lev * level + g.rel * |mean|) / (deviation + eps))^2 -- the caller reduces it over the wave.
 template <int CR, int CG>
-__device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                          float inv_win, const float *__restrict__ guard_tab, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
-                                          const float *__restrict__ ext_tab, float *__restrict__ sink)
+__device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
+                                           float inv_win, const float *__restrict__ guard_tab, float level, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
+                                           const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
     const int cgrp = min(lane / CG, NG - 1), cl = lane - (lane / CG) * CG;
@@ -492,7 +494,7 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
     const int r0 = cgrp * CR;
     const int nfr8 = (nfr + 7) & ~7;
     const float *cnt = cnt_tab + cgrp * nfr8;          // rows padded to a multiple of 8 with zeros
-    bool bad = false;
+    float vacc = 0.0f;
     // column-independent table entries: the update table of this lane's rows, the first window's extra rows
     int u[CR - 1];                                    // leaving row offset | entering row offset << 16 (floats)
 #pragma unroll
@@ -511,11 +513,11 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
         float *col = img + min(c, ncep - 1);
         // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name
         const float piv = col[0];
-        float2 gcol = ((const float2 *)guard_tab)[cb + cl];         // (absolute, per |window mean|); padded to a multiple of CG columns
+        const float4 gcol = ((const float4 *)guard_tab)[cb + cl];   // (absolute, per level, per |window mean|, the same with replayed means); padded to a multiple of CG columns
         // column 0 (the log frame energy, |mean| ~ 10): when its deviation is small against its level, its window means have been summed
-        // in the reference's own order (c0_exact) and the relative part of its guard does not apply
+        // in the reference's own order (c0_exact) and the window-mean part of its guard does not apply
         const bool is_c0 = c0_exact && cb + cl == 0;
-        gcol.y = is_c0 ? 0.0f : gcol.y;
+        const float g_abs = __fmaf_rn(gcol.y, level, gcol.x), g_rel = is_c0 ? gcol.w : gcol.z;
         float mr[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) mr[i] = (c0_exact && cb == 0) ? mref[min(r0 + i, nfr - 1)] : 0.0f;
@@ -578,7 +580,8 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
             var = fmaxf(var, 0.0f);
             const float sd = __builtin_amdgcn_sqrtf(var);
             const float rstd = __builtin_amdgcn_rcpf(sd + FLT_EPSILON);
-            if (act && r0 + i < nfr) bad |= sd < __fmaf_rn(gcol.y, fabsf(m + piv), gcol.x);
+            const float bq = __fmaf_rn(g_rel, fabsf(m + piv), g_abs) * rstd;
+            vacc = (act && r0 + i < nfr) ? __fmaf_rn(bq, bq, vacc) : vacc;
             o[i] = (is_c0 ? own[i] - mr[i] : (own[i] - piv) - m) * rstd;
             if (i + 1 < CR) {
                 S = (S + da[i]) - dl[i];
@@ -594,7 +597,7 @@ __device__ __forceinline__ bool fast_cmvn(float *__restrict__ img, const float *
         }
     }
     WAVE_SYNC();
-    return bad;
+    return vacc;
 }
 
 // PROF: development aid -- shader-clock totals per phase of wave 0 of workgroup 0 (tools/gpu_fast_phase_profile.py)
@@ -620,7 +623,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,
                                                           long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr,
-                                                          const KwsNnPlan *__restrict__ QNp = nullptr, const int *__restrict__ sel = nullptr)
+                                                          const KwsNnPlan *__restrict__ QNp = nullptr, const int *__restrict__ sel = nullptr,
+                                                          float *__restrict__ tap_logits = nullptr)
 {
     static_assert(QCP == 0 || !NET, "the int8 network follows the feature-emitting form");
     static_assert(!MFE || (!NET && QCP == 0 && !FROM_CEP && !PROF), "the MFE form is the spectral prefix: mel energies to HBM");
@@ -729,6 +733,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         const int half = lane_c >> 5, t = lane_c & 31;
         // a mel filter's taps are consecutive bins: first bin (as an offset into a frame's power row) + NZ weights, zero beyond its end
         const int start1 = FP.tap_start1[lane_c], start2 = FP.tap_start2[lane_c];
+        float lvl2 = 0.0f;                                               // sum of this lane's log-mel^2 (the guard's level)
         float w1[NZ], w2[NZ2];
     #pragma unroll
         for (int n = 0; n < NZ; ++n) w1[n] = FP.tap_w1[lane_c * KWS_FAST_NZ_MAX + n];
@@ -807,9 +812,14 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int slot = 4 * half + s;
-                if (slot < nfc && t < NF) img[(fbase + slot) * fs + t + (slot == 1 ? adj1 : 0)] = macc[s];
+                const bool on = slot < nfc && t < NF;
+                if (on) img[(fbase + slot) * fs + t + (slot == 1 ? adj1 : 0)] = macc[s];
+                // the guard's level: sum of log-mel^2 over the clip (a frame parked for the wave's NEXT clip counts here instead: one frame of 49)
+                if (!MFE) lvl2 = on ? __fmaf_rn(macc[s], macc[s], lvl2) : lvl2;
             }
-            if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2 + (sl2 == 1 ? adj1 : 0)] = macc[4];
+            const bool on2 = DG > 4 && sl2 < nfc && j2 < NF;
+            if (on2) img[(fbase + sl2) * fs + j2 + (sl2 == 1 ? adj1 : 0)] = macc[4];
+            if (!MFE && DG > 4) lvl2 = on2 ? __fmaf_rn(macc[4], macc[4], lvl2) : lvl2;
         };
         fast_i2 nxt[2][8];
         fetch(0, nxt);
@@ -1063,6 +1073,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             float e0 = 0.0f;
             if (lane_l < nfr) e0 = elog[lane_l];
             v4f acc[4][2];
+            // raised wave priority for the transform's 16 DG MFMAs, as for the convolution's contraction loop (fast_conv_tiles)
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int rnd = 0; rnd < 2; ++rnd) {
                 float2 a[2][DG];
@@ -1086,6 +1098,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                             acc[2 * rnd + m2][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m2][g].y, dB[g][1][nt], acc[2 * rnd + m2][nt], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             WAVE_SYNC();                                     // every operand of the transform is in a register
             // Coefficients above NF/2 are never written by the reference's transform: they keep the log-mel input, doubled and
             // scaled (fast-dct-fft.cpp:71-74, numpy.hpp:392-397).  cmvnw normalises every column by its own mean and deviation,
@@ -1116,7 +1129,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         float *fout = features ? features + (size_t)clip * (nfr * ncep) : nullptr;
         int8_t *qclip = q_out ? q_out + (size_t)clip * (nfr * ncep) : nullptr;
         int8_t *const act1 = (int8_t *)R1;                              // [KWS_A1_ROWS][QCP]: row = time + tap, padding = the input zero point
-        bool bad;
+        float vlane = 0.0f;
         int lane_m = lane;
         asm volatile("" : "+v"(lane_m));
         float *const csink = F + FP.sink_off + lane_m;
@@ -1187,11 +1200,19 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             for (int i = lane_m; i < KWS_A1_ROWS * (QCP / 4); i += KWS_WAVE) ((int *)act1)[i] = z1;
             WAVE_SYNC();
         }
-        if constexpr (MFE) bad = false;                   // nothing is divided by a deviation here: the mel energies leave as they are
-        else if (cr == 13) bad = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
-        else bad = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
-        if (__any(bad)) {
-            if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
+        // the guard (kws_fast.h): V = variance estimate of a logit difference's error; the clip stays iff V max(c1 P^2, c2) <= 1
+        float gV = 0.0f;
+        if constexpr (!MFE) {                             // (MFE: nothing is divided by a deviation: the mel energies leave as they are)
+            const float level = FROM_CEP ? 0.0f : __builtin_amdgcn_sqrtf(wave_sum(lvl2) * FP.lvl_inv);
+            if (cr == 13) vlane = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            else vlane = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
+        }
+        if constexpr (!NET) {
+            // the scores are another kernel's (or an int8 network's): P = 1/4, the largest p (1 - p) there is.  !(x <= 1): a NaN hands the clip on
+            if (!MFE && !(gV * fmaxf(FP.g_c1 * 0.0625f, FP.g_c2) <= 1.0f)) {
+                if (lane == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
+            }
         }
         if constexpr (!NET) {
             // ---- what leaves the chip, and the network's quantised input: one pass over the feature image, consecutive lanes take
@@ -1224,7 +1245,9 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             const NnMfmaLds<QCP> qctx = nn_mfma_lds_ctx<QCP>(QN, (const v4i *)(qs + Q_WB1), (const v4i *)(qs + Q_WB2), (const int *)(qs + Q_RQ), lane);
             const NnHeadTab q_head = nn_head_tab(qs + Q_HEAD);
             const NnTaps no_taps = { nullptr, 0, nullptr, nullptr, nullptr, nullptr };
+            __builtin_amdgcn_s_setprio(1);                   // the matrix-core sections of the int8 network go first, like the float contraction loop
             nn_mfma_clip<QCP>(qctx, QN, q_head, act1, act2, vec, (const int8_t *)qs, (const int8_t *)qs + 32 * 256, lane, clip, scores, no_taps);
+            __builtin_amdgcn_s_setprio(0);
             WAVE_SYNC();
         }
         if constexpr (!NET) continue;
@@ -1287,10 +1310,18 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             tot = group_sum(tot + tot1, S) + shared[FP.fc_b_off + uc];
             tot = fminf(fmaxf(tot, FP.fc_min), FP.fc_max);
             const bool on = unit < fc_out;
+            if (tap_logits && on && sl == 0) tap_logits[(size_t)clip * n_labels + unit] = tot;       // kws_set_logits_tap
             const float mx = wave_max(on ? tot : -FLT_MAX);
             const float e = expf((tot - mx) * FP.beta);
             const float sum = wave_sum(on && sl == 0 ? e : 0.0f);
-            if (on && sl == 0) scores[(size_t)clip * n_labels + unit] = e / sum;
+            const float pr = e / sum;
+            if (on && sl == 0) scores[(size_t)clip * n_labels + unit] = pr;
+            // the guard, a posteriori: |d score_i| <= p_i (1 - p_i) max_j |d(z_i - z_j)|, so the clip's own scores say how much of the
+            // logit error's k sigma reaches a score (a saturated softmax passes next to nothing).  !(x <= 1): a NaN hands the clip on
+            const float pq = wave_max(on && sl == 0 ? pr * (1.0f - pr) : 0.0f);
+            if (!(gV * fmaxf(FP.g_c1 * pq * pq, FP.g_c2) <= 1.0f)) {
+                if (lane_n == 0) flag_list[atomicAdd(flag_count, 1)] = clip;
+            }
         }
         WAVE_SYNC();
         FPH(8);
@@ -1306,7 +1337,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true, int QCP = 0, bool MFE = false>
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
-                         long long *prof_out, hipStream_t stream, const float *cep = nullptr, const KwsNnPlan *d_nn = nullptr, const int *sel = nullptr)
+                         long long *prof_out, hipStream_t stream, const float *cep = nullptr, const KwsNnPlan *d_nn = nullptr, const int *sel = nullptr,
+                         float *tap_logits = nullptr)
 {
     const size_t smem = ((size_t)FP.shared_floats + FP.q_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
     // the opt-in for more than 64 KB of dynamic LDS is per device (and this instantiation): one bit per device, set once
@@ -1323,13 +1355,13 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
     hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
-                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel);
+                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel, tap_logits);
     return (int)hipGetLastError();
 }
 
 int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                     float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
-                    const KwsNnPlan *d_nn)
+                    const KwsNnPlan *d_nn, float *tap_logits)
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
@@ -1345,6 +1377,7 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
         return (int)hipErrorInvalidValue;
     }
 #define KWS_FAST_ARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream
+#define KWS_FAST_NARGS KWS_FAST_ARGS, nullptr, nullptr, nullptr, tap_logits
     if (FP.mfe) {
         if (scores || q_out || !features) return (int)hipErrorInvalidValue;          // the MFE form has one output: the mel matrix
         if (FP.dct_groups == 4)
@@ -1356,13 +1389,13 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
         return (int)hipErrorInvalidValue;
     }
     if (FP.dct_groups == 4)
-        return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_ARGS)
-                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 4, false>(KWS_FAST_ARGS))
+        return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_NARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_NARGS)
+                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 4, false>(KWS_FAST_NARGS))
                        : (FP.nz <= 4 ? launch_fast_t<4, 4, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false, false, false>(KWS_FAST_ARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 4, false, false, false>(KWS_FAST_ARGS));
     if (FP.dct_groups == 5)
-        return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 5, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false>(KWS_FAST_ARGS)
-                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 5, false>(KWS_FAST_ARGS))
+        return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 5, false>(KWS_FAST_NARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false>(KWS_FAST_NARGS)
+                                                                                              : launch_fast_t<KWS_FAST_NZ_MAX, 5, false>(KWS_FAST_NARGS))
                        : (FP.nz <= 4 ? launch_fast_t<4, 5, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false, false, false>(KWS_FAST_ARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false>(KWS_FAST_ARGS));
     return (int)hipErrorInvalidValue;
@@ -1377,13 +1410,13 @@ size_t kws_fast_qnet_bytes(int qcp)
 // cmvnw + (fused float network | features / int8 tensor) from cepstra in HBM, ring-indexed per P.ring_* (continuous mode)
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
                                  float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
-                                 const int *sel)
+                                 const int *sel, float *tap_logits)
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
     // mel taps / DCT are not part of this variant: one instantiation serves every model
     return FP.fuse ? launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list,
-                                                      n_cu, nullptr, stream, cep, nullptr, sel)
+                                                      n_cu, nullptr, stream, cep, nullptr, sel, tap_logits)
                    : launch_fast_t<4, 4, false, true, false>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count,
                                                              flag_list, n_cu, nullptr, stream, cep, nullptr, sel);
 }

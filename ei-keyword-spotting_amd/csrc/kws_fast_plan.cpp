@@ -7,66 +7,71 @@ static const int kLdsBytes = 160 * 1024;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// The cmvnw guard (kws_fast.h).  cmvnw turns a cepstral coefficient x into (x - mean) / (deviation + eps) over a window of
-// its column, so whatever the fast arithmetic moved in x or in the window's mean comes out divided by the deviation:
-//     |feature - reference| <= (E[c] + kappa[c] |mean|) / deviation   (+ a few 1e-6 |feature| from the deviation itself)
-// and the clip goes back to the exact kernels when a window's deviation is below (E[c] + kappa[c] |mean|) / kFeatureTol.
-//   E[c]: what the re-ordered fp32 arithmetic moves in column c -- absolute, because the log turns the relative error of a mel energy
-//     into an absolute one:
-//       c = 0            log(frame energy): a lane reduction instead of the reference's 129 sequential additions (relative 1e-7 .. 1e-6
-//                        of the energy = that much absolute in its log: one or two ulps of a value near -10).  Largest seen 1.6e-6
-//       1 <= c <= NF/2   DCT outputs: both transforms (the reference's FFT-based one, the matrix cores' dot products) round at the
-//                        level of their INPUTS -- log-mel values of magnitude 16 (digital silence) to ~30 (a few LSB of signal) -- not
-//                        of the small coefficient they produce: ~u sqrt(NF) |log-mel| each, two independent realisations.  Replaying
-//                        the reference's DCT order does not help: a one-ulp difference in one log-mel input re-draws its roundings
-//                        (measured on the oracle: same spread).  Measured over ~10^7 windows of the nine families: median ~2e-6,
-//                        99.9 % 1.5e-5 (NF 40) / 1.1e-5 (NF 32), largest 3.4e-5 / 2.4e-5.  The guard uses the 99.9 % value: a window in
-//                        the last 0.1 % must ALSO have a deviation within a factor ~2 of its threshold and feed a sensitive logit to
-//                        cost more than 1e-4, and the families test has not found one (worst score error ~7e-5)
-//       c > NF/2         the reference leaves 2 sqrt(1/2NF) x the log-mel input there: one fp32 log of difference.  Largest seen 8e-7
-//   kappa[c] |mean|: the reference's window mean is a sequential fp32 sum of win_size values and carries ~u sqrt(win_size) |mean| of
-//     rounding noise of its own; the running sums here are more accurate, so the DIFFERENCE is that noise (largest seen 2.1e-6 |mean|).
-//     Column 0 (|mean| ~ 10 for quiet audio) is exempt: the kernel replays the reference's summation order for it, kappa[0] = 0.
-// Source of the numbers: the guard switched off on the nine input families of tests/kws_families.py (4 096 clips each;
-// tools/gpu_fast_families.py, profiles/r03_fast_families_noguard.txt).
-// kFeatureTol is the feature error the network may see for its scores to stay within north_star's 1e-4: the measured ratio
-// score error / largest feature error of a clip is usually 0.05 .. 0.3 (softmax outputs, errors of random sign) and reaches ~1 on a
-// few clips; tests/test_gpu_fast_families.py holds the whole chain to 1e-4 on 9 x 8 192 clips per model.
+// The guard (kws_fast.h): which clips the fast kernel may keep.  Round 4: the tolerance is a
+// property of the LOADED MODEL.  cmvnw turns a cepstral coefficient x into (x - mean) / (deviation + eps) over a window of its column, so
+// whatever the fast arithmetic moved in x or in the window's mean comes out divided by the deviation; the graph then carries a feature
+// error into the logits with a gain that depends on its weights (kws_gain.cpp: col_gain[c], calibrated at kws_create).  The kernel sums
+//     V = sigma_net^2 + sum over windows (r, c) of ( col_gain[c] (E_c + kappa_c |mean|) / (deviation + eps) )^2
+// -- the variance of the error of a logit difference under independent feature errors of rms size (E_c + kappa_c |mean|) / deviation --
+// and keeps the clip iff   k sqrt(V) x 1.1 P <= score tolerance   and   k sqrt(V) <= 0.1,   P = max p (1 - p) of the clip's own scores
+// (|d score_i| <= p_i (1 - p_i) max_j |d(z_i - z_j)|; P = 1/4 where the scores are not known inside the kernel).
+//   E_c, the rms error of a cepstral coefficient (profiles/r04_gain_study.txt: the guard switched off on eleven input families x three
+//   models, every clip against the oracle; fp32 rounds relative to the operand's magnitude, so the errors scale with the clip's rms
+//   log-mel level M -- measured ratio error / M: 1.1e-7 .. 1.7e-7 over all families for the DCT outputs, p99 of a clip 3.4e-7):
+//       c = 0            log(frame energy): alpha0 |c0| (its own magnitude, ~|mean| for this column)      alpha0 = 1.0e-7
+//       1 <= c <= NF/2   DCT outputs: both transforms round at the level of their inputs                  1.7e-7 x M
+//       c > NF/2         stale log-mel values x 2 sqrt(1/2NF): one fp32 log of difference                 4.0e-8 x M
+//   kappa_c |mean|: the reference's window mean is a sequential fp32 sum of win_size values and carries rounding noise of its own;
+//       the running sums here are more accurate, so the DIFFERENCE is that noise: rms 0.5e-6 |mean| (0.2e-6 for lively columns, more
+//       where the summed values are nearly equal).  Column 0 when its means were replayed in the reference's order: 0.
+//   Second table (cepstra from the exact kernels: continuous mode, the second tier): E_c = a floor of 2e-7 below which the reference's own
+//   rounding decides a near-constant column, kappa as above.
+//   k = 4.5 standard deviations; 1.1 = margin for the linearisation of the softmax over a logit error of up to 0.1.
+// int8 graphs (no float logits to protect: the network is bit-exact from its input tensor on, what matters is how many input values
+// change): col_gain = the constant for which the rule reads  k x rms bound of the clip's feature errors <= 1e-4.
+static const float kGuardK = 4.5f, kGuardLin = 1.1f, kGuardScoreTol = 1.0e-4f, kGuardLogitCap = 0.1f;
+static const float kAlpha0 = 1.0e-7f, kAlphaDct = 1.7e-7f, kAlphaStale = 4.0e-8f, kKappa = 0.5e-6f, kFloorCep = 2.0e-7f, kC0Share = 0.05f;
+
 static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &shared)
 {
-    const int ncep = h->dsp.n_cepstral, NF = h->model.dsp.num_filters;     // (MFE block: the filters are the columns)
-    // the score tolerance divided by the largest measured ratio score error / largest feature error of a clip (1.28: one clip of the
-    // "bursts" family through the 49x40 graph, found when the second tier first ran with 1e-4) -- for the terms whose constant is the
-    // largest value seen.  The DCT term uses the 99.9 % value of its error and the plain 1e-4 (see above): its tail is thin, and at the
-    // stricter tolerance a few hundredths of a percent of the bench's own clips would take the second tier for nothing
-    const float kFeatureTol = 1.0e-4f / 1.3f, kDctTol = 1.0e-4f;
-    float e0 = 2.0e-6f, ek = 3.8e-7f * (float)NF, es = 1.0e-6f, kappa = 2.2e-6f, scale = 1.0f;
-    if (const char *ev = getenv("KWS_DEV_FAST_GUARD_SCALE")) scale = (float)atof(ev);      // development aid: 0 switches the guard off (tools/gpu_fast_families.py)
-    if (const char *ev = getenv("KWS_DEV_FAST_GUARD")) (void)sscanf(ev, "%f,%f,%f,%f", &e0, &ek, &es, &kappa);   // development aid: E[0], E[k], E[stale], kappa
-    while (shared.size() & 1) shared.push_back(0.0f);
-    F.guard_off = (int)shared.size();
-    h->fast_guard_abs.clear(); h->fast_guard_rel.clear();
-    for (int c = 0; c < round_up(ncep, F.cg); c++) {
-        // column 0: the kernel drops the relative part whenever it has computed the exact window means, and it computes them whenever
-        // the relative part could flag a window -- so towards the caller (kws_fast_guard) column 0 has none
-        const float a = scale * (c == 0 ? e0 / kFeatureTol : c <= NF / 2 ? ek / kDctTol : es / kFeatureTol), r = scale * kappa / kFeatureTol;
-        // the kernel leaves the columns above NF/2 unscaled (the reference's carry 2 sqrt(1/2NF): cmvnw's output does not see a
-        // per-column factor), so their deviations and means are 1 / unit times the reference's there
-        const float unit = c > NF / 2 ? 2.0f * h->dsp.dct_s1 : 1.0f;
-        shared.push_back(a / unit);
-        shared.push_back(r);
-        if (c < ncep) { h->fast_guard_abs.push_back(a); h->fast_guard_rel.push_back(c == 0 ? 0.0f : r); }
-    }
-    // Second table: the windows whose cepstra are the exact kernels' (bit-identical to the reference's): E[c] is gone, what remains is the
-    // window mean's kappa |mean| and a floor below which the reference's own rounding decides a near-constant column (its mean's noise
-    // scales with the magnitude of the summed values, which |mean| under-states for a column that changes sign: 2e-7 / kFeatureTol)
-    F.guard_cep_off = (int)shared.size();
-    h->fast_guard2_abs.clear(); h->fast_guard2_rel.clear();
-    for (int c = 0; c < round_up(ncep, F.cg); c++) {
-        const float a = scale * 2.0e-7f / kFeatureTol, r = scale * kappa / kFeatureTol;
-        shared.push_back(a);                       // FROM_CEP images hold the reference's values in every column: no unit change
-        shared.push_back(r);
-        if (c < ncep) { h->fast_guard2_abs.push_back(a); h->fast_guard2_rel.push_back(c == 0 ? 0.0f : r); }
+    const int ncep = h->dsp.n_cepstral, NF = h->model.dsp.num_filters, nfr = h->dsp.n_frames;     // (MFE block: the filters are the columns)
+    float a0 = kAlpha0, ad = kAlphaDct, as = kAlphaStale, kappa = kKappa, scale = 1.0f;
+    if (const char *ev = getenv("KWS_DEV_FAST_GUARD_SCALE")) scale = (float)atof(ev);      // development aid: 0 switches the guard off (tests/gain_study.py)
+    if (const char *ev = getenv("KWS_DEV_FAST_GUARD")) (void)sscanf(ev, "%f,%f,%f,%f", &a0, &ad, &as, &kappa);   // development aid
+    std::vector<float> gain((size_t)ncep, 0.0f);
+    if (h->is_float && h->gain.calibrated) gain = h->gain.col;
+    else for (float &g : gain) g = 4.0f / (kGuardLin * sqrtf((float)(nfr * ncep)));
+    h->fast_gain_used = gain;
+    F.g_c1 = (kGuardK * kGuardLin / kGuardScoreTol) * (kGuardK * kGuardLin / kGuardScoreTol);
+    F.g_c2 = (kGuardK / kGuardLogitCap) * (kGuardK / kGuardLogitCap);
+    F.v_net = (h->is_float && h->gain.calibrated) ? h->gain.sigma_net * h->gain.sigma_net : 0.0f;
+    F.lvl_inv = 1.0f / (float)(nfr * NF);
+    while (shared.size() & 3) shared.push_back(0.0f);
+    for (int tier = 0; tier < 2; tier++) {
+        (tier == 0 ? F.guard_off : F.guard_cep_off) = (int)shared.size();
+        for (int k = 0; k < 4; k++) h->fast_guard_coef[tier][k].clear();
+        for (int c = 0; c < round_up(ncep, F.cg); c++) {
+            const float g = scale * (c < ncep ? gain[(size_t)c] : 0.0f);
+            // the kernel leaves the columns above NF/2 unscaled (the reference's carry 2 sqrt(1/2NF): cmvnw's output does not see a
+            // per-column factor), so their deviations and means are 1 / unit times the reference's there
+            const float unit = (tier == 0 && c > NF / 2) ? 2.0f * h->dsp.dct_s1 : 1.0f;
+            float coef[4];
+            if (tier == 0) {
+                coef[0] = 0.0f;
+                coef[1] = c == 0 ? 0.0f : g * (c <= NF / 2 ? ad : as) / unit;
+                coef[2] = g * (c == 0 ? a0 + kappa : kappa);
+                coef[3] = g * (c == 0 ? a0 : kappa);
+            } else {
+                coef[0] = g * kFloorCep;
+                coef[1] = 0.0f;
+                coef[2] = g * kappa;
+                coef[3] = c == 0 ? 0.0f : g * kappa;
+            }
+            for (int k = 0; k < 4; k++) {
+                shared.push_back(coef[k]);
+                if (c < ncep) h->fast_guard_coef[tier][k].push_back(k == 1 ? coef[k] * unit : coef[k]);     // towards the caller: in the reference's units
+            }
+        }
     }
     // numpy::pad_1d_symmetric's row order, for the replayed window means of column 0
     std::vector<int> pmap;
@@ -81,8 +86,12 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
             for (int v : cnt) mult = std::min(mult, v);
         }
         F.c0_factor = sqrtf((float)mult * (float)nfr / (float)win) * 0.98f;      // 2 % for the fp32 statistics of the test itself
-        F.c0_abs = scale * e0 / kFeatureTol;
-        F.c0_rel = scale * kappa / kFeatureTol;
+        // column 0's window means are replayed unless the un-replayed ones would cost less than kC0Share of the variance a clip may carry
+        // at P = 1/4:  n_frames (gain0 kappa |mean| / deviation)^2 <= share / max(c1 / 16, c2)
+        const float budget = 1.0f / std::max(F.g_c1 / 16.0f, F.g_c2);
+        const float per_dev = gain[0] * sqrtf((float)nfr / (kC0Share * budget));
+        F.c0_abs = scale * kFloorCep * per_dev;
+        F.c0_rel = scale * kappa * per_dev;
         F.c0_inv_rows = 1.0f / (float)nfr;
     }
     F.pad_off = (int)shared.size();
@@ -405,6 +414,9 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
 
 EI_IMPULSE_ERROR build_fast_plans(kws_handle *h)
 {
+    // float32 graphs of the tuned DSP shapes: the guard needs the graph's logit gain (kws_gain.cpp), ~50 ms of host work per model
+    if (h->is_float && !h->dsp.generic && h->nnf.n_blocks > 0 && h->nnf.blk[0].in_w == h->dsp.n_frames && h->nnf.blk[0].in_c == h->dsp.n_cepstral)
+        kws_calibrate_gain(h);
     h->fast_plain_ok = build_fast_plain(h) == EI_IMPULSE_OK;
     if (!h->fast_plain_ok) h->fast_why = kws_last_error();
     h->fast_fused_ok = h->fast_plain_ok && build_fast_fused(h) == EI_IMPULSE_OK;

@@ -35,7 +35,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
                        int *ran_nn, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
                                  float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
-                                 const int *sel = nullptr);
+                                 const int *sel = nullptr, float *tap_logits = nullptr);
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
                       float *tap_logits, int n_cu, hipStream_t stream, const int *sel = nullptr);
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);
@@ -43,7 +43,8 @@ void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k);
 int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *scores, int8_t *tap_pooled,
                   int pooled_stride, int8_t *tap_fc, int8_t *tap_out_q, int grid_cap, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
-                    int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream, const KwsNnPlan *d_nn = nullptr);
+                    int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream, const KwsNnPlan *d_nn = nullptr,
+                    float *tap_logits = nullptr);
 size_t kws_fast_qnet_bytes(int qcp);     // LDS bytes of the fused int8 network's shared tables (kws_fast.hip)
 int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream);
@@ -208,16 +209,21 @@ struct kws_handle {
     // KWS_MODE_FAST (kws_fast.h): host copies of a float graph's constants (the fused plan re-lays them out), the two plans,
     // and the list of clips the fast kernel hands back to the exact kernels
     struct HostF32 { std::vector<float> w[KWS_MAX_BLOCKS], bias[KWS_MAX_BLOCKS], addc[KWS_MAX_BLOCKS], fc_w, fc_b; } hostf;
+    // kws_gain.cpp: logit gain per cepstral column of a float32 graph (calibrated at kws_create), the fused network's re-ordering noise
+    struct Gain { std::vector<float> col; float sigma_net = 0.0f, total = 0.0f; int calibrated = 0, n_inputs = 0; } gain;
     KwsFastPlan fast_plain{}, fast_fused{}, fast_q{};   // features / int8 tensor to HBM; float32 graph fused; int8 two-block graph fused
     const KwsFastPlan *d_fast_plain = nullptr, *d_fast_fused = nullptr, *d_fast_q = nullptr;     // the same plans in device memory
     const KwsNnPlan *d_nn = nullptr;                    // the int8 plan in device memory (the fused form reads it from there)
     bool fast_plain_ok = false, fast_fused_ok = false, fast_q_ok = false;
     std::string fast_why;
-    std::vector<float> fast_guard2_abs, fast_guard2_rel;   // second tier (exact cepstra -> fast cmvnw + network)
-    std::vector<float> fast_guard_abs, fast_guard_rel;    // host copy of the cmvnw guard's per-column thresholds (kws_fast_guard)
+    // host copy of the guard's per-column coefficients, [tier - 1][kind][column]: kind 0 absolute, 1 per log-mel level, 2 per |window mean|,
+    // 3 per |window mean| when column 0's window means were replayed in the reference's order (kws_fast_guard)
+    std::vector<float> fast_guard_coef[2][4];
+    std::vector<float> fast_gain_used;                     // the per-column gain those coefficients were built with (float32 graph: gain.col)
     int mode = KWS_MODE_EXACT;
     int *d_flags = nullptr;       // [0] = count, [1 + i] = clip index: the clips the fast kernel handed back (first tier)
     int *d_flags2 = nullptr;      // the same for the second tier: the clips that go to the exact cmvnw + network
+    float *tap_logits = nullptr;  // kws_set_logits_tap: FULLY_CONNECTED outputs of the batch calls' clips (float32 graphs), device [B][labels]
     float *s_cep = nullptr;       // [B][n_features] exact cepstra of the first tier's clips (indexed by clip)
     size_t flags_cap = 0, cep_cap = 0;
 
@@ -253,6 +259,8 @@ struct ScratchUse {
 EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h);
 EI_IMPULSE_ERROR build_nn_plan(kws_handle *h);
 EI_IMPULSE_ERROR build_fast_plans(kws_handle *h);     // kws_fast_plan.cpp; never fatal: sets fast_*_ok
+#define KWS_GAIN_INPUTS 16
+void kws_calibrate_gain(kws_handle *h);               // kws_gain.cpp
 
 // kws_api.cpp: stage launchers shared with the stream / SDK entry points (kws_sdk.cpp); internal, not exported
 #define KWS_INTERNAL __attribute__((visibility("hidden")))

@@ -77,14 +77,43 @@ int kws_fast_is_fused(const kws_handle *h);
  *                            (bit-identical to the reference's), then the fast cmvnw + network from those -- about 0.4 x the exact path;
  *   kws_fast_exact_count     clips the second tier handed back in turn: they were finished by the exact kernels and carry the exact
  *                            mode's bits.
- * When a tier hands a clip back: a cmvnw window of cepstral column c whose deviation is below abs_thr[c] + rel_thr[c] * |window mean|
- * (kws_fast_guard; tier 1: the fp32 re-ordering moves a coefficient by a bounded amount -- the DCT's outputs above all --, tier 2: only
- * the reference's own summation order moves its window mean; both are divided by the deviation).  The arrays hold one
- * value per cepstral coefficient of a frame; KWS_ERROR_UNSUPPORTED_MODEL if the model has no fast mode.
+ * When a tier hands a clip back -- the rule follows from the LOADED MODEL: cmvnw divides whatever the fast arithmetic
+ * moved in a cepstral coefficient, or in a window's mean, by the window's deviation; the graph carries a feature error into its logits with
+ * a gain that depends on its weights.  kws_create measures that gain per cepstral column (reverse differentiation of the float graph on a
+ * calibration set: kws_fast_gain) and the kernels sum, per clip,
+ *     V = sigma_net^2 + sum over cmvnw windows (row r, column c) of ((abs[c] + lev[c] x level + rel[c] x |window mean|) / (deviation + eps))^2
+ * -- an estimate of the variance of the error of a logit difference; abs / lev / rel = gain[c] x the rms error of a coefficient (absolute,
+ * per unit of the clip's rms log-mel level, per unit of |mean|: kws_fast_guard), level = 0 for tier 2.  The clip stays in its tier iff
+ *     V x max(g_c1 x P^2, g_c2) <= 1,    g_c1 = (k_sigma x lin_margin / score_tol)^2,  g_c2 = (k_sigma / logit_cap)^2,
+ * P = the largest p (1 - p) among the clip's own scores where the network runs in the same launch (|d score| <= p (1 - p) x the error of
+ * a logit difference: a saturated softmax passes nothing on), 1/4 otherwise.  In words: k_sigma standard deviations of the estimated logit
+ * error, through the clip's own softmax, must stay below the score tolerance of 1e-4.  A calibrated statistical estimate, not a bound
+ * (a worst-case bound through the weights' row sums would refuse every model); tests/test_gpu_fast_families.py re-evaluates the rule
+ * from the oracle's cepstra and holds scores AND logits to it on eleven input families.
+ * int8 graphs have no float logits to protect (the network is bit-exact from its int8 input tensor on): gain[c] is the constant for which
+ * the rule reads "k_sigma x the rms of the clip's feature error estimates <= 1e-4", calibrated = 0.
+ *   kws_fast_guard   coef [4][n_columns]: abs, lev, rel, and rel when column 0's window means were replayed in the reference's order
+ *   kws_fast_gain    gain [n_columns] of a float32 graph (logit-difference error per unit of feature error, rms over a column's rows)
  * kws_streams_step_device and kws_cmvn_inference_batch_device start from exact cepstra: their one fast tier is tier 2. */
+typedef struct {
+    float score_tol, k_sigma, lin_margin, logit_cap;   /* 1e-4, 4.5, 1.1, 0.1 */
+    float g_c1, g_c2;                                  /* as above */
+    float sigma_net;                                   /* float32 graphs fused behind the features: what the matrix cores' summation order moves in a logit difference */
+    float total_gain;                                  /* sqrt(sum over all features of gain^2) */
+    float uniform_feature_tol;                         /* the feature error of random sign, the same size on every feature, that exactly meets the rule at P = 1/4 */
+    int calibrated, n_columns, n_frames;
+} kws_fast_tolerance;
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
 EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);
-EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, int tier, float *abs_thr, float *rel_thr);
+EI_IMPULSE_ERROR kws_fast_guard(const kws_handle *h, int tier, float *coef);
+EI_IMPULSE_ERROR kws_fast_gain(const kws_handle *h, float *gain);
+EI_IMPULSE_ERROR kws_fast_tolerance_info(const kws_handle *h, kws_fast_tolerance *out);
+
+/* float32 graphs: the device-resident batch entry points that produce scores (kws_run_classifier_batch_device,
+ * kws_cmvn_inference_batch_device) also write every clip's FULLY_CONNECTED outputs -- the logits the SOFTMAX reads -- to
+ * logits [B][label_count] (device) until the tap is cleared with NULL; both modes, every tier of KWS_MODE_FAST.  A score near 0 or 1 hides
+ * its logit (d score = p (1 - p) d logit): the parity tests of the fast mode hold the logits themselves.  B is the calling batch's. */
+EI_IMPULSE_ERROR kws_set_logits_tap(kws_handle *h, float *logits);
 
 /* The model used by the SDK-style entry points run_classifier()/run_inference().  If none was set,
  * the first call loads the file named by the environment variable KWS_MODEL on device KWS_DEVICE (0). */

@@ -27,13 +27,16 @@ static void walk(kws_handle *h)
     (void)kws_nn_kernel_name(h); (void)kws_mfcc_kernel_name(h); (void)kws_frame_count(h); (void)kws_filter_count(h);
     const size_t B = 5;
     std::vector<int16_t> pcm(B * n + 8, 1);
-    std::vector<float> scores(B * C + 1), feats(B * F + 1), thr(256), rel(256);
+    std::vector<float> scores(B * C + 1), feats(B * F + 1), thr(4 * 256), rel(256);
     std::vector<int8_t> q(B * F + 1);
     const bool is_float = kws_model_is_float(h) != 0;
     for (int mode = 0; mode < 2; mode++) {
         if (kws_set_mode(h, mode) != EI_IMPULSE_OK) continue;
-        (void)kws_fast_guard(h, 1, thr.data(), rel.data());
-        (void)kws_fast_guard(h, 2, thr.data(), rel.data());
+        (void)kws_fast_guard(h, 1, thr.data());
+        (void)kws_fast_guard(h, 2, thr.data());
+        (void)kws_fast_gain(h, rel.data());
+        kws_fast_tolerance tolinfo;
+        (void)kws_fast_tolerance_info(h, &tolinfo);
         // "device" pointers are host heap under the stub: the entry points' host logic runs, launches are no-ops
         (void)kws_run_classifier_batch_device(h, pcm.data(), B, scores.data(), feats.data(), is_float ? nullptr : q.data(), nullptr);
         (void)kws_run_classifier_batch_device(h, pcm.data(), B, scores.data(), nullptr, nullptr, nullptr);
@@ -76,9 +79,24 @@ static void walk(kws_handle *h)
     (void)run_classifier_continuous(&sig, &res, false);
 }
 
+// --gain: print what kws_create calibrated for a float32 graph (kws_gain.cpp is host code: the stub runtime is all it needs) --
+// tests/test_gain_calibration.py compares it with Jacobians of the oracle's network
+static void print_gain(const char *path, kws_handle *h)
+{
+    kws_fast_tolerance t;
+    std::vector<float> g(256, 0.0f), coef(4 * 256, 0.0f);
+    if (kws_fast_tolerance_info(h, &t) != EI_IMPULSE_OK || kws_fast_guard(h, 1, coef.data()) != EI_IMPULSE_OK) { printf("GAIN %s none\n", path); return; }
+    printf("GAIN %s calibrated %d columns %d frames %d k %.9g lin %.9g cap %.9g c1 %.9g c2 %.9g sigma_net %.9g total %.9g uniform_tol %.9g :", path, t.calibrated,
+           t.n_columns, t.n_frames, t.k_sigma, t.lin_margin, t.logit_cap, t.g_c1, t.g_c2, t.sigma_net, t.total_gain, t.uniform_feature_tol);
+    if (t.calibrated && kws_fast_gain(h, g.data()) == EI_IMPULSE_OK)
+        for (int c = 0; c < t.n_columns; c++) printf(" %.9g", g[c]);
+    printf("\n");
+}
+
 int main(int argc, char **argv)
 {
-    for (int i = 1; i < argc; i++) {
+    const bool gain_only = argc > 1 && strcmp(argv[1], "--gain") == 0;
+    for (int i = gain_only ? 2 : 1; i < argc; i++) {
         FILE *f = fopen(argv[i], "rb");
         if (!f) { printf("%s rc open-failed\n", argv[i]); continue; }
         std::vector<unsigned char> blob;
@@ -90,7 +108,9 @@ int main(int argc, char **argv)
         const EI_IMPULSE_ERROR rc = kws_create(blob.data(), blob.size(), 0, &h);
         printf("%s rc %d\n", argv[i], (int)rc);
         fflush(stdout);
-        if (rc == EI_IMPULSE_OK) { walk(h); kws_destroy(h); }
+        if (rc == EI_IMPULSE_OK && gain_only) print_gain(argv[i], h);
+        else if (rc == EI_IMPULSE_OK) walk(h);
+        if (rc == EI_IMPULSE_OK) kws_destroy(h);
     }
     return 0;
 }

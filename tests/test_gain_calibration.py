@@ -1,0 +1,143 @@
+"""CPU: the model-dependent half of KWS_MODE_FAST's guard (ei-keyword-spotting_amd/csrc/kws_gain.cpp).
+
+kws_create calibrates, per cepstral column, how far a logit difference of the loaded float32 graph moves per unit of feature error,
+and derives the feature tolerance of the fast mode from it.  That is host code, so it runs here without a GPU: the library's host
+side is built against the stub HIP runtime of tests/sanitize (device memory = host heap, launches do nothing) and its driver prints
+what kws_create calibrated (`kws_host_san --gain`).  Held against the C oracle:
+  * the judge's experiment: the oracle's features of real clips, every one moved by +- the library's uniform feature tolerance with
+    random signs, must leave every score within 1e-4 -- for every committed float32 model and for a deliberately high-gain one;
+  * the calibrated column gains against Jacobians of the oracle's network (central differences) on real clips' features: calibration
+    runs on random standardised matrices, the clips are what the network really sees;
+  * a model with its first convolution's weights x 8 must come out with ~8 x the gain and ~1/8 of the tolerance.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kws_testlib import MODELS, ROOT, Oracle, OracleModel
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import eon_import  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+pytestmark = pytest.mark.skipif(not (os.path.exists(CLANG) and shutil.which("gcc")), reason="needs ROCm's clang++ and gcc")
+FLOAT_MODELS = ["cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "cfg5_dscnn_mfcc40_f32.kwsm"]
+
+
+@pytest.fixture(scope="module")
+def host_exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("kws_host_stub"))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sanitize"), "OUT=" + out, os.path.join(out, "kws_host_san")])
+    return os.path.join(out, "kws_host_san")
+
+
+def calibrated(host_exe, path):
+    out = subprocess.run([host_exe, "--gain", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0 and "Sanitizer" not in out.stderr, out.stderr[-2000:]
+    ln = [x for x in out.stdout.splitlines() if x.startswith("GAIN")][0].split()
+    info = {ln[i]: float(ln[i + 1]) for i in range(2, ln.index(":"), 2)}
+    return info, np.array([float(x) for x in ln[ln.index(":") + 1:]])
+
+
+def scaled_first_conv(path, factor, out_path):
+    """the float32 model with its first convolution's filter x factor (a deliberately high-gain graph: the logits move `factor` times as
+    far per unit of feature error wherever the ReLU pattern is unchanged)"""
+    tensors, nodes, t_in, t_out, meta = eon_import.parse_blob(open(path, "rb").read())
+    conv = [nd for nd in nodes if nd["op"] == 1][0]
+    t = tensors[conv["in"][1]]
+    t["data"] = (np.frombuffer(t["data"], np.float32) * np.float32(factor)).astype(np.float32).tobytes()
+    open(out_path, "wb").write(eon_import.serialise(tensors, nodes, t_in, t_out, meta))
+
+
+def perturbation_experiment(om, o, tol, n=256, seeds=(0, 4100)):
+    worst = 0.0
+    for seed in seeds:
+        s, f, _ = om.run_batch(o.synth(seed, 0, n), want_features=True)
+        rng = np.random.default_rng(seed + 1)
+        for i in range(n):
+            fp = f[i] + np.float32(tol) * rng.choice([-1.0, 1.0], f.shape[1]).astype(np.float32)
+            worst = max(worst, float(np.abs(om.nn_invoke_f32(fp) - s[i]).max()))
+    return worst
+
+
+@pytest.mark.parametrize("name", FLOAT_MODELS)
+def test_uniform_feature_tolerance_keeps_scores_within_1e4(name, host_exe):
+    o = Oracle()
+    path = os.path.join(MODELS, name)
+    info, gain = calibrated(host_exe, path)
+    assert info["calibrated"] == 1 and len(gain) == int(info["columns"]) and np.isfinite(gain).all() and (gain > 0).all()
+    # the tolerance follows from the gain: k sigma x 1.1 x 1/4 x total gain x tol = 1e-4 (minus the network's own re-ordering noise)
+    tol = info["uniform_tol"]
+    expect = np.sqrt(max(16.0 / info["c1"] - info["sigma_net"] ** 2, 0.0)) / info["total"]
+    assert abs(tol - expect) <= 1e-3 * expect
+    assert abs(info["total"] - np.sqrt((gain ** 2).sum() * info["frames"])) <= 1e-3 * info["total"]
+    worst = perturbation_experiment(OracleModel(o, path), o, tol)
+    print("\n%s: total gain %.3g, uniform feature tolerance %.3g; oracle features +- that, random signs, 512 clips: max |dscore| %.3g"
+          % (name, info["total"], tol, worst))
+    assert worst <= 1e-4
+    # ... and the tolerance is not absurdly tight either: ten times it does break the bar (the test can fail)
+    assert perturbation_experiment(OracleModel(o, path), o, 10 * tol, n=128, seeds=(0,)) > 1e-4
+
+
+@pytest.mark.parametrize("name", FLOAT_MODELS)
+def test_calibrated_gain_against_jacobians_on_real_clips(name, host_exe):
+    o = Oracle()
+    path = os.path.join(MODELS, name)
+    om = OracleModel(o, path)
+    info, gain = calibrated(host_exe, path)
+    nfr, ncep, L = int(info["frames"]), int(info["columns"]), om.n_labels
+    n = 10
+    _, f, _ = om.run_batch(o.synth(0, 0, n), want_features=True)
+
+    def logits(x):
+        _, taps = om.nn_invoke_f32(x, taps=True)
+        return np.array([t for t in taps if len(t) == L][-2], np.float64)
+
+    h = np.float32(2.0 ** -7)
+    ratios, totals = [], []
+    for i in range(n):
+        J = np.zeros((L, nfr * ncep))
+        for k in range(nfr * ncep):
+            fp, fm = f[i].copy(), f[i].copy()
+            fp[k] += h
+            fm[k] -= h
+            J[:, k] = (logits(fp) - logits(fm)) / (np.float64(fp[k]) - np.float64(fm[k]))
+        Jd = (J[:, None, :] - J[None, :, :]).reshape(L * L, nfr, ncep)
+        col = np.sqrt((Jd ** 2).sum(axis=1).max(axis=0) / nfr)           # this clip's gain per column, as kws_gain.cpp defines it
+        ratios.append(col / gain)
+        totals.append(np.sqrt((Jd ** 2).sum(axis=(1, 2)).max()))
+    ratios = np.array(ratios)
+    print("\n%s: real clips' column gain / calibrated: median %.2f, p90 %.2f, max %.2f; total gain of a clip: median %.3g, max %.3g, calibrated %.3g"
+          % (name, np.median(ratios), np.quantile(ratios, 0.9), ratios.max(), np.median(totals), max(totals), info["total"]))
+    # the calibration keeps the largest value per column over its inputs: a typical clip sits below it, none far above, and it is not
+    # a loose bound either.  (k_sigma = 4.5 absorbs a clip whose gain is above the calibrated one: 4.5 / 2.2 is still two sigma.)
+    assert 0.4 <= np.median(ratios) <= 1.1
+    assert ratios.max() <= 2.2
+    assert max(totals) <= 1.5 * info["total"] and np.median(totals) >= 0.4 * info["total"]
+
+
+def test_high_gain_model_gets_a_tighter_tolerance(host_exe, tmp_path):
+    o = Oracle()
+    base = os.path.join(MODELS, "cfg2_mfcc40_f32.kwsm")
+    hot = str(tmp_path / "cfg2_conv1_x8.kwsm")
+    scaled_first_conv(base, 8.0, hot)
+    i0, g0 = calibrated(host_exe, base)
+    i1, g1 = calibrated(host_exe, hot)
+    print("\nfirst convolution x 8: total gain %.3g -> %.3g, uniform feature tolerance %.3g -> %.3g" % (i0["total"], i1["total"], i0["uniform_tol"], i1["uniform_tol"]))
+    assert 5.0 <= i1["total"] / i0["total"] <= 12.0
+    assert i1["uniform_tol"] <= i0["uniform_tol"] / 5.0
+    # the tighter tolerance is what the hotter graph needs: at ITS tolerance the bar holds, at the base model's it does not
+    om = OracleModel(o, hot)
+    assert perturbation_experiment(om, o, i1["uniform_tol"], n=128, seeds=(0,)) <= 1e-4
+    assert perturbation_experiment(om, o, i0["uniform_tol"], n=128, seeds=(0,)) > 1e-4
+
+
+def test_int8_models_use_the_feature_level_rule(host_exe):
+    info, gain = calibrated(host_exe, os.path.join(MODELS, "l476_no_yes.kwsm"))
+    assert info["calibrated"] == 0 and len(gain) == 0
+    # k_sigma x (rms feature error estimate) <= 1e-4: a uniform error of 1e-4 / k_sigma on every feature sits exactly on the rule
+    assert abs(info["uniform_tol"] - 1e-4 / info["k"]) <= 1e-3 * info["uniform_tol"]

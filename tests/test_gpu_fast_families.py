@@ -5,9 +5,14 @@ by clip.  Bar: float32 scores within 1e-4 (north_star); int8 graphs: the network
 rate reported.  Per family the test prints max |score - oracle|, max |feature - oracle| and the fallback rate.
 
 The guards that decide which clips leave the fast kernel (tier 1 -> exact cepstra + fast cmvnw / network) and which of those end in the
-exact kernels (tier 2 -> exact) are read from the library (kws_fast_guard) and re-evaluated here on the oracle's cepstra: clips well
-inside a guard (margin < 0.9) MUST have been handed on, clips well outside it (margin > 1.1) must not, and every clip must meet the bar
-wherever it ended; the families are built so that hundreds of clips sit at 0.5x .. 2x either guard."""
+exact kernels (tier 2 -> exact) follow from the LOADED MODEL since round 4 (kws.h: kws_fast_guard / kws_fast_gain /
+kws_fast_tolerance_info): per clip the kernels estimate the variance V of the error of a logit difference from the
+windows' deviations, the graph's calibrated gain per cepstral column and the clip's log-mel level, and keep the clip iff
+k_sigma sqrt(V) stays below the score tolerance through the clip's own softmax.  The rule is re-evaluated here from the oracle's
+cepstra, log-mel energies and scores: clips well inside a guard (margin < 0.9) MUST have been handed on, clips well outside it
+(margin > 1.1) must not, every clip must meet the 1e-4 score bar wherever it ended, and -- float32 graphs -- the LOGITS of every clip a
+fast tier kept must sit within k_sigma sqrt(V) of the oracle's (the claim the guard makes); the families are built so that hundreds of
+clips sit at 0.5x .. 2x either guard."""
 import multiprocessing as mp
 import os
 
@@ -44,7 +49,14 @@ def _oracle_worker(args):
     s, f, q = om.run_batch(pcm, want_features=True)
     cep = np.stack([o.mfcc_nocmvn(p, om.cfg) for p in pcm])
     sdw, mw = column_conditioning(cep, om.cfg.win_size, full=True)
-    return s, f, q, sdw.astype(np.float32), mw.astype(np.float32)
+    z = np.zeros_like(s)
+    if o.L.kwso_model_is_float(om.h):
+        for i in range(len(pcm)):
+            _, taps = om.nn_invoke_f32(f[i], taps=True)
+            z[i] = [t for t in taps if len(t) == om.n_labels][-2]            # the tensor SOFTMAX reads
+    # the clip's rms log-mel level (what the fast kernel's rounding errors scale with)
+    lvl = np.array([np.sqrt((np.log(o.mfe(p, om.cfg)[0].astype(np.float64)) ** 2).mean()) for p in pcm], np.float32)
+    return s, f, q, sdw.astype(np.float32), mw.astype(np.float32), z, lvl
 
 
 @pytest.fixture(scope="module")
@@ -55,7 +67,7 @@ def pool():
 
 def oracle_clips(pool, path, pcm, chunk=128):
     parts = pool.map(_oracle_worker, [(path, pcm[i:i + chunk]) for i in range(0, len(pcm), chunk)])
-    return [np.concatenate([p[k] for p in parts]) for k in range(5)]
+    return [np.concatenate([p[k] for p in parts]) for k in range(7)]
 
 
 def family_pcm(pkg, name, n, seed):
@@ -89,17 +101,40 @@ def run_device(pkg, gm, mode, pcm_t):
     gm.set_mode(mode)
     s = torch.zeros((n, gm.n_labels), dtype=torch.float32, device="cuda:0")
     f = torch.zeros((n, gm.n_features), dtype=torch.float32, device="cuda:0")
+    z = torch.zeros((n, gm.n_labels), dtype=torch.float32, device="cuda:0")
     q = None if gm.is_float else torch.zeros((n, gm.n_features), dtype=torch.int8, device="cuda:0")
+    if gm.is_float:
+        gm.set_logits_tap(z.data_ptr())
     gm.run_classifier_batch_device(pcm_t.data_ptr(), n, s.data_ptr(), f.data_ptr(), q.data_ptr() if q is not None else None)
     torch.cuda.synchronize()
-    return s.cpu().numpy(), f.cpu().numpy(), (q.cpu().numpy() if q is not None else None)
+    if gm.is_float:
+        gm.set_logits_tap(None)
+    return s.cpu().numpy(), f.cpu().numpy(), (q.cpu().numpy() if q is not None else None), z.cpu().numpy()
 
 
-def guard_margin(gm, sdw, mw, tier):
-    """per clip: min over cmvnw windows of deviation / (abs_thr[c] + rel_thr[c] |mean|) of that tier's guard -- below 1 the tier hands the clip on"""
-    a, rel = gm.fast_guard(tier)
-    thr = a[None, None, :] + rel[None, None, :] * np.abs(mw)
-    return (sdw / thr).reshape(len(sdw), -1).min(axis=1)
+def guard_variance(gm, sdw, mw, lvl, tier):
+    """The guard's variance estimate V of that tier, re-evaluated from the oracle's windows (kws.h): (lo, hi) per clip -- column 0's
+    window-mean term is dropped when the kernel replayed its means in the reference's order, a decision taken inside the kernel: lo assumes
+    it did, hi that it did not."""
+    coef = gm.fast_guard(tier).astype(np.float64)                     # [4][columns]: abs, per level, per |mean|, per |mean| with replayed means
+    tol = gm.fast_tolerance()
+    level = lvl.astype(np.float64)[:, None, None] if tier == 1 else 0.0
+    rd = 1.0 / (sdw.astype(np.float64) + 1.1920929e-7)
+    base = coef[0][None, None, :] + coef[1][None, None, :] * level
+    v = []
+    for rel in (coef[3], coef[2]):
+        b = (base + rel[None, None, :] * np.abs(mw)) * rd
+        v.append((b * b).reshape(len(sdw), -1).sum(axis=1) + tol["sigma_net"] ** 2)
+    return v[0], v[1]
+
+
+def guard_margin(gm, sdw, mw, lvl, tier, pq):
+    """per clip (lo, hi): 1 / sqrt(V max(g_c1 P^2, g_c2)) -- below 1 the tier hands the clip on"""
+    tol = gm.fast_tolerance()
+    vlo, vhi = guard_variance(gm, sdw, mw, lvl, tier)
+    w = np.maximum(tol["g_c1"] * pq.astype(np.float64) ** 2, tol["g_c2"])
+    with np.errstate(divide="ignore"):
+        return 1.0 / np.sqrt(vhi * w), 1.0 / np.sqrt(vlo * w)
 
 
 @pytest.mark.parametrize("name", ["cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "l476_no_yes.kwsm"])
@@ -111,11 +146,12 @@ def test_fast_mode_on_adversarial_input_families(name, pkg, pool):
     n = N_PER_FAMILY
     near1, near2 = np.zeros(4, int), np.zeros(4, int)          # clips at 0.5-0.9, 0.9-1.1, 1.1-2, 2-4 x each tier's guard, all families
     worst = 0.0
+    worst_sigma = {}
     print()
     for fam in FAMILIES:
         host = family_pcm(pkg, fam, n, seed=11)
         pcm = torch.from_numpy(host).to("cuda:0")
-        s1, f1, q1 = run_device(pkg, gm, pkg.MODE_FAST, pcm)
+        s1, f1, q1, z1 = run_device(pkg, gm, pkg.MODE_FAST, pcm)
         n_t2, n_ex = gm.fast_fallback_count(), gm.fast_exact_count()
         if gm.fast_is_fused:                                   # the form bench.py times: scores only, features never leave the chip
             gm.set_mode(pkg.MODE_FAST)
@@ -124,24 +160,45 @@ def test_fast_mode_on_adversarial_input_families(name, pkg, pool):
             torch.cuda.synchronize()
             assert (s2.cpu().numpy() == s1).all(), fam
             assert (gm.fast_fallback_count(), gm.fast_exact_count()) == (n_t2, n_ex), fam
-        s0, f0, q0 = run_device(pkg, gm, pkg.MODE_EXACT, pcm)
-        so, fo, qo, sdw, mw = oracle_clips(pool, path, host)
+        s0, f0, q0, z0 = run_device(pkg, gm, pkg.MODE_EXACT, pcm)
+        so, fo, qo, sdw, mw, zo, lvl = oracle_clips(pool, path, host)
         assert (bits(f0) == bits(fo)).all(), fam               # the exact kernels stay bit-exact on these inputs too
-        m1, m2 = guard_margin(gm, sdw, mw, 1), guard_margin(gm, sdw, mw, 2)
+        # P of the rule: the clip's own largest p (1 - p) where the network runs behind the features in the same launch (fused float32
+        # graphs), 1/4 otherwise (int8 graphs; kws.h)
+        pq = (so * (1.0 - so)).max(axis=1) if (gm.is_float and gm.fast_is_fused) else np.full(n, 0.25)
+        (m1lo, m1hi), (m2lo, m2hi) = guard_margin(gm, sdw, mw, lvl, 1, pq), guard_margin(gm, sdw, mw, lvl, 2, pq)
         exact = (bits(f1) == bits(f0)).all(axis=1)             # a clip the exact kernels finished carries their bits
         ds = np.abs(s1 - so).max(axis=1)
         df = np.abs(f1 - fo).max(axis=1)
-        near1 += np.histogram(m1, [0.5, 0.9, 1.1, 2.0, 4.0])[0]
-        near2 += np.histogram(m2, [0.5, 0.9, 1.1, 2.0, 4.0])[0]
+        near1 += np.histogram(m1hi, [0.5, 0.9, 1.1, 2.0, 4.0])[0]
+        near2 += np.histogram(m2hi, [0.5, 0.9, 1.1, 2.0, 4.0])[0]
         line = "%-22s %-15s second tier %5d (%5.1f %%), exact kernels %5d (%5.1f %%) of %d  max |score - oracle| %.3g  max |feature - oracle| %.3g" % (
             name, fam, n_t2, 100.0 * n_t2 / n, n_ex, 100.0 * n_ex / n, n, ds.max(), df[~exact].max() if (~exact).any() else 0.0)
         assert not np.isnan(s1).any(), fam
         # the guards do what they say: a clip well inside the first tier's goes on to the second, one well inside the second tier's
         # is finished by the exact kernels (and has their bits), one well outside stays where it is
-        assert (m1 < 0.9).sum() <= n_t2 <= (m1 < 1.1).sum(), (fam, n_t2, int((m1 < 0.9).sum()), int((m1 < 1.1).sum()))
-        assert (m2 < 0.9).sum() <= n_ex <= (m2 < 1.1).sum(), (fam, n_ex, int((m2 < 0.9).sum()), int((m2 < 1.1).sum()))
-        assert exact[m2 < 0.9].all() and not exact[m2 > 1.1].any(), fam
+        assert (m1hi < 0.9).sum() <= n_t2 <= (m1lo < 1.1).sum(), (fam, n_t2, int((m1hi < 0.9).sum()), int((m1lo < 1.1).sum()))
+        in_t2 = m1lo < 1.1                                      # a clip can only reach the exact kernels through the second tier
+        assert ((m2hi < 0.9) & (m1hi < 0.9)).sum() <= n_ex <= ((m2lo < 1.1) & in_t2).sum(), (fam, n_ex, int(((m2hi < 0.9) & (m1hi < 0.9)).sum()), int(((m2lo < 1.1) & in_t2).sum()))
+        assert exact[(m2hi < 0.9) & (m1hi < 0.9)].all() and not exact[(m2lo > 1.1) | (m1lo > 1.1)].any(), fam
         assert (bits(s1[exact]) == bits(s0[exact])).all(), fam
+        if gm.is_float:
+            # the claim the guard makes, held at the LOGITS (a saturated score hides its logit): every clip a fast tier kept has its
+            # logit differences within k_sigma sqrt(V) of the oracle's -- V re-evaluated from the oracle -- and within the linearisation cap
+            tol = gm.fast_tolerance()
+            dz = z1 - zo
+            dzp = np.abs(dz[:, :, None] - dz[:, None, :]).reshape(n, -1).max(axis=1)
+            assert (bits(z1[exact]) == bits(z0[exact])).all(), fam
+            v1 = guard_variance(gm, sdw, mw, lvl, 1)[1]
+            v2 = guard_variance(gm, sdw, mw, lvl, 2)[1]
+            kept1, kept2 = m1lo > 1.1, (~exact) & (m1hi < 0.9)         # surely stayed in tier 1 / surely finished by tier 2
+            for kept, v, what in ((kept1, v1, "tier 1"), (kept2, v2, "tier 2")):
+                if kept.any():
+                    r = dzp[kept] / np.sqrt(v[kept])
+                    worst_sigma[what] = max(worst_sigma.get(what, 0.0), float(r.max()))
+                    assert r.max() <= tol["k_sigma"], (fam, what, float(r.max()))
+            assert dzp[~exact].max(initial=0.0) <= tol["logit_cap"], (fam, float(dzp[~exact].max()))
+            line += "  max |dlogit| %.3g" % dzp.max()
         if gm.is_float:
             assert ds.max() <= FAST_SCORE_TOL, line
             worst = max(worst, float(ds.max()))
@@ -156,7 +213,7 @@ def test_fast_mode_on_adversarial_input_families(name, pkg, pool):
             line += "  int8 flips / clip %.4f  clips with a changed score %d" % (flips.mean(), int(changed.sum()))
             assert flips.mean() <= 0.1 and changed.mean() <= 0.02, line
         print(line)
-    print("%s: clips at 0.5-0.9 / 0.9-1.1 / 1.1-2 / 2-4 x the guard: first tier %s, second tier %s; worst score error %.3g"
-          % (name, near1.tolist(), near2.tolist(), worst))
+    print("%s: clips at 0.5-0.9 / 0.9-1.1 / 1.1-2 / 2-4 x the guard: first tier %s, second tier %s; worst score error %.3g; worst logit error in "
+          "units of the guard's sigma: %s (k_sigma = %.2g)" % (name, near1.tolist(), near2.tolist(), worst, worst_sigma, gm.fast_tolerance()["k_sigma"]))
     assert (near1 >= 100).all() and (near2 >= 100).all()       # both guards' neighbourhoods were really probed
     gm.close()
