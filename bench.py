@@ -13,7 +13,9 @@ Two arithmetic modes of the same library are timed (include/kws/kws.h):
     the exact kernels inside the same call (their share is reported as config.fast_fallback_rate);
   * KWS_MODE_EXACT -- MFCC features bit-identical to the reference's, scores within 1e-6; reported under "modes".
 At N = 1 the same run also times the model the reference DOES ship (49x13 MFCC, int8) and the other BASELINE configurations;
-they are reported under "also".
+they are reported under "also".  BASELINE configs[3] ("int8 ... bit-exact check, batch 65 536, 1 GPU") is the line "int8_exact": the
+reference's own int8 impulse in KWS_MODE_EXACT -- bit-identical to the reference end to end -- with a roofline object of its own.  The
+KWS_MODE_FAST lines of int8 graphs are NOT that configuration (an int8 input value may sit one step away): they say so.
 
 One "step" = one pass of the hot path over one batch of B synthetic 1 s @ 16 kHz int16 clips per GPU, the clips already
 resident in HBM (generated on the device by kws_synth_clips_device).  N > 1: one process per GPU, clips sharded contiguously
@@ -50,6 +52,14 @@ WORKLOADS = {
     "cfg5_dscnn_mfcc40_f32.kwsm": "BASELINE configs[4] shape: 49x40 MFCC + 7-block depthwise-separable CNN, 12 labels, fp32, synthetic weights",
 }
 CLIP_LEN = 16000
+
+
+def free_port():
+    """a TCP port nobody is bound to right now on 127.0.0.1 (asked of the kernel, not derived from the pid)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def default_batch(world):
@@ -181,7 +191,10 @@ class GpuBackend:
         m.set_mode(self.pkg.MODE_FAST if mode == "fast" else self.pkg.MODE_EXACT)
         self.scores = torch.empty((self.B, m.n_labels), dtype=torch.float32, device=self.dev)
         self.gathered = torch.empty((self.world * self.B, m.n_labels), dtype=torch.float32, device=self.dev) if self.use_comm else self.scores
-        return {"labels": m.n_labels, "is_float": m.is_float, "nn_kernel": m.nn_kernel, "fused": bool(m.fast_is_fused and mode == "fast")}
+        tol = m.fast_tolerance() if mode == "fast" else None
+        return {"labels": m.n_labels, "is_float": m.is_float, "nn_kernel": m.nn_kernel, "fused": bool(m.fast_is_fused and mode == "fast"),
+                "entry_tier": tol["entry_tier"] if tol else None,
+                "guard": {k: tol[k] for k in ("k_sigma", "score_tol", "total_gain", "uniform_feature_tol", "calibrated")} if tol else None}
 
     def events(self, steps):
         self.ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
@@ -214,6 +227,16 @@ class GpuBackend:
     def fallback(self):
         return self.model.fast_fallback_count()
 
+    def exact_count(self):
+        return self.model.fast_exact_count()
+
+    def comm_info(self):
+        """what RCCL itself says about the communicator (not what the launcher said)"""
+        if self.comm is None:
+            return None
+        self.comm.wait(self.stream)                                   # deadline-guarded: a missing / failed rank is an error here, not a hang
+        return {"ranks_seen_by_rccl": self.comm.ranks_seen_by_rccl, "rccl_version": self.comm.rccl_version}
+
     def close_model(self):
         if self.model is not None:
             self.model.close()
@@ -244,7 +267,7 @@ class CpuOracleBackend:
         self.scores = self.torch.zeros((self.B, self.model.n_labels), dtype=self.torch.float32)
         self.gathered = self.torch.zeros((self.world * self.B, self.model.n_labels), dtype=self.torch.float32) if self.use_comm else self.scores
         return {"labels": self.model.n_labels, "is_float": bool(self.oracle.L.kwso_model_is_float(self.model.h)),
-                "nn_kernel": "oracle (CPU test double)", "fused": False}
+                "nn_kernel": "oracle (CPU test double)", "fused": False, "entry_tier": None, "guard": None}
 
     def events(self, steps):
         self.t = [0.0, 0.0]
@@ -275,12 +298,21 @@ class CpuOracleBackend:
     def fallback(self):
         return 0
 
+    def exact_count(self):
+        return 0
+
+    def comm_info(self):
+        import torch.distributed as dist
+        return {"ranks_seen_by_rccl": None, "rccl_version": None, "gloo_world_size": dist.get_world_size()} if self.use_comm else None
+
     def close_model(self):
         pass
 
 
-def timed_steps(backend, steps, warmup, barrier, max_over_ranks):
-    """W untimed steps, then exactly K steps bracketed by barrier + device synchronisation on both sides; the MAX over ranks."""
+def timed_steps(backend, steps, warmup, barrier, max_over_ranks, own=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + device synchronisation on both sides; the MAX over ranks.
+    own (a list): receives this rank's own time for its K steps, up to its own synchronisation and before the closing barrier -- the
+    per-rank figure behind the skew reported for N > 1."""
     backend.events(steps)
     for _ in range(warmup):
         backend.step()
@@ -288,16 +320,21 @@ def timed_steps(backend, steps, warmup, barrier, max_over_ranks):
     t0 = time.perf_counter()
     for k in range(steps):
         backend.step(k)
-    backend.sync(); barrier(); backend.sync()
+    backend.sync()
+    if own is not None:
+        own.append(time.perf_counter() - t0)
+    barrier(); backend.sync()
     return max_over_ranks(time.perf_counter() - t0)
 
 
-def measure(backend, model_path, mode, steps, warmup, barrier, max_over_ranks):
+def measure(backend, model_path, mode, steps, warmup, barrier, max_over_ranks, gather_ranks=None):
     info = backend.load(model_path, mode)
-    dt = timed_steps(backend, steps, warmup, barrier, max_over_ranks)
+    own = []
+    dt = timed_steps(backend, steps, warmup, barrier, max_over_ranks, own)
     ms_path, ms_gather = backend.phase_ms(steps)
     res = dict(info, model=os.path.basename(model_path), mode=mode, dt=dt, ms_path=ms_path, ms_gather=ms_gather, checksum=backend.checksum(), checksum0=backend.checksum_class0(),
-               fallback=backend.fallback() if mode == "fast" else 0)
+               fallback=backend.fallback() if mode == "fast" else 0, exact_count=backend.exact_count() if mode == "fast" else 0,
+               comm=backend.comm_info(), rank_dt=gather_ranks(own[0]) if gather_ranks else [own[0]])
     backend.close_model()
     return res
 
@@ -341,7 +378,7 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the N ranks ourselves, one per GPU, and pass rank 0's JSON line through
-        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        port = os.environ.get("MASTER_PORT") or str(free_port())
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
                "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
@@ -381,6 +418,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_ranks(dt):
+        """every rank's own time for its K steps (control plane: gloo)"""
+        if not use_comm:
+            return [dt]
+        ts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ts, torch.tensor([dt], dtype=torch.float64))
+        return [float(t.item()) for t in ts]
+
     if a.dry_run_cpu:
         backend = CpuOracleBackend(rank, world, B)
     else:
@@ -393,8 +438,8 @@ def main():
             dist.broadcast_object_list(ids, src=0)
             backend.make_comm(ids[0])
 
-    r = measure(backend, a.model, a.mode, a.steps, a.warmup, barrier, max_over_ranks)
-    others, also = [], []
+    r = measure(backend, a.model, a.mode, a.steps, a.warmup, barrier, max_over_ranks, gather_ranks)
+    others, also, int8_exact = [], [], None
     if world == 1 and not a.no_also and not a.dry_run_cpu:
         side_steps = max(20, a.steps // 8)
         others.append(measure(backend, a.model, "exact" if a.mode == "fast" else "fast", side_steps, a.warmup, barrier, max_over_ranks))
@@ -402,6 +447,8 @@ def main():
             if not os.path.samefile(mp_, a.model):
                 for md in ("fast", "exact"):
                     also.append(measure(backend, mp_, md, side_steps, min(a.warmup, 5), barrier, max_over_ranks))
+        # BASELINE configs[3]: the reference's own int8 impulse, bit-exact (KWS_MODE_EXACT), with as many timed steps as the headline
+        int8_exact = measure(backend, SHIPPED_MODEL, "exact", max(side_steps, a.steps // 2), min(a.warmup, 5), barrier, max_over_ranks)
 
     if not a.dry_run_cpu and backend.comm is not None:
         backend.comm.close()
@@ -421,9 +468,10 @@ def main():
 
     def parity(x):
         if x["mode"] == "fast":
-            return ("scores within 1e-4 of the reference's (KWS_MODE_FAST; ill-conditioned clips re-run exactly)" if x["is_float"] else
-                    "KWS_MODE_FAST: MFCC within tolerance, network bit-exact from the int8 tensor on (an input value may move one step at a "
-                    "rounding boundary)") + " -- tests/test_gpu_fast_mode.py, tests/test_gpu_fast_families.py"
+            return ("scores within 1e-4 of the reference's (KWS_MODE_FAST: which clips the fast tiers keep follows from the loaded graph's calibrated logit gain, "
+                    "DESIGN.md 4.4.1; the others are finished by the exact kernels inside the call)" if x["is_float"] else
+                    "KWS_MODE_FAST on an int8 graph is NOT bit-exact (MFCC within tolerance, the network bit-exact from the int8 tensor on, an input value may move "
+                    "one step at a rounding boundary): this line is not BASELINE configs[3] -- see int8_exact") + " -- tests/test_gpu_fast_mode.py, tests/test_gpu_fast_families.py"
         return ("MFCC features + logits bit-exact, scores <= 1e-6 vs the reference's float kernels" if x["is_float"]
                 else "bit-exact vs reference") + " -- tests/test_gpu_parity.py"
 
@@ -453,13 +501,16 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype(r),
         "data": "synthetic" + (" (DRY RUN ON CPU: oracle + gloo stand in for the GPU library + RCCL; not a measurement)" if a.dry_run_cpu else ""),
         "config": {"workload": workload(r["model"]), "mode": r["mode"], "clips_per_gpu": B, "global_batch": world * B, "kwsm_file": r["model"],
-                   "parity": parity(r), "network_fused_into_mfcc_kernel": r["fused"], "clips_rerun_by_exact_kernels_last_step": r["fallback"],
-                   "fast_fallback_rate": round(r["fallback"] / float(B), 6),
-                   "fast_fallback_note": "share of this workload's clips the fast kernel handed back to the exact kernels (cmvnw guard, DESIGN.md 4.4); "
-                                         "other input families: profiles/r03_fast_families.txt (tests/test_gpu_fast_families.py)",
+                   "parity": parity(r), "network_fused_into_mfcc_kernel": r["fused"], "clips_handed_on_by_the_first_fast_tier_last_step": r["fallback"],
+                   "clips_finished_by_exact_kernels_last_step": r["exact_count"],
+                   "fast_fallback_rate": round(r["fallback"] / float(B), 6), "fast_entry_tier": r["entry_tier"], "fast_guard": r["guard"],
+                   "fast_fallback_note": "share of this workload's clips the entry tier of KWS_MODE_FAST handed on (the guard derived from the loaded graph's logit gain, "
+                                         "DESIGN.md 4.4.1); other input families: profiles/r04_fast_families.txt (tests/test_gpu_fast_families.py)",
                    "collective": ("all_gather(scores) over RCCL (kws_allgather_scores, %d ranks)" % world) if use_comm else "none",
                    "lib_sha256": lib_sha256()},
-        "collective": {"allgather_ms_per_step": round(r["ms_gather"], 4), "inside_timed_region": True, "ranks": world} if use_comm else None,
+        "collective": dict({"allgather_ms_per_step": round(r["ms_gather"], 4), "inside_timed_region": True, "ranks": world,
+                            "per_rank_clips_per_s": [round(B * a.steps / t, 1) for t in r["rank_dt"]],
+                            "rank_time_skew_max_over_min": round(max(r["rank_dt"]) / min(r["rank_dt"]), 5)}, **(r["comm"] or {})) if use_comm else None,
         "roofline": roof,
         "checksum": r["checksum"],
         "checksum_class0": r["checksum0"],
@@ -467,7 +518,7 @@ def main():
 
     def line(x, steps):
         return {"kwsm_file": x["model"], "mode": x["mode"], "workload": workload(x["model"]), "value": round(B * steps / x["dt"], 1),
-                "fast_fallback_rate": round(x["fallback"] / float(B), 6),
+                "fast_fallback_rate": round(x["fallback"] / float(B), 6), "fast_exact_rate": round(x["exact_count"] / float(B), 6), "fast_entry_tier": x["entry_tier"],
                 "unit": "clips/s", "ms_per_step": round(x["dt"] / steps * 1e3, 4), "steps": steps, "dtype": dtype(x), "parity": parity(x),
                 "network_kernel": "fused into kws_fast_kernel" if x["fused"] else x["nn_kernel"],
                 "hbm_frac": round((CLIP_LEN * 2 + x["labels"] * 4) * B / (x["ms_path"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -475,6 +526,16 @@ def main():
         out["modes"] = [line(r, a.steps)] + [line(x, side_steps) for x in others]
     if also:
         out["also"] = [line(x, side_steps) for x in also]
+    if int8_exact is not None:
+        x, st = int8_exact, max(side_steps, a.steps // 2)
+        ab = CLIP_LEN * 2 + x["labels"] * 4
+        ach = ab * B / (x["ms_path"] * 1e-3) / 1e9
+        out["int8_exact"] = dict(line(x, st), configs="BASELINE configs[3]: int8-quantised weights/activations, bit-exact (the reference's own impulse; every MFCC feature, "
+                                                     "int8 tensor and score identical to the reference's), batch 65 536, 1x MI355X",
+                                 roofline={"bound": "hbm", "kernel": "kws_mfcc8_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": ab * B,
+                                           "hot_path_ms": round(x["ms_path"], 4),
+                                           "hot_path_ms_note": "HIP events around the hot-path call: kws_mfcc8_kernel (MFCC -> int8 tensor) + kws_nn_mfma_kernel"})
     if cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out))

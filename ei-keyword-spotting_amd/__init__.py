@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "kws_streams_create", "kws_streams_destroy", "kws_streams_init", "kws_streams_step_device",
     "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count", "kws_fast_exact_count", "kws_fast_guard",
     "kws_set_logits_tap", "kws_fast_gain", "kws_fast_tolerance_info",
-    "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_allgather_scores", "kws_comm_destroy",
+    "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_comm_ranks_seen", "kws_comm_rccl_version", "kws_comm_wait", "kws_allgather_scores", "kws_comm_destroy",
     "kws_wav_info_from_memory", "kws_wav_decode_mono", "kws_resample_length", "kws_resample_device",
     "kws_synth_clips_device", "kws_mix_audio_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = [
 class FastTolerance(C.Structure):
     _fields_ = [("score_tol", C.c_float), ("k_sigma", C.c_float), ("lin_margin", C.c_float), ("logit_cap", C.c_float), ("g_c1", C.c_float),
                 ("g_c2", C.c_float), ("sigma_net", C.c_float), ("total_gain", C.c_float), ("uniform_feature_tol", C.c_float),
-                ("calibrated", C.c_int), ("n_columns", C.c_int), ("n_frames", C.c_int)]
+                ("calibrated", C.c_int), ("n_columns", C.c_int), ("n_frames", C.c_int), ("entry_tier", C.c_int)]
 
 
 class KwsError(RuntimeError):
@@ -99,6 +99,9 @@ def lib():
         L.kws_comm_create.argtypes = [vp, sz, i32, i32, i32, C.POINTER(vp)]
         L.kws_comm_world_size.argtypes = [vp]
         L.kws_comm_rank.argtypes = [vp]
+        if hasattr(L, "kws_comm_ranks_seen"):
+            L.kws_comm_ranks_seen.argtypes = [vp]
+            L.kws_comm_wait.argtypes = [vp, vp]
         L.kws_allgather_scores.argtypes = [vp, vp, vp, sz, i32, vp]
         L.kws_comm_destroy.argtypes = [vp]
         L.kws_set_mode.argtypes = [vp, i32]
@@ -366,6 +369,19 @@ class Comm:
 
     def allgather_scores(self, local_ptr, all_ptr, clips_per_rank, label_count, stream=None):
         _check(self.L.kws_allgather_scores(self.c, local_ptr, all_ptr, clips_per_rank, label_count, stream))
+
+    @property
+    def ranks_seen_by_rccl(self):
+        """ncclCommCount of this communicator"""
+        return int(self.L.kws_comm_ranks_seen(self.c))
+
+    @property
+    def rccl_version(self):
+        return int(self.L.kws_comm_rccl_version())
+
+    def wait(self, stream=None):
+        """everything enqueued on `stream` has completed -- or KwsError after KWS_COMM_TIMEOUT_MS / when a peer failed (communicator aborted)"""
+        _check(self.L.kws_comm_wait(self.c, stream))
 
     def close(self):
         if getattr(self, "c", None):

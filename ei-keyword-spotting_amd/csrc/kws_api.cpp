@@ -56,6 +56,7 @@ void kws_destroy(kws_handle *h)
     if (h->s_q) (void)hipFree(h->s_q);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_flags2) (void)hipFree(h->d_flags2);
+    if (h->d_flags3) (void)hipFree(h->d_flags3);
     if (h->s_cep) (void)hipFree(h->s_cep);
     for (auto &g : h->g_sets) for (void *p : { (void *)g.ws, (void *)g.mfcc, (void *)g.feat }) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
@@ -160,12 +161,13 @@ EI_IMPULSE_ERROR kws_fast_tolerance_info(const kws_handle *h, kws_fast_tolerance
     out->calibrated = (h->is_float && h->gain.calibrated) ? 1 : 0;
     out->n_columns = (int)h->fast_guard_coef[0][0].size();
     out->n_frames = h->dsp.n_frames;
-    out->sigma_net = out->calibrated ? h->gain.sigma_net : 0.0f;
+    out->entry_tier = h->fast_entry_tier;
+    out->sigma_net = sqrtf(F.v_net);       // the terms of V that do not depend on the clip: the fused network's re-ordering noise, the deviation's own error
     // sum of gain^2 over every feature: a feature error of rms size t on every feature gives V = sigma_net^2 + t^2 x this
     double g2 = 0.0;
     for (float g : h->fast_gain_used) g2 += (double)g * (double)g * (double)h->dsp.n_frames;
     out->total_gain = (float)sqrt(g2);
-    const double vmax = std::min(16.0 / (double)F.g_c1, 1.0 / (double)F.g_c2) - (double)out->sigma_net * (double)out->sigma_net;
+    const double vmax = std::min(16.0 / (double)F.g_c1, 1.0 / (double)F.g_c2) - (double)F.v_net;
     out->uniform_feature_tol = (vmax > 0.0 && g2 > 0.0) ? (float)sqrt(vmax / g2) : 0.0f;
     return EI_IMPULSE_OK;
 }
@@ -198,9 +200,11 @@ static EI_IMPULSE_ERROR ensure_flags(kws_handle *h, size_t B)
     if (B + 1 <= h->flags_cap) return EI_IMPULSE_OK;
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_flags2) (void)hipFree(h->d_flags2);
-    h->d_flags = h->d_flags2 = nullptr; h->flags_cap = 0;
+    if (h->d_flags3) (void)hipFree(h->d_flags3);
+    h->d_flags = h->d_flags2 = h->d_flags3 = nullptr; h->flags_cap = 0;
     HIP_TRY(hipMalloc((void **)&h->d_flags, (B + 1) * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&h->d_flags2, (B + 1) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&h->d_flags3, (B + 1) * sizeof(int)));
     HIP_TRY(hipMemset(h->d_flags2, 0, sizeof(int)));
     h->flags_cap = B + 1;
     return EI_IMPULSE_OK;
@@ -208,6 +212,7 @@ static EI_IMPULSE_ERROR ensure_flags(kws_handle *h, size_t B)
 
 static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *fx, bool want_f, int8_t *q,
                                              hipStream_t s);
+static EI_IMPULSE_ERROR classify_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *f, int8_t *q, hipStream_t s);
 int grid_cap_mfcc(const kws_handle *h) { return h->n_cu * 8; }
 int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 
@@ -392,9 +397,10 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
     EI_IMPULSE_ERROR e = ensure_flags(h, B);
     if (e) return e;
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));      // kws_fast_exact_count describes the LAST fast call: this path has one fast tier
     KwsDspPlan PR = h->dsp;
     PR.ring_rows = ring_rows; PR.ring_head = ring_head;
-    const bool fused = h->is_float && h->fast_fused_ok;
+    const bool fused = scores && h->is_float && h->fast_fused_ok;       // scores == NULL: features / int8 tensor only (extract_mfcc_features)
     float *fx = features ? features : h->s_mfcc;
     int8_t *q = h->is_float ? nullptr : (q_out ? q_out : h->s_q);
     int rc = 0;
@@ -403,13 +409,14 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
         rc = kws_launch_fast_from_cepstra(PR, h->fast_plain, h->d_fast_plain, mfcc, (int)B, nullptr, fx, nullptr, h->nn.in_scale, h->nn.in_zp, h->d_flags,
                                           h->d_flags + 1, h->n_cu, s);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(h->d_flags3, 0, sizeof(int), s));
     }
     const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
+    int *const fl = (fused && features) ? h->d_flags3 : h->d_flags;      // the feature-emitting launch's list stands (kws_internal.h: d_flags3)
     rc = kws_launch_fast_from_cepstra(PR, FP, fused ? h->d_fast_fused : h->d_fast_plain, mfcc, (int)B, scores, fused ? nullptr : fx, q,
-                                      h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s, nullptr, h->tap_logits);
+                                      h->nn.in_scale, h->nn.in_zp, fl, fl + 1, h->n_cu, s, nullptr, h->tap_logits);
     if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (!fused) {
+    if (!fused && scores) {
         if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, h->tap_logits, s))) return e; }
         else {
             rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s);
@@ -421,6 +428,8 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
     rc = kws_launch_cmvn_nn(PR, h->nn, mfcc, (int)B, (h->is_float || features) ? fx : nullptr, q, h->is_float ? nullptr : scores, nullptr, h->pooled_tap_bytes,
                             nullptr, nullptr, grid_cap_nn(h), &ran_nn, s, h->d_flags);
     if (rc) return fail(KWS_ERROR_HIP, "CMVN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIP_TRY(hipMemcpyAsync(h->d_flags2, h->d_flags, sizeof(int), hipMemcpyDeviceToDevice, s));     // handed on = finished by the exact kernels
+    if (!scores) return EI_IMPULSE_OK;
     if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, h->tap_logits, h->n_cu, s, h->d_flags);
     else if (!ran_nn) rc = kws_launch_nn(h->nn, q, (int)B, scores, nullptr, h->pooled_tap_bytes, nullptr, nullptr, grid_cap_nn(h), s, h->d_flags);
     if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -599,11 +608,12 @@ static EI_IMPULSE_ERROR rerun_flagged_device(kws_handle *h, const int16_t *pcm, 
         rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_plain, h->d_fast_plain, h->s_cep, (int)B, nullptr, (h->is_float || want_f) ? fx : nullptr, q,
                                           h->nn.in_scale, h->nn.in_zp, h->d_flags2, h->d_flags2 + 1, h->n_cu, s, h->d_flags);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        if (fused) HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));      // the fused form lists the same windows again
+        if (fused) HIP_TRY(hipMemsetAsync(h->d_flags3, 0, sizeof(int), s));      // the feature-emitting launch's list stands (kws_internal.h: d_flags3)
     }
     if (fused) {
+        int *const fl = want_f ? h->d_flags3 : h->d_flags2;
         rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, h->s_cep, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
-                                          h->d_flags2, h->d_flags2 + 1, h->n_cu, s, h->d_flags, h->tap_logits);
+                                          fl, fl + 1, h->n_cu, s, h->d_flags, h->tap_logits);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     } else if (scores) {
         if (h->is_float) rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, h->tap_logits, h->n_cu, s, h->d_flags);
@@ -652,6 +662,25 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
         if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
     }
+    if (h->fast_entry_tier >= 2 && (scores || want_f || q)) {
+        // the graph's gain leaves the first tier no room (build_guard): every clip's cepstra come from the exact kernels, then the fast
+        // cmvnw + network with the second tier's guard and the exact kernels for what that hands on (the continuous mode's path) -- or,
+        // entry tier 3, the exact kernels throughout
+        if (h->fast_entry_tier >= 3) {
+            HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));
+            if (!scores) return mfcc_fused_device(h, pcm, 0, B, fx, q, s);
+            return classify_device(h, pcm, B, scores, fx, q, s);
+        }
+        const size_t F = h->model.nn_input_frame_size;
+        if (B > h->cep_cap) {
+            if (h->s_cep) (void)hipFree(h->s_cep);
+            h->s_cep = nullptr; h->cep_cap = 0;
+            HIP_TRY(hipMalloc((void **)&h->s_cep, B * F * sizeof(float)));
+            h->cep_cap = B;
+        }
+        if ((e = spectral_device(h, h->dsp, pcm, 0, B, h->s_cep, nullptr, s))) return e;
+        return cmvn_nn_fast_device(h, h->s_cep, B, scores, s, 0, 0, want_f ? fx : nullptr, q);
+    }
     if (scores && !h->is_float && h->fast_q_ok) {
         // int8 graph of the matrix-core shape: the network runs in the same launch on the quantised tensor it has just produced in LDS;
         // the feature matrix / the tensor only go to HBM when the caller asked for them (q is the caller's buffer or the scratch the
@@ -663,15 +692,16 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
     }
     if (fused && want_f) {
         // the fused kernel keeps the feature matrix on chip: a caller who also wants it gets it from the feature-emitting form first
-        // (both launches list the same ill-conditioned clips: the list is restarted in between)
+        // (that launch knows no scores: its guard assumes the largest p (1 - p) there is, and its list decides for features and scores)
         rc = kws_launch_fast(h->dsp, h->fast_plain, h->d_fast_plain, pcm, (int)B, nullptr, fx, nullptr, h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1,
                              h->n_cu, s);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
-        HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(h->d_flags3, 0, sizeof(int), s));
     }
     const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
+    int *const fl = (fused && want_f) ? h->d_flags3 : h->d_flags;          // the feature-emitting launch's list stands (kws_internal.h: d_flags3)
     rc = kws_launch_fast(h->dsp, FP, fused ? h->d_fast_fused : h->d_fast_plain, pcm, (int)B, scores, fused ? nullptr : fx, fused ? nullptr : q, h->nn.in_scale,
-                         h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s, nullptr, h->tap_logits);
+                         h->nn.in_zp, fl, fl + 1, h->n_cu, s, nullptr, h->tap_logits);
     if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
     if (scores && !fused) {
         if (h->is_float) { if ((e = nn_f32_device(h, fx, B, scores, h->tap_logits, s))) return e; }

@@ -75,12 +75,12 @@ struct KwsFastPlan {
     // window's mean, comes out of cmvnw divided by the window's deviation; weighted with the graph's logit gain per column (kws_gain.cpp)
     // and summed in quadrature over the clip's windows it estimates the variance V of a logit difference's error:
     //     V = v_net + sum over windows (r, c) of ((g.abs + g.lev x level + g.rel x |mean|) / (deviation + eps))^2,
-    // level = the clip's rms log-mel energy (fp32 rounds relative to it).  The clip stays in the fast kernel iff
+    // level = the clip's log-mel level: mean over the frames of |mean over the filters of the log-mel energies| (fp32 rounds relative to it).  The clip stays in the fast kernel iff
     //     V x max(g_c1 x P^2, g_c2) <= 1,     P = the largest p (1 - p) of its scores (1/4 where the network runs in another kernel):
     // g_c1 = (k sigma x margin / score tolerance)^2, g_c2 = (k sigma / largest logit error the linearisation is trusted for)^2.
-    int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x float4 { abs, lev, rel, rel when column 0's means were replayed }
+    int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x float4 { abs, lev, rel, alternative rel: column 0 with its means replayed; the other columns for a clip with digitally silent frames }
     int guard_cep_off;            // the same for windows that arrive as the exact kernels' cepstra (no spectral terms): continuous mode, second tier
-    float g_c1, g_c2, v_net, lvl_inv;   // lvl_inv = 1 / (n_frames x filters): level^2 = lvl_inv x sum of log-mel^2
+    float g_c1, g_c2, v_net, lvl_inv;   // lvl_inv = 1 / (n_frames x sqrt(filters)): level = lvl_inv x sum over the frames of |the DCT's coefficient 0|
     float c0_factor, c0_abs, c0_rel, c0_inv_rows;   // column 0: the exact window means are only computed when c0_factor x (plain deviation of
                                   // the column) < c0_abs + c0_rel x (its largest magnitude); c0_factor = sqrt(c0_mult n_frames / win_size),
                                   // c0_mult = how often every window holds every row at least (0: always compute them)

@@ -485,7 +485,7 @@ __device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *
 //  ((g.abs + g.lev * level + g.rel * |mean|) / (deviation + eps))^2 -- the caller reduces it over the wave.
 template <int CR, int CG>
 __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                           float inv_win, const float *__restrict__ guard_tab, float level, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
+                                           float inv_win, const float *__restrict__ guard_tab, float level, bool silent, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
                                            const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
@@ -513,11 +513,13 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
         float *col = img + min(c, ncep - 1);
         // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name
         const float piv = col[0];
-        const float4 gcol = ((const float4 *)guard_tab)[cb + cl];   // (absolute, per level, per |window mean|, the same with replayed means); padded to a multiple of CG columns
+        const float4 gcol = ((const float4 *)guard_tab)[cb + cl];   // (absolute, per level, per |window mean|, its alternative); padded to a multiple of CG columns
         // column 0 (the log frame energy, |mean| ~ 10): when its deviation is small against its level, its window means have been summed
-        // in the reference's own order (c0_exact) and the window-mean part of its guard does not apply
+        // in the reference's own order (c0_exact) and the window-mean part of its guard does not apply.  The other columns: a clip with
+        // digitally silent frames has runs of identical values in every column, and the reference's sequential window sums then round
+        // systematically instead of randomly: the alternative coefficient is the larger one measured on such clips.
         const bool is_c0 = c0_exact && cb + cl == 0;
-        const float g_abs = __fmaf_rn(gcol.y, level, gcol.x), g_rel = is_c0 ? gcol.w : gcol.z;
+        const float g_abs = __fmaf_rn(gcol.y, level, gcol.x), g_rel = (cb + cl == 0 ? c0_exact : silent) ? gcol.w : gcol.z;
         float mr[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) mr[i] = (c0_exact && cb == 0) ? mref[min(r0 + i, nfr - 1)] : 0.0f;
@@ -572,7 +574,7 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
 #pragma unroll
         for (int i = 0; i < CR - 1; ++i) { dl[i] -= piv; da[i] -= piv; }
         float S = S0 + S1, Q = Q0 + Q1;
-        float o[CR];
+        float o[CR], gq[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) {
             const float m = S * inv_win;
@@ -580,8 +582,9 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
             var = fmaxf(var, 0.0f);
             const float sd = __builtin_amdgcn_sqrtf(var);
             const float rstd = __builtin_amdgcn_rcpf(sd + FLT_EPSILON);
-            const float bq = __fmaf_rn(g_rel, fabsf(m + piv), g_abs) * rstd;
-            vacc = (act && r0 + i < nfr) ? __fmaf_rn(bq, bq, vacc) : vacc;
+            // the guard's term of this window; summed below, under the predicate the store needs anyway (measured: a select of its own per
+            // window here -- compare, scalar and, conditional move -- cost 2.6 % of the whole kernel, 17 x 2 of them per clip)
+            gq[i] = __fmaf_rn(g_rel, fabsf(m + piv), g_abs) * rstd;
             o[i] = (is_c0 ? own[i] - mr[i] : (own[i] - piv) - m) * rstd;
             if (i + 1 < CR) {
                 S = (S + da[i]) - dl[i];
@@ -593,7 +596,9 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
 #pragma unroll
         for (int i = 0; i < CR; ++i) {
             const int r = r0 + i;
-            *((act && r < nfr) ? col + r * fs : sink) = o[i];      // no branch per value: rows / columns outside the matrix go to the sink
+            const bool live = act && r < nfr;
+            *(live ? col + r * fs : sink) = o[i];                  // no branch per value: rows / columns outside the matrix go to the sink
+            vacc = live ? __fmaf_rn(gq[i], gq[i], vacc) : vacc;
         }
     }
     WAVE_SYNC();
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         const int half = lane_c >> 5, t = lane_c & 31;
         // a mel filter's taps are consecutive bins: first bin (as an offset into a frame's power row) + NZ weights, zero beyond its end
         const int start1 = FP.tap_start1[lane_c], start2 = FP.tap_start2[lane_c];
-        float lvl2 = 0.0f;                                               // sum of this lane's log-mel^2 (the guard's level)
+        float lvl_sum = 0.0f;                                            // the guard's level: this lane's share of sum_frames |sum_filters log-mel| / sqrt(NF)
         float w1[NZ], w2[NZ2];
     #pragma unroll
         for (int n = 0; n < NZ; ++n) w1[n] = FP.tap_w1[lane_c * KWS_FAST_NZ_MAX + n];
@@ -812,14 +817,9 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int slot = 4 * half + s;
-                const bool on = slot < nfc && t < NF;
-                if (on) img[(fbase + slot) * fs + t + (slot == 1 ? adj1 : 0)] = macc[s];
-                // the guard's level: sum of log-mel^2 over the clip (a frame parked for the wave's NEXT clip counts here instead: one frame of 49)
-                if (!MFE) lvl2 = on ? __fmaf_rn(macc[s], macc[s], lvl2) : lvl2;
+                if (slot < nfc && t < NF) img[(fbase + slot) * fs + t + (slot == 1 ? adj1 : 0)] = macc[s];
             }
-            const bool on2 = DG > 4 && sl2 < nfc && j2 < NF;
-            if (on2) img[(fbase + sl2) * fs + j2 + (sl2 == 1 ? adj1 : 0)] = macc[4];
-            if (!MFE && DG > 4) lvl2 = on2 ? __fmaf_rn(macc[4], macc[4], lvl2) : lvl2;
+            if (DG > 4 && sl2 < nfc && j2 < NF) img[(fbase + sl2) * fs + j2 + (sl2 == 1 ? adj1 : 0)] = macc[4];
         };
         fast_i2 nxt[2][8];
         fetch(0, nxt);
@@ -1120,6 +1120,14 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                     }
                 }
             if (lane_l < nfr) img[lane_l * fs] = e0;
+            // The transform's coefficient 0 -- sum_k log-mel[r][k] / sqrt(NF), replaced by the log frame energy above -- is the frame's mean
+            // log-mel level x sqrt(NF): what the fp32 rounding of the spectral phase scales with (the guard's `level`, kws_fast.h).  The
+            // lanes of column 0 (lm == 0) hold it for sixteen rows each.
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lvl_sum += (16 * mt + 4 * lq + i < nfr) ? fabsf(acc[mt][0][i]) : 0.0f;      // (the row predicate of the stores above)
+            lvl_sum = lm == 0 ? lvl_sum : 0.0f;
             WAVE_SYNC();
         }
         FPH(4);
@@ -1143,10 +1151,13 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // sqrt(c0_mult n_frames / win_size) x the column's plain deviation over the n_frames rows; if that already clears the relative
         // guard at the column's largest magnitude, the running-sum mean is good enough for every window (error kappa |mean| / deviation
         // below the feature tolerance) and the pass is skipped -- the usual case for audio whose loudness changes over the second.
-        bool c0_exact = false;
+        bool c0_exact = false, silent = false;
         if constexpr (!MFE) {
             const bool on = lane_m < nfr;
             const float x0 = img[min(lane_m, nfr - 1) * fs];
+            // a frame without any energy: zero handling put FLT_EPSILON there, and its log (bit-identical in both tiers: the reference's own
+            // polynomial) sits in column 0
+            silent = __any(on && x0 == fast_log(FLT_EPSILON));
             const float mu = wave_sum(on ? x0 : 0.0f) * FP.c0_inv_rows;
             const float d0 = on ? x0 - mu : 0.0f;
             const float sd0 = __builtin_amdgcn_sqrtf(wave_sum(d0 * d0) * FP.c0_inv_rows);
@@ -1203,9 +1214,9 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // the guard (kws_fast.h): V = variance estimate of a logit difference's error; the clip stays iff V max(c1 P^2, c2) <= 1
         float gV = 0.0f;
         if constexpr (!MFE) {                             // (MFE: nothing is divided by a deviation: the mel energies leave as they are)
-            const float level = FROM_CEP ? 0.0f : __builtin_amdgcn_sqrtf(wave_sum(lvl2) * FP.lvl_inv);
-            if (cr == 13) vlane = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
-            else vlane = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            const float level = FROM_CEP ? 0.0f : wave_sum(lvl_sum) * FP.lvl_inv;
+            if (cr == 13) vlane = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            else vlane = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
         }
         if constexpr (!NET) {

@@ -16,26 +16,35 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // and keeps the clip iff   k sqrt(V) x 1.1 P <= score tolerance   and   k sqrt(V) <= 0.1,   P = max p (1 - p) of the clip's own scores
 // (|d score_i| <= p_i (1 - p_i) max_j |d(z_i - z_j)|; P = 1/4 where the scores are not known inside the kernel).
 //   E_c, the rms error of a cepstral coefficient (profiles/r04_gain_study.txt: the guard switched off on eleven input families x three
-//   models, every clip against the oracle; fp32 rounds relative to the operand's magnitude, so the errors scale with the clip's rms
-//   log-mel level M -- measured ratio error / M: 1.1e-7 .. 1.7e-7 over all families for the DCT outputs, p99 of a clip 3.4e-7):
-//       c = 0            log(frame energy): alpha0 |c0| (its own magnitude, ~|mean| for this column)      alpha0 = 1.0e-7
+//   models, every clip against the oracle; fp32 rounds relative to the operand's magnitude, so the errors scale with the clip's
+//   log-mel level M = mean over the frames of |mean over the filters of the log-mel energies| -- measured ratio error / M: 1.1e-7 .. 2.0e-7
+//   over all families for the DCT outputs, p99 of a clip 3.5e-7):
+//       c = 0            log(frame energy): the lane-tree sum against the reference's 129 sequential additions
+//                        (relative in the energy = absolute in its log) + the rounding of the log itself     6e-7 + 1.0e-7 |c0|
 //       1 <= c <= NF/2   DCT outputs: both transforms round at the level of their inputs                  1.7e-7 x M
 //       c > NF/2         stale log-mel values x 2 sqrt(1/2NF): one fp32 log of difference                 4.0e-8 x M
 //   kappa_c |mean|: the reference's window mean is a sequential fp32 sum of win_size values and carries rounding noise of its own;
-//       the running sums here are more accurate, so the DIFFERENCE is that noise: rms 0.5e-6 |mean| (0.2e-6 for lively columns, more
-//       where the summed values are nearly equal).  Column 0 when its means were replayed in the reference's order: 0.
-//   Second table (cepstra from the exact kernels: continuous mode, the second tier): E_c = a floor of 2e-7 below which the reference's own
+//       the running sums here are more accurate, so the DIFFERENCE is that noise.  Lively values round at random: rms 0.5e-6 |mean| for the DCT
+//       outputs, 0.35e-6 for the stale columns (fits per family: 0.16e-6 .. 0.30e-6).  Runs of IDENTICAL values -- digitally silent frames: zero
+//       handling writes the same FLT_EPSILON into every filter of such a frame -- round systematically, the same way add after add: 0.73e-6 ..
+//       0.93e-6 measured (word + digital silence, sub-frame bursts in silence); the kernel sees such frames in column 0 (log FLT_EPSILON,
+//       exactly) and takes 0.9e-6 for every column of the clip.  Column 0 when its means were replayed in the reference's order: 0.
+//   Second table (cepstra from the exact kernels: continuous mode, the second tier): E_c = a floor of 3e-7 below which the reference's own
 //   rounding decides a near-constant column, kappa as above.
+//   The deviation itself (running sums of pivot-shifted values in fp32 against the reference's double-precision walk) is good to a relative
+//   rho ~ 3e-7, which moves every feature by rho |feature|: over a standardised column that adds (rho x total gain)^2 to V, like sigma_net^2.
 //   k = 4.5 standard deviations; 1.1 = margin for the linearisation of the softmax over a logit error of up to 0.1.
 // int8 graphs (no float logits to protect: the network is bit-exact from its input tensor on, what matters is how many input values
 // change): col_gain = the constant for which the rule reads  k x rms bound of the clip's feature errors <= 1e-4.
 static const float kGuardK = 4.5f, kGuardLin = 1.1f, kGuardScoreTol = 1.0e-4f, kGuardLogitCap = 0.1f;
-static const float kAlpha0 = 1.0e-7f, kAlphaDct = 1.7e-7f, kAlphaStale = 4.0e-8f, kKappa = 0.5e-6f, kFloorCep = 2.0e-7f, kC0Share = 0.05f;
+static const float kAbs0 = 6.0e-7f, kAlpha0 = 1.0e-7f, kAlphaDct = 1.7e-7f, kAlphaStale = 4.0e-8f, kKappa = 0.5e-6f, kKappaStale = 0.35e-6f, kKappaSilent = 0.9e-6f, kFloorCep = 3.0e-7f, kRhoDev = 3.0e-7f,
+                   kC0Share = 0.05f;
 
 static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &shared)
 {
     const int ncep = h->dsp.n_cepstral, NF = h->model.dsp.num_filters, nfr = h->dsp.n_frames;     // (MFE block: the filters are the columns)
     float a0 = kAlpha0, ad = kAlphaDct, as = kAlphaStale, kappa = kKappa, scale = 1.0f;
+    const float e0 = kAbs0, kappa_s = kKappaStale;
     if (const char *ev = getenv("KWS_DEV_FAST_GUARD_SCALE")) scale = (float)atof(ev);      // development aid: 0 switches the guard off (tests/gain_study.py)
     if (const char *ev = getenv("KWS_DEV_FAST_GUARD")) (void)sscanf(ev, "%f,%f,%f,%f", &a0, &ad, &as, &kappa);   // development aid
     std::vector<float> gain((size_t)ncep, 0.0f);
@@ -44,8 +53,11 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
     h->fast_gain_used = gain;
     F.g_c1 = (kGuardK * kGuardLin / kGuardScoreTol) * (kGuardK * kGuardLin / kGuardScoreTol);
     F.g_c2 = (kGuardK / kGuardLogitCap) * (kGuardK / kGuardLogitCap);
-    F.v_net = (h->is_float && h->gain.calibrated) ? h->gain.sigma_net * h->gain.sigma_net : 0.0f;
-    F.lvl_inv = 1.0f / (float)(nfr * NF);
+    double tot2 = 0.0;
+    for (float g : gain) tot2 += (double)g * (double)g * (double)nfr;
+    F.v_net = (float)((double)kRhoDev * (double)kRhoDev * tot2) + ((h->is_float && h->gain.calibrated) ? h->gain.sigma_net * h->gain.sigma_net : 0.0f);
+    F.v_net *= scale * scale;
+    F.lvl_inv = 1.0f / ((float)nfr * sqrtf((float)NF));      // level = mean over the frames of |mean over the filters of the log-mel energies|
     while (shared.size() & 3) shared.push_back(0.0f);
     for (int tier = 0; tier < 2; tier++) {
         (tier == 0 ? F.guard_off : F.guard_cep_off) = (int)shared.size();
@@ -55,23 +67,44 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
             // the kernel leaves the columns above NF/2 unscaled (the reference's carry 2 sqrt(1/2NF): cmvnw's output does not see a
             // per-column factor), so their deviations and means are 1 / unit times the reference's there
             const float unit = (tier == 0 && c > NF / 2) ? 2.0f * h->dsp.dct_s1 : 1.0f;
+            const float kap = c > NF / 2 ? kappa_s : kappa;
             float coef[4];
+            // coef[3]: column 0 -- with its window means replayed in the reference's order; the others -- for a clip with silent frames
             if (tier == 0) {
-                coef[0] = 0.0f;
+                coef[0] = c == 0 ? g * e0 : 0.0f;
                 coef[1] = c == 0 ? 0.0f : g * (c <= NF / 2 ? ad : as) / unit;
-                coef[2] = g * (c == 0 ? a0 + kappa : kappa);
-                coef[3] = g * (c == 0 ? a0 : kappa);
+                coef[2] = g * (c == 0 ? a0 + kap : kap);
+                coef[3] = g * (c == 0 ? a0 : kKappaSilent);
             } else {
                 coef[0] = g * kFloorCep;
                 coef[1] = 0.0f;
-                coef[2] = g * kappa;
-                coef[3] = c == 0 ? 0.0f : g * kappa;
+                coef[2] = g * kap;
+                coef[3] = c == 0 ? 0.0f : g * kKappaSilent;
             }
             for (int k = 0; k < 4; k++) {
                 shared.push_back(coef[k]);
                 if (c < ncep) h->fast_guard_coef[tier][k].push_back(k == 1 ? coef[k] * unit : coef[k]);     // towards the caller: in the reference's units
             }
         }
+    }
+    // Where a batch call starts (performance routing only: every tier applies its guard whatever the entry).  A graph whose gain leaves
+    // the first tier no room -- a typical well-conditioned clip (level 10; deviations 1.5 / 1 / 0.5 and |means| 8 / 1 / 2.2 for column 0 /
+    // the DCT outputs / the stale columns) would already be handed on -- starts at the second tier: exact cepstra for every clip, then
+    // the fast cmvnw + network; one that leaves the second tier no room either runs the exact kernels throughout.
+    {
+        int entry = 3;
+        for (int tier = 1; tier >= 0; tier--) {
+            double v = (double)F.v_net;
+            for (int c = 0; c < ncep; c++) {
+                const double dev = c == 0 ? 1.5 : c <= NF / 2 ? 1.0 : 0.5, mean = c == 0 ? 8.0 : c <= NF / 2 ? 1.0 : 2.2;
+                const double b = ((double)h->fast_guard_coef[tier][0][(size_t)c] + (double)h->fast_guard_coef[tier][1][(size_t)c] * 10.0 +
+                                  (double)h->fast_guard_coef[tier][2][(size_t)c] * mean) / dev;
+                v += (double)nfr * b * b;
+            }
+            if (v * (double)std::max(F.g_c1 / 16.0f, F.g_c2) <= 1.0) entry = tier + 1;
+        }
+        if (const char *ev = getenv("KWS_DEV_FAST_ENTRY")) entry = std::max(1, std::min(3, atoi(ev)));      // development / test aid: the tier's kernels whatever the routing
+        h->fast_entry_tier = entry;
     }
     // numpy::pad_1d_symmetric's row order, for the replayed window means of column 0
     std::vector<int> pmap;

@@ -219,10 +219,13 @@ struct kws_handle {
     // host copy of the guard's per-column coefficients, [tier - 1][kind][column]: kind 0 absolute, 1 per log-mel level, 2 per |window mean|,
     // 3 per |window mean| when column 0's window means were replayed in the reference's order (kws_fast_guard)
     std::vector<float> fast_guard_coef[2][4];
+    int fast_entry_tier = 1;                               // 1: batch calls start in the fast kernel; 2: from exact cepstra; 3: exact kernels (build_guard)
     std::vector<float> fast_gain_used;                     // the per-column gain those coefficients were built with (float32 graph: gain.col)
     int mode = KWS_MODE_EXACT;
     int *d_flags = nullptr;       // [0] = count, [1 + i] = clip index: the clips the fast kernel handed back (first tier)
     int *d_flags2 = nullptr;      // the same for the second tier: the clips that go to the exact cmvnw + network
+    int *d_flags3 = nullptr;      // sink: when a call wants the feature matrix AND fused scores, the feature-emitting launch's list (P = 1/4) decides
+                                  // for both -- the features are then the ones kws_extract_mfcc_batch_device returns -- and the fused launch's goes here
     float *tap_logits = nullptr;  // kws_set_logits_tap: FULLY_CONNECTED outputs of the batch calls' clips (float32 graphs), device [B][labels]
     float *s_cep = nullptr;       // [B][n_features] exact cepstra of the first tier's clips (indexed by clip)
     size_t flags_cap = 0, cep_cap = 0;

@@ -83,7 +83,8 @@ int kws_fast_is_fused(const kws_handle *h);
  * calibration set: kws_fast_gain) and the kernels sum, per clip,
  *     V = sigma_net^2 + sum over cmvnw windows (row r, column c) of ((abs[c] + lev[c] x level + rel[c] x |window mean|) / (deviation + eps))^2
  * -- an estimate of the variance of the error of a logit difference; abs / lev / rel = gain[c] x the rms error of a coefficient (absolute,
- * per unit of the clip's rms log-mel level, per unit of |mean|: kws_fast_guard), level = 0 for tier 2.  The clip stays in its tier iff
+ * per unit of the clip's log-mel level = mean over its frames of |mean over the filters of the log-mel energies|, per unit of |mean|:
+ * kws_fast_guard), level = 0 for tier 2.  The clip stays in its tier iff
  *     V x max(g_c1 x P^2, g_c2) <= 1,    g_c1 = (k_sigma x lin_margin / score_tol)^2,  g_c2 = (k_sigma / logit_cap)^2,
  * P = the largest p (1 - p) among the clip's own scores where the network runs in the same launch (|d score| <= p (1 - p) x the error of
  * a logit difference: a saturated softmax passes nothing on), 1/4 otherwise.  In words: k_sigma standard deviations of the estimated logit
@@ -92,16 +93,21 @@ int kws_fast_is_fused(const kws_handle *h);
  * from the oracle's cepstra and holds scores AND logits to it on eleven input families.
  * int8 graphs have no float logits to protect (the network is bit-exact from its int8 input tensor on): gain[c] is the constant for which
  * the rule reads "k_sigma x the rms of the clip's feature error estimates <= 1e-4", calibrated = 0.
- *   kws_fast_guard   coef [4][n_columns]: abs, lev, rel, and rel when column 0's window means were replayed in the reference's order
+ *   kws_fast_guard   coef [4][n_columns]: abs, lev, rel, and the alternative rel: column 0 -- when its window means were replayed in the reference's
+ *                    order (a decision of the kernel); the other columns -- for a clip with digitally silent frames (a frame energy of exactly 0)
  *   kws_fast_gain    gain [n_columns] of a float32 graph (logit-difference error per unit of feature error, rms over a column's rows)
  * kws_streams_step_device and kws_cmvn_inference_batch_device start from exact cepstra: their one fast tier is tier 2. */
 typedef struct {
     float score_tol, k_sigma, lin_margin, logit_cap;   /* 1e-4, 4.5, 1.1, 0.1 */
     float g_c1, g_c2;                                  /* as above */
-    float sigma_net;                                   /* float32 graphs fused behind the features: what the matrix cores' summation order moves in a logit difference */
+    float sigma_net;                                   /* sqrt of the clip-independent part of V: the matrix cores' summation order in a fused float32 graph, the
+                                                          relative error of a window's deviation (x total_gain) */
     float total_gain;                                  /* sqrt(sum over all features of gain^2) */
     float uniform_feature_tol;                         /* the feature error of random sign, the same size on every feature, that exactly meets the rule at P = 1/4 */
     int calibrated, n_columns, n_frames;
+    int entry_tier;                                    /* where kws_run_classifier_batch_device starts in KWS_MODE_FAST: 1 the fast kernel; 2 exact cepstra for
+                                                          every clip, then the fast cmvnw + network (a graph whose gain leaves tier 1 no room: a typical
+                                                          clip would be handed on anyway); 3 the exact kernels.  Routing only: every tier applies its guard */
 } kws_fast_tolerance;
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
 EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);
@@ -199,6 +205,12 @@ EI_IMPULSE_ERROR kws_comm_unique_id(void *id, size_t nbytes);
 EI_IMPULSE_ERROR kws_comm_create(const void *id, size_t nbytes, int world_size, int rank, int device, kws_comm **out);
 int kws_comm_world_size(const kws_comm *c);
 int kws_comm_rank(const kws_comm *c);
+int kws_comm_ranks_seen(const kws_comm *c);     /* ncclCommCount of the communicator: what RCCL itself says (kws_comm_create refuses a mismatch) */
+int kws_comm_rccl_version(void);                /* ncclGetVersion of the loaded librccl (0: not loadable); its major version must be the rccl.h's this library was built with */
+/* Waits until everything enqueued on `stream` (the batch call and its all-gather) has completed -- against a deadline (environment variable
+ * KWS_COMM_TIMEOUT_MS, default 120 000; kws_comm_create's wait for the other ranks uses the same one): if a peer has failed or nothing moves,
+ * the communicator is aborted (ncclCommAbort) and KWS_ERROR_HIP returned instead of hanging. */
+EI_IMPULSE_ERROR kws_comm_wait(kws_comm *c, void *stream);
 EI_IMPULSE_ERROR kws_allgather_scores(kws_comm *c, const float *local_scores, float *all_scores, size_t clips_per_rank, int label_count,
                                       void *stream);
 void kws_comm_destroy(kws_comm *c);

@@ -24,6 +24,7 @@ hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSucc
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

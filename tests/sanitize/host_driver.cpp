@@ -86,8 +86,8 @@ static void print_gain(const char *path, kws_handle *h)
     kws_fast_tolerance t;
     std::vector<float> g(256, 0.0f), coef(4 * 256, 0.0f);
     if (kws_fast_tolerance_info(h, &t) != EI_IMPULSE_OK || kws_fast_guard(h, 1, coef.data()) != EI_IMPULSE_OK) { printf("GAIN %s none\n", path); return; }
-    printf("GAIN %s calibrated %d columns %d frames %d k %.9g lin %.9g cap %.9g c1 %.9g c2 %.9g sigma_net %.9g total %.9g uniform_tol %.9g :", path, t.calibrated,
-           t.n_columns, t.n_frames, t.k_sigma, t.lin_margin, t.logit_cap, t.g_c1, t.g_c2, t.sigma_net, t.total_gain, t.uniform_feature_tol);
+    printf("GAIN %s calibrated %d columns %d frames %d k %.9g lin %.9g cap %.9g c1 %.9g c2 %.9g sigma_net %.9g total %.9g uniform_tol %.9g entry %d :", path, t.calibrated,
+           t.n_columns, t.n_frames, t.k_sigma, t.lin_margin, t.logit_cap, t.g_c1, t.g_c2, t.sigma_net, t.total_gain, t.uniform_feature_tol, t.entry_tier);
     if (t.calibrated && kws_fast_gain(h, g.data()) == EI_IMPULSE_OK)
         for (int c = 0; c < t.n_columns; c++) printf(" %.9g", g[c]);
     printf("\n");

@@ -104,3 +104,19 @@ def test_bench_spawns_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["collective"]["ranks"] == 2
     assert abs(j["checksum"] - 8.0) < 0.1                       # 8 softmax rows
+    # round 4: the line carries every rank's own rate and the spread between the ranks, and what the communicator itself reports
+    # (the dry run has no RCCL: the gloo group's size stands in, ranks_seen_by_rccl is null)
+    c = j["collective"]
+    assert len(c["per_rank_clips_per_s"]) == 2 and all(v > 0 for v in c["per_rank_clips_per_s"]) and c["rank_time_skew_max_over_min"] >= 1.0
+    assert c["ranks_seen_by_rccl"] is None and c["gloo_world_size"] == 2
+
+
+def test_rendezvous_port_is_asked_of_the_kernel():
+    """bench.py --gpus N without a launcher takes MASTER_PORT when set, otherwise a port the kernel reports free (round 3's pid-derived
+    port could collide)"""
+    import socket
+    from bench import free_port
+    p = free_port()
+    assert 1024 < p < 65536
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", p))                               # still free

@@ -70,7 +70,7 @@ def test_uniform_feature_tolerance_keeps_scores_within_1e4(name, host_exe):
     path = os.path.join(MODELS, name)
     info, gain = calibrated(host_exe, path)
     assert info["calibrated"] == 1 and len(gain) == int(info["columns"]) and np.isfinite(gain).all() and (gain > 0).all()
-    # the tolerance follows from the gain: k sigma x 1.1 x 1/4 x total gain x tol = 1e-4 (minus the network's own re-ordering noise)
+    # the tolerance follows from the gain: k sigma x 1.1 x 1/4 x total gain x tol = 1e-4 (minus the clip-independent part of the variance)
     tol = info["uniform_tol"]
     expect = np.sqrt(max(16.0 / info["c1"] - info["sigma_net"] ** 2, 0.0)) / info["total"]
     assert abs(tol - expect) <= 1e-3 * expect

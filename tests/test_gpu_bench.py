@@ -26,6 +26,9 @@ def test_bench_force_collective_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["config"]["mode"] == "fast" and j["config"]["clips_per_gpu"] == 4096
     assert j["collective"]["ranks"] == 1 and j["collective"]["allgather_ms_per_step"] > 0
+    # round 4: what RCCL itself reports for the communicator (ncclCommCount, ncclGetVersion), every rank's own rate
+    assert j["collective"]["ranks_seen_by_rccl"] == 1 and j["collective"]["rccl_version"] >= 20000
+    assert len(j["collective"]["per_rank_clips_per_s"]) == 1 and j["collective"]["rank_time_skew_max_over_min"] == 1.0
     assert "RCCL" in j["config"]["collective"]
     assert abs(j["checksum"] - 4096.0) < 0.05                               # the gathered scores: 4096 softmax rows
     assert j["value"] > 1e5 and j["roofline"]["kernel"] == "kws_fast_kernel"
@@ -46,9 +49,26 @@ def test_allgather_scores_c_abi_world_size_one():
     stream = torch.cuda.current_stream().cuda_stream
     gm.run_classifier_batch_device(pcm.data_ptr(), B, s.data_ptr(), None, None, stream)
     comm.allgather_scores(s.data_ptr(), allg.data_ptr(), B, 4, stream)     # same stream: no synchronisation in between
+    comm.wait(stream)                                                      # deadline-guarded wait (kws_comm_wait)
     torch.cuda.synchronize()
     assert torch.equal(allg, s) and float(s.sum()) > 0
+    assert comm.ranks_seen_by_rccl == 1 and comm.rccl_version // 10000 == 2
     with pytest.raises(pkg.KwsError):
         pkg.Comm(b"\0" * 16, 1, 0, 0)                                       # id too short
     comm.close()
     gm.close()
+
+
+def test_comm_create_times_out_when_a_rank_is_missing():
+    """a communicator for two ranks of which only one shows up: kws_comm_create must give up at the deadline (KWS_COMM_TIMEOUT_MS) with
+    KWS_ERROR_HIP instead of waiting for ever.  In a process of its own: the abandoned helper thread stays
+    inside RCCL."""
+    code = ("import sys, time; sys.path.insert(0, %r); import torch; from __graft_entry__ import load_package; pkg = load_package(); t0 = time.time()\n"
+            "try:\n    pkg.Comm(pkg.Comm.unique_id(), 2, 0, 0); print('CREATED')\n"
+            "except pkg.KwsError as e:\n    print('TIMEOUT %%.1f %%s' %% (time.time() - t0, e))\n"
+            "import os; sys.stdout.flush(); os._exit(0)\n") % ROOT
+    env = dict(os.environ, KWS_COMM_TIMEOUT_MS="4000")
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=env)
+    ln = [x for x in out.stdout.splitlines() if x.startswith(("TIMEOUT", "CREATED"))]
+    assert ln and ln[0].startswith("TIMEOUT"), (out.stdout[-500:], out.stderr[-1500:])
+    assert 3.0 <= float(ln[0].split()[1]) <= 30.0 and "not every rank joined" in ln[0]

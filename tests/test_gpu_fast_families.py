@@ -54,9 +54,14 @@ def _oracle_worker(args):
         for i in range(len(pcm)):
             _, taps = om.nn_invoke_f32(f[i], taps=True)
             z[i] = [t for t in taps if len(t) == om.n_labels][-2]            # the tensor SOFTMAX reads
-    # the clip's rms log-mel level (what the fast kernel's rounding errors scale with)
-    lvl = np.array([np.sqrt((np.log(o.mfe(p, om.cfg)[0].astype(np.float64)) ** 2).mean()) for p in pcm], np.float32)
-    return s, f, q, sdw.astype(np.float32), mw.astype(np.float32), z, lvl
+    # the clip's log-mel level (what the fast kernel's rounding errors scale with): mean over the frames of |mean over the filters|
+    # ... and whether it has digitally silent frames (a frame energy of exactly 0, which zero handling turns into FLT_EPSILON)
+    lvl, sil = np.zeros(len(pcm), np.float32), np.zeros(len(pcm), bool)
+    for i, p in enumerate(pcm):
+        mel, en = o.mfe(p, om.cfg)
+        lvl[i] = np.abs(np.log(mel.astype(np.float64)).mean(axis=1)).mean()
+        sil[i] = (en == np.float32(1.1920929e-7)).any()
+    return s, f, q, sdw.astype(np.float32), mw.astype(np.float32), z, lvl, sil
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +72,7 @@ def pool():
 
 def oracle_clips(pool, path, pcm, chunk=128):
     parts = pool.map(_oracle_worker, [(path, pcm[i:i + chunk]) for i in range(0, len(pcm), chunk)])
-    return [np.concatenate([p[k] for p in parts]) for k in range(7)]
+    return [np.concatenate([p[k] for p in parts]) for k in range(8)]
 
 
 def family_pcm(pkg, name, n, seed):
@@ -112,26 +117,28 @@ def run_device(pkg, gm, mode, pcm_t):
     return s.cpu().numpy(), f.cpu().numpy(), (q.cpu().numpy() if q is not None else None), z.cpu().numpy()
 
 
-def guard_variance(gm, sdw, mw, lvl, tier):
+def guard_variance(gm, sdw, mw, lvl, sil, tier):
     """The guard's variance estimate V of that tier, re-evaluated from the oracle's windows (kws.h): (lo, hi) per clip -- column 0's
     window-mean term is dropped when the kernel replayed its means in the reference's order, a decision taken inside the kernel: lo assumes
-    it did, hi that it did not."""
-    coef = gm.fast_guard(tier).astype(np.float64)                     # [4][columns]: abs, per level, per |mean|, per |mean| with replayed means
+    it did, hi that it did not.  The other columns take the alternative coefficient for clips with digitally silent frames."""
+    coef = gm.fast_guard(tier).astype(np.float64)                     # [4][columns]: abs, per level, per |mean|, the alternative per |mean|
     tol = gm.fast_tolerance()
     level = lvl.astype(np.float64)[:, None, None] if tier == 1 else 0.0
     rd = 1.0 / (sdw.astype(np.float64) + 1.1920929e-7)
     base = coef[0][None, None, :] + coef[1][None, None, :] * level
+    rel = np.where(sil[:, None], coef[3][None, :], coef[2][None, :])    # [clips][columns]
     v = []
-    for rel in (coef[3], coef[2]):
-        b = (base + rel[None, None, :] * np.abs(mw)) * rd
+    for rel0 in (coef[3][0], coef[2][0]):
+        rel[:, 0] = rel0
+        b = (base + rel[:, None, :] * np.abs(mw)) * rd
         v.append((b * b).reshape(len(sdw), -1).sum(axis=1) + tol["sigma_net"] ** 2)
     return v[0], v[1]
 
 
-def guard_margin(gm, sdw, mw, lvl, tier, pq):
+def guard_margin(gm, sdw, mw, lvl, sil, tier, pq):
     """per clip (lo, hi): 1 / sqrt(V max(g_c1 P^2, g_c2)) -- below 1 the tier hands the clip on"""
     tol = gm.fast_tolerance()
-    vlo, vhi = guard_variance(gm, sdw, mw, lvl, tier)
+    vlo, vhi = guard_variance(gm, sdw, mw, lvl, sil, tier)
     w = np.maximum(tol["g_c1"] * pq.astype(np.float64) ** 2, tol["g_c2"])
     with np.errstate(divide="ignore"):
         return 1.0 / np.sqrt(vhi * w), 1.0 / np.sqrt(vlo * w)
@@ -158,15 +165,18 @@ def test_fast_mode_on_adversarial_input_families(name, pkg, pool):
             s2 = torch.zeros((n, gm.n_labels), dtype=torch.float32, device="cuda:0")
             gm.run_classifier_batch_device(pcm.data_ptr(), n, s2.data_ptr())
             torch.cuda.synchronize()
-            assert (s2.cpu().numpy() == s1).all(), fam
-            assert (gm.fast_fallback_count(), gm.fast_exact_count()) == (n_t2, n_ex), fam
+            # (without the feature matrix the one launch knows the clip's own scores and may keep a saturated clip that the feature-emitting
+            # launch -- which must assume the largest p (1 - p) there is -- hands on: fewer clips leave, the scores agree within the bar)
+            assert np.abs(s2.cpu().numpy() - s1).max() <= FAST_SCORE_TOL, fam
+            n_t2s, n_exs = gm.fast_fallback_count(), gm.fast_exact_count()
+            assert n_t2s <= n_t2, (fam, n_t2s, n_t2)
         s0, f0, q0, z0 = run_device(pkg, gm, pkg.MODE_EXACT, pcm)
-        so, fo, qo, sdw, mw, zo, lvl = oracle_clips(pool, path, host)
+        so, fo, qo, sdw, mw, zo, lvl, sil = oracle_clips(pool, path, host)
         assert (bits(f0) == bits(fo)).all(), fam               # the exact kernels stay bit-exact on these inputs too
-        # P of the rule: the clip's own largest p (1 - p) where the network runs behind the features in the same launch (fused float32
-        # graphs), 1/4 otherwise (int8 graphs; kws.h)
-        pq = (so * (1.0 - so)).max(axis=1) if (gm.is_float and gm.fast_is_fused) else np.full(n, 0.25)
-        (m1lo, m1hi), (m2lo, m2hi) = guard_margin(gm, sdw, mw, lvl, 1, pq), guard_margin(gm, sdw, mw, lvl, 2, pq)
+        # P of the rule: 1/4 -- the call above asked for the feature matrix, and the feature-emitting launch's list decides for features and
+        # scores (kws.h); the scores-only call (fused float32 graphs: the clip's own largest p (1 - p)) was held to the bar above
+        pq = np.full(n, 0.25)
+        (m1lo, m1hi), (m2lo, m2hi) = guard_margin(gm, sdw, mw, lvl, sil, 1, pq), guard_margin(gm, sdw, mw, lvl, sil, 2, pq)
         exact = (bits(f1) == bits(f0)).all(axis=1)             # a clip the exact kernels finished carries their bits
         ds = np.abs(s1 - so).max(axis=1)
         df = np.abs(f1 - fo).max(axis=1)
@@ -189,8 +199,8 @@ def test_fast_mode_on_adversarial_input_families(name, pkg, pool):
             dz = z1 - zo
             dzp = np.abs(dz[:, :, None] - dz[:, None, :]).reshape(n, -1).max(axis=1)
             assert (bits(z1[exact]) == bits(z0[exact])).all(), fam
-            v1 = guard_variance(gm, sdw, mw, lvl, 1)[1]
-            v2 = guard_variance(gm, sdw, mw, lvl, 2)[1]
+            v1 = guard_variance(gm, sdw, mw, lvl, sil, 1)[1]
+            v2 = guard_variance(gm, sdw, mw, lvl, sil, 2)[1]
             kept1, kept2 = m1lo > 1.1, (~exact) & (m1hi < 0.9)         # surely stayed in tier 1 / surely finished by tier 2
             for kept, v, what in ((kept1, v1, "tier 1"), (kept2, v2, "tier 2")):
                 if kept.any():

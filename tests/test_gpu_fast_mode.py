@@ -94,18 +94,23 @@ def test_fast_mode_float_scores_within_1e4_of_the_oracle_on_a_full_batch(name, p
     z_t.zero_()
     s2, _, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm, want_f=False)           # scores only: the features never leave the chip
     z2 = z_t.cpu().numpy().copy()
+    n_fb_scores_only = gm.fast_fallback_count()
     gm.set_logits_tap(None)
     so, fo, _, zo = oracle_all(path, seed, B, want_logits=True)
     d_s, d_f, d_z = np.abs(s - so).max(), np.abs(f - fo).max(), pair_error(z, zo).max()
     mx = so.max(axis=1)
-    print("\n%s fast mode, %d clips: max |score - oracle| = %.3g, max |logit difference - oracle| = %.3g, max |feature - oracle| = %.3g, %d clips handed back; "
-          "the oracle's winning score: median %.2f, > 0.999 on %.1f %% of the clips" % (name, B, d_s, d_z, d_f, n_fallback, np.median(mx), 100.0 * (mx > 0.999).mean()))
+    print("\n%s fast mode, %d clips: max |score - oracle| = %.3g, max |logit difference - oracle| = %.3g, max |feature - oracle| = %.3g, %d clips handed back "
+          "(%d when only the scores are asked for); the oracle's winning score: median %.2f, > 0.999 on %.1f %% of the clips"
+          % (name, B, d_s, d_z, d_f, n_fallback, n_fb_scores_only, np.median(mx), 100.0 * (mx > 0.999).mean()))
     assert not np.isnan(s).any()
     assert d_s <= FAST_SCORE_TOL
     assert d_z <= FAST_LOGIT_TOL                          # every clip, at the logits: no saturation to hide behind
     assert (mx > 0.999).mean() < 0.05                     # ... and the model's softmax is not saturated anyway
     assert d_f <= FAST_FEATURE_TOL
-    assert (s2 == s).all() and (z2 == z).all()
+    # without the feature matrix the one launch knows the clip's own scores: it may keep a (saturated) clip that the feature-emitting launch,
+    # which assumes the largest p (1 - p) there is, hands on -- never the other way round
+    n_fallback2 = n_fb_scores_only
+    assert n_fallback2 <= n_fallback and np.abs(s2 - s).max() <= FAST_SCORE_TOL and pair_error(z2, zo).max() <= FAST_LOGIT_TOL
     assert n_fallback < B // 100                         # synthetic clips are well-conditioned: the fast kernel keeps them
     assert (np.abs(s.sum(1) - 1.0) <= 1e-5).all()
     gm.close()
@@ -238,12 +243,18 @@ def test_fast_mode_depthwise_separable_graph_is_fused_and_extract_mfcc(pkg, orac
     B = 4096
     host = oracle.synth(77, 0, B)
     pcm = torch.from_numpy(host).to("cuda:0")
+    # round 4: this graph's logit gain (~42 per unit of rms feature error x sqrt(features); the headline graph: 8) leaves the first tier
+    # no room -- its batch calls start from the exact kernels' cepstra and run the fast cmvnw + the fused network from there
+    assert gm.fast_tolerance()["entry_tier"] == 2
     s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
-    s2, _, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm, want_f=False)              # one launch: PCM -> scores
+    n_fb = gm.fast_fallback_count()
+    s2, _, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm, want_f=False)              # exact cepstra -> cmvnw + fused network: scores
+    n_fb2 = gm.fast_fallback_count()
     so, fo, _ = om.run_batch(host, want_features=True)
-    print("\ncfg5 fp32 fused in fast mode, %d clips: max |score - oracle| = %.3g" % (B, np.abs(s2 - so).max()))
+    print("\ncfg5 fp32 in fast mode (entry tier 2), %d clips: max |score - oracle| = %.3g, %d clips finished by the exact kernels (%d when only the scores are asked for)"
+          % (B, np.abs(s2 - so).max(), n_fb, n_fb2))
     assert np.abs(s - so).max() <= FAST_SCORE_TOL and np.abs(f - fo).max() <= FAST_FEATURE_TOL
-    assert (s2 == s).all()
+    assert np.abs(s2 - so).max() <= FAST_SCORE_TOL and n_fb2 <= n_fb
     f2 = torch.zeros((B, gm.n_features), dtype=torch.float32, device="cuda:0")
     gm.extract_mfcc_batch_device(pcm.data_ptr(), B, f2.data_ptr())
     torch.cuda.synchronize()
@@ -263,7 +274,7 @@ FUSED_DW_GRAPHS = {
 
 
 @pytest.mark.parametrize("key", sorted(FUSED_DW_GRAPHS))
-def test_fast_mode_fused_depthwise_separable_graphs(key, pkg, oracle, tmp_path):
+def test_fast_mode_fused_depthwise_separable_graphs(key, pkg, oracle, tmp_path, monkeypatch):
     """Depthwise-separable float graphs in the fused fast kernel: depthwise first block, depth multiplier 2, VALID pooling with a
     dropped tail, ragged SAME windows, 40-channel inputs, eight blocks -- each against the restated float kernels
     (reference/depthwiseconv_float.h:25, reference/conv.h:28-99) within the fast mode's score tolerance, incl. the special clips."""
@@ -273,6 +284,9 @@ def test_fast_mode_fused_depthwise_separable_graphs(key, pkg, oracle, tmp_path):
     from dequantize_model import dequantize
     from kws_testlib import synth_model_blob
     blob = dequantize(synth_model_blob(**FUSED_DW_GRAPHS[key]))
+    # these random-weight graphs have whatever logit gain their draws gave them: most would be routed past the first tier (round 4).  This
+    # test is about the fused kernel's arithmetic: start every batch call in it (the guards still decide which clips it keeps)
+    monkeypatch.setenv("KWS_DEV_FAST_ENTRY", "1")
     p = tmp_path / ("%s.kwsm" % key)
     p.write_bytes(blob)
     om = OracleModel(oracle, str(p))
@@ -493,7 +507,7 @@ def test_fast_mode_guard_follows_the_model_gain(pkg, oracle, tmp_path):
         gm.set_logits_tap(None)
         so, fo, _, zo = oracle_all(path, seed, B, want_logits=True)
         exact = (bits(f) == bits(fe)).all(axis=1)
-        res[tag] = dict(gain=tol["total_gain"], tol=tol["uniform_feature_tol"], t2=n_t2, ex=n_ex, ds=float(np.abs(s - so).max()),
+        res[tag] = dict(gain=tol["total_gain"], tol=tol["uniform_feature_tol"], entry=tol["entry_tier"], t2=n_t2, ex=n_ex, ds=float(np.abs(s - so).max()),
                         dz=float(pair_error(z_t.cpu().numpy(), zo)[~exact].max(initial=0.0)), pq=float(np.median((so * (1 - so)).max(axis=1))))
         assert (bits(fe) == bits(fo)).all()
         assert res[tag]["ds"] <= FAST_SCORE_TOL, res
@@ -502,5 +516,7 @@ def test_fast_mode_guard_follows_the_model_gain(pkg, oracle, tmp_path):
     print("\nfirst convolution x 8 on %d clips: %s" % (B, res))
     assert 5.0 <= res["hot"]["gain"] / res["base"]["gain"] <= 12.0
     assert res["hot"]["tol"] <= res["base"]["tol"] / 5.0
-    assert res["base"]["t2"] <= B // 100                      # the base model keeps the bench's clips in the fast kernel ...
-    assert res["hot"]["t2"] >= 10 * max(res["base"]["t2"], 10)   # ... the hot one hands the unsaturated ones on: the guard tightened
+    # the base model starts in the fast kernel and keeps the bench's clips there; the hot one's gain leaves the first tier no room: its
+    # batch calls start from the exact kernels' cepstra (or run the exact kernels throughout)
+    assert res["base"]["entry"] == 1 and res["base"]["t2"] <= B // 50
+    assert res["hot"]["entry"] >= 2
