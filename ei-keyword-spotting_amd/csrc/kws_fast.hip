@@ -483,7 +483,10 @@ __device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *
 //  ds_bpermute) + those few rows, instead of a walk over every row.
 //  Returns this lane's share of the guard's variance estimate (kws_fast.h): sum over its windows of
 //  ((g.abs + g.lev * level + g.rel * |mean|) / (deviation + eps))^2 -- the caller reduces it over the wave.
-template <int CR, int CG>
+//  DEFER: the guard's terms are kept in registers and summed in the store loop, under the predicate the stores need anyway -- a select
+//  of its own per window (compare, scalar and, conditional move: 17 x 2 per clip) costs 2.6 % of the whole kernel; the forms with the int8
+//  network behind them sit at 256 registers and would spill the CR extra values (+7 % there): they sum in place.
+template <int CR, int CG, bool DEFER>
 __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
                                            float inv_win, const float *__restrict__ guard_tab, float level, bool silent, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
                                            const float *__restrict__ ext_tab, float *__restrict__ sink)
@@ -574,7 +577,7 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
 #pragma unroll
         for (int i = 0; i < CR - 1; ++i) { dl[i] -= piv; da[i] -= piv; }
         float S = S0 + S1, Q = Q0 + Q1;
-        float o[CR], gq[CR];
+        float o[CR], gq[DEFER ? CR : 1];
 #pragma unroll
         for (int i = 0; i < CR; ++i) {
             const float m = S * inv_win;
@@ -582,9 +585,9 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
             var = fmaxf(var, 0.0f);
             const float sd = __builtin_amdgcn_sqrtf(var);
             const float rstd = __builtin_amdgcn_rcpf(sd + FLT_EPSILON);
-            // the guard's term of this window; summed below, under the predicate the store needs anyway (measured: a select of its own per
-            // window here -- compare, scalar and, conditional move -- cost 2.6 % of the whole kernel, 17 x 2 of them per clip)
-            gq[i] = __fmaf_rn(g_rel, fabsf(m + piv), g_abs) * rstd;
+            const float gterm = __fmaf_rn(g_rel, fabsf(m + piv), g_abs) * rstd;       // the guard's term of this window
+            if constexpr (DEFER) gq[i] = gterm;
+            else vacc = (act && r0 + i < nfr) ? __fmaf_rn(gterm, gterm, vacc) : vacc;
             o[i] = (is_c0 ? own[i] - mr[i] : (own[i] - piv) - m) * rstd;
             if (i + 1 < CR) {
                 S = (S + da[i]) - dl[i];
@@ -598,7 +601,7 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
             const int r = r0 + i;
             const bool live = act && r < nfr;
             *(live ? col + r * fs : sink) = o[i];                  // no branch per value: rows / columns outside the matrix go to the sink
-            vacc = live ? __fmaf_rn(gq[i], gq[i], vacc) : vacc;
+            if constexpr (DEFER) vacc = live ? __fmaf_rn(gq[i], gq[i], vacc) : vacc;
         }
     }
     WAVE_SYNC();
@@ -1215,8 +1218,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         float gV = 0.0f;
         if constexpr (!MFE) {                             // (MFE: nothing is divided by a deviation: the mel energies leave as they are)
             const float level = FROM_CEP ? 0.0f : wave_sum(lvl_sum) * FP.lvl_inv;
-            if (cr == 13) vlane = fast_cmvn<13, 16>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
-            else vlane = fast_cmvn<17, 20>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            if (cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
         }
         if constexpr (!NET) {
