@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "kws_extract_mfe_batch_device", "kws_set_mode", "kws_get_mode", "kws_fast_is_fused", "kws_fast_fallback_count", "kws_fast_exact_count", "kws_fast_guard",
     "kws_set_logits_tap", "kws_fast_gain", "kws_fast_tolerance_info",
     "kws_comm_unique_id", "kws_comm_create", "kws_comm_world_size", "kws_comm_rank", "kws_comm_ranks_seen", "kws_comm_rccl_version", "kws_comm_wait", "kws_allgather_scores", "kws_comm_destroy",
-    "kws_wav_info_from_memory", "kws_wav_decode_mono", "kws_resample_length", "kws_resample_device",
+    "kws_wav_info_from_memory", "kws_wav_decode_mono", "kws_resample_length", "kws_resample_device", "kws_resample_device_ex",
     "kws_synth_clips_device", "kws_mix_audio_device", "kws_device_malloc", "kws_device_free", "kws_memcpy_h2d", "kws_memcpy_d2h",
     "kws_device_synchronize",
 ]
@@ -143,6 +143,8 @@ def lib():
             L.kws_resample_length.restype = sz
             L.kws_resample_length.argtypes = [sz, i32, i32]
             L.kws_resample_device.argtypes = [vp, sz, i32, vp, sz, i32, vp]
+        if hasattr(L, "kws_resample_device_ex"):
+            L.kws_resample_device_ex.argtypes = [vp, sz, i32, vp, sz, i32, i32, vp]
         L.kws_streams_create.argtypes = [vp, sz, C.POINTER(vp)]
         L.kws_streams_destroy.argtypes = [vp]
         L.kws_streams_init.argtypes = [vp]
@@ -420,8 +422,12 @@ def resample_length(n_in, sr_in, sr_out):
     return lib().kws_resample_length(n_in, sr_in, sr_out)
 
 
-def resample_device(in_ptr, n_in, sr_in, out_ptr, n_out, sr_out, stream=None):
-    _check(lib().kws_resample_device(in_ptr, n_in, sr_in, out_ptr, n_out, sr_out, stream))
+RESAMPLE_EXACT_POSITIONS = 1
+
+
+def resample_device(in_ptr, n_in, sr_in, out_ptr, n_out, sr_out, stream=None, flags=0):
+    """flags = 0: the reference's behaviour (resampy's integer table stepping + librosa's fix_length); RESAMPLE_EXACT_POSITIONS: exact tap positions"""
+    _check(lib().kws_resample_device_ex(in_ptr, n_in, sr_in, out_ptr, n_out, sr_out, flags, stream))
 
 
 def synth_clips_device(seed, first_clip, n_clips, clip_len, out_ptr, stream=None):

@@ -7,6 +7,8 @@
 // resampler to scipy.signal.resample_poly within a stated tolerance (tests/test_audio_ingest.py) -- not to the reference's output.
 #include "kws_internal.h"
 
+#include <map>
+
 #include <cmath>
 
 static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -110,7 +112,7 @@ static double bessel_i0(double x)
     return sum;
 }
 static const int kResZeros = 64, kResPrecision = 512;
-static void resample_table(std::vector<float> &win, std::vector<float> &delta)
+static void resample_table(std::vector<double> &win, std::vector<double> &delta)
 {
     const double rolloff = 0.9475937167399596, beta = 14.769656459379492;
     const int n = kResZeros * kResPrecision;
@@ -121,13 +123,13 @@ static void resample_table(std::vector<float> &win, std::vector<float> &delta)
         const double sinc = a == 0.0 ? 1.0 : sin(M_PI * a) / (M_PI * a);
         const double r = (double)i / (double)n;                   // position in the right half of the symmetric window
         const double taper = bessel_i0(beta * sqrt(std::max(0.0, 1.0 - r * r))) / i0b;
-        win[(size_t)i] = (float)(rolloff * sinc * taper);
+        win[(size_t)i] = rolloff * sinc * taper;                  // float64, as resampy's table
     }
     for (int i = 0; i < n; i++) delta[(size_t)i] = win[(size_t)i + 1] - win[(size_t)i];
-    delta[(size_t)n] = 0.0f;
+    delta[(size_t)n] = 0.0;
 }
 
-EI_IMPULSE_ERROR kws_resample_device(const float *in, size_t n_in, int sr_in, float *out, size_t n_out, int sr_out, void *stream)
+EI_IMPULSE_ERROR kws_resample_device_ex(const float *in, size_t n_in, int sr_in, float *out, size_t n_out, int sr_out, int flags, void *stream)
 {
     if (!in || !out || sr_in <= 0 || sr_out <= 0 || n_in == 0 || n_in > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_resample_device: bad argument");
     if (n_out != kws_resample_length(n_in, sr_in, sr_out)) return fail(KWS_ERROR_BAD_ARGUMENT, "n_out must be kws_resample_length(n_in, sr_in, sr_out) = %zu",
@@ -138,26 +140,44 @@ EI_IMPULSE_ERROR kws_resample_device(const float *in, size_t n_in, int sr_in, fl
         HIP_TRY(hipMemcpyAsync(out, in, n_in * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return EI_IMPULSE_OK;
     }
+    // one table pair per device, built on first use; the pointers are copied while the lock is held (the function statics
+    // of round 3 were re-allocated -- and leaked -- when another device called, under a concurrent caller on the first one)
+    struct Tables { double *win = nullptr, *delta = nullptr; };
     static std::mutex mu;
-    static float *d_win = nullptr, *d_delta = nullptr;           // one table per process (and device 0's context: the tool's use)
-    static int d_dev = -1;
+    static std::map<int, Tables> tables;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    Tables tb;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!d_win || d_dev != dev) {
-            std::vector<float> win, delta;
+        Tables &slot = tables[dev];
+        if (!slot.win) {
+            std::vector<double> win, delta;
             resample_table(win, delta);
-            HIP_TRY(hipMalloc((void **)&d_win, win.size() * sizeof(float)));
-            HIP_TRY(hipMalloc((void **)&d_delta, delta.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_delta, delta.data(), delta.size() * sizeof(float), hipMemcpyHostToDevice));
-            d_dev = dev;
+            double *dw = nullptr, *dd = nullptr;
+            HIP_TRY(hipMalloc((void **)&dw, win.size() * sizeof(double)));
+            if (hipMalloc((void **)&dd, delta.size() * sizeof(double)) != hipSuccess) { (void)hipFree(dw); return fail(KWS_ERROR_HIP, "hipMalloc failed"); }
+            if (hipMemcpy(dw, win.data(), win.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dd, delta.data(), delta.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(dw); (void)hipFree(dd);
+                return fail(KWS_ERROR_HIP, "uploading the resampler's table failed");
+            }
+            slot.win = dw; slot.delta = dd;
         }
+        tb = slot;
     }
-    int rc = kws_launch_resample(in, n_in, out, n_out, (double)sr_out / (double)sr_in, d_win, d_delta, kResZeros * kResPrecision, kResPrecision, (hipStream_t)stream);
+    const double ratio = (double)sr_out / (double)sr_in;
+    const bool exact = (flags & KWS_RESAMPLE_EXACT_POSITIONS) != 0;
+    // the reference's length: resampy writes int(n ratio) samples, librosa's fix_length pads with zeros up to ceil(n ratio)
+    const size_t n_valid = exact ? n_out : std::min(n_out, (size_t)((double)n_in * ratio));
+    int rc = kws_launch_resample(in, n_in, out, n_out, n_valid, ratio, tb.win, tb.delta, kResZeros * kResPrecision, kResPrecision, exact ? 1 : 0, (hipStream_t)stream);
     if (rc) return fail(KWS_ERROR_HIP, "resample kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
+}
+
+EI_IMPULSE_ERROR kws_resample_device(const float *in, size_t n_in, int sr_in, float *out, size_t n_out, int sr_out, void *stream)
+{
+    return kws_resample_device_ex(in, n_in, sr_in, out, n_out, sr_out, 0, stream);
 }
 
 }  // extern "C"

@@ -51,8 +51,8 @@ int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
 int kws_launch_mix_audio(const float *words, const int *word_len, size_t word_stride, const float *noise, const int *start, float word_vol,
                          float bg_vol, int n, size_t n_clips, int16_t *out, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
-int kws_launch_resample(const float *in, size_t n_in, float *out, size_t n_out, double ratio, const float *win, const float *delta, int nwin, int precision,
-                        hipStream_t stream);
+int kws_launch_resample(const float *in, size_t n_in, float *out, size_t n_out, size_t n_valid, double ratio, const double *win, const double *delta, int nwin,
+                        int precision, int exact, hipStream_t stream);
 // kws_generic.hip: the exact MFCC block for configurations outside the tuned kernel (KwsDspPlan::generic)
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid);
 int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,

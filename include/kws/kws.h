@@ -236,7 +236,12 @@ EI_IMPULSE_ERROR kws_mix_audio_device(const float *words, const int *word_len, s
  *                             WAVE_FORMAT_EXTENSIBLE; unknown chunks are skipped)
  *   kws_wav_decode_mono       host: samples -> float32 in [-1, 1), channels averaged; out == NULL only reports *frames / *sample_rate
  *   kws_resample_length       ceil(n_in * sr_out / sr_in), librosa's output length
- *   kws_resample_device       device -> device; sr_in == sr_out copies (librosa.load leaves such a file alone) */
+ *   kws_resample_device       device -> device; sr_in == sr_out copies (librosa.load leaves such a file alone).  The reference's behaviour:
+ *                             resampy's published loop (a wing walks the table in truncated integer steps with one interpolation factor,
+ *                             float32 accumulation, floor(n ratio) samples, then librosa's fix_length zero padding up to ceil(n ratio))
+ *   kws_resample_device_ex    flags = KWS_RESAMPLE_EXACT_POSITIONS: every tap's table position exact, products summed in double, every
+ *                             sample computed -- 5e-8 .. 7e-7 from the analytic signal where the reference's stepping is 6e-4 .. 2e-3 away */
+#define KWS_RESAMPLE_EXACT_POSITIONS 1
 typedef struct {
     int channels, sample_rate, bits_per_sample, is_float;
     size_t frames, data_offset;
@@ -245,6 +250,7 @@ EI_IMPULSE_ERROR kws_wav_info_from_memory(const void *bytes, size_t nbytes, kws_
 EI_IMPULSE_ERROR kws_wav_decode_mono(const void *bytes, size_t nbytes, float *out, size_t out_cap, size_t *frames, int *sample_rate);
 size_t kws_resample_length(size_t n_in, int sr_in, int sr_out);
 EI_IMPULSE_ERROR kws_resample_device(const float *in, size_t n_in, int sr_in, float *out, size_t n_out, int sr_out, void *stream);
+EI_IMPULSE_ERROR kws_resample_device_ex(const float *in, size_t n_in, int sr_in, float *out, size_t n_out, int sr_out, int flags, void *stream);
 
 /* deterministic synthetic clips generated directly in HBM (include/kws/kws_synth.h) */
 EI_IMPULSE_ERROR kws_synth_clips_device(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len,

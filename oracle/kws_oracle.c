@@ -1600,13 +1600,19 @@ void kwso_mix_audio(const float *word, int word_len, const float *noise_window, 
             float b = (float)(0.5 * (double)bg_vol) * noise_window[i];   /* 0.5 * bg_vol * ndarray(float32): the scalar takes the array's dtype */
             x = a + (double)b;                              /* list + ndarray -> float64 */
         }
-        /* sf.write(subtype PCM_16) of doubles: libsndfile's d2les_array, lrint(x * 0x7FFF) and the low 16 bits of it -- clipping
-           (SFC_SET_CLIPPING) is off by default and python-soundfile does not switch it on, so a value beyond full scale WRAPS.  The
-           reference's own parameters cannot get there (|0.5 word + 0.5 bg| <= 1 for volumes <= 1); assumed from libsndfile's published
-           source, not checked against it here (PARITY UNPINNED). */
-        double r = rint(x * 32767.0);
-        if (!(r > -9.0e18 && r < 9.0e18)) r = 0.0;           /* outside long long (or NaN): lrint's result is unspecified; zero here */
-        out[i] = (int16_t)(uint16_t)((unsigned long long)(long long)r & 0xffffull);
+        /* sf.write(subtype = 'PCM_16') of float64 data: python-soundfile switches libsndfile's clipping ON when it opens a file
+           (SoundFile._open: sf_command(SFC_SET_CLIPPING, SF_TRUE)), so pcm.c converts with d2s_clip_array, not d2s_array:
+               scaled = x * 2^31;  >= 0x7FFFFFFF -> 0x7FFF;  <= -2^31 -> 0x8000;  else lrint(scaled) >> 16
+           -- saturating, and a TRUNCATING (floor) reduction of the rounded 32-bit value, which sits one LSB below lrint(x * 32767) for
+           about half of the negative samples.  Round 3 had the no-clipping rule (lrint(x * 0x7FFF), wrapped); ADVICE round 3 pointed to
+           python-soundfile's source.  Restated from libsndfile's / python-soundfile's published sources, not run against them here
+           (PARITY UNPINNED).  NaN: what x86's cvtsd2si returns (INT_MIN) >> 16. */
+        const double scaled = x * 2147483648.0;
+        int32_t v;
+        if (scaled >= 2147483647.0) { out[i] = 0x7FFF; continue; }
+        if (scaled <= -2147483648.0 || scaled != scaled) { out[i] = (int16_t)-32768; continue; }
+        v = (int32_t)lrint(scaled);
+        out[i] = (int16_t)(v >> 16);
     }
 }
 

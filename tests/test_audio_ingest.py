@@ -115,12 +115,19 @@ def test_resampler_against_the_analytic_signal_and_scipy(sr_in, pkg):
     n_out = pkg.resample_length(n_in, sr_in, sr_out)
     d_in = torch.from_numpy(x).to("cuda:0")
     d_out = torch.zeros(n_out, dtype=torch.float32, device="cuda:0")
-    pkg.resample_device(d_in.data_ptr(), n_in, sr_in, d_out.data_ptr(), n_out, sr_out)
+    pkg.resample_device(d_in.data_ptr(), n_in, sr_in, d_out.data_ptr(), n_out, sr_out, flags=pkg.RESAMPLE_EXACT_POSITIONS)
     torch.cuda.synchronize()
     y = d_out.cpu().numpy()
     want = band_limited(np.arange(n_out) / sr_out, freqs, amps, phases)
     edge = 200
     err = np.abs(y - want)[edge:-edge].max()
+    # the default (the reference's behaviour: resampy's truncated integer table step) is the coarser one at non-integer ratios
+    d_ref = torch.zeros(n_out, dtype=torch.float32, device="cuda:0")
+    pkg.resample_device(d_in.data_ptr(), n_in, sr_in, d_ref.data_ptr(), n_out, sr_out)
+    torch.cuda.synchronize()
+    err_ref = np.abs(d_ref.cpu().numpy() - want)[edge:-edge].max()
+    print("\n%d -> %d Hz: reference-behaviour resampler: max |resampled - analytic| %.3g" % (sr_in, sr_out, err_ref))
+    assert err_ref <= 5e-3
     g = np.gcd(sr_in, sr_out)
     ys = resample_poly(x.astype(np.float64), sr_out // g, sr_in // g)[:n_out]
     err_scipy = np.abs(ys - want[:len(ys)])[edge:-edge].max()
@@ -129,6 +136,74 @@ def test_resampler_against_the_analytic_signal_and_scipy(sr_in, pkg):
     assert np.abs(y[edge:-edge] - ys[edge:len(y) - edge]).max() <= err_scipy + 5e-6      # scipy's default polyphase filter is the coarser of the two
     with pytest.raises(pkg.KwsError):
         pkg.resample_device(d_in.data_ptr(), n_in, sr_in, d_out.data_ptr(), n_out + 1, sr_out)
+
+
+def resampy_loop(x, sr_in, sr_out):
+    """The published loop of resampy 0.2's resample_f (interpn.py) with the "kaiser_best" filter, as librosa.load(sr = ...) ran it in the
+    reference's day, followed by librosa's fix_length -- restated from the published sources for this test (PARITY UNPINNED: neither package is
+    installable here).  float64 table built from the filter's published parameters; a float32 output array."""
+    from scipy.special import i0
+    num_zeros, precision, rolloff, beta = 64, 512, 0.9475937167399596, 14.769656459379492
+    n = num_zeros * precision
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    r = np.arange(n + 1) / n
+    taper = i0(beta * np.sqrt(np.maximum(0.0, 1.0 - r * r))) / i0(beta)          # scipy.signal.kaiser(2 n + 1, beta)[n:]
+    interp_win = taper * sinc_win
+    ratio = float(sr_out) / sr_in
+    if ratio < 1:
+        interp_win = interp_win * ratio
+    interp_delta = np.zeros_like(interp_win)
+    interp_delta[:-1] = np.diff(interp_win)
+    y = np.zeros(int(len(x) * ratio), np.float32)
+    scale = min(1.0, ratio)
+    time_increment = 1.0 / ratio
+    index_step = int(scale * precision)
+    time_register = 0.0
+    nwin, n_orig = len(interp_win), len(x)
+    for t in range(len(y)):
+        nn = int(time_register)
+        frac = scale * (time_register - nn)
+        index_frac = frac * precision
+        offset = int(index_frac)
+        eta = index_frac - offset
+        for i in range(min(nn + 1, (nwin - offset) // index_step)):
+            weight = interp_win[offset + i * index_step] + eta * interp_delta[offset + i * index_step]
+            y[t] += weight * x[nn - i]
+        frac = scale - frac
+        index_frac = frac * precision
+        offset = int(index_frac)
+        eta = index_frac - offset
+        for k in range(min(n_orig - nn - 1, (nwin - offset) // index_step)):
+            weight = interp_win[offset + k * index_step] + eta * interp_delta[offset + k * index_step]
+            y[t] += weight * x[nn + k + 1]
+        time_register += time_increment
+    n_fix = int(np.ceil(len(x) * ratio))                                          # librosa.resample: util.fix_length(y_hat, n_samples)
+    return np.concatenate([y, np.zeros(n_fix - len(y), np.float32)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr_in", [8000, 22050, 44100])
+def test_default_resampler_follows_resampys_published_loop(sr_in, pkg):
+    """kws_resample_device (no flags) = the reference's behaviour: resampy's integer table stepping with one
+    interpolation factor per wing, float32 accumulation, floor(n ratio) samples + fix_length's zero padding -- held to the loop restated
+    above on a short signal, sample for sample within float32 rounding of the sum."""
+    import torch
+    rng = np.random.default_rng(sr_in)
+    n_in = 1501
+    x = (rng.standard_normal(n_in) * 0.2).astype(np.float32)
+    want = resampy_loop(x, sr_in, 16000)
+    n_out = pkg.resample_length(n_in, sr_in, 16000)
+    assert n_out == len(want)
+    d_in = torch.from_numpy(x).to("cuda:0")
+    d_out = torch.full((n_out,), 7.0, dtype=torch.float32, device="cuda:0")
+    pkg.resample_device(d_in.data_ptr(), n_in, sr_in, d_out.data_ptr(), n_out, 16000)
+    torch.cuda.synchronize()
+    y = d_out.cpu().numpy()
+    n_valid = int(n_in * 16000.0 / sr_in)
+    assert (y[n_valid:] == 0).all()                                               # fix_length's padding, not a computed sample
+    d = np.abs(y - want).max()
+    print("\n%d -> 16000 Hz, %d samples: max |kernel - resampy's loop| = %.3g (%d of %d identical)" % (sr_in, n_out, d, int((y == want).sum()), n_out))
+    assert d <= 2e-6                          # same taps, same order, float32 accumulation on both sides; the time register differs by ~1e-12 relative
 
 
 @pytest.mark.gpu
