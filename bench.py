@@ -192,6 +192,8 @@ class GpuBackend:
         self.scores = torch.empty((self.B, m.n_labels), dtype=torch.float32, device=self.dev)
         self.gathered = torch.empty((self.world * self.B, m.n_labels), dtype=torch.float32, device=self.dev) if self.use_comm else self.scores
         tol = m.fast_tolerance() if mode == "fast" else None
+        if tol and tol["dev_overrides"]:
+            raise SystemExit("bench.py: a KWS_DEV_FAST_* development switch is set in the environment: KWS_MODE_FAST would be outside its tolerance; refusing to measure")
         return {"labels": m.n_labels, "is_float": m.is_float, "nn_kernel": m.nn_kernel, "fused": bool(m.fast_is_fused and mode == "fast"),
                 "entry_tier": tol["entry_tier"] if tol else None,
                 "guard": {k: tol[k] for k in ("k_sigma", "score_tol", "total_gain", "uniform_feature_tol", "calibrated")} if tol else None}

@@ -110,6 +110,7 @@ struct DspCfg {
     int axes, num_cepstral, num_filters, fft_length, win_size, low_frequency, high_frequency, pre_shift;
     float frame_length, frame_stride, pre_cof;
     int block = DSP_BLOCK_MFCC;
+    int quantize_fb = 0;           // EIDSP_QUANTIZE_FILTERBANK (SDK/dsp/config.hpp:75-77): mel weights snapped to numpy.hpp:52's table
 };
 struct Model {
     std::vector<Tensor> t;
@@ -125,7 +126,8 @@ float h_fast_log(float a);
 float h_freq_to_mel(float f);
 float h_mel_to_freq(float mel);
 void h_linspace(float start, float stop, uint32_t number, float *out);
-std::vector<float> h_filterbank(int num_filter, int coefficients, uint32_t fs, uint32_t low, uint32_t high);
+std::vector<float> h_filterbank(int num_filter, int coefficients, uint32_t fs, uint32_t low, uint32_t high, bool quantize = false);
+float h_quantize_zero_one(float value);
 void h_twiddles(int nfft, std::vector<float2> &tw);
 void h_super_twiddles(int ncfft, std::vector<float2> &st);
 void h_pad_map(int rows, int pad, std::vector<int> &map);
@@ -219,6 +221,7 @@ struct kws_handle {
     // host copy of the guard's per-column coefficients, [tier - 1][kind][column]: kind 0 absolute, 1 per log-mel level, 2 per |window mean|,
     // 3 per |window mean| when column 0's window means were replayed in the reference's order (kws_fast_guard)
     std::vector<float> fast_guard_coef[2][4];
+    int fast_dev_overrides = 0;                            // bit set: a KWS_DEV_FAST_* switch that changes results was read at kws_create
     int fast_entry_tier = 1;                               // 1: batch calls start in the fast kernel; 2: from exact cepstra; 3: exact kernels (build_guard)
     std::vector<float> fast_gain_used;                     // the per-column gain those coefficients were built with (float32 graph: gain.col)
     int mode = KWS_MODE_EXACT;

@@ -74,7 +74,13 @@ bool parse_model(const void *blob, size_t nbytes, Model &m)
     d.axes = r.i32(); d.num_cepstral = r.i32(); d.num_filters = r.i32(); d.fft_length = r.i32(); d.win_size = r.i32();
     d.low_frequency = r.i32(); d.high_frequency = r.i32(); d.pre_shift = r.i32();
     d.frame_length = r.f32(); d.frame_stride = r.f32(); d.pre_cof = r.f32();
-    d.block = version == 2 ? r.i32() : DSP_BLOCK_MFCC;          // version 2: the DSP block type follows
+    {
+        // version 2: one more i32 -- bits 0..7 the DSP block type, bit 8 EIDSP_QUANTIZE_FILTERBANK; anything else is not a model of ours
+        const int v = version == 2 ? r.i32() : 0;
+        if (v & ~0x1ff) return false;
+        d.block = v & 0xff;
+        d.quantize_fb = (v >> 8) & 1;
+    }
     if (d.block != DSP_BLOCK_MFCC && d.block != DSP_BLOCK_MFE) return false;
     if (r.bad || nt > 4096 || nn > 4096 || nl > 1024) return false;
     for (uint32_t i = 0; i < nl; i++) {
@@ -190,8 +196,50 @@ void h_linspace(float start, float stop, uint32_t number, float *out)           
     out[number - 1] = stop;
 }
 
+// EIDSP_QUANTIZE_FILTERBANK = 1 (the SDK's default, SDK/dsp/config.hpp:75-77): a mel weight is stored as an index into
+// quantized_values_one_zero[] (numpy.hpp:52) and read back through it (numpy.hpp:423-468, 222-250).  That table holds, ascending, every
+// fraction a / b with b <= 22 and every i / 100 -- 231 distinct values, each a correctly rounded float division, so it is generated here
+// from the rule (tests/test_oracle_vs_reference.py pins the restatement's copy of the same rule entry by entry against the compiled
+// reference).  quantize_zero_one's search keeps the reference's quirks: out-of-range values return the table VALUE cast to the index
+// type (0 below; 1 above, i.e. 1/100), the final pick between the two neighbours is made in float arithmetic.
+float h_quantize_zero_one(float value)
+{
+    static const std::vector<float> tab = [] {
+        std::vector<std::pair<int, int>> fr;
+        auto add = [&](int a, int b) {
+            for (const auto &f : fr) if ((long)f.first * b == (long)a * f.second) return;
+            fr.push_back({ a, b });
+        };
+        for (int b = 1; b <= 22; b++) for (int a = 0; a <= b; a++) add(a, b);
+        for (int a = 0; a <= 100; a++) add(a, 100);
+        std::sort(fr.begin(), fr.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return (long)x.first * y.second < (long)y.first * x.second; });
+        std::vector<float> t;
+        for (const auto &f : fr) t.push_back((float)f.first / (float)f.second);
+        return t;
+    }();
+    const int length = (int)tab.size();
+    int ix = -1;
+    for (int i = 0; i < length && ix < 0; i++) if (tab[(size_t)i] == value) ix = i;
+    if (ix < 0) {
+        if (value < tab[0]) ix = (uint8_t)tab[0];
+        else if (value > tab[(size_t)length - 1]) ix = (uint8_t)tab[(size_t)length - 1];
+        else {
+            int lo = 0, hi = length - 1;
+            bool hit = false;
+            while (lo <= hi) {
+                const int mid = (hi + lo) / 2;
+                if (value < tab[(size_t)mid]) hi = mid - 1;
+                else if (value > tab[(size_t)mid]) lo = mid + 1;
+                else { ix = (uint8_t)tab[(size_t)mid]; hit = true; break; }     // unreachable for numbers; a NaN ends here as in the reference
+            }
+            if (!hit) ix = (tab[(size_t)lo] - value) < (value - tab[(size_t)hi]) ? lo : hi;
+        }
+    }
+    return tab[(size_t)std::min(ix, std::min(247, length - 1))];
+}
+
 // feature::filterbanks (feature.hpp:54-171) + functions::triangle (functions.hpp:90-104), dense [coeff][M]
-std::vector<float> h_filterbank(int num_filter, int coefficients, uint32_t fs, uint32_t low, uint32_t high)
+std::vector<float> h_filterbank(int num_filter, int coefficients, uint32_t fs, uint32_t low, uint32_t high, bool quantize)
 {
     std::vector<float> fb((size_t)coefficients * num_filter, 0.0f);
     const int np = num_filter + 2;
@@ -218,7 +266,7 @@ std::vector<float> h_filterbank(int num_filter, int coefficients, uint32_t fs, u
         }
         for (int zx = 0; zx < zn; zx++) {
             const int bin = left + zx;
-            if (bin >= 0 && bin < coefficients) fb[(size_t)bin * num_filter + i] = o[zx];
+            if (bin >= 0 && bin < coefficients) fb[(size_t)bin * num_filter + i] = quantize ? h_quantize_zero_one(o[zx]) : o[zx];
         }
     }
     return fb;

@@ -109,7 +109,7 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
         if (!same) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "DCT constants of the kernel build differ from this host's (%d filters)", N);
     }
     const uint32_t high = c.high_frequency == 0 ? fs / 2 : (uint32_t)c.high_frequency;   // feature.hpp:203-205
-    std::vector<float> fb = h_filterbank(N, P.n_bins, fs, (uint32_t)c.low_frequency, high);
+    std::vector<float> fb = h_filterbank(N, P.n_bins, fs, (uint32_t)c.low_frequency, high, c.quantize_fb != 0);
     std::vector<int> fstart(N + 1, 0), fbin;
     std::vector<float> fw;
     int max_nz = 0;

@@ -108,6 +108,8 @@ typedef struct {
     int entry_tier;                                    /* where kws_run_classifier_batch_device starts in KWS_MODE_FAST: 1 the fast kernel; 2 exact cepstra for
                                                           every clip, then the fast cmvnw + network (a graph whose gain leaves tier 1 no room: a typical
                                                           clip would be handed on anyway); 3 the exact kernels.  Routing only: every tier applies its guard */
+    int dev_overrides;                                 /* non-zero: a KWS_DEV_FAST_* development switch (guard off / scaled, no re-run) was set in the environment when
+                                                          the model was created -- KWS_MODE_FAST results are then outside the documented tolerance */
 } kws_fast_tolerance;
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
 EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);

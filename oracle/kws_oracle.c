@@ -91,6 +91,65 @@ static void linspace(float start, float stop, uint32_t number, float *out)
 }
 
 /* ====================================================================== */
+/*  EIDSP_QUANTIZE_FILTERBANK = 1             numpy.hpp:52, 423-468        */
+/*  The table quantized_values_one_zero[] holds, in ascending order, every  */
+/*  fraction a/b with b <= 22 and every i/100 (231 distinct values, each     */
+/*  written as a float division): built here from that rule -- IEEE division */
+/*  is correctly rounded, so the spelling of a fraction does not matter --    */
+/*  and pinned entry by entry against the compiled reference                  */
+/*  (tests/test_oracle_vs_reference.py).                                      */
+/* ====================================================================== */
+static float g_qtab[256];
+static int g_qtab_n = 0;
+static void qtab_build(void)
+{
+    /* (numerator, denominator) pairs in lowest terms, sorted by value */
+    int num[256], den[256], n = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int b = pass ? 100 : 1; b <= (pass ? 100 : 22); b++)
+            for (int a = 0; a <= b; a++) {
+                int dup = 0;
+                for (int k = 0; k < n && !dup; k++) dup = (long)num[k] * b == (long)a * den[k];
+                if (!dup && n < 256) { num[n] = a; den[n] = b; n++; }
+            }
+    for (int i = 1; i < n; i++)                           /* insertion sort by a/b (cross-multiplication: exact) */
+        for (int j = i; j > 0 && (long)num[j] * den[j - 1] < (long)num[j - 1] * den[j]; j--) {
+            int t = num[j]; num[j] = num[j - 1]; num[j - 1] = t;
+            t = den[j]; den[j] = den[j - 1]; den[j - 1] = t;
+        }
+    for (int i = 0; i < n; i++) g_qtab[i] = (float)num[i] / (float)den[i];
+    g_qtab_n = n;
+}
+
+/* quantize_zero_one followed by dequantize_zero_one, with the reference's quirks: the early returns for out-of-range values return the
+ * TABLE VALUE converted to uint8_t (0 below the table; 1 -- i.e. entry 1 = 1/100 -- above it), the `return ...[mid]` inside the binary
+ * search is unreachable (exact matches are caught by the linear scan), and the final pick is made in float arithmetic. */
+float kwso_quantize_zero_one(float value)
+{
+    if (!g_qtab_n) qtab_build();
+    const int length = g_qtab_n;
+    int ix_out = -1;
+    for (int ix = 0; ix < length && ix_out < 0; ix++) if (g_qtab[ix] == value) ix_out = ix;
+    if (ix_out < 0) {
+        if (value < g_qtab[0]) ix_out = (uint8_t)g_qtab[0];
+        else if (value > g_qtab[length - 1]) ix_out = (uint8_t)g_qtab[length - 1];
+        else {
+            int lo = 0, hi = length - 1;
+            while (lo <= hi) {
+                int mid = (hi + lo) / 2;
+                if (value < g_qtab[mid]) hi = mid - 1;
+                else if (value > g_qtab[mid]) lo = mid + 1;
+                else { lo = hi = mid; break; }               /* (NaN lands here in the reference too: neither < nor >) */
+            }
+            if (lo == hi) ix_out = (uint8_t)g_qtab[lo];       /* the reference returns the table VALUE as the index */
+            else ix_out = (g_qtab[lo] - value) < (value - g_qtab[hi]) ? lo : hi;
+        }
+    }
+    if (ix_out > 247) ix_out = 247;                           /* dequantize_zero_one's clamp (beyond the table's 231 entries: never reached) */
+    return g_qtab[ix_out];
+}
+
+/* ====================================================================== */
 /*  mel filterbank (transposed)        feature.hpp:54-171, functions.hpp:90-104 */
 /* ====================================================================== */
 int kwso_filterbanks(const kwso_mfcc_config *c, float *fb_t)
@@ -134,7 +193,9 @@ int kwso_filterbanks(const kwso_mfcc_config *c, float *fb_t)
         }
         for (int zx = 0; zx < zn; zx++) {
             int bin = left + zx;
-            if (bin >= 0 && bin < coefficients) fb_t[(size_t)bin * num_filter + i] = o[zx];
+            /* EIDSP_QUANTIZE_FILTERBANK: the weight is stored as a table index and read back through the table (feature.hpp:154-158,
+               numpy.hpp:222-250) */
+            if (bin >= 0 && bin < coefficients) fb_t[(size_t)bin * num_filter + i] = c->quantize_filterbank ? kwso_quantize_zero_one(o[zx]) : o[zx];
         }
         free(z); free(o);
     }
@@ -790,7 +851,14 @@ kwso_model *kwso_model_load(const void *blob, size_t nbytes)
     m->dsp.win_size = rd_i32(&r); m->dsp.low_frequency = rd_i32(&r); m->dsp.high_frequency = rd_i32(&r);
     m->dsp.pre_shift = rd_i32(&r);
     m->dsp.frame_length = rd_f32(&r); m->dsp.frame_stride = rd_f32(&r); m->dsp.pre_cof = rd_f32(&r);
-    m->dsp_block = version == 2 ? rd_i32(&r) : 0;     /* 0: extract_mfcc_features, 1: extract_mfe_features (L432 SDK copy) */
+    {
+        /* version 2: one more i32 -- bits 0..7 the DSP block (0: extract_mfcc_features, 1: extract_mfe_features of the L432 SDK copy),
+           bit 8 EIDSP_QUANTIZE_FILTERBANK */
+        const int v = version == 2 ? rd_i32(&r) : 0;
+        m->dsp_block = v & 0xff;
+        m->dsp.quantize_filterbank = (v >> 8) & 1;
+        if (v & ~0x1ff) r.bad = 1;
+    }
     m->dsp.sampling_frequency = (int)m->frequency;
     if (r.bad || m->n_tensors > 4096 || m->n_nodes > 4096 || m->n_labels > 1024) { kwso_model_free(m); return NULL; }
     m->labels = (char **)calloc(m->n_labels ? m->n_labels : 1, sizeof(char *));

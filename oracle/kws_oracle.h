@@ -39,6 +39,8 @@ typedef struct {
     float pre_cof;
     int   pre_shift;
     int   sampling_frequency;
+    int   quantize_filterbank;  /* EIDSP_QUANTIZE_FILTERBANK (SDK/dsp/config.hpp:75-77; the SDK's default is 1, the demos build with 0): the
+                                   triangle weights are snapped to numpy.hpp:52's table of fractions */
 } kwso_mfcc_config;
 
 /* ---- DSP leaves ------------------------------------------------------- */
@@ -49,6 +51,7 @@ int   kwso_num_frames(size_t n, const kwso_mfcc_config *c);      /* processing.h
 int   kwso_frame_length_samples(const kwso_mfcc_config *c);      /* processing.hpp:208 */
 /* fb_t[coeff][num_filters] (transposed), coeff = fft_length/2+1        feature.hpp:54-171 */
 int   kwso_filterbanks(const kwso_mfcc_config *c, float *fb_t);
+float kwso_quantize_zero_one(float value);             /* numpy.hpp:423-468: dequantize_zero_one(quantize_zero_one(value)) */
 /* y = pre-emphasised samples [offset, offset+length)                   processing.hpp:52-138 */
 int   kwso_preemphasis(const int16_t *pcm, size_t n, float cof, int shift,
                        size_t offset, size_t length, float *out);

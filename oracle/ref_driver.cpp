@@ -197,10 +197,28 @@ int eiref_power_spectrum(float *frame, size_t frame_size, float *out, int fft_le
 /* filterbank in the transposed [coefficients][num_filters] layout mfe() uses */
 int eiref_filterbanks(int num_filters, int fft_length, int low_frequency, int high_frequency, float *out) {
     int coefficients = fft_length / 2 + 1;
+#if EIDSP_QUANTIZE_FILTERBANK
+    /* the build with the SDK's default option (oracle/Makefile: libei_ref_l476_qfb.so): the matrix holds table indices; hand the
+       de-quantised weights out, as numpy::dot_by_row reads them (numpy.hpp:222-250) */
+    EI_DSP_QUANTIZED_MATRIX(fb, num_filters, coefficients, &numpy::dequantize_zero_one);
+    if (!fb.buffer) return -1;
+    int r = speechpy::feature::filterbanks(&fb, num_filters, coefficients, EI_CLASSIFIER_FREQUENCY, low_frequency, high_frequency, true);
+    for (int i = 0; i < num_filters * coefficients; i++) out[i] = fb.dequantization_fn(fb.buffer[i]);
+    return r;
+#else
     matrix_t fb(num_filters, coefficients, out);
     memset(out, 0, sizeof(float) * num_filters * coefficients);
     return speechpy::feature::filterbanks(&fb, num_filters, coefficients, EI_CLASSIFIER_FREQUENCY,
                                           low_frequency, high_frequency, true);
+#endif
+}
+int eiref_quantize_filterbank(void) { return EIDSP_QUANTIZE_FILTERBANK; }
+/* numpy::quantize_zero_one / dequantize_zero_one (numpy.hpp:423-468) and the table behind them */
+float eiref_quantize_zero_one(float v) { return numpy::dequantize_zero_one(numpy::quantize_zero_one(v)); }
+int eiref_quantized_table(float *out, int cap) {
+    const int n = (int)(sizeof(quantized_values_one_zero) / sizeof(float));
+    for (int i = 0; i < n && i < cap; i++) out[i] = quantized_values_one_zero[i];
+    return n;
 }
 
 float eiref_log(float x) { return numpy::log(x); }

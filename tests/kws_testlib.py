@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # KWS_ORACLE_SO: another build of oracle/kws_oracle.c (tests/test_sanitizers.py points it at the ASan + UBSan build)
 ORACLE_SO = os.environ.get("KWS_ORACLE_SO") or os.path.join(ROOT, "oracle", "libkws_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libei_ref_l476.so")
+REF_QFB_SO = os.path.join(ROOT, "oracle", "_ref", "libei_ref_l476_qfb.so")      # the same sources with EIDSP_QUANTIZE_FILTERBANK at the SDK's default (1)
 MODELS = os.path.join(ROOT, "models")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CLIP_LEN = 16000
@@ -23,7 +24,7 @@ class MfccConfig(C.Structure):
     _fields_ = [("num_cepstral", C.c_int), ("frame_length", C.c_float), ("frame_stride", C.c_float),
                 ("num_filters", C.c_int), ("fft_length", C.c_int), ("win_size", C.c_int),
                 ("low_frequency", C.c_int), ("high_frequency", C.c_int), ("pre_cof", C.c_float),
-                ("pre_shift", C.c_int), ("sampling_frequency", C.c_int)]
+                ("pre_shift", C.c_int), ("sampling_frequency", C.c_int), ("quantize_filterbank", C.c_int)]
 
     def copy(self, **kw):
         c = MfccConfig()
@@ -127,6 +128,11 @@ class Oracle:
     # ---- DSP
     def num_frames(self, n, cfg):
         return self.L.kwso_num_frames(n, C.byref(cfg))
+
+    def quantize_zero_one(self, v):
+        self.L.kwso_quantize_zero_one.restype = C.c_float
+        self.L.kwso_quantize_zero_one.argtypes = [C.c_float]
+        return self.L.kwso_quantize_zero_one(float(v))
 
     def filterbanks(self, cfg):
         out = np.zeros((cfg.fft_length // 2 + 1, cfg.num_filters), np.float32)
@@ -341,10 +347,14 @@ class ReferenceL432Dsp:
 
 
 class Reference:
-    """The unmodified reference SDK compiled by oracle/Makefile (target ref)."""
+    """The unmodified reference SDK compiled by oracle/Makefile (target ref).  qfb: the build with EIDSP_QUANTIZE_FILTERBANK = 1."""
 
-    def __init__(self):
-        L = self.L = C.CDLL(REF_SO)
+    def __init__(self, qfb=False):
+        L = self.L = C.CDLL(REF_QFB_SO if qfb else REF_SO)
+        assert L.eiref_quantize_filterbank() == (1 if qfb else 0)
+        L.eiref_quantize_zero_one.restype = C.c_float
+        L.eiref_quantize_zero_one.argtypes = [C.c_float]
+        L.eiref_quantized_table.argtypes = [C.c_void_p, C.c_int]
         L.eiref_label.restype = C.c_char_p
         L.eiref_run_classifier.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.eiref_extract_mfcc.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,

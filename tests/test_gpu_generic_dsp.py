@@ -148,3 +148,27 @@ def test_general_kernels_host_batch_over_two_streams(pkg, oracle, tmp_path):
     got = np.stack([out[0][0].cpu().numpy(), out[0][4095].cpu().numpy(), out[1][0].cpu().numpy(), out[1][4095].cpu().numpy()])
     assert (bits(got) == bits(want)).all()
     gm.close()
+
+
+@pytest.mark.parametrize("name", ["l476", "fft512", "fft1024_f20"])
+def test_quantized_filterbank_models_on_gpu(name, pkg, oracle, tmp_path):
+    """A model built for an application that compiles the SDK with its default EIDSP_QUANTIZE_FILTERBANK = 1 (.kwsm: bit 8 of the DSP word,
+    tools/eon_import.py --quantize-filterbank): the mel weights are snapped to numpy.hpp:52's table.  The exact kernels must reproduce the
+    reference's features (golden from the reference built with the option at its default) and the oracle's scores, bit for bit."""
+    from test_oracle_golden import QFB_CASES
+    kw = QFB_CASES[name]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "qfb_l476.npz"))
+    blob_kw = dict(BLOCKS, seed=3, quantize_filterbank=True, fft_length=kw.get("fft_length", 256), num_filters=kw.get("num_filters", 32),
+                   ncep=kw.get("num_cepstral", 13), low=kw.get("low_frequency", 300), high=kw.get("high_frequency", 4000))
+    blob = synth_model_blob(**blob_kw)
+    path = str(tmp_path / "q.kwsm")
+    open(path, "wb").write(blob)
+    om = OracleModel(oracle, path)
+    assert om.cfg.quantize_filterbank == 1
+    gm = pkg.Model(blob=blob)
+    clips = oracle.synth(int(g["seed"]), 0, int(g["n"]))
+    s, f, q = gm.run_classifier_batch(clips, want_features=True)
+    assert (bits(f) == bits(g[name])).all(), name                      # the reference's own features
+    so, fo, qo = om.run_batch(clips, want_features=True)
+    assert (bits(f) == bits(fo)).all() and (q == qo).all() and (bits(s) == bits(so)).all(), name
+    gm.close()

@@ -311,3 +311,19 @@ def test_synthetic_models_are_not_saturated(name):
     assert (mx > 0.999).mean() < 0.05
     assert np.median((s * (1 - s)).max(axis=1)) > 0.1
     assert (np.bincount(s.argmax(axis=1), minlength=m.n_labels) > 0).sum() >= 3      # not one class for every clip
+
+
+QFB_CASES = {"l476": dict(), "fft512": dict(fft_length=512, high_frequency=0),
+             "fft1024_f20": dict(fft_length=1024, num_filters=20, num_cepstral=12, low_frequency=0, high_frequency=0)}
+
+
+def test_quantized_filterbank_golden(oracle):
+    """EIDSP_QUANTIZE_FILTERBANK = 1 (the SDK's default; the demos build with 0): features and filterbank matrices from the reference built
+    with the option at its default (tools/make_golden.py --only-qfb), bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "qfb_l476.npz"))
+    clips = oracle.synth(int(g["seed"]), 0, int(g["n"]))
+    for name, kw in QFB_CASES.items():
+        cfg = L476_CONFIG().copy(quantize_filterbank=1, **kw)
+        assert (bits(oracle.filterbanks(cfg)) == bits(g[name + "_fb"])).all(), name
+        for i, c in enumerate(clips):
+            assert (bits(oracle.extract_mfcc(c, cfg)) == bits(g[name][i])).all(), (name, i)

@@ -1,9 +1,11 @@
 """Pins the C restatement against the UNMODIFIED reference compiled in place by `make -C oracle ref`
 (only where /root/reference exists; skipped on the GPU box).  Randomised, broader than the goldens."""
+import os
+
 import numpy as np
 import pytest
 
-from kws_testlib import L476_CONFIG, bits, special_clips
+from kws_testlib import L476_CONFIG, Reference, bits, special_clips
 
 pytestmark = pytest.mark.skipif(
     not __import__("kws_testlib").have_reference(), reason="oracle/_ref not built")
@@ -295,3 +297,37 @@ def test_random_mfcc_configurations(oracle, reference):
         cfg = L476_CONFIG().copy(**cfg_kw)
         for c in clips:
             assert (bits(oracle.extract_mfcc(c, cfg)) == bits(reference.extract_mfcc(c, cfg))).all(), (seed, cfg_kw)
+
+
+def test_quantized_filterbank_option_pinned(oracle):
+    """EIDSP_QUANTIZE_FILTERBANK = 1, the SDK's default (SDK/dsp/config.hpp:75-77): a second build of
+    the unmodified reference with the option at its default (oracle/_ref/libei_ref_l476_qfb.so) pins (a) the table the restatement
+    generates from its rule -- every fraction a / b with b <= 22 and every i / 100 -- entry by entry against numpy.hpp:52's, (b)
+    quantize_zero_one incl. its out-of-range quirks on a dense sweep, (c) the filterbank matrices, (d) extract_mfcc_features, bit for bit."""
+    from kws_testlib import REF_QFB_SO
+    if not os.path.exists(REF_QFB_SO):
+        pytest.skip("oracle/_ref/libei_ref_l476_qfb.so not built (make -C oracle ref)")
+    ref = Reference(qfb=True)
+    tab = np.zeros(256, np.float32)
+    n = ref.L.eiref_quantized_table(tab.ctypes.data_as(__import__("ctypes").c_void_p), 256)
+    assert n == 231
+    for v in tab[:n]:
+        assert bits(np.float32(oracle.quantize_zero_one(v))) == bits(np.float32(v))       # every table value is a fixed point ...
+    rng = np.random.default_rng(5)
+    sweep = np.concatenate([rng.random(20000).astype(np.float32), (tab[:n - 1] + tab[1:n]) / np.float32(2), np.float32([-0.5, -1e-9, 1.0000001, 1.5, 3.0])])
+    for v in sweep:
+        assert bits(np.float32(oracle.quantize_zero_one(v))) == bits(np.float32(ref.L.eiref_quantize_zero_one(float(v)))), v
+    clips = oracle.synth(9, 0, 6)
+    changed = 0
+    for kw in (dict(), dict(num_filters=40, num_cepstral=40, high_frequency=0), dict(num_filters=40, num_cepstral=13, low_frequency=0, high_frequency=0),
+               dict(fft_length=512, num_filters=32, high_frequency=0), dict(fft_length=1024, num_filters=20, low_frequency=0, high_frequency=0),
+               dict(low_frequency=50, high_frequency=6000, num_cepstral=20)):
+        cfg = L476_CONFIG().copy(quantize_filterbank=1, **kw)
+        fo, fr = oracle.filterbanks(cfg), ref.filterbanks(cfg)
+        assert (bits(fo) == bits(fr)).all(), kw
+        # a triangle weight is (bin - left) / (middle - left): a fraction whose denominator is the filter's half width in bins, so the table
+        # (denominators up to 22) reproduces narrow filters exactly -- the shipped fft-256 configurations -- and only moves wide ones
+        changed += int((fo != oracle.filterbanks(cfg.copy(quantize_filterbank=0))).any())
+        for c in clips:
+            assert (bits(oracle.extract_mfcc(c, cfg)) == bits(ref.extract_mfcc(c, cfg))).all(), kw
+    assert changed >= 1

@@ -11,7 +11,8 @@ test oracle (kwso_model_load) understand.  Only *data* is extracted (tensor shap
 parameters, weight bytes, op parameters, labels, DSP settings) -- no reference code.
 
 Blob layout (all little endian, 4-byte aligned):
-  char  magic[4] = "KWSM"; u32 version = 1 (MFCC block) | 2 (one more i32 behind pre_cof: DSP block type, 0 = MFCC, 1 = MFE)
+  char  magic[4] = "KWSM"; u32 version = 1 (MFCC block) | 2 (one more i32 behind pre_cof: bits 0..7 DSP block type, 0 = MFCC, 1 = MFE;
+                                                             bit 8 EIDSP_QUANTIZE_FILTERBANK = 1, the SDK's default build option)
   u32 n_tensors, n_nodes, n_labels, input_tensor, output_tensor
   u32 raw_sample_count, sampling_frequency, nn_input_frame_size
   dsp : i32 axes, num_cepstral, num_filters, fft_length, win_size, low_frequency, high_frequency, pre_shift
@@ -140,7 +141,8 @@ def _pad4(b):
 
 def serialise(tensors, nodes, t_in, t_out, meta):
     d = meta["dsp"]
-    block = int(d.get("block", 0))             # 0: MFCC (extract_mfcc_features), 1: MFE (extract_mfe_features, the newer SDK copy)
+    # 0: MFCC (extract_mfcc_features), 1: MFE (extract_mfe_features, the newer SDK copy); bit 8: EIDSP_QUANTIZE_FILTERBANK = 1
+    block = int(d.get("block", 0)) | (0x100 if d.get("quantize_filterbank") else 0)
     out = [b"KWSM", struct.pack("<I", 2 if block else 1),
            struct.pack("<5I", len(tensors), len(nodes), len(meta["labels"]), t_in, t_out),
            struct.pack("<3I", meta["raw_sample_count"], meta["frequency"], meta["nn_input_frame_size"]),
@@ -186,7 +188,8 @@ def parse_blob(blob):
     d = rd("8i3f")
     dsp = dict(zip(("axes", "num_cepstral", "num_filters", "fft_length", "win_size", "low_frequency", "high_frequency",
                     "pre_shift", "frame_length", "frame_stride", "pre_cof"), d))
-    dsp["block"] = rd("i")[0] if version == 2 else 0
+    v = rd("i")[0] if version == 2 else 0
+    dsp["block"], dsp["quantize_filterbank"] = v & 0xff, (v >> 8) & 1
     labels = []
     for _ in range(nl):
         (ln,) = rd("I")
@@ -218,12 +221,15 @@ def parse_blob(blob):
     return tensors, nodes, t_in, t_out, meta
 
 
-def import_export(export_dir, dsp_block="auto"):
-    """dsp_block: "auto" (MFE only if the metadata instantiates ei_dsp_config_mfe_t and no MFCC block), "mfcc" or "mfe" """
+def import_export(export_dir, dsp_block="auto", quantize_filterbank=False):
+    """dsp_block: "auto" (MFE only if the metadata instantiates ei_dsp_config_mfe_t and no MFCC block), "mfcc" or "mfe";
+    quantize_filterbank: the application builds the SDK with EIDSP_QUANTIZE_FILTERBANK = 1 (its default, SDK/dsp/config.hpp:75-77; a
+    compile-time option of the SDK, not recorded in the export -- the reference's demos build with 0)"""
     with open(f"{export_dir}/tflite-model/trained_model_compiled.cpp") as f:
         tensors, nodes, t_in, t_out = parse_compiled_model(f.read())
     with open(f"{export_dir}/model-parameters/model_metadata.h") as f:
         meta = parse_metadata(f.read(), dsp_block)
+    meta["dsp"]["quantize_filterbank"] = 1 if quantize_filterbank else 0
     return serialise(tensors, nodes, t_in, t_out, meta), (tensors, nodes, meta)
 
 
@@ -233,8 +239,10 @@ def main():
     ap.add_argument("out", help="output .kwsm path")
     ap.add_argument("--dsp-block", choices=("auto", "mfcc", "mfe"), default="auto",
                     help="which DSP block the impulse uses (auto: the one model_metadata.h instantiates)")
+    ap.add_argument("--quantize-filterbank", action="store_true",
+                    help="the application builds the SDK with EIDSP_QUANTIZE_FILTERBANK=1 (the SDK's default; the reference's demos use 0)")
     a = ap.parse_args()
-    blob, (tensors, nodes, meta) = import_export(a.export_dir, a.dsp_block)
+    blob, (tensors, nodes, meta) = import_export(a.export_dir, a.dsp_block, a.quantize_filterbank)
     with open(a.out, "wb") as f:
         f.write(blob)
     print(f"{a.out}: {len(blob)} bytes, {len(tensors)} tensors, {len(nodes)} nodes, labels={meta['labels']}",

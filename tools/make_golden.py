@@ -160,7 +160,25 @@ def graphs(ref):
     print("graphs_l476.npz", os.path.getsize(os.path.join(GOLDEN, "graphs_l476.npz")), "bytes")
 
 
+def qfb(synth, cfg):
+    """EIDSP_QUANTIZE_FILTERBANK = 1 (the SDK's default): extract_mfcc_features of the reference built with the option at its default
+    (oracle/_ref/libei_ref_l476_qfb.so), for configurations whose filters are wide enough for the table to move a weight (fft 512 / 1024)
+    and for the shipped one (where it is the identity)."""
+    ref = Reference(qfb=True)
+    clips = synth.synth(12, 0, 8)
+    out = {"seed": np.int32(12), "n": np.int32(8)}
+    for name, kw in (("l476", dict()), ("fft512", dict(fft_length=512, high_frequency=0)),
+                     ("fft1024_f20", dict(fft_length=1024, num_filters=20, num_cepstral=12, low_frequency=0, high_frequency=0))):
+        c = cfg.copy(quantize_filterbank=1, **kw)
+        out[name] = np.stack([ref.extract_mfcc(x, c) for x in clips])
+        out[name + "_fb"] = ref.filterbanks(c)
+    np.savez_compressed(os.path.join(GOLDEN, "qfb_l476.npz"), **out)
+    print("qfb_l476.npz", os.path.getsize(os.path.join(GOLDEN, "qfb_l476.npz")), "bytes")
+
+
 def main():
+    if "--only-qfb" in sys.argv:
+        return qfb(Oracle(), L476_CONFIG())
     ref = Reference()
     if "--only-mfcc40" in sys.argv:
         return mfcc40(ref, Oracle(), L476_CONFIG())

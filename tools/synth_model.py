@@ -163,7 +163,7 @@ def calibrate_head(tensors, nodes, t_in, tfw, tfb, tfo, logit_std, seed, n_cal=2
 
 def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((30, 7, 7), (10, 7, 7)), n_labels=4,
                      conv_bias=False, add_bias=True, num_filters=32, raw_samples=16000, fft_length=256, frame_length=0.02,
-                     frame_stride=0.02, pre_cof=0.98, dsp_block="mfcc", logit_std=None):
+                     frame_stride=0.02, pre_cof=0.98, dsp_block="mfcc", logit_std=None, quantize_filterbank=False):
     """blocks: sequence of
          (out_channels, taps, pool)              CONV_2D 1xK (+ optional int32 bias) -> ADD(int8 per-channel)+ReLU -> MAX_POOL
          ("dw", depth_mult, taps, pool, act)     DEPTHWISE_CONV_2D 1xK with int32 bias and fused activation -> MAX_POOL
@@ -300,7 +300,8 @@ def synth_model_blob(seed, ncep=13, win_size=101, low=300, high=4000, blocks=((3
     meta = {"labels": ["label%d" % i for i in range(n_labels)],
             "dsp": {"axes": 1, "num_cepstral": ncep, "frame_length": frame_length, "frame_stride": frame_stride, "num_filters": num_filters,
                     "fft_length": fft_length, "win_size": win_size, "low_frequency": low, "high_frequency": high,
-                    "pre_cof": pre_cof, "pre_shift": 1, "block": 1 if dsp_block == "mfe" else 0},
+                    "pre_cof": pre_cof, "pre_shift": 1, "block": 1 if dsp_block == "mfe" else 0,
+                    "quantize_filterbank": 1 if quantize_filterbank else 0},
             "raw_sample_count": raw_samples, "frequency": 16000, "nn_input_frame_size": F}
     return eon_import.serialise(tensors, nodes, t_in, tso, meta)
 
