@@ -48,11 +48,23 @@ typedef enum {
 
 /* dsp/numpy_types.h:234-253 with EIDSP_SIGNAL_C_FN_POINTER=1: 16 bytes on x86-64.
  * get_data(offset, length, out) must write `length` floats starting at sample `offset`,
- * returns 0 on success; it is never asked for data beyond total_length. */
+ * returns 0 on success; it is never asked for data beyond total_length.
+ * The SDK's DEFAULT in C++ is the other form (get_data is a std::function, 40 bytes with libstdc++): a C++ application written for
+ * that form defines KWS_SIGNAL_STD_FUNCTION before including this header -- signal_t is then that class, the C structure is called
+ * kws_c_signal_t, and inline overloads at the end of this header bridge the two (nothing in the library's ABI changes). */
+#if defined(__cplusplus) && defined(KWS_SIGNAL_STD_FUNCTION)
+typedef struct kws_c_signal {
+    int (*get_data)(size_t, size_t, float *);
+    size_t total_length;
+} kws_c_signal_t;
+#define KWS_C_SIGNAL_T kws_c_signal_t
+#else
 typedef struct ei_signal_t {
     int (*get_data)(size_t, size_t, float *);
     size_t total_length;
 } signal_t;
+#define KWS_C_SIGNAL_T signal_t
+#endif
 
 /* dsp/numpy_types.h:55-127 (ei::matrix_t data members; the C++ class adds ctor/dtor only) */
 typedef struct ei_matrix {
@@ -87,7 +99,11 @@ typedef struct {
  * the library sees it when the application is linked against it). */
 #ifndef KWS_BUILDING_LIBRARY
 __attribute__((weak)) extern const int kws_app_label_count;
+#ifdef __cplusplus
+extern __attribute__((weak)) const int kws_app_label_count = EI_CLASSIFIER_LABEL_COUNT;      /* (a C++ const needs `extern` to be visible to the library) */
+#else
 __attribute__((weak)) const int kws_app_label_count = EI_CLASSIFIER_LABEL_COUNT;
+#endif
 #endif
 
 typedef struct {
@@ -98,14 +114,14 @@ typedef struct {
 
 /* classifier/ei_run_classifier.h:650  -- DSP blocks + run_inference on one window of audio.
  * `debug` prints the features and per-class scores through ei_printf, as the reference does. */
-EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, bool debug);
+EI_IMPULSE_ERROR run_classifier(KWS_C_SIGNAL_T *signal, ei_impulse_result_t *result, bool debug);
 
 /* classifier/ei_run_classifier.h:293  -- quantise, run the network, dequantise */
 EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result, bool debug);
 
 /* classifier/ei_run_classifier.h:164, 184, 134 -- continuous (sliced) mode */
 void run_classifier_init(void);
-EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t *result, bool debug);
+EI_IMPULSE_ERROR run_classifier_continuous(KWS_C_SIGNAL_T *signal, ei_impulse_result_t *result, bool debug);
 float run_moving_average_filter(ei_impulse_maf *maf, float classification);
 
 /* porting/ei_classifier_porting.h:45-76 -- platform hooks.  The reference requires the application
@@ -120,5 +136,9 @@ void ei_printf_float(float f);
 
 #ifdef __cplusplus
 }
+#endif
+
+#if defined(__cplusplus) && defined(KWS_SIGNAL_STD_FUNCTION)
+#include "ei_compat_cxx.hpp"      /* ei::signal_t with a std::function member + inline bridges onto the C entry points above */
 #endif
 #endif
