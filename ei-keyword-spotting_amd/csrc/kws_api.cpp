@@ -82,7 +82,11 @@ int kws_pooled_tap_bytes(const kws_handle *h) { return h->pooled_tap_bytes; }
 int kws_model_is_float(const kws_handle *h) { return h->is_float ? 1 : 0; }
 // (the tuned kernel of the int16 batch paths; float samples -- the SDK's signal_t callback -- run kws_mfcc_kernel, the same arithmetic on
 // the older lane layout)
-const char *kws_mfcc_kernel_name(const kws_handle *h) { return h->dsp.generic ? "kws_spectral_generic_kernel" : h->dsp.n_frames < 16 ? "kws_mfcc_kernel" : "kws_mfcc8_kernel"; }
+const char *kws_mfcc_kernel_name(const kws_handle *h)
+{
+    if (h->dsp.generic) return kws_generic_uses_lds(h->dsp) ? "kws_spectral_lds_kernel" : "kws_spectral_generic_kernel";
+    return h->dsp.n_frames < 16 ? "kws_mfcc_kernel" : "kws_mfcc8_kernel";
+}
 const char *kws_nn_kernel_name(const kws_handle *h)
 {
     return h->is_float ? "kws_nn_f32_kernel" : kws_nn_uses_mfma(h->nn) ? "kws_nn_mfma_kernel" : "kws_nn_kernel";

@@ -11,35 +11,43 @@
 //   kws_spectral_generic_kernel : pre-emphasis, frame, KissFFT of any factorisation, power spectrum, energy, mel, log, DCT
 //                                 -> cepstra before cmvnw [clip][frame][ncep]   (speechpy::feature::mfcc, feature.hpp:370-439)
 //   kws_cmvn_generic_kernel     : processing::cmvnw (processing.hpp:326-389) + the int8 input quantisation, one thread per element
+#include <atomic>
+#include <cstdlib>
+
 #include "kws_device.h"
+
+bool kws_generic_uses_lds(const KwsDspPlan &P);
 
 #define GL 64                                     // lanes interleaved in the scratch
 
-__device__ __forceinline__ cf g_ld(const float *c, int idx) { cf v; v.r = c[(size_t)(2 * idx) * GL]; v.i = c[(size_t)(2 * idx + 1) * GL]; return v; }
-__device__ __forceinline__ void g_st(float *c, int idx, cf v) { c[(size_t)(2 * idx) * GL] = v.r; c[(size_t)(2 * idx + 1) * GL] = v.i; }
+// S = lanes interleaved in the array (GL: the global scratch of kws_spectral_generic_kernel; LCH: the per-lane DCT arrays in LDS of
+// kws_spectral_lds_kernel)
+template <int S> __device__ __forceinline__ cf g_ld(const float *c, int idx) { cf v; v.r = c[(size_t)(2 * idx) * S]; v.i = c[(size_t)(2 * idx + 1) * S]; return v; }
+template <int S> __device__ __forceinline__ void g_st(float *c, int idx, cf v) { c[(size_t)(2 * idx) * S] = v.r; c[(size_t)(2 * idx + 1) * S] = v.i; }
 
 // kf_bfly2 / kf_bfly3 / kf_bfly4 / kf_bfly5 (kiss_fft.cpp:15-192) on the sub-array starting at complex index `base`
+template <int S>
 __device__ void g_bfly(float *F, int base, int fstride, int m, int p, const float2 *__restrict__ tw)
 {
     if (p == 2) {
         for (int k = 0; k < m; k++) {
-            const cf t = cmul(g_ld(F, base + k + m), to_cf(tw[k * fstride]));
-            const cf a = g_ld(F, base + k);
-            g_st(F, base + k + m, csub(a, t));
-            g_st(F, base + k, cadd(a, t));
+            const cf t = cmul(g_ld<S>(F, base + k + m), to_cf(tw[k * fstride]));
+            const cf a = g_ld<S>(F, base + k);
+            g_st<S>(F, base + k + m, csub(a, t));
+            g_st<S>(F, base + k, cadd(a, t));
         }
     } else if (p == 4) {
         for (int k = 0; k < m; k++) {
-            cf f0 = g_ld(F, base + k), f1 = g_ld(F, base + k + m), f2 = g_ld(F, base + k + 2 * m), f3 = g_ld(F, base + k + 3 * m);
+            cf f0 = g_ld<S>(F, base + k), f1 = g_ld<S>(F, base + k + m), f2 = g_ld<S>(F, base + k + 2 * m), f3 = g_ld<S>(F, base + k + 3 * m);
             bfly4(f0, f1, f2, f3, to_cf(tw[k * fstride]), to_cf(tw[k * fstride * 2]), to_cf(tw[k * fstride * 3]));
-            g_st(F, base + k, f0); g_st(F, base + k + m, f1); g_st(F, base + k + 2 * m, f2); g_st(F, base + k + 3 * m, f3);
+            g_st<S>(F, base + k, f0); g_st<S>(F, base + k + m, f1); g_st<S>(F, base + k + 2 * m, f2); g_st<S>(F, base + k + 3 * m, f3);
         }
     } else if (p == 3) {
         const cf epi3 = to_cf(tw[fstride * m]);
         for (int k = 0; k < m; k++) {
-            cf f0 = g_ld(F, base + k);
-            const cf s1 = cmul(g_ld(F, base + k + m), to_cf(tw[k * fstride]));
-            const cf s2 = cmul(g_ld(F, base + k + 2 * m), to_cf(tw[k * fstride * 2]));
+            cf f0 = g_ld<S>(F, base + k);
+            const cf s1 = cmul(g_ld<S>(F, base + k + m), to_cf(tw[k * fstride]));
+            const cf s2 = cmul(g_ld<S>(F, base + k + 2 * m), to_cf(tw[k * fstride * 2]));
             const cf s3 = cadd(s1, s2);
             cf s0 = csub(s1, s2);
             cf f1, f2;
@@ -52,12 +60,12 @@ __device__ void g_bfly(float *F, int base, int fstride, int m, int p, const floa
             f2.i = f1.i - s0.r;
             f1.r -= s0.i;
             f1.i += s0.r;
-            g_st(F, base + k, f0); g_st(F, base + k + m, f1); g_st(F, base + k + 2 * m, f2);
+            g_st<S>(F, base + k, f0); g_st<S>(F, base + k + m, f1); g_st<S>(F, base + k + 2 * m, f2);
         }
     } else {    // 5
         const cf ya = to_cf(tw[fstride * m]), yb = to_cf(tw[fstride * 2 * m]);
         for (int u = 0; u < m; u++) {
-            cf F0 = g_ld(F, base + u), F1 = g_ld(F, base + u + m), F2 = g_ld(F, base + u + 2 * m), F3 = g_ld(F, base + u + 3 * m), F4 = g_ld(F, base + u + 4 * m);
+            cf F0 = g_ld<S>(F, base + u), F1 = g_ld<S>(F, base + u + m), F2 = g_ld<S>(F, base + u + 2 * m), F3 = g_ld<S>(F, base + u + 3 * m), F4 = g_ld<S>(F, base + u + 4 * m);
             const cf s0 = F0;
             const cf s1 = cmul(F1, to_cf(tw[u * fstride])), s2 = cmul(F2, to_cf(tw[2 * u * fstride]));
             const cf s3 = cmul(F3, to_cf(tw[3 * u * fstride])), s4 = cmul(F4, to_cf(tw[4 * u * fstride]));
@@ -78,7 +86,7 @@ __device__ void g_bfly(float *F, int base, int fstride, int m, int p, const floa
             a = s10.r * yb.i; b = s9.r * ya.i; s12.i = a - b;
             F2 = cadd(s11, s12);
             F3 = csub(s11, s12);
-            g_st(F, base + u, F0); g_st(F, base + u + m, F1); g_st(F, base + u + 2 * m, F2); g_st(F, base + u + 3 * m, F3); g_st(F, base + u + 4 * m, F4);
+            g_st<S>(F, base + u, F0); g_st<S>(F, base + u + m, F1); g_st<S>(F, base + u + 2 * m, F2); g_st<S>(F, base + u + 3 * m, F3); g_st<S>(F, base + u + 4 * m, F4);
         }
     }
 }
@@ -87,6 +95,7 @@ __device__ void g_bfly(float *F, int base, int fstride, int m, int p, const floa
 // kf_work's recursion (kiss_fft.cpp:232-296) is replayed level by level: the leaves' strided copies first (a mixed-radix digit
 // reversal), then the butterflies of every level from the innermost out -- sub-transforms of one level are independent, so the
 // order between them does not matter, the order inside one butterfly is the reference's.
+template <int S>
 __device__ void g_rfft(const float *in, float *tmp, float *spec, int nfft, const int *__restrict__ fac, int n_levels,
                        const float2 *__restrict__ tw, const float2 *__restrict__ stw)
 {
@@ -100,24 +109,24 @@ __device__ void g_rfft(const float *in, float *tmp, float *spec, int nfft, const
             i += k * stride;
             stride *= p;
         }
-        cf v; v.r = in[(size_t)(2 * i) * GL]; v.i = in[(size_t)(2 * i + 1) * GL];
-        g_st(tmp, o, v);
+        cf v; v.r = in[(size_t)(2 * i) * S]; v.i = in[(size_t)(2 * i + 1) * S];
+        g_st<S>(tmp, o, v);
     }
     for (int l = n_levels - 1; l >= 0; l--) {
         const int p = fac[2 * l], m = fac[2 * l + 1];
         int fstride = 1;
         for (int q = 0; q < l; q++) fstride *= fac[2 * q];
-        for (int base = 0; base < ncfft; base += p * m) g_bfly(tmp, base, fstride, m, p, tw);
+        for (int base = 0; base < ncfft; base += p * m) g_bfly<S>(tmp, base, fstride, m, p, tw);
     }
-    const cf t0 = g_ld(tmp, 0);
+    const cf t0 = g_ld<S>(tmp, 0);
     cf dc, ny;
     dc.r = t0.r + t0.i; dc.i = 0.0f;
     ny.r = t0.r - t0.i; ny.i = 0.0f;
-    g_st(spec, 0, dc);
-    g_st(spec, ncfft, ny);
+    g_st<S>(spec, 0, dc);
+    g_st<S>(spec, ncfft, ny);
     for (int k = 1; k <= ncfft / 2; k++) {
-        const cf fpk = g_ld(tmp, k);
-        cf fpnk = g_ld(tmp, ncfft - k);
+        const cf fpk = g_ld<S>(tmp, k);
+        cf fpnk = g_ld<S>(tmp, ncfft - k);
         fpnk.i = -fpnk.i;
         const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
         const cf twv = cmul(f2k, to_cf(stw[k - 1]));
@@ -126,8 +135,8 @@ __device__ void g_rfft(const float *in, float *tmp, float *spec, int nfft, const
         lo.i = (f1k.i + twv.i) * 0.5f;
         hi.r = (f1k.r - twv.r) * 0.5f;
         hi.i = (twv.i - f1k.i) * 0.5f;
-        g_st(spec, k, lo);
-        g_st(spec, ncfft - k, hi);
+        g_st<S>(spec, k, lo);
+        g_st<S>(spec, ncfft - k, hi);
     }
 }
 
@@ -173,10 +182,10 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
             w_in[(size_t)n * GL] = y;
         }
         // ---- power spectrum: kiss_fftr, sqrt(re^2 + im^2) in double, (1/fft) * mag^2 (numpy.hpp:1410, processing.hpp:306-309)
-        g_rfft(w_in, w_tmp, w_spec, fft, P.fft_fac, P.fft_levels, P.tw, P.stw);
+        g_rfft<GL>(w_in, w_tmp, w_spec, fft, P.fft_fac, P.fft_levels, P.tw, P.stw);
         float energy = 0.0f;
         for (int k = 0; k < nbins; k++) {
-            const cf v = g_ld(w_spec, k);
+            const cf v = g_ld<GL>(w_spec, k);
             const double re = (double)v.r, im = (double)v.i;
             const float mag = (float)g_dsqrt(__fma_rn(re, re, im * im));
             const float sq = mag * mag;
@@ -205,12 +214,12 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
             w_in[(size_t)i * GL] = w_mel[(size_t)(2 * i) * GL];
             w_in[(size_t)(NF - 1 - i) * GL] = w_mel[(size_t)(2 * i + 1) * GL];
         }
-        g_rfft(w_in, w_tmp, w_spec, NF, P.dct_fac, P.dct_levels, P.dct_tw, P.dct_stw);
+        g_rfft<GL>(w_in, w_tmp, w_spec, NF, P.dct_fac, P.dct_levels, P.dct_tw, P.dct_stw);
         float *orow = mfcc_out + (size_t)clip * out_stride + (size_t)ring_out_row(P, f) * ncep;
         for (int i = 0; i < ncep; i++) {
             float d;
             if (i <= half) {
-                const cf r = g_ld(w_spec, i);
+                const cf r = g_ld<GL>(w_spec, i);
                 const float a = r.r * P.dct_cos[i];
                 const float b = r.i * P.dct_sin[i];
                 d = a + b;
@@ -222,6 +231,255 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
             orow[i] = d;
         }
         orow[0] = fast_log(energy);                                // feature.hpp:425-429
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  kws_spectral_lds_kernel (round 4): the same function as kws_spectral_generic_kernel -- any factorisation, any
+//  frame / filter count, every operation in the reference's order -- without the lane-interleaved scratch in HBM.  One wave per workgroup
+//  owns a chunk of LCH consecutive frames of a clip:
+//    * per frame, the wave transforms it COOPERATIVELY: the frame's samples are loaded coalesced, pre-emphasised, and dealt into kf_work's
+//      leaf order (a mixed-radix digit reversal, tabulated once per workgroup); then level by level, innermost first, the butterflies of
+//      a level -- ncfft / p of them, all independent -- are spread over the 64 lanes (butterfly b = (sub-transform b / m, index b % m));
+//      each is kf_bfly2 / 3 / 4 / 5 exactly as g_bfly computes it.  kiss_fftr's split and the power spectrum (double-precision magnitude)
+//      run per bin pair, straight into the chunk's power rows in LDS.
+//    * per chunk: frame energies (a lane per frame: numpy::sum is a sequential sum), the mel filterbank ((frame, filter) items over the
+//      lanes, ascending-bin dot products), log, and the DCT (a lane per frame: the NF-point transform is small; g_rfft on lane-interleaved
+//      arrays in LDS), c0 <- log(energy), cepstra to HBM.
+//  LDS: complex buffer 2 (ncfft + ncfft/16) floats, the frame's samples fft_len, the leaf-order table ncfft ints, LCH power rows of
+//  n_bins | 1 floats, LCH mel rows, the DCT's arrays 3 NF + 2 per frame: 27 KB for fft 512 / 32 filters (LCH = 16), i.e. five waves per
+//  CU instead of a scratch that lived in L2.
+// ---------------------------------------------------------------------------------------------------------
+#define LCH 16                                    // frames per chunk (= lanes that carry the per-frame sequential parts)
+__device__ __forceinline__ int zpad(int p) { return p + (p >> 4); }             // complex index -> padded complex index
+__device__ __forceinline__ cf z_ld(const float *z, int p) { const float2 v = *(const float2 *)(z + 2 * zpad(p)); cf c; c.r = v.x; c.i = v.y; return c; }
+__device__ __forceinline__ void z_st(float *z, int p, cf v) { *(float2 *)(z + 2 * zpad(p)) = make_float2(v.r, v.i); }
+
+// one butterfly of a level: kf_bfly2 / 3 / 4 / 5 (kiss_fft.cpp:15-192) at index k of the sub-transform starting at `base` -- the body of
+// g_bfly's loops, operation for operation
+__device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstride, int m, int p, const float2 *__restrict__ tw)
+{
+    if (p == 2) {
+        const cf t = cmul(z_ld(Z, base + k + m), to_cf(tw[k * fstride]));
+        const cf a = z_ld(Z, base + k);
+        z_st(Z, base + k + m, csub(a, t));
+        z_st(Z, base + k, cadd(a, t));
+    } else if (p == 4) {
+        cf f0 = z_ld(Z, base + k), f1 = z_ld(Z, base + k + m), f2 = z_ld(Z, base + k + 2 * m), f3 = z_ld(Z, base + k + 3 * m);
+        bfly4(f0, f1, f2, f3, to_cf(tw[k * fstride]), to_cf(tw[k * fstride * 2]), to_cf(tw[k * fstride * 3]));
+        z_st(Z, base + k, f0); z_st(Z, base + k + m, f1); z_st(Z, base + k + 2 * m, f2); z_st(Z, base + k + 3 * m, f3);
+    } else if (p == 3) {
+        const cf epi3 = to_cf(tw[fstride * m]);
+        cf f0 = z_ld(Z, base + k);
+        const cf s1 = cmul(z_ld(Z, base + k + m), to_cf(tw[k * fstride]));
+        const cf s2 = cmul(z_ld(Z, base + k + 2 * m), to_cf(tw[k * fstride * 2]));
+        const cf s3 = cadd(s1, s2);
+        cf s0 = csub(s1, s2);
+        cf f1, f2;
+        f1.r = f0.r - s3.r * 0.5f;
+        f1.i = f0.i - s3.i * 0.5f;
+        s0.r *= epi3.i;
+        s0.i *= epi3.i;
+        f0 = cadd(f0, s3);
+        f2.r = f1.r + s0.i;
+        f2.i = f1.i - s0.r;
+        f1.r -= s0.i;
+        f1.i += s0.r;
+        z_st(Z, base + k, f0); z_st(Z, base + k + m, f1); z_st(Z, base + k + 2 * m, f2);
+    } else {    // 5
+        const cf ya = to_cf(tw[fstride * m]), yb = to_cf(tw[fstride * 2 * m]);
+        const int u = k;
+        cf F0 = z_ld(Z, base + u), F1 = z_ld(Z, base + u + m), F2 = z_ld(Z, base + u + 2 * m), F3 = z_ld(Z, base + u + 3 * m), F4 = z_ld(Z, base + u + 4 * m);
+        const cf s0 = F0;
+        const cf s1 = cmul(F1, to_cf(tw[u * fstride])), s2 = cmul(F2, to_cf(tw[2 * u * fstride]));
+        const cf s3 = cmul(F3, to_cf(tw[3 * u * fstride])), s4 = cmul(F4, to_cf(tw[4 * u * fstride]));
+        const cf s7 = cadd(s1, s4), s10 = csub(s1, s4), s8 = cadd(s2, s3), s9 = csub(s2, s3);
+        float tt, a, b;
+        tt = s7.r + s8.r; F0.r = F0.r + tt;
+        tt = s7.i + s8.i; F0.i = F0.i + tt;
+        cf s5, s6, s11, s12;
+        a = s7.r * ya.r; b = s8.r * yb.r; s5.r = (s0.r + a) + b;
+        a = s7.i * ya.r; b = s8.i * yb.r; s5.i = (s0.i + a) + b;
+        a = s10.i * ya.i; b = s9.i * yb.i; s6.r = a + b;
+        a = s10.r * ya.i; b = s9.r * yb.i; s6.i = (-a) - b;
+        F1 = csub(s5, s6);
+        F4 = cadd(s5, s6);
+        a = s7.r * yb.r; b = s8.r * ya.r; s11.r = (s0.r + a) + b;
+        a = s7.i * yb.r; b = s8.i * ya.r; s11.i = (s0.i + a) + b;
+        a = s10.i * yb.i; b = s9.i * ya.i; s12.r = (-a) + b;
+        a = s10.r * yb.i; b = s9.r * ya.i; s12.i = a - b;
+        F2 = cadd(s11, s12);
+        F3 = csub(s11, s12);
+        z_st(Z, base + u, F0); z_st(Z, base + u + m, F1); z_st(Z, base + u + 2 * m, F2); z_st(Z, base + u + 3 * m, F3); z_st(Z, base + u + 4 * m, F4);
+    }
+}
+
+struct LdsLayout { int z, y, perm, ps, ps_stride, mel, mel_stride, dct, total; };
+__host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins)
+{
+    LdsLayout L;
+    const int ncfft = fft / 2;
+    L.z = 0;
+    L.y = L.z + 2 * (ncfft + (ncfft >> 4) + 1);
+    L.perm = L.y + fft;
+    L.ps = L.perm + ncfft;
+    L.ps_stride = nbins | 1;
+    L.mel = L.ps + LCH * L.ps_stride;
+    L.mel_stride = nf | 1;
+    L.dct = L.mel + LCH * L.mel_stride;
+    L.total = L.dct + (3 * nf + 2) * LCH;
+    return L;
+}
+
+template <bool F32IN>
+__global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips, float *__restrict__ mfcc_out,
+                                                               const float *__restrict__ wrap, int out_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) float glds[];
+    const int lane = threadIdx.x;
+    const int nfr = P.n_frames, NF = P.n_filters, ncep = P.n_cepstral, fft = P.fft_len, nbins = P.n_bins, ncfft = fft >> 1;
+    const LdsLayout L = lds_layout(fft, NF, nbins);
+    float *Z = glds + L.z, *Y = glds + L.y, *PS = glds + L.ps, *MEL = glds + L.mel, *DCT = glds + L.dct;
+    int *perm = (int *)(glds + L.perm);
+    const int chunks = (nfr + LCH - 1) / LCH;
+    const int used = P.frame_len < fft ? P.frame_len : fft;      // numpy::rfft: truncate to fft_length or zero-pad (numpy.hpp:1097-1111)
+    const double inv_fft = 1.0 / (double)(float)fft;             // processing.hpp:306-309
+    // kf_work's leaf order (kiss_fft.cpp:232-296): output position o of the strided copies reads input point perm[o]
+    for (int o = lane; o < ncfft; o += 64) {
+        int rem = o, i = 0, stride = 1;
+        for (int l = 0; l < P.fft_levels; l++) {
+            const int p = P.fft_fac[2 * l], m = P.fft_fac[2 * l + 1];
+            const int k = rem / m;
+            rem -= k * m;
+            i += k * stride;
+            stride *= p;
+        }
+        perm[o] = i;
+    }
+    WAVE_SYNC();
+    for (int item = blockIdx.x; item < n_clips * chunks; item += gridDim.x) {
+        const int clip = item / chunks, f0 = (item - clip * chunks) * LCH;
+        const int nfc = min(LCH, nfr - f0);
+        const size_t cbase = (size_t)clip * P.n_samples;
+        auto sample = [&](int n) -> float {
+            return F32IN ? ((const float *)pcm_v)[cbase + n] : (float)((const int16_t *)pcm_v)[cbase + n] * (1.0f / 32768.0f);     // numpy::int16_to_float
+        };
+        for (int fi = 0; fi < nfc; fi++) {
+            // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing ----
+            const int off = (f0 + fi) * P.frame_stride;
+            for (int n = lane; n < fft; n += 64) {
+                float y = 0.0f;
+                if (n < used) {
+                    const int sidx = off + n;
+                    const float prev = (sidx == 0) ? (wrap ? wrap[clip] : sample(P.n_samples - 1)) : sample(sidx - 1);
+                    const float pl = P.pre_cof * prev;
+                    y = sample(sidx) - pl;
+                }
+                Y[n] = y;
+            }
+            WAVE_SYNC();
+            for (int o = lane; o < ncfft; o += 64) {
+                const int i = perm[o];
+                cf v; v.r = Y[2 * i]; v.i = Y[2 * i + 1];
+                z_st(Z, o, v);
+            }
+            WAVE_SYNC();
+            // ---- kf_work's levels, innermost first; the butterflies of a level are independent of each other ------------------
+            for (int l = P.fft_levels - 1; l >= 0; l--) {
+                const int p = P.fft_fac[2 * l], m = P.fft_fac[2 * l + 1];
+                int fstride = 1;
+                for (int q = 0; q < l; q++) fstride *= P.fft_fac[2 * q];
+                const int nb = ncfft / p;
+                for (int b = lane; b < nb; b += 64) {
+                    const int g = b / m, k = b - g * m;
+                    z_bfly_one(Z, g * p * m, k, fstride, m, p, P.tw);
+                }
+                WAVE_SYNC();
+            }
+            // ---- kiss_fftr's split (kiss_fftr.cpp:84-119) + power spectrum: sqrt(re^2 + im^2) in double, (1/fft) * mag^2 ---------
+            float *ps = PS + fi * L.ps_stride;
+            auto power = [&](cf v) -> float {
+                const double re = (double)v.r, im = (double)v.i;
+                const float mag = (float)g_dsqrt(__fma_rn(re, re, im * im));
+                const float sq = mag * mag;
+                return (float)(inv_fft * (double)sq);
+            };
+            if (lane == 0) {
+                const cf t0 = z_ld(Z, 0);
+                cf dc, ny;
+                dc.r = t0.r + t0.i; dc.i = 0.0f;
+                ny.r = t0.r - t0.i; ny.i = 0.0f;
+                ps[0] = power(dc);
+                ps[ncfft] = power(ny);
+            }
+            for (int k = 1 + lane; k <= ncfft / 2; k += 64) {
+                const cf fpk = z_ld(Z, k);
+                cf fpnk = z_ld(Z, ncfft - k);
+                fpnk.i = -fpnk.i;
+                const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                const cf twv = cmul(f2k, to_cf(P.stw[k - 1]));
+                cf lo, hi;
+                lo.r = (f1k.r + twv.r) * 0.5f;
+                lo.i = (f1k.i + twv.i) * 0.5f;
+                hi.r = (f1k.r - twv.r) * 0.5f;
+                hi.i = (twv.i - f1k.i) * 0.5f;
+                // bin ncfft / 2 is written twice by the reference (k == ncfft - k): the second store wins -- the same value pair here
+                ps[k] = power(lo);
+                ps[ncfft - k] = power(hi);
+            }
+            WAVE_SYNC();
+        }
+        // ---- frame energies: numpy::sum, ascending (numpy.hpp:88-94): a lane per frame --------------------------------------
+        float energy = 0.0f;
+        if (lane < nfc) {
+            const float *ps = PS + lane * L.ps_stride;
+            for (int k = 0; k < nbins; k++) energy += ps[k];
+            if (energy == 0.0f) energy = FLT_EPSILON;
+            if (P.mfe_energy) P.mfe_energy[(size_t)clip * nfr + f0 + lane] = energy;
+        }
+        // ---- mel filterbank: dot_by_row over the non-zero weights in ascending bin order, zero handling, log ----------------
+        for (int it = lane; it < nfc * NF; it += 64) {
+            const int fi = it / NF, j = it - fi * NF;
+            const float *ps = PS + fi * L.ps_stride;
+            float acc = 0.0f;
+            for (int n = P.filt_start[j]; n < P.filt_start[j + 1]; n++) {
+                const float prod = ps[P.filt_bin[n]] * P.filt_w[n];
+                acc += prod;
+            }
+            if (acc == 0.0f) acc = FLT_EPSILON;
+            if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)ring_out_row(P, f0 + fi) * NF + j] = acc;
+            MEL[fi * L.mel_stride + j] = fast_log(acc);
+        }
+        WAVE_SYNC();
+        if (!P.mfe_mel && lane < nfc) {
+            // ---- numpy::dct2 (numpy.hpp:378-401) -> dct::transform (fast-dct-fft.cpp:37-80), a lane per frame on lane-interleaved arrays:
+            //      even/odd reorder, kiss_fftr(NF), v[i] = re cos + im sin for i <= NF/2 only, x2, ortho scale; c0 <- log(energy) ------
+            const float *mel = MEL + lane * L.mel_stride;
+            float *d_in = DCT + lane, *d_tmp = d_in + (size_t)NF * LCH, *d_spec = d_tmp + (size_t)NF * LCH;
+            const int half = NF / 2;
+            for (int i = 0; i < half; i++) {
+                d_in[(size_t)i * LCH] = mel[2 * i];
+                d_in[(size_t)(NF - 1 - i) * LCH] = mel[2 * i + 1];
+            }
+            g_rfft<LCH>(d_in, d_tmp, d_spec, NF, P.dct_fac, P.dct_levels, P.dct_tw, P.dct_stw);
+            float *orow = mfcc_out + (size_t)clip * out_stride + (size_t)ring_out_row(P, f0 + lane) * ncep;
+            for (int i = 0; i < ncep; i++) {
+                float d;
+                if (i <= half) {
+                    const cf r = g_ld<LCH>(d_spec, i);
+                    const float a = r.r * P.dct_cos[i];
+                    const float b = r.i * P.dct_sin[i];
+                    d = a + b;
+                } else {
+                    d = mel[i];                                        // never written by the transform: the input stays
+                }
+                d = d * 2.0f;
+                d = d * (i == 0 ? P.dct_s0 : P.dct_s1);
+                orow[i] = d;
+            }
+            orow[0] = fast_log(energy);                                // feature.hpp:425-429
+        }
+        WAVE_SYNC();
     }
 }
 
@@ -255,7 +513,15 @@ __global__ void kws_cmvn_generic_kernel(KwsDspPlan P, const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid) { return (size_t)grid * g_ws_floats(P.fft_len, P.n_filters) * GL * sizeof(float); }
+// the LDS-resident kernel serves every general configuration whose arrays fit a CU's LDS twice over (fft up to 2048 with 64 filters);
+// KWS_DEV_GENERIC_SCRATCH=1 keeps the round-1 kernel with its scratch in HBM (same-box comparisons)
+bool kws_generic_uses_lds(const KwsDspPlan &P)
+{
+    static const bool forced_scratch = getenv("KWS_DEV_GENERIC_SCRATCH") != nullptr;
+    return !forced_scratch && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins).total * sizeof(float) <= 72 * 1024;
+}
+
+size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid) { if (kws_generic_uses_lds(P)) return 64; return (size_t)grid * g_ws_floats(P.fft_len, P.n_filters) * GL * sizeof(float); }
 
 int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
                                 int out_stride, float *ws, int grid, hipStream_t stream)
@@ -263,6 +529,28 @@ int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
     if (out_stride == 0) out_stride = P.n_frames * (P.mfe_mel ? P.n_filters : P.n_cepstral);
+    if (kws_generic_uses_lds(P)) {
+        const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins).total * sizeof(float);
+        static std::atomic<unsigned long long> attr_done{ 0 };
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return (int)hipGetLastError();
+            attr_done.fetch_or(bit, std::memory_order_release);
+        }
+        const long litems = (long)n_clips * ((P.n_frames + LCH - 1) / LCH);
+        // persistent-ish grid: as many one-wave workgroups as the LDS lets a CU hold (up to 8), times the CUs (grid = 8 x CUs from the caller)
+        int lgrid = grid * 2;
+        if (litems < lgrid) lgrid = (int)litems;
+        if (pcm_is_float)
+            hipLaunchKernelGGL(kws_spectral_lds_kernel<true>, dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
+        else
+            hipLaunchKernelGGL(kws_spectral_lds_kernel<false>, dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
+        return (int)hipGetLastError();
+    }
     const long items = (long)n_clips * ((P.n_frames + GL - 1) / GL);
     if (items < grid) grid = (int)items;
     if (pcm_is_float)

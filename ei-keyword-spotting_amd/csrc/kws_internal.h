@@ -55,6 +55,7 @@ int kws_launch_resample(const float *in, size_t n_in, float *out, size_t n_out, 
                         int precision, int exact, hipStream_t stream);
 // kws_generic.hip: the exact MFCC block for configurations outside the tuned kernel (KwsDspPlan::generic)
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid);
+bool kws_generic_uses_lds(const KwsDspPlan &P);       // the LDS-resident cooperative kernel serves this configuration (else: the scratch-in-HBM kernel)
 int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
                                 int out_stride, float *ws, int grid, hipStream_t stream);
 int kws_launch_cmvn_generic(const KwsDspPlan &P, const float *mfcc, int n_clips, float *features, int8_t *q_out, float in_scale, int in_zp,

@@ -45,7 +45,7 @@ int kws_frame_count(const kws_handle *h);                /* MFCC rows (49) */
 int kws_filter_count(const kws_handle *h);               /* mel filters of the DSP block (32) */
 int kws_pooled_tap_bytes(const kws_handle *h);           /* bytes/clip of the pooled-activation tap */
 const char *kws_nn_kernel_name(const kws_handle *h);    /* which network kernel serves this model (diagnostics) */
-const char *kws_mfcc_kernel_name(const kws_handle *h);  /* "kws_mfcc_kernel" (tuned shapes) or "kws_spectral_generic_kernel" */
+const char *kws_mfcc_kernel_name(const kws_handle *h);  /* "kws_mfcc8_kernel" / "kws_mfcc_kernel" (tuned shapes), "kws_spectral_lds_kernel" (general shapes), "kws_spectral_generic_kernel" (those whose arrays exceed the LDS) */
 int kws_model_is_float(const kws_handle *h);             /* 1: float32 graph (EI_CLASSIFIER_TFLITE_INPUT_QUANTIZED == 0) */
 
 /* ---- arithmetic mode of the device-resident batch hot path (kws_run_classifier_batch_device, kws_extract_mfcc_batch_device,

@@ -66,7 +66,7 @@ def test_general_mfcc_kernels_bit_exact(name, pkg, oracle, tmp_path):
     gm.cmvn_inference_batch_device(mf.data_ptr(), len(clips), s2.data_ptr())
     torch.cuda.synchronize()
     assert (bits(s2.cpu().numpy()) == bits(so)).all(), name
-    if gm.mfcc_kernel == "kws_spectral_generic_kernel":
+    if gm.mfcc_kernel in ("kws_spectral_lds_kernel", "kws_spectral_generic_kernel"):
         with pytest.raises(pkg.KwsError):
             gm.set_mode(pkg.MODE_FAST)                  # the fast kernel is built for the tuned configurations only
     else:
@@ -121,7 +121,7 @@ def test_general_kernels_host_batch_over_two_streams(pkg, oracle, tmp_path):
     path = str(tmp_path / "m.kwsm")
     open(path, "wb").write(blob)
     gm = pkg.Model(blob=blob)
-    assert gm.mfcc_kernel == "kws_spectral_generic_kernel"
+    assert gm.mfcc_kernel in ("kws_spectral_lds_kernel", "kws_spectral_generic_kernel")
     om = OracleModel(oracle, path)
     n = 2 * 8192 + 700
     clips = oracle.synth(21, 0, n)

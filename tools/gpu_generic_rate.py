@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""General-shape DSP configurations (fft 128 / 512 / 1024, 99 frames, ...): time per clip and per frame of the exact MFCC stage on the
+LDS-resident cooperative kernel (kws_spectral_lds_kernel, round 4) against the round-1 kernel with its scratch in HBM
+(KWS_DEV_GENERIC_SCRATCH=1, run in a child process) and against the tuned kernel's shape (fft 256, 49 frames).
+
+    python tools/gpu_generic_rate.py [n_clips]
+"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = {
+    "tuned fft256 49 frames (kws_mfcc8_kernel)": dict(),
+    "fft512 49 frames": dict(fft_length=512),
+    "fft512 2 s clips, 99 frames": dict(fft_length=512, raw_samples=32000),
+    "fft128 49 frames": dict(fft_length=128, win_size=51),
+    "fft256 stride 10 ms, 98 frames": dict(frame_stride=0.01, win_size=31),
+    "fft1024 50 ms frames, 36 filters": dict(fft_length=1024, num_filters=36, ncep=17, frame_length=0.05, frame_stride=0.025, win_size=21, blocks=((8, 3, 1), (4, 3, 1))),
+}
+
+
+def child(n):
+    import torch
+    from __graft_entry__ import load_package
+    from kws_testlib import synth_model_blob
+    pkg = load_package()
+    for name, kw in CASES.items():
+        blob = synth_model_blob(seed=3, **dict(dict(blocks=((8, 3, 7), (4, 3, 7)), n_labels=3), **kw))
+        gm = pkg.Model(blob=blob)
+        ns = gm.clip_samples
+        pcm = torch.empty((n, ns), dtype=torch.int16, device="cuda:0")
+        pkg.synth_clips_device(0, 0, n, ns, pcm.data_ptr())
+        mf = torch.zeros((n, gm.n_features), dtype=torch.float32, device="cuda:0")
+        ft = torch.zeros((n, gm.n_features), dtype=torch.float32, device="cuda:0")
+        res = []
+        for fn in (lambda: gm.mfcc_batch_device(pcm.data_ptr(), n, mf.data_ptr()), lambda: gm.extract_mfcc_batch_device(pcm.data_ptr(), n, ft.data_ptr())):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            res.append((time.perf_counter() - t0) / reps)
+        print("RATE|%s|%s|%d|%.6f|%.6f" % (name, gm.mfcc_kernel, gm.n_frames, res[0], res[1]), flush=True)
+        gm.close()
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        return child(int(sys.argv[2]))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    rows = {}
+    for tag, env in (("lds", {}), ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"})):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if out.returncode != 0:
+            print(tag, "FAILED", out.stderr[-1500:])
+        for ln in out.stdout.splitlines():
+            if ln.startswith("RATE|"):
+                _, name, kern, nfr, t_spec, t_all = ln.split("|")
+                rows.setdefault(name, {})[tag] = (kern, int(nfr), float(t_spec), float(t_all))
+    print("# %d clips per call; speechpy::feature::mfcc (cepstra before cmvnw) and extract_mfcc_features (with cmvnw); ns per frame = time / (clips x frames)" % n)
+    for name, r in rows.items():
+        parts = []
+        for tag in ("lds", "scratch"):
+            if tag in r:
+                kern, nfr, ts, ta = r[tag]
+                parts.append("%s [%s]: mfcc %.3f ms (%.1f ns/frame), extract %.3f ms (%.1f ns/frame)" % (tag, kern, ts * 1e3, ts / (n * nfr) * 1e9, ta * 1e3, ta / (n * nfr) * 1e9))
+        print("%-40s %s" % (name, "  |  ".join(parts)))
+
+
+if __name__ == "__main__":
+    main()
