@@ -170,7 +170,21 @@ EI_IMPULSE_ERROR kws_resample_device_ex(const float *in, size_t n_in, int sr_in,
     const bool exact = (flags & KWS_RESAMPLE_EXACT_POSITIONS) != 0;
     // the reference's length: resampy writes int(n ratio) samples, librosa's fix_length pads with zeros up to ceil(n ratio)
     const size_t n_valid = exact ? n_out : std::min(n_out, (size_t)((double)n_in * ratio));
-    int rc = kws_launch_resample(in, n_in, out, n_out, n_valid, ratio, tb.win, tb.delta, kResZeros * kResPrecision, kResPrecision, exact ? 1 : 0, (hipStream_t)stream);
+    // the reference's time register: resampy adds the increment once per output sample (interpn.py: time_register += time_increment); the values
+    // it passes through are built the same way here and handed to the kernel (this step is data-set preparation, not the hot path: the
+    // table is allocated, copied and freed around the launch)
+    double *d_treg = nullptr;
+    if (!exact && n_valid > 0) {
+        std::vector<double> treg(n_valid);
+        const double inc = 1.0 / ratio;
+        double tr = 0.0;
+        for (size_t t = 0; t < n_valid; t++) { treg[t] = tr; tr += inc; }
+        HIP_TRY(hipMalloc((void **)&d_treg, n_valid * sizeof(double)));
+        if (hipMemcpyAsync(d_treg, treg.data(), n_valid * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+            hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { (void)hipFree(d_treg); return fail(KWS_ERROR_HIP, "uploading the resampler's time register failed"); }
+    }
+    int rc = kws_launch_resample(in, n_in, out, n_out, n_valid, ratio, tb.win, tb.delta, kResZeros * kResPrecision, kResPrecision, exact ? 1 : 0, d_treg, (hipStream_t)stream);
+    if (d_treg) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(d_treg); }
     if (rc) return fail(KWS_ERROR_HIP, "resample kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
 }

@@ -314,8 +314,10 @@ __device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstrid
     }
 }
 
-struct LdsLayout { int z, y, perm, ps, ps_stride, mel, mel_stride, dct, total; };
-__host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins)
+// + the model's tables, staged once per workgroup (every read of them sits on a lane's serial path: from L2 a tap of a mel filter or a
+// twiddle costs a round trip of ~1 us; measured: the first version, tables in L2, ran at 9.9 ns per frame against the scratch kernel's 12.4)
+struct LdsLayout { int z, y, perm, ps, ps_stride, mel, mel_stride, dct, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, total; };
+__host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int nnz)
 {
     LdsLayout L;
     const int ncfft = fft / 2;
@@ -327,7 +329,15 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins)
     L.mel = L.ps + LCH * L.ps_stride;
     L.mel_stride = nf | 1;
     L.dct = L.mel + LCH * L.mel_stride;
-    L.total = L.dct + (3 * nf + 2) * LCH;
+    L.tw = (L.dct + (3 * nf + 2) * LCH + 1) & ~1;       // float2 tables: 8-byte aligned
+    L.stw = L.tw + 2 * ncfft;
+    L.dtw = L.stw + 2 * (ncfft / 2 + 1);
+    L.dstw = L.dtw + 2 * (nf / 2 + 1);
+    L.dcs = L.dstw + 2 * (nf / 4 + 1);
+    L.fstart = L.dcs + 2 * (nf / 2 + 1);
+    L.fbin = L.fstart + nf + 1;
+    L.fw = L.fbin + nnz + 4;                              // (+4: the mel loop reads whole batches of four taps)
+    L.total = L.fw + nnz + 4;
     return L;
 }
 
@@ -338,9 +348,20 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
     extern __shared__ __attribute__((aligned(16))) float glds[];
     const int lane = threadIdx.x;
     const int nfr = P.n_frames, NF = P.n_filters, ncep = P.n_cepstral, fft = P.fft_len, nbins = P.n_bins, ncfft = fft >> 1;
-    const LdsLayout L = lds_layout(fft, NF, nbins);
+    const int nnz = P.filt_nnz;
+    const LdsLayout L = lds_layout(fft, NF, nbins, nnz);
     float *Z = glds + L.z, *Y = glds + L.y, *PS = glds + L.ps, *MEL = glds + L.mel, *DCT = glds + L.dct;
     int *perm = (int *)(glds + L.perm);
+    float2 *l_tw = (float2 *)(glds + L.tw), *l_stw = (float2 *)(glds + L.stw), *l_dtw = (float2 *)(glds + L.dtw), *l_dstw = (float2 *)(glds + L.dstw);
+    float *l_dcos = glds + L.dcs, *l_dsin = l_dcos + NF / 2 + 1, *l_fw = glds + L.fw;
+    int *l_fstart = (int *)(glds + L.fstart), *l_fbin = (int *)(glds + L.fbin);
+    for (int i = lane; i < ncfft; i += 64) l_tw[i] = P.tw[i];
+    for (int i = lane; i < ncfft / 2; i += 64) l_stw[i] = P.stw[i];
+    for (int i = lane; i < NF / 2; i += 64) l_dtw[i] = P.dct_tw[i];
+    for (int i = lane; i < NF / 4; i += 64) l_dstw[i] = P.dct_stw[i];
+    for (int i = lane; i <= NF / 2; i += 64) { l_dcos[i] = P.dct_cos[i]; l_dsin[i] = P.dct_sin[i]; }
+    for (int i = lane; i <= NF; i += 64) l_fstart[i] = P.filt_start[i];
+    for (int i = lane; i < nnz + 4; i += 64) { l_fbin[i] = i < nnz ? P.filt_bin[i] : 0; l_fw[i] = i < nnz ? P.filt_w[i] : 0.0f; }
     const int chunks = (nfr + LCH - 1) / LCH;
     const int used = P.frame_len < fft ? P.frame_len : fft;      // numpy::rfft: truncate to fft_length or zero-pad (numpy.hpp:1097-1111)
     const double inv_fft = 1.0 / (double)(float)fft;             // processing.hpp:306-309
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                 const int nb = ncfft / p;
                 for (int b = lane; b < nb; b += 64) {
                     const int g = b / m, k = b - g * m;
-                    z_bfly_one(Z, g * p * m, k, fstride, m, p, P.tw);
+                    z_bfly_one(Z, g * p * m, k, fstride, m, p, l_tw);
                 }
                 WAVE_SYNC();
             }
@@ -417,7 +438,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                 cf fpnk = z_ld(Z, ncfft - k);
                 fpnk.i = -fpnk.i;
                 const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
-                const cf twv = cmul(f2k, to_cf(P.stw[k - 1]));
+                const cf twv = cmul(f2k, to_cf(l_stw[k - 1]));
                 cf lo, hi;
                 lo.r = (f1k.r + twv.r) * 0.5f;
                 lo.i = (f1k.i + twv.i) * 0.5f;
@@ -433,7 +454,15 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         float energy = 0.0f;
         if (lane < nfc) {
             const float *ps = PS + lane * L.ps_stride;
-            for (int k = 0; k < nbins; k++) energy += ps[k];
+            int k = 0;
+            for (; k + 8 <= nbins; k += 8) {                       // eight reads in flight, then the eight ordered additions
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = ps[k + e];
+#pragma unroll
+                for (int e = 0; e < 8; e++) energy += v[e];
+            }
+            for (; k < nbins; k++) energy += ps[k];
             if (energy == 0.0f) energy = FLT_EPSILON;
             if (P.mfe_energy) P.mfe_energy[(size_t)clip * nfr + f0 + lane] = energy;
         }
@@ -442,9 +471,19 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
             const int fi = it / NF, j = it - fi * NF;
             const float *ps = PS + fi * L.ps_stride;
             float acc = 0.0f;
-            for (int n = P.filt_start[j]; n < P.filt_start[j + 1]; n++) {
-                const float prod = ps[P.filt_bin[n]] * P.filt_w[n];
-                acc += prod;
+            const int n1 = l_fstart[j + 1];
+            for (int n = l_fstart[j]; n < n1; n += 4) {            // four taps per trip (the tables are padded by four): bins, then their power values, then
+                int bn[4];                                         // the ordered sum; a tap past the filter's end adds an exact +0 (acc >= +0: no bit moves)
+                float wv[4], pv[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { bn[e] = l_fbin[n + e]; wv[e] = l_fw[n + e]; }
+#pragma unroll
+                for (int e = 0; e < 4; e++) pv[e] = ps[bn[e]];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float prod = n + e < n1 ? pv[e] * wv[e] : 0.0f;
+                    acc += prod;
+                }
             }
             if (acc == 0.0f) acc = FLT_EPSILON;
             if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)ring_out_row(P, f0 + fi) * NF + j] = acc;
@@ -461,14 +500,14 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                 d_in[(size_t)i * LCH] = mel[2 * i];
                 d_in[(size_t)(NF - 1 - i) * LCH] = mel[2 * i + 1];
             }
-            g_rfft<LCH>(d_in, d_tmp, d_spec, NF, P.dct_fac, P.dct_levels, P.dct_tw, P.dct_stw);
+            g_rfft<LCH>(d_in, d_tmp, d_spec, NF, P.dct_fac, P.dct_levels, l_dtw, l_dstw);
             float *orow = mfcc_out + (size_t)clip * out_stride + (size_t)ring_out_row(P, f0 + lane) * ncep;
             for (int i = 0; i < ncep; i++) {
                 float d;
                 if (i <= half) {
                     const cf r = g_ld<LCH>(d_spec, i);
-                    const float a = r.r * P.dct_cos[i];
-                    const float b = r.i * P.dct_sin[i];
+                    const float a = r.r * l_dcos[i];
+                    const float b = r.i * l_dsin[i];
                     d = a + b;
                 } else {
                     d = mel[i];                                        // never written by the transform: the input stays
@@ -518,7 +557,7 @@ __global__ void kws_cmvn_generic_kernel(KwsDspPlan P, const float *__restrict__ 
 bool kws_generic_uses_lds(const KwsDspPlan &P)
 {
     static const bool forced_scratch = getenv("KWS_DEV_GENERIC_SCRATCH") != nullptr;
-    return !forced_scratch && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins).total * sizeof(float) <= 72 * 1024;
+    return !forced_scratch && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz).total * sizeof(float) <= 72 * 1024;
 }
 
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid) { if (kws_generic_uses_lds(P)) return 64; return (size_t)grid * g_ws_floats(P.fft_len, P.n_filters) * GL * sizeof(float); }
@@ -530,7 +569,7 @@ int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is
     if (n_clips <= 0) return 0;
     if (out_stride == 0) out_stride = P.n_frames * (P.mfe_mel ? P.n_filters : P.n_cepstral);
     if (kws_generic_uses_lds(P)) {
-        const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins).total * sizeof(float);
+        const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz).total * sizeof(float);
         static std::atomic<unsigned long long> attr_done{ 0 };
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();

@@ -52,7 +52,7 @@ int kws_launch_mix_audio(const float *words, const int *word_len, size_t word_st
                          float bg_vol, int n, size_t n_clips, int16_t *out, hipStream_t stream);
 int kws_launch_quantize(const float *f, int8_t *q, size_t n, float scale, int zp, hipStream_t stream);
 int kws_launch_resample(const float *in, size_t n_in, float *out, size_t n_out, size_t n_valid, double ratio, const double *win, const double *delta, int nwin,
-                        int precision, int exact, hipStream_t stream);
+                        int precision, int exact, const double *treg, hipStream_t stream);
 // kws_generic.hip: the exact MFCC block for configurations outside the tuned kernel (KwsDspPlan::generic)
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid);
 bool kws_generic_uses_lds(const KwsDspPlan &P);       // the LDS-resident cooperative kernel serves this configuration (else: the scratch-in-HBM kernel)

@@ -219,20 +219,22 @@ int kws_launch_mix_audio(const float *words, const int *word_len, size_t word_st
 //  resample_f as librosa.load ran it in the reference's day -- a wing walks the table in steps of the truncated integer
 //  int(scale x precision) from offset int(frac x precision), with ONE interpolation factor eta per wing; at most (nwin - offset) / step
 //  taps; the output is a float32 array, so every `y[t] += weight * x` rounds to float32; resampy produces floor(n ratio) samples and
-//  librosa's fix_length pads with zeros up to ceil(n ratio): n_valid.  (resampy advances its time register by repeated addition; here it is
-//  t x increment -- the two differ by ~1e-12 relative, which can move a truncation once in ~1e9 samples.)
+//  librosa's fix_length pads with zeros up to ceil(n ratio): n_valid.  resampy advances its time register by repeated addition
+//  (time_register += time_increment): at the output samples whose time is an integer number of input samples -- every 160th for 44.1 -> 16
+//  kHz -- the accumulated value can sit one ulp below it and the loop then starts one input sample earlier with a fraction just under 1, so
+//  the register's values come from the host, which builds them by that same repeated addition (treg).
 //  EXACT = true (KWS_RESAMPLE_EXACT_POSITIONS): every tap's table position computed exactly, products summed in double, every sample
 //  computed: 5e-8 .. 7e-7 from the analytic signal, where the integer stepping costs 6e-4 .. 2e-3 at non-integer ratios.
 // ---------------------------------------------------------------------------------------------------------
 template <bool EXACT>
 __global__ void kws_resample_kernel(const float *__restrict__ x, int n_in, float *__restrict__ y, size_t n_out, size_t n_valid, double ratio,
-                                    const double *__restrict__ win, const double *__restrict__ delta, int nwin, int precision)
+                                    const double *__restrict__ win, const double *__restrict__ delta, int nwin, int precision, const double *__restrict__ treg)
 {
     const double scale = ratio < 1.0 ? ratio : 1.0, time_inc = 1.0 / ratio;
     const int index_step = (int)(scale * (double)precision);
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_out; t += (size_t)gridDim.x * blockDim.x) {
         if (t >= n_valid) { y[t] = 0.0f; continue; }               // librosa.util.fix_length's zero padding
-        const double time_register = (double)t * time_inc;
+        const double time_register = (!EXACT && treg) ? treg[t] : (double)t * time_inc;
         const int n = (int)time_register;
         const double frac = scale * (time_register - (double)n);
         if constexpr (EXACT) {
@@ -269,12 +271,12 @@ __global__ void kws_resample_kernel(const float *__restrict__ x, int n_in, float
 }
 
 int kws_launch_resample(const float *in, size_t n_in, float *out, size_t n_out, size_t n_valid, double ratio, const double *win, const double *delta, int nwin,
-                        int precision, int exact, hipStream_t stream)
+                        int precision, int exact, const double *treg, hipStream_t stream)
 {
     (void)hipGetLastError();
     if (n_out == 0) return 0;
     const int grid = (int)std::min<size_t>((n_out + 255) / 256, 65536);
-    if (exact) hipLaunchKernelGGL(kws_resample_kernel<true>, dim3(grid), dim3(256), 0, stream, in, (int)n_in, out, n_out, n_valid, ratio, win, delta, nwin, precision);
-    else hipLaunchKernelGGL(kws_resample_kernel<false>, dim3(grid), dim3(256), 0, stream, in, (int)n_in, out, n_out, n_valid, ratio, win, delta, nwin, precision);
+    if (exact) hipLaunchKernelGGL(kws_resample_kernel<true>, dim3(grid), dim3(256), 0, stream, in, (int)n_in, out, n_out, n_valid, ratio, win, delta, nwin, precision, nullptr);
+    else hipLaunchKernelGGL(kws_resample_kernel<false>, dim3(grid), dim3(256), 0, stream, in, (int)n_in, out, n_out, n_valid, ratio, win, delta, nwin, precision, treg);
     return (int)hipGetLastError();
 }

@@ -123,6 +123,7 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     }
     fstart[N] = (int)fbin.size();
     P.max_nz = max_nz;
+    P.filt_nnz = (int)fbin.size();
     if (max_nz > kws_mfcc_max_nz()) P.generic = 1;            // the tuned kernel keeps a filter's taps in registers
     std::vector<int> pmap;
     h_pad_map(nfr, P.pad, pmap);

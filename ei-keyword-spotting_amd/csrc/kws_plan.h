@@ -21,6 +21,7 @@ struct KwsDspPlan {
     float inv_fft;      // 1/fft_len (power of two => exact)
     float dct_s0, dct_s1;   // sqrtf(1/(4N)), sqrtf(1/(2N))                numpy.hpp:392-397
     int max_nz;         // longest mel filter (non-zero taps)
+    int filt_nnz;       // non-zero weights of the whole filterbank (length of filt_bin / filt_w)
     // device tables
     const float2 *tw;        // [fft_len/2]  kiss_fft twiddles              kiss_fft.cpp:351-357
     const float2 *stw;       // [fft_len/4]  kiss_fftr super twiddles       kiss_fftr.cpp:52-58
