@@ -244,13 +244,16 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
 //      each is kf_bfly2 / 3 / 4 / 5 exactly as g_bfly computes it.  kiss_fftr's split and the power spectrum (double-precision magnitude)
 //      run per bin pair, straight into the chunk's power rows in LDS.
 //    * per chunk: frame energies (a lane per frame: numpy::sum is a sequential sum), the mel filterbank ((frame, filter) items over the
-//      lanes, ascending-bin dot products), log, and the DCT (a lane per frame: the NF-point transform is small; g_rfft on lane-interleaved
-//      arrays in LDS), c0 <- log(energy), cepstra to HBM.
+//      lanes, ascending-bin dot products), log, and the DCT of all the chunk's frames at once ((frame, butterfly) items over the lanes),
+//      c0 <- log(energy), cepstra to HBM.
 //  LDS: complex buffer 2 (ncfft + ncfft/16) floats, the frame's samples fft_len, the leaf-order table ncfft ints, LCH power rows of
 //  n_bins | 1 floats, LCH mel rows, the DCT's arrays 3 NF + 2 per frame: 27 KB for fft 512 / 32 filters (LCH = 16), i.e. five waves per
 //  CU instead of a scratch that lived in L2.
 // ---------------------------------------------------------------------------------------------------------
 #define LCH 16                                    // frames per chunk (= lanes that carry the per-frame sequential parts)
+// development aid: shader-clock totals per phase of workgroup 0 (kws_dev_generic_prof; tools/gpu_generic_rate.py --prof)
+__device__ long long g_gen_prof[8];
+#define GPH(i) do { const long long now_ = clock64(); if (blockIdx.x == 0 && lane == 0) g_gen_prof[i] += now_ - tlast_; tlast_ = now_; } while (0)
 __device__ __forceinline__ int zpad(int p) { return p + (p >> 4); }             // complex index -> padded complex index
 __device__ __forceinline__ cf z_ld(const float *z, int p) { const float2 v = *(const float2 *)(z + 2 * zpad(p)); cf c; c.r = v.x; c.i = v.y; return c; }
 __device__ __forceinline__ void z_st(float *z, int p, cf v) { *(float2 *)(z + 2 * zpad(p)) = make_float2(v.r, v.i); }
@@ -329,7 +332,7 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int 
     L.mel = L.ps + LCH * L.ps_stride;
     L.mel_stride = nf | 1;
     L.dct = L.mel + LCH * L.mel_stride;
-    L.tw = (L.dct + (3 * nf + 2) * LCH + 1) & ~1;       // float2 tables: 8-byte aligned
+    L.tw = (L.dct + (2 * (nf / 2 + (nf >> 5) + 1) + 2 * (nf / 2 + 1)) * LCH + 1) & ~1;       // (the DCT's buffers per frame); float2 tables: 8-byte aligned
     L.stw = L.tw + 2 * ncfft;
     L.dtw = L.stw + 2 * (ncfft / 2 + 1);
     L.dstw = L.dtw + 2 * (nf / 2 + 1);
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         perm[o] = i;
     }
     WAVE_SYNC();
+    long long tlast_ = clock64();
     for (int item = blockIdx.x; item < n_clips * chunks; item += gridDim.x) {
         const int clip = item / chunks, f0 = (item - clip * chunks) * LCH;
         const int nfc = min(LCH, nfr - f0);
@@ -399,12 +403,14 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                 Y[n] = y;
             }
             WAVE_SYNC();
+            GPH(0);
             for (int o = lane; o < ncfft; o += 64) {
                 const int i = perm[o];
                 cf v; v.r = Y[2 * i]; v.i = Y[2 * i + 1];
                 z_st(Z, o, v);
             }
             WAVE_SYNC();
+            GPH(1);
             // ---- kf_work's levels, innermost first; the butterflies of a level are independent of each other ------------------
             for (int l = P.fft_levels - 1; l >= 0; l--) {
                 const int p = P.fft_fac[2 * l], m = P.fft_fac[2 * l + 1];
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                 }
                 WAVE_SYNC();
             }
+            GPH(2);
             // ---- kiss_fftr's split (kiss_fftr.cpp:84-119) + power spectrum: sqrt(re^2 + im^2) in double, (1/fft) * mag^2 ---------
             float *ps = PS + fi * L.ps_stride;
             auto power = [&](cf v) -> float {
@@ -449,6 +456,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                 ps[ncfft - k] = power(hi);
             }
             WAVE_SYNC();
+            GPH(3);
         }
         // ---- frame energies: numpy::sum, ascending (numpy.hpp:88-94): a lane per frame --------------------------------------
         float energy = 0.0f;
@@ -466,6 +474,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
             if (energy == 0.0f) energy = FLT_EPSILON;
             if (P.mfe_energy) P.mfe_energy[(size_t)clip * nfr + f0 + lane] = energy;
         }
+        GPH(4);
         // ---- mel filterbank: dot_by_row over the non-zero weights in ascending bin order, zero handling, log ----------------
         for (int it = lane; it < nfc * NF; it += 64) {
             const int fi = it / NF, j = it - fi * NF;
@@ -490,34 +499,85 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
             MEL[fi * L.mel_stride + j] = fast_log(acc);
         }
         WAVE_SYNC();
-        if (!P.mfe_mel && lane < nfc) {
-            // ---- numpy::dct2 (numpy.hpp:378-401) -> dct::transform (fast-dct-fft.cpp:37-80), a lane per frame on lane-interleaved arrays:
-            //      even/odd reorder, kiss_fftr(NF), v[i] = re cos + im sin for i <= NF/2 only, x2, ortho scale; c0 <- log(energy) ------
-            const float *mel = MEL + lane * L.mel_stride;
-            float *d_in = DCT + lane, *d_tmp = d_in + (size_t)NF * LCH, *d_spec = d_tmp + (size_t)NF * LCH;
-            const int half = NF / 2;
-            for (int i = 0; i < half; i++) {
-                d_in[(size_t)i * LCH] = mel[2 * i];
-                d_in[(size_t)(NF - 1 - i) * LCH] = mel[2 * i + 1];
+        GPH(5);
+        if (!P.mfe_mel) {
+            // ---- numpy::dct2 (numpy.hpp:378-401) -> dct::transform (fast-dct-fft.cpp:37-80) for the chunk's frames AT ONCE: even/odd reorder
+            //      into kf_work's leaf order, then the NF/2-point transform's levels with (frame, butterfly) items over the lanes (a lane per
+            //      frame walking g_rfft on generic pointers was 30 % of the first version), kiss_fftr's split, v[i] = re cos + im sin for
+            //      i <= NF/2 only, x2, ortho scale; c0 <- log(energy).  Per frame: a padded complex buffer of NF/2 points + the split's output.
+            const int nc = NF >> 1, zs = 2 * (nc + (nc >> 4) + 1), ss = 2 * (nc + 1);      // floats per frame: transform buffer, spectrum
+            float *DZ = DCT, *DS = DCT + LCH * zs;
+            for (int it = lane; it < nfc * nc; it += 64) {
+                const int fi = it / nc, o = it - fi * nc;
+                int rem = o, i = 0, stride = 1;
+                for (int l = 0; l < P.dct_levels; l++) {
+                    const int p = P.dct_fac[2 * l], m = P.dct_fac[2 * l + 1];
+                    const int k = rem / m;
+                    rem -= k * m;
+                    i += k * stride;
+                    stride *= p;
+                }
+                // dct::transform's reorder: in[j] = v[2 j], in[NF - 1 - j] = v[2 j + 1] for j < NF / 2; kiss_fftr reads (in[2 i], in[2 i + 1])
+                const float *mel = MEL + fi * L.mel_stride;
+                auto reord = [&](int q) { return q < nc ? mel[2 * q] : mel[2 * (NF - 1 - q) + 1]; };
+                cf v; v.r = reord(2 * i); v.i = reord(2 * i + 1);
+                z_st(DZ + fi * zs, o, v);
             }
-            g_rfft<LCH>(d_in, d_tmp, d_spec, NF, P.dct_fac, P.dct_levels, l_dtw, l_dstw);
-            float *orow = mfcc_out + (size_t)clip * out_stride + (size_t)ring_out_row(P, f0 + lane) * ncep;
-            for (int i = 0; i < ncep; i++) {
+            WAVE_SYNC();
+            for (int l = P.dct_levels - 1; l >= 0; l--) {
+                const int p = P.dct_fac[2 * l], m = P.dct_fac[2 * l + 1];
+                int fstride = 1;
+                for (int q = 0; q < l; q++) fstride *= P.dct_fac[2 * q];
+                const int nb = nc / p;
+                for (int it = lane; it < nfc * nb; it += 64) {
+                    const int fi = it / nb, b = it - fi * nb;
+                    const int g = b / m, k = b - g * m;
+                    z_bfly_one(DZ + fi * zs, g * p * m, k, fstride, m, p, l_dtw);
+                }
+                WAVE_SYNC();
+            }
+            for (int it = lane; it < nfc * (nc / 2 + 1); it += 64) {
+                const int fi = it / (nc / 2 + 1), k = it - fi * (nc / 2 + 1);
+                const float *Zf = DZ + fi * zs;
+                float *sp = DS + fi * ss;
+                if (k == 0) {
+                    const cf t0 = z_ld(Zf, 0);
+                    sp[0] = t0.r + t0.i; sp[1] = 0.0f;
+                    sp[2 * nc] = t0.r - t0.i; sp[2 * nc + 1] = 0.0f;
+                } else {
+                    const cf fpk = z_ld(Zf, k);
+                    cf fpnk = z_ld(Zf, nc - k);
+                    fpnk.i = -fpnk.i;
+                    const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    const cf twv = cmul(f2k, to_cf(l_dstw[k - 1]));
+                    sp[2 * k] = (f1k.r + twv.r) * 0.5f;
+                    sp[2 * k + 1] = (f1k.i + twv.i) * 0.5f;
+                    sp[2 * (nc - k)] = (f1k.r - twv.r) * 0.5f;             // (k == nc - k: written second, as in the reference)
+                    sp[2 * (nc - k) + 1] = (twv.i - f1k.i) * 0.5f;
+                }
+            }
+            WAVE_SYNC();
+            // the energies sit in the lanes of the first frames: hand them to the items through LDS (the transform buffer is dead)
+            if (lane < nfc) DZ[lane] = energy;
+            WAVE_SYNC();
+            for (int it = lane; it < nfc * ncep; it += 64) {
+                const int fi = it / ncep, i = it - fi * ncep;
+                const float *mel = MEL + fi * L.mel_stride, *sp = DS + fi * ss;
                 float d;
-                if (i <= half) {
-                    const cf r = g_ld<LCH>(d_spec, i);
-                    const float a = r.r * l_dcos[i];
-                    const float b = r.i * l_dsin[i];
+                if (i <= nc) {
+                    const float a = sp[2 * i] * l_dcos[i];
+                    const float b = sp[2 * i + 1] * l_dsin[i];
                     d = a + b;
                 } else {
                     d = mel[i];                                        // never written by the transform: the input stays
                 }
                 d = d * 2.0f;
                 d = d * (i == 0 ? P.dct_s0 : P.dct_s1);
-                orow[i] = d;
+                if (i == 0) d = fast_log(DZ[fi]);                      // c0 <- log(energy), feature.hpp:425-429
+                mfcc_out[(size_t)clip * out_stride + (size_t)ring_out_row(P, f0 + fi) * ncep + i] = d;
             }
-            orow[0] = fast_log(energy);                                // feature.hpp:425-429
         }
+        GPH(6);
         WAVE_SYNC();
     }
 }
@@ -558,6 +618,14 @@ bool kws_generic_uses_lds(const KwsDspPlan &P)
 {
     static const bool forced_scratch = getenv("KWS_DEV_GENERIC_SCRATCH") != nullptr;
     return !forced_scratch && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz).total * sizeof(float) <= 72 * 1024;
+}
+
+// development aid (not in the public headers): read and clear the phase clocks of kws_spectral_lds_kernel's workgroup 0
+extern "C" __attribute__((visibility("default"))) int kws_dev_generic_prof(long long *out8)
+{
+    long long zero[8] = { 0 };
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gen_prof), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gen_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid) { if (kws_generic_uses_lds(P)) return 64; return (size_t)grid * g_ws_floats(P.fft_len, P.n_filters) * GL * sizeof(float); }

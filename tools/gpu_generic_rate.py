@@ -53,6 +53,15 @@ def child(n):
             torch.cuda.synchronize()
             res.append((time.perf_counter() - t0) / reps)
         print("RATE|%s|%s|%d|%.6f|%.6f" % (name, gm.mfcc_kernel, gm.n_frames, res[0], res[1]), flush=True)
+        if gm.mfcc_kernel == "kws_spectral_lds_kernel" and hasattr(pkg.lib(), "kws_dev_generic_prof"):
+            import ctypes
+            buf = (ctypes.c_longlong * 8)()
+            pkg.lib().kws_dev_generic_prof(buf)                  # clear
+            gm.mfcc_batch_device(pcm.data_ptr(), n, mf.data_ptr())
+            torch.cuda.synchronize()
+            pkg.lib().kws_dev_generic_prof(buf)
+            tot = float(sum(buf)) or 1.0
+            print("PROF|%s|" % name + " ".join("%s %.0f%%" % (nm, 100.0 * v / tot) for nm, v in zip(("load", "perm", "levels", "split+power", "energy", "mel", "dct+out", "-"), buf)) + " | clocks per frame of workgroup 0: %.0f" % (tot / max(1, (n * ((gm.n_frames + 15) // 16) // 4096)) / 16), flush=True)
         gm.close()
 
 
@@ -66,6 +75,8 @@ def main():
         if out.returncode != 0:
             print(tag, "FAILED", out.stderr[-1500:])
         for ln in out.stdout.splitlines():
+            if ln.startswith("PROF|") and tag == "lds":
+                print(ln)
             if ln.startswith("RATE|"):
                 _, name, kern, nfr, t_spec, t_all = ln.split("|")
                 rows.setdefault(name, {})[tag] = (kern, int(nfr), float(t_spec), float(t_all))
