@@ -250,7 +250,9 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
 //  n_bins | 1 floats, LCH mel rows, the DCT's arrays 3 NF + 2 per frame: 27 KB for fft 512 / 32 filters (LCH = 16), i.e. five waves per
 //  CU instead of a scratch that lived in L2.
 // ---------------------------------------------------------------------------------------------------------
-#define LCH 16                                    // frames per chunk (= lanes that carry the per-frame sequential parts)
+#ifndef LCH
+#define LCH 8                                     // frames per chunk (measured, 8 192 clips of fft 512 x 49 frames: 16 -> 2.29 ms, 8 -> 1.29 ms, 4 -> 1.30 ms: the LDS per wave decides how many waves a CU holds)
+#endif
 // development aid: shader-clock totals per phase of workgroup 0 (kws_dev_generic_prof; tools/gpu_generic_rate.py --prof)
 __device__ long long g_gen_prof[8];
 #define GPH(i) do { const long long now_ = clock64(); if (blockIdx.x == 0 && lane == 0) g_gen_prof[i] += now_ - tlast_; tlast_ = now_; } while (0)
@@ -326,7 +328,7 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int 
     const int ncfft = fft / 2;
     L.z = 0;
     L.y = L.z + 2 * (ncfft + (ncfft >> 4) + 1);
-    L.perm = L.y + fft;
+    L.perm = L.y;                                         // (the sample buffer of the first version is gone: samples go straight to their leaves)
     L.ps = L.perm + ncfft;
     L.ps_stride = nbins | 1;
     L.mel = L.ps + LCH * L.ps_stride;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
     const int nfr = P.n_frames, NF = P.n_filters, ncep = P.n_cepstral, fft = P.fft_len, nbins = P.n_bins, ncfft = fft >> 1;
     const int nnz = P.filt_nnz;
     const LdsLayout L = lds_layout(fft, NF, nbins, nnz);
-    float *Z = glds + L.z, *Y = glds + L.y, *PS = glds + L.ps, *MEL = glds + L.mel, *DCT = glds + L.dct;
+    float *Z = glds + L.z, *PS = glds + L.ps, *MEL = glds + L.mel, *DCT = glds + L.dct;
     int *perm = (int *)(glds + L.perm);
     float2 *l_tw = (float2 *)(glds + L.tw), *l_stw = (float2 *)(glds + L.stw), *l_dtw = (float2 *)(glds + L.dtw), *l_dstw = (float2 *)(glds + L.dstw);
     float *l_dcos = glds + L.dcs, *l_dsin = l_dcos + NF / 2 + 1, *l_fw = glds + L.fw;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
     const int chunks = (nfr + LCH - 1) / LCH;
     const int used = P.frame_len < fft ? P.frame_len : fft;      // numpy::rfft: truncate to fft_length or zero-pad (numpy.hpp:1097-1111)
     const double inv_fft = 1.0 / (double)(float)fft;             // processing.hpp:306-309
-    // kf_work's leaf order (kiss_fft.cpp:232-296): output position o of the strided copies reads input point perm[o]
+    // kf_work's leaf order (kiss_fft.cpp:232-296): output position o of the strided copies reads input point i; perm[i] = o
     for (int o = lane; o < ncfft; o += 64) {
         int rem = o, i = 0, stride = 1;
         for (int l = 0; l < P.fft_levels; l++) {
@@ -378,9 +380,21 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
             i += k * stride;
             stride *= p;
         }
-        perm[o] = i;
+        perm[i] = o;                                               // inverse: input point i is leaf o
     }
     WAVE_SYNC();
+    // the levels' parameters, once: (p, m, twiddle stride, butterflies, 2^20 / m + 1 for b / m with b < 4096)
+    constexpr int MAXLEV = 8;
+    int lv_p[MAXLEV], lv_m[MAXLEV], lv_fs[MAXLEV], lv_inv[MAXLEV];
+#pragma unroll
+    for (int l = 0; l < MAXLEV; l++) {
+        const int ll = min(l, P.fft_levels - 1);
+        lv_p[l] = P.fft_fac[2 * ll]; lv_m[l] = P.fft_fac[2 * ll + 1];
+        int fsv = 1;
+        for (int q = 0; q < ll; q++) fsv *= P.fft_fac[2 * q];
+        lv_fs[l] = fsv;
+        lv_inv[l] = (int)((1u << 20) / (unsigned)lv_m[l] + 1u);
+    }
     long long tlast_ = clock64();
     for (int item = blockIdx.x; item < n_clips * chunks; item += gridDim.x) {
         const int clip = item / chunks, f0 = (item - clip * chunks) * LCH;
@@ -390,35 +404,38 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
             return F32IN ? ((const float *)pcm_v)[cbase + n] : (float)((const int16_t *)pcm_v)[cbase + n] * (1.0f / 32768.0f);     // numpy::int16_to_float
         };
         for (int fi = 0; fi < nfc; fi++) {
-            // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing ----
+            // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing.  Eight samples
+            //      per lane and trip, all sixteen loads (sample, predecessor) requested before the first is used, no branch per sample: the
+            //      first version's loop waited for two dependent round trips per sample (16 per fft-512 frame: 40 % of the kernel)
             const int off = (f0 + fi) * P.frame_stride;
-            for (int n = lane; n < fft; n += 64) {
-                float y = 0.0f;
-                if (n < used) {
-                    const int sidx = off + n;
-                    const float prev = (sidx == 0) ? (wrap ? wrap[clip] : sample(P.n_samples - 1)) : sample(sidx - 1);
-                    const float pl = P.pre_cof * prev;
-                    y = sample(sidx) - pl;
+            for (int n0 = 0; n0 < fft; n0 += 8 * 64) {
+                float xv[8], pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int n = n0 + 64 * j + lane;
+                    const int sidx = off + min(n, used - 1);          // clamped: lanes past the used samples re-read one (their y is 0)
+                    xv[j] = sample(sidx);
+                    pv[j] = sample(sidx == 0 ? P.n_samples - 1 : sidx - 1);
                 }
-                Y[n] = y;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int n = n0 + 64 * j + lane;
+                    const float prev = (wrap && off + n == 0) ? wrap[clip] : pv[j];
+                    const float pl = P.pre_cof * prev;
+                    // sample n is the real (n even) or imaginary (n odd) part of kiss_fftr's input point n / 2, which sits at leaf perm[n / 2]
+                    if (n < fft) Z[2 * zpad(perm[n >> 1]) + (n & 1)] = n < used ? xv[j] - pl : 0.0f;
+                }
             }
             WAVE_SYNC();
             GPH(0);
-            for (int o = lane; o < ncfft; o += 64) {
-                const int i = perm[o];
-                cf v; v.r = Y[2 * i]; v.i = Y[2 * i + 1];
-                z_st(Z, o, v);
-            }
-            WAVE_SYNC();
-            GPH(1);
             // ---- kf_work's levels, innermost first; the butterflies of a level are independent of each other ------------------
-            for (int l = P.fft_levels - 1; l >= 0; l--) {
-                const int p = P.fft_fac[2 * l], m = P.fft_fac[2 * l + 1];
-                int fstride = 1;
-                for (int q = 0; q < l; q++) fstride *= P.fft_fac[2 * q];
+#pragma unroll
+            for (int l = MAXLEV - 1; l >= 0; l--) {
+                if (l >= P.fft_levels) continue;
+                const int p = lv_p[l], m = lv_m[l], fstride = lv_fs[l];
                 const int nb = ncfft / p;
                 for (int b = lane; b < nb; b += 64) {
-                    const int g = b / m, k = b - g * m;
+                    const int g = (int)(((unsigned)b * (unsigned)lv_inv[l]) >> 20), k = b - g * m;
                     z_bfly_one(Z, g * p * m, k, fstride, m, p, l_tw);
                 }
                 WAVE_SYNC();
