@@ -251,7 +251,7 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
 //  CU instead of a scratch that lived in L2.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef LCH
-#define LCH 8                                     // frames per chunk (measured, 8 192 clips of fft 512 x 49 frames: 16 -> 2.29 ms, 8 -> 1.29 ms, 4 -> 1.30 ms: the LDS per wave decides how many waves a CU holds)
+#define LCH 8                                     // frames per chunk (measured, 8 192 clips of fft 512 x 49 frames: 16 -> 2.29 ms, 8 -> 1.29 / 1.30 ms in two calls, 4 -> 1.30 ms; 4 is faster on fft 1024 and on 98 frames, slower on fft 128: profiles/r04_generic_rate.txt.  The LDS per wave bounds how many waves a CU holds)
 #endif
 // development aid: shader-clock totals per phase of workgroup 0 (kws_dev_generic_prof; tools/gpu_generic_rate.py --prof)
 __device__ long long g_gen_prof[8];

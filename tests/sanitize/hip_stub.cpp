@@ -25,6 +25,9 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, 
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+// (device variables: the host-only build has their host shadows; no kernel runs here, so the shadow is the variable)
+hipError_t hipMemcpyFromSymbol(void *d, const void *sym, size_t n, size_t off, hipMemcpyKind) { memcpy(d, (const char *)sym + off, n); return hipSuccess; }
+hipError_t hipMemcpyToSymbol(const void *sym, const void *s, size_t n, size_t off, hipMemcpyKind) { memcpy((char *)const_cast<void *>(sym) + off, s, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
