@@ -323,6 +323,34 @@ static int stage_ms(hipEvent_t a, hipEvent_t b)
     return (int)(ms + 0.5f);
 }
 
+// The caller's callback is asked for exactly what the reference's DSP block asks it, in the reference's order (a stateful callback --
+// a file reader, a ring buffer that counts its reads -- sees the same sequence; 98 calls for the shipped 49-frame window):
+//   processing.hpp:68       the pre-emphasis constructor: the window's last `shift` samples, return value unchecked (buffer calloc'd)
+//   processing.hpp:86-94    per frame of speechpy::feature::mfe's loop (feature.hpp:263-281, through ei_run_dsp.h:252-253): the `shift`
+//                           samples before the frame unless it starts inside the first `shift`, then the frame's frame_length samples
+// Every answer lands at its own offset of the window x (what the kernels read: the frames, the sample before each, the wrap sample).
+// The constructor runs before the reference sizes its output (ei_run_dsp.h:267, 279-286): its call is made on the error paths too.
+// gather_frames_like_reference returns the callback's first non-zero return value (EIDSP_ERR(ret) in the reference), 0 otherwise.
+static void gather_constructor_call(signal_t *signal, size_t total_length, int shift, float *eos)
+{
+    for (int i = 0; i < shift; ++i) eos[i] = 0.0f;
+    if (total_length >= (size_t)shift) (void)signal->get_data(total_length - (size_t)shift, (size_t)shift, eos);
+}
+static int gather_frames_like_reference(signal_t *signal, float *x, int n_frames, int frame_len, int stride, int shift)
+{
+    for (int f = 0; f < n_frames; ++f) {
+        const size_t off = (size_t)f * (size_t)stride;
+        // (the reference's shortening of a frame that would pass the end, feature.hpp:267-270, cannot fire: the frame count comes from the length)
+        if (off >= (size_t)shift) {
+            const int r = signal->get_data(off - (size_t)shift, (size_t)shift, x + off - shift);
+            if (r != 0) return r;
+        }
+        const int r = signal->get_data(off, (size_t)frame_len, x + off);
+        if (r != 0) return r;
+    }
+    return 0;
+}
+
 EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, bool debug)
 {
     kws_handle *h = kws_default_model();
@@ -330,22 +358,35 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     if (EI_IMPULSE_ERROR le = check_result_layout(h)) return le;
     const size_t n = h->model.raw_sample_count, C = h->model.labels.size();
-    // The reference sizes its frame count from signal->total_length (ei_run_dsp.h:277-286); a length that yields another
-    // feature count than the model's is EIDSP_MATRIX_SIZE_MISMATCH there (-> EI_IMPULSE_DSP_ERROR).
-    if (signal->total_length != n) { ei_printf("ERR: Failed to run DSP process (%d)\n", -1002); return fail(EI_IMPULSE_DSP_ERROR, "signal length %zu, model window %zu", signal->total_length, n); }
+    // The reference sizes its frame count from signal->total_length and refuses (EIDSP_MATRIX_SIZE_MISMATCH -> EI_IMPULSE_DSP_ERROR) a
+    // window whose feature matrix would be LARGER than the model's (ei_run_dsp.h:277-284).  A SHORTER window it takes: fewer frames,
+    // normalised among themselves, the rest of the network's input left at its calloc'd zeros.  KNOWN DEVIATION: every other length is
+    // refused here, with the reference's message for the longer case (tests/test_get_data_sequence.py records both behaviours).
+    if (signal->total_length != n) {
+        float eos_unused = 0.0f;                                                 // the pre-emphasis object exists by then: its call has been made
+        gather_constructor_call(signal, signal->total_length, h->dsp.pre_shift, &eos_unused);
+        ei_printf("ERR: Failed to run DSP process (%d)\n", -1002);
+        return fail(EI_IMPULSE_DSP_ERROR, "signal length %zu, model window %zu", signal->total_length, n);
+    }
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
     uint64_t t0 = ei_read_timer_ms();
     EI_IMPULSE_ERROR e = ensure_ws(h, n);
     if (e) return e;
     kws_handle::Ws &w = h->ws;
-    // gather the window through the caller's callback (float samples, as the SDK hands them to the DSP block) straight
-    // into pinned memory
-    const size_t chunk = 4000;
-    for (size_t off = 0; off < n; off += chunk) {
-        const size_t len = std::min(chunk, n - off);
-        int r = signal->get_data(off, len, w.h_x + off);
+    // gather the window through the caller's callback (float samples, as the SDK hands them to the DSP block) straight into pinned
+    // memory, with the reference's own sequence of calls; samples no frame covers (between frames of a stride above the frame length,
+    // behind the last frame) are never asked for -- nor read by the kernels
+    {
+        float eos = 0.0f;                                                        // (the plan admits pre_shift == 1 only)
+        const int nfr = h->dsp.n_frames, frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
+        gather_constructor_call(signal, n, h->dsp.pre_shift, &eos);
+        const int r = gather_frames_like_reference(signal, w.h_x, nfr, frame_len, stride, h->dsp.pre_shift);
         if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
+        // x[-1] of the window is its last sample (processing.hpp:104-106 reads _end_of_signal_buffer): where no frame reaches the
+        // window's end (the shipped shape: the last frame ends at 15 680 of 16 000) the constructor's answer is the only copy.  A frame
+        // that covers it has fetched the same sample (a callback that fails the first call only would differ: 0 in the reference)
+        if ((size_t)(nfr - 1) * (size_t)stride + (size_t)frame_len < n) w.h_x[n - 1] = eos;
     }
     int dsp_ms = 0;
     uint64_t t1 = t0;
@@ -431,7 +472,7 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     g_cont_first_run = true;
     const size_t n_claimed = signal->total_length;
     float eos = 0.0f;                                                           // _end_of_signal_buffer (calloc)
-    if (n_claimed >= 1) (void)signal->get_data(n_claimed - (size_t)m.dsp.pre_shift, (size_t)m.dsp.pre_shift, &eos);
+    gather_constructor_call(signal, n_claimed, m.dsp.pre_shift, &eos);          // before the size check below, as in the reference
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
     const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)ncep;
@@ -447,7 +488,8 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     kws_handle::Ws &w = h->ws;
     memset(w.h_x, 0, n_x * sizeof(float));
     {
-        int r = signal->get_data(0, needed, w.h_x);
+        // frame by frame, as the reference asks (gather_frames_like_reference)
+        const int r = gather_frames_like_reference(signal, w.h_x, nf, frame_len, stride, m.dsp.pre_shift);
         if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
     }
     w.h_s[0] = eos;                                                              // staged through pinned memory

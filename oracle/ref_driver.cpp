@@ -61,10 +61,17 @@ void DebugLog(const char *s) { ei_printf("%s", s); }
 static const int16_t *g_pcm = NULL;
 static size_t g_pcm_len = 0;
 static size_t g_get_data_calls = 0;
+/* (offset, length, return value) of every call, for the boundary tests: what a caller's callback sees, in order */
+static long long *g_trace = NULL;
+static int g_trace_cap = 0, g_trace_n = 0;
 static int pcm_get_data(size_t offset, size_t length, float *out_ptr) {
     g_get_data_calls++;
-    if (offset + length > g_pcm_len) return -1;
-    return numpy::int16_to_float(g_pcm + offset, out_ptr, length);
+    const int r = offset + length > g_pcm_len ? -1 : numpy::int16_to_float(g_pcm + offset, out_ptr, length);
+    if (g_trace && g_trace_n < g_trace_cap) {
+        g_trace[3 * g_trace_n] = (long long)offset; g_trace[3 * g_trace_n + 1] = (long long)length; g_trace[3 * g_trace_n + 2] = r;
+    }
+    if (g_trace) g_trace_n++;
+    return r;
 }
 
 extern "C" {
@@ -119,6 +126,9 @@ int eiref_continuous(const int16_t *slice, size_t n, float *scores, int *produce
     return (int)r;
 }
 int eiref_slice_size(void) { return EI_CLASSIFIER_SLICE_SIZE; }
+/* arm (buf != NULL) / disarm the get_data trace; eiref_trace_count = calls seen since it was armed (may exceed cap) */
+void eiref_trace_get_data(long long *buf /*[3 * cap]*/, int cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+int eiref_trace_count(void) { return g_trace_n; }
 
 /* extract_mfcc_features with an arbitrary ei_dsp_config_mfcc_t.
  * features must hold rows*num_cepstral floats; returns EIDSP code. */

@@ -11,6 +11,20 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
+def host_exe(tmp_path_factory):
+    """The library's HOST code linked against the stub HIP runtime of tests/sanitize (device memory = host heap, launches do nothing):
+    what kws_create builds and what the SDK entry points do before any device work can be looked at without a GPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") and shutil.which("gcc")):
+        pytest.skip("needs ROCm's clang++ and gcc")
+    out = str(tmp_path_factory.mktemp("kws_host_stub"))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "sanitize"), "OUT=" + out, os.path.join(out, "kws_host_san")])
+    return os.path.join(out, "kws_host_san")
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from kws_testlib import Oracle
     return Oracle()

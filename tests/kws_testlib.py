@@ -512,6 +512,19 @@ class Reference:
         offs = np.cumsum([0] + self.tensor_bytes)
         return {int(i): out[offs[i]:offs[i + 1]].copy() for i in ids if sizes[i] >= 0}
 
+    def traced(self, fn, *args, cap=4096):
+        """fn(*args) with every get_data call the reference makes recorded: (result of fn, int64 [n_calls, 3] = offset, length, return value)."""
+        buf = np.zeros((cap, 3), np.int64)
+        self.L.eiref_trace_get_data.argtypes = [C.c_void_p, C.c_int]
+        self.L.eiref_trace_get_data(_ptr(buf), cap)
+        try:
+            out = fn(*args)
+            n = self.L.eiref_trace_count()
+        finally:
+            self.L.eiref_trace_get_data(None, 0)
+        assert n <= cap, n
+        return out, buf[:n].copy()
+
     def continuous_init(self):
         self.L.eiref_continuous_init()
 

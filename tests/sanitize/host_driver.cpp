@@ -13,9 +13,12 @@
 #include "../../include/kws/kws.h"
 
 static std::vector<float> g_audio;
+static bool g_tracing = false;
 static int get_data(size_t off, size_t len, float *out)
 {
-    if (off + len > g_audio.size()) return -1;
+    const int r = off + len > g_audio.size() ? -1 : 0;
+    if (g_tracing) printf(" %zu %zu %d", off, len, r);
+    if (r) return r;
     memcpy(out, g_audio.data() + off, len * sizeof(float));
     return 0;
 }
@@ -79,6 +82,35 @@ static void walk(kws_handle *h)
     (void)run_classifier_continuous(&sig, &res, false);
 }
 
+// --trace: the (offset, length, return value) of every call the SDK entry points make to the application's get_data, in order -- host
+// logic that runs before any device work, so the stub runtime shows it; tests/test_get_data_sequence.py compares it with what the
+// compiled reference asks its callback (tests/golden/get_data_trace_l476.npz).  The callback refuses ranges beyond the real buffer, as the
+// reference's test driver does (oracle/ref_driver.cpp pcm_get_data).  The process's first continuous call is the reference's `first_run`.
+static void print_trace(kws_handle *h)
+{
+    const size_t n = (size_t)kws_clip_samples(h);
+    (void)kws_set_default_model(h);
+    signal_t sig;
+    sig.get_data = &get_data;
+    ei_impulse_result_t res;
+    auto one = [&](const char *tag, size_t real, size_t claimed, bool continuous) {
+        g_audio.assign(real, 0.25f);
+        sig.total_length = claimed;
+        memset(&res, 0, sizeof res);
+        printf("TRACE %s", tag);
+        g_tracing = true;
+        const EI_IMPULSE_ERROR rc = continuous ? run_classifier_continuous(&sig, &res, false) : run_classifier(&sig, &res, false);
+        g_tracing = false;
+        printf(" | total_length_after %zu error %d\n", sig.total_length, rc == EI_IMPULSE_DSP_ERROR ? 1 : 0);
+    };
+    one("oneshot", n, n, false);
+    one("oneshot_short", n - 1, n - 1, false);
+    run_classifier_init();
+    one("continuous_first", n / 4, n / 4, true);
+    one("continuous_second", n / 4, n / 4, true);
+    one("continuous_short", n / 8, n / 8, true);
+}
+
 // --gain: print what kws_create calibrated for a float32 graph (kws_gain.cpp is host code: the stub runtime is all it needs) --
 // tests/test_gain_calibration.py compares it with Jacobians of the oracle's network
 static void print_gain(const char *path, kws_handle *h)
@@ -95,8 +127,8 @@ static void print_gain(const char *path, kws_handle *h)
 
 int main(int argc, char **argv)
 {
-    const bool gain_only = argc > 1 && strcmp(argv[1], "--gain") == 0;
-    for (int i = gain_only ? 2 : 1; i < argc; i++) {
+    const bool gain_only = argc > 1 && strcmp(argv[1], "--gain") == 0, trace_only = argc > 1 && strcmp(argv[1], "--trace") == 0;
+    for (int i = gain_only || trace_only ? 2 : 1; i < argc; i++) {
         FILE *f = fopen(argv[i], "rb");
         if (!f) { printf("%s rc open-failed\n", argv[i]); continue; }
         std::vector<unsigned char> blob;
@@ -109,6 +141,7 @@ int main(int argc, char **argv)
         printf("%s rc %d\n", argv[i], (int)rc);
         fflush(stdout);
         if (rc == EI_IMPULSE_OK && gain_only) print_gain(argv[i], h);
+        else if (rc == EI_IMPULSE_OK && trace_only) print_trace(h);
         else if (rc == EI_IMPULSE_OK) walk(h);
         if (rc == EI_IMPULSE_OK) kws_destroy(h);
     }

@@ -28,11 +28,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(CLANG) and shutil.which("gcc
 FLOAT_MODELS = ["cfg2_mfcc40_f32.kwsm", "l476_no_yes_f32.kwsm", "cfg5_dscnn_mfcc40_f32.kwsm"]
 
 
-@pytest.fixture(scope="module")
-def host_exe(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("kws_host_stub"))
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "sanitize"), "OUT=" + out, os.path.join(out, "kws_host_san")])
-    return os.path.join(out, "kws_host_san")
+# (host_exe: tests/conftest.py)
 
 
 def calibrated(host_exe, path):

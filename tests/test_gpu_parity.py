@@ -159,13 +159,15 @@ def test_run_classifier_drop_in(pkg, gpu476, l476, oracle):
     rc = pkg.lib().run_classifier(ctypes.byref(sig), ctypes.byref(res), False)
     assert rc == 0
     assert sig.total_length == 16000                              # caller's struct untouched
-    # the documented deviation: the window is gathered with four get_data calls of 4 000 samples, in
-    # order, instead of the reference's 98 small ones
-    assert calls == [(0, 4000), (4000, 4000), (8000, 4000), (12000, 4000)]
+    # the callback is asked what the reference asks it, in its order: 98 calls (tests/golden/get_data_trace_l476.npz, recorded from the
+    # compiled reference; tests/test_get_data_sequence.py holds the other scenarios on CPU)
+    want = np.load(os.path.join(GOLDEN, "get_data_trace_l476.npz"))["oneshot"]
+    assert len(calls) == 98 and calls == [(int(o), int(n)) for o, n, _ in want]
     got = np.float32([res.classification[i].value for i in range(4)])
     assert [res.classification[i].label.decode() for i in range(4)] == ["no", "noise", "unknown", "yes"]
     assert (bits(got) == bits(l476.run_batch(clip)[0])).all()
-    # error convention: get_data failure -> EI_IMPULSE_DSP_ERROR (-5); wrong window length -> -5
+    # error convention: get_data failure -> EI_IMPULSE_DSP_ERROR (-5), as in the reference; a window of another length -> -5 (the reference
+    # refuses only a LONGER one, ei_run_dsp.h:279-284: a shorter one it classifies from its fewer frames -- known deviation)
     bad = pkg.GET_DATA_FN(lambda o, l, p: -7)
     assert pkg.lib().run_classifier(ctypes.byref(pkg.Signal(bad, 16000)), ctypes.byref(res), False) == -5
     assert pkg.lib().run_classifier(ctypes.byref(pkg.Signal(cb, 8000)), ctypes.byref(res), False) == -5

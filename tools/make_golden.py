@@ -176,10 +176,33 @@ def qfb(synth, cfg):
     print("qfb_l476.npz", os.path.getsize(os.path.join(GOLDEN, "qfb_l476.npz")), "bytes")
 
 
+def get_data_trace(ref):
+    """What the reference asks the application's get_data callback, in order: (offset, length, return value) per call, for the scenarios
+    tests/sanitize/host_driver.cpp --trace replays through the library (one-shot, one-shot with a window one sample short, the process's first
+    continuous call, a later one -- total_length grown by a frame length in the caller's struct, ei_run_dsp.h:318-326 --, a half slice).
+    The callback refuses ranges beyond the real buffer (oracle/ref_driver.cpp pcm_get_data).  MUST be the first user of
+    run_classifier_continuous in its process (the reference's function-static first_run): run as  make_golden.py --only-trace."""
+    n, out = 16000, {}
+    clip = Oracle().synth(5, 0, 1)[0]
+    (r, _s, tl, _gc), t = ref.traced(ref.run_classifier, clip)
+    out["oneshot"], out["oneshot_meta"] = t, np.int64([tl, int(r != 0)])
+    (r, _s, tl, _gc), t = ref.traced(ref.run_classifier, clip[:n - 1])
+    out["oneshot_short"], out["oneshot_short_meta"] = t, np.int64([tl, int(r != 0)])
+    ref.continuous_init()
+    for tag, m in (("continuous_first", n // 4), ("continuous_second", n // 4), ("continuous_short", n // 8)):
+        (r, _p, _s, tl), t = ref.traced(ref.continuous, clip[:m])
+        out[tag], out[tag + "_meta"] = t, np.int64([tl, int(r != 0)])
+    np.savez_compressed(os.path.join(GOLDEN, "get_data_trace_l476.npz"), **out)
+    for k in ("oneshot", "oneshot_short", "continuous_first", "continuous_second", "continuous_short"):
+        print(k, len(out[k]), "calls; total_length after, error:", out[k + "_meta"].tolist(), "first:", out[k][:3].tolist())
+
+
 def main():
     if "--only-qfb" in sys.argv:
         return qfb(Oracle(), L476_CONFIG())
     ref = Reference()
+    if "--only-trace" in sys.argv:
+        return get_data_trace(ref)
     if "--only-mfcc40" in sys.argv:
         return mfcc40(ref, Oracle(), L476_CONFIG())
     if "--only-mfe-block" in sys.argv:
