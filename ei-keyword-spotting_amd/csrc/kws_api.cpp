@@ -281,7 +281,7 @@ EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void 
 }
 
 // extract_mfcc_features + quantisation in one launch (fused kernel)
-EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s)
+EI_IMPULSE_ERROR mfcc_fused_device_plan(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s)
 {
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     if (h->model.dsp.block == DSP_BLOCK_MFE) {
@@ -289,27 +289,30 @@ EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float,
         // the input quantisation of an int8 graph.  The float feature matrix is needed either way.
         if (!features) return fail(KWS_ERROR_BAD_ARGUMENT, "the MFE block needs a float feature buffer");
         if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
-        const KwsDspPlan &P = h->dsp;
         int rc = kws_launch_mfe(P, pcm, is_float, (int)B, features, nullptr, nullptr, 0, grid_cap_mfcc(h), s);
         if (!rc) rc = kws_launch_mfe_norm(features, (int)B, P.n_frames, P.n_filters, P.win_size, P.pad_map, P.n_frames + 2 * P.pad, grid_cap_nn(h), s);
         if (!rc && q) rc = kws_launch_quantize(features, q, B * h->model.nn_input_frame_size, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "MFE block launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
     }
-    if (h->dsp.generic) {
+    if (P.generic) {
         // cepstra -> g_mfcc, then cmvnw + quantisation (the general kernels are two launches; the cepstra go through HBM)
         kws_handle::GenericBuf *g = nullptr;
         EI_IMPULSE_ERROR e = generic_for(h, s, B, &g);
         if (e) return e;
-        int rc = kws_launch_spectral_generic(h->dsp, pcm, is_float, (int)B, g->mfcc, nullptr, 0, g->ws, grid_cap_mfcc(h), s);
-        if (!rc) rc = kws_launch_cmvn_generic(h->dsp, g->mfcc, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, s);
+        int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, g->mfcc, nullptr, 0, g->ws, grid_cap_mfcc(h), s);
+        if (!rc) rc = kws_launch_cmvn_generic(P, g->mfcc, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
     }
     if (((uintptr_t)pcm & 15) != 0) return fail(KWS_ERROR_BAD_ARGUMENT, "pcm must be 16-byte aligned");
-    int rc = kws_launch_mfcc_fused(h->dsp, pcm, is_float, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s);
+    int rc = kws_launch_mfcc_fused(P, pcm, is_float, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, h->n_cu * 8, s);
     if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
     return EI_IMPULSE_OK;
+}
+EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s)
+{
+    return mfcc_fused_device_plan(h, h->dsp, pcm, is_float, B, features, q, s);
 }
 
 // float32 models: the network reads the feature matrix itself (ei_run_classifier.h:447-452 copies it into the input tensor)

@@ -12,6 +12,7 @@
 
 #include <mutex>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/kws/kws.h"
@@ -158,6 +159,7 @@ struct kws_handle {
     const KwsNnPlanF32 *d_nnf = nullptr;   // the same plan in device memory (the float kernel reads it from there)
     int pooled_tap_bytes = 0;
     std::vector<void *> dev_allocs;
+    std::map<int, const int *> pad_maps_by_rows;     // kws_plan_for_length: cmvnw pad maps for other row counts than the model's (device, in dev_allocs)
     // scratch for the combined entry points (grown on demand)
     float *s_mfcc = nullptr;      // cepstra before CMVN, [B][n_features]
     int8_t *s_q = nullptr;
@@ -282,6 +284,12 @@ KWS_INTERNAL int grid_cap_nn(const kws_handle *h);
 KWS_INTERNAL EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc,
                                  const float *wrap, hipStream_t s, int out_stride = 0);
 KWS_INTERNAL EI_IMPULSE_ERROR mfcc_fused_device(kws_handle *h, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s);
+// the same with another plan than the handle's own (kws_plan_for_length: a window of another length, SDK one-shot path)
+KWS_INTERNAL EI_IMPULSE_ERROR mfcc_fused_device_plan(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *features, int8_t *q, hipStream_t s);
+// frames the reference's framing yields for a window of n samples (processing.hpp:194-284; 0 when none fits), and the handle's DSP plan
+// re-targeted at such a window: same tables, n_samples / n_frames / cmvnw's pad map for that row count (maps are cached on the handle)
+KWS_INTERNAL int kws_frames_for_length(const kws_handle *h, size_t n);
+KWS_INTERNAL EI_IMPULSE_ERROR kws_plan_for_length(kws_handle *h, size_t n, KwsDspPlan *out);
 KWS_INTERNAL EI_IMPULSE_ERROR nn_f32_device(kws_handle *h, const float *features, size_t B, float *scores, float *tap_logits, hipStream_t s);
 KWS_INTERNAL EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, float *features, int8_t *q, float *scores,
                                 int8_t *tap_pooled, int8_t *tap_fc, int8_t *tap_out, hipStream_t s, int ring_rows = 0, int ring_head = 0);

@@ -142,6 +142,35 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     return EI_IMPULSE_OK;
 }
 
+int kws_frames_for_length(const kws_handle *h, size_t n)
+{
+    const KwsDspPlan &P = h->dsp;
+    const float stride_f = roundf((float)h->model.frequency * h->model.dsp.frame_stride);          // as build_dsp_plan
+    if (n < (size_t)P.frame_len || n > (1u << 30)) return 0;
+    return (int)floorf((float)(n - (size_t)P.frame_len) / stride_f);
+}
+
+EI_IMPULSE_ERROR kws_plan_for_length(kws_handle *h, size_t n, KwsDspPlan *out)
+{
+    const int nfr = kws_frames_for_length(h, n);
+    if (nfr < 1 || nfr > h->dsp.n_frames) return fail(KWS_ERROR_BAD_ARGUMENT, "a window of %zu samples has %d frames (the model's: %d)", n, nfr, h->dsp.n_frames);
+    *out = h->dsp;
+    out->n_samples = (int)n;
+    out->n_frames = nfr;
+    if (nfr != h->dsp.n_frames) {
+        auto it = h->pad_maps_by_rows.find(nfr);
+        if (it == h->pad_maps_by_rows.end()) {
+            std::vector<int> pmap;
+            h_pad_map(nfr, out->pad, pmap);
+            const int *d = nullptr;
+            if (EI_IMPULSE_ERROR e = h->upload(pmap, &d)) return e;
+            it = h->pad_maps_by_rows.emplace(nfr, d).first;
+        }
+        out->pad_map = it->second;
+    }
+    return EI_IMPULSE_OK;
+}
+
 static EI_IMPULSE_ERROR build_nn_plan_f32(kws_handle *h);
 
 // Recognise the Edge Impulse 1-D CNN family and fold its per-model constants.

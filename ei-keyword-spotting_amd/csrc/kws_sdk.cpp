@@ -289,13 +289,20 @@ EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result
 
 // run_classifier's device work on the workspace stream: H2D of the window, extract_mfcc_features, the network, D2H of the
 // scores.  debug: the stream is drained after the DSP block and the features are printed, as the SDK's sequential code does.
-static EI_IMPULSE_ERROR oneshot_enqueue(kws_handle *h, kws_handle::Ws &w, size_t n, size_t C, bool debug, uint64_t t0, int *dsp_ms, uint64_t *t1)
+// other: the plan for a window of another length than the model's (kws_plan_for_length) -- its fewer rows fill the head of the feature
+// matrix, the rest stays at the zeros the reference's calloc left there (ei_run_classifier.h: features_matrix), and the network's input
+// is quantised from that whole matrix as run_inference does.
+static EI_IMPULSE_ERROR oneshot_enqueue(kws_handle *h, kws_handle::Ws &w, size_t n, size_t C, bool debug, uint64_t t0, int *dsp_ms, uint64_t *t1,
+                                        const KwsDspPlan *other = nullptr)
 {
     const size_t F = h->model.nn_input_frame_size;
     EI_IMPULSE_ERROR e = EI_IMPULSE_OK;
     (void)hipEventRecord(w.ev[0], w.st);
     if (hipMemcpyAsync(w.d_x, w.h_x, n * sizeof(float), hipMemcpyHostToDevice, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "h2d copy failed");
-    if (!e) e = mfcc_fused_device(h, w.d_x, 1, 1, w.d_f, h->is_float ? nullptr : w.d_q, w.st);
+    if (!e && other) {
+        if (hipMemsetAsync(w.d_f, 0, F * sizeof(float), w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "memset failed");
+        if (!e) e = mfcc_fused_device_plan(h, *other, w.d_x, 1, 1, w.d_f, nullptr, w.st);
+    } else if (!e) e = mfcc_fused_device(h, w.d_x, 1, 1, w.d_f, h->is_float ? nullptr : w.d_q, w.st);
     (void)hipEventRecord(w.ev[1], w.st);                     // the stage boundary of ei_run_classifier.h:669 / 696, on the device's clock
     if (debug) {
         if (!e && hipMemcpyAsync(w.h_f, w.d_f, F * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
@@ -309,7 +316,8 @@ static EI_IMPULSE_ERROR oneshot_enqueue(kws_handle *h, kws_handle::Ws &w, size_t
         ei_printf("Running neural network...\n");
         *t1 = ei_read_timer_ms();
     }
-    if (!e) e = h->is_float ? nn_f32_device(h, w.d_f, 1, w.d_s, nullptr, w.st) : kws_nn_batch_device(h, w.d_q, 1, w.d_s, nullptr, nullptr, nullptr, w.st);
+    if (!e && other) e = kws_run_inference_batch_device(h, w.d_f, 1, w.d_s, w.st);
+    else if (!e) e = h->is_float ? nn_f32_device(h, w.d_f, 1, w.d_s, nullptr, w.st) : kws_nn_batch_device(h, w.d_q, 1, w.d_s, nullptr, nullptr, nullptr, w.st);
     if (!e && hipMemcpyAsync(w.h_s, w.d_s, C * sizeof(float), hipMemcpyDeviceToHost, w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "d2h copy failed");
     (void)hipEventRecord(w.ev[2], w.st);
     return e;
@@ -328,20 +336,23 @@ static int stage_ms(hipEvent_t a, hipEvent_t b)
 //   processing.hpp:68       the pre-emphasis constructor: the window's last `shift` samples, return value unchecked (buffer calloc'd)
 //   processing.hpp:86-94    per frame of speechpy::feature::mfe's loop (feature.hpp:263-281, through ei_run_dsp.h:252-253): the `shift`
 //                           samples before the frame unless it starts inside the first `shift`, then the frame's frame_length samples
+// An MFE block (L432 copy, ei_run_dsp.h:369-418, 420-470) hands the application's signal to feature::mfe itself -- no pre-emphasis object:
+// the frames only (shift = 0 here), 49 calls for its window.
 // Every answer lands at its own offset of the window x (what the kernels read: the frames, the sample before each, the wrap sample).
 // The constructor runs before the reference sizes its output (ei_run_dsp.h:267, 279-286): its call is made on the error paths too.
 // gather_frames_like_reference returns the callback's first non-zero return value (EIDSP_ERR(ret) in the reference), 0 otherwise.
+static int gather_shift(const kws_handle *h) { return h->model.dsp.block == DSP_BLOCK_MFE ? 0 : h->dsp.pre_shift; }
 static void gather_constructor_call(signal_t *signal, size_t total_length, int shift, float *eos)
 {
     for (int i = 0; i < shift; ++i) eos[i] = 0.0f;
-    if (total_length >= (size_t)shift) (void)signal->get_data(total_length - (size_t)shift, (size_t)shift, eos);
+    if (shift > 0 && total_length >= (size_t)shift) (void)signal->get_data(total_length - (size_t)shift, (size_t)shift, eos);
 }
 static int gather_frames_like_reference(signal_t *signal, float *x, int n_frames, int frame_len, int stride, int shift)
 {
     for (int f = 0; f < n_frames; ++f) {
         const size_t off = (size_t)f * (size_t)stride;
         // (the reference's shortening of a frame that would pass the end, feature.hpp:267-270, cannot fire: the frame count comes from the length)
-        if (off >= (size_t)shift) {
+        if (shift > 0 && off >= (size_t)shift) {
             const int r = signal->get_data(off - (size_t)shift, (size_t)shift, x + off - shift);
             if (r != 0) return r;
         }
@@ -358,35 +369,52 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     if (!signal || !signal->get_data || !result) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
     if (EI_IMPULSE_ERROR le = check_result_layout(h)) return le;
     const size_t n = h->model.raw_sample_count, C = h->model.labels.size();
-    // The reference sizes its frame count from signal->total_length and refuses (EIDSP_MATRIX_SIZE_MISMATCH -> EI_IMPULSE_DSP_ERROR) a
-    // window whose feature matrix would be LARGER than the model's (ei_run_dsp.h:277-284).  A SHORTER window it takes: fewer frames,
-    // normalised among themselves, the rest of the network's input left at its calloc'd zeros.  KNOWN DEVIATION: every other length is
-    // refused here, with the reference's message for the longer case (tests/test_get_data_sequence.py records both behaviours).
-    if (signal->total_length != n) {
+    // The reference sizes its frame count from signal->total_length (ei_run_dsp.h:277-286, processing.hpp:194-284).  A window with 1 ..
+    // n_frames frames (640 .. 16 319 samples for the shipped impulse) it classifies from the frames that fit: normalised among themselves,
+    // x[-1] = the last sample of THAT window, the rest of the network's input at its calloc'd zeros -- 15 999 samples give 48 frames, 16 001
+    // give 49 with another wrap sample.  The same here, on the handle's plan re-targeted at that length; recorded from the compiled
+    // reference in tests/golden/other_length_l476.npz.
+    // Outside that range the reference has no result to match: its check for a matrix that does not fit (ei_run_dsp.h:279-284) and
+    // feature.hpp's EIDSP_INPUT_MATRIX_EMPTY end in EIDSP_ERR = printf + assert(false) (dsp/config.hpp:65-67; the return-code form does not
+    // compile for this SDK copy) -- an abort, or under NDEBUG a run into the overflow (observed: 16 320, 16 321, 16 640, 17 000 samples) or
+    // a crash (639).  The library returns EI_IMPULSE_DSP_ERROR there with the message run_classifier prints for a failed DSP block.  Also
+    // refused: other lengths for an MFE block (the same rule in the L432 copy's text, ei_run_dsp.h:381-386, but that copy's run_classifier
+    // cannot be compiled here to pin it).
+    const size_t n2 = signal->total_length;
+    const int shift = gather_shift(h);
+    const int nfr2 = n2 == n ? h->dsp.n_frames : kws_frames_for_length(h, n2);
+    if (n2 != n && (nfr2 > h->dsp.n_frames || nfr2 < 1 || h->model.dsp.block == DSP_BLOCK_MFE)) {
         float eos_unused = 0.0f;                                                 // the pre-emphasis object exists by then: its call has been made
-        gather_constructor_call(signal, signal->total_length, h->dsp.pre_shift, &eos_unused);
-        ei_printf("ERR: Failed to run DSP process (%d)\n", -1002);
-        return fail(EI_IMPULSE_DSP_ERROR, "signal length %zu, model window %zu", signal->total_length, n);
+        gather_constructor_call(signal, n2, shift, &eos_unused);
+        if (nfr2 > h->dsp.n_frames) {                                            // ei_run_dsp.h:280-282
+            ei_printf("out_matrix = %hux%hu\n", (unsigned short)1, (unsigned short)h->model.nn_input_frame_size);
+            ei_printf("calculated size = %hux%hu\n", (unsigned short)nfr2, (unsigned short)h->dsp.n_cepstral);
+        }
+        const int code = nfr2 < 1 ? -1006 : -1002;                               // EIDSP_INPUT_MATRIX_EMPTY / EIDSP_MATRIX_SIZE_MISMATCH
+        ei_printf("ERR: Failed to run DSP process (%d)\n", code);
+        return fail(EI_IMPULSE_DSP_ERROR, "signal length %zu (%d frames), model window %zu (%d frames)", n2, nfr2, n, h->dsp.n_frames);
     }
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
     uint64_t t0 = ei_read_timer_ms();
-    EI_IMPULSE_ERROR e = ensure_ws(h, n);
+    EI_IMPULSE_ERROR e = ensure_ws(h, std::max(n, n2) + 16);
     if (e) return e;
     kws_handle::Ws &w = h->ws;
+    KwsDspPlan other_plan;
+    if (n2 != n && (e = kws_plan_for_length(h, n2, &other_plan))) return e;
     // gather the window through the caller's callback (float samples, as the SDK hands them to the DSP block) straight into pinned
     // memory, with the reference's own sequence of calls; samples no frame covers (between frames of a stride above the frame length,
     // behind the last frame) are never asked for -- nor read by the kernels
     {
         float eos = 0.0f;                                                        // (the plan admits pre_shift == 1 only)
-        const int nfr = h->dsp.n_frames, frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
-        gather_constructor_call(signal, n, h->dsp.pre_shift, &eos);
-        const int r = gather_frames_like_reference(signal, w.h_x, nfr, frame_len, stride, h->dsp.pre_shift);
+        const int nfr = nfr2, frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
+        gather_constructor_call(signal, n2, shift, &eos);
+        const int r = gather_frames_like_reference(signal, w.h_x, nfr, frame_len, stride, shift);
         if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
         // x[-1] of the window is its last sample (processing.hpp:104-106 reads _end_of_signal_buffer): where no frame reaches the
         // window's end (the shipped shape: the last frame ends at 15 680 of 16 000) the constructor's answer is the only copy.  A frame
         // that covers it has fetched the same sample (a callback that fails the first call only would differ: 0 in the reference)
-        if ((size_t)(nfr - 1) * (size_t)stride + (size_t)frame_len < n) w.h_x[n - 1] = eos;
+        if (shift > 0 && (size_t)(nfr - 1) * (size_t)stride + (size_t)frame_len < n2) w.h_x[n2 - 1] = eos;
     }
     int dsp_ms = 0;
     uint64_t t1 = t0;
@@ -394,7 +422,7 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     // waits once; the cancellation hook the SDK polls between the stages (ei_run_classifier.h:689-691) is polled after the
     // wait with the same return value.  (Replaying the four stream operations as a captured HIP graph was measured too:
     // 90.7 vs 90.3 us per call, no gain on this runtime -- most of the call is the single wave's MFCC.)
-    e = oneshot_enqueue(h, w, n, C, debug, t0, &dsp_ms, &t1);
+    e = oneshot_enqueue(h, w, n2, C, debug, t0, &dsp_ms, &t1, n2 != n ? &other_plan : nullptr);
     if (e == EI_IMPULSE_CANCELED) return e;
     if (!e && hipStreamSynchronize(w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "run_classifier: device work failed");
     if (e) return e;
@@ -472,7 +500,7 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     g_cont_first_run = true;
     const size_t n_claimed = signal->total_length;
     float eos = 0.0f;                                                           // _end_of_signal_buffer (calloc)
-    gather_constructor_call(signal, n_claimed, m.dsp.pre_shift, &eos);          // before the size check below, as in the reference
+    gather_constructor_call(signal, n_claimed, gather_shift(h), &eos);          // before the size check below, as in the reference
     const int frame_len = h->dsp.frame_len, stride = h->dsp.frame_stride;
     const int nf = n_claimed >= (size_t)frame_len ? (int)floorf((float)(n_claimed - (size_t)frame_len) / (float)stride) : 0;
     const size_t feature_size = (size_t)(nf > 0 ? nf : 0) * (size_t)ncep;
@@ -489,7 +517,7 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
     memset(w.h_x, 0, n_x * sizeof(float));
     {
         // frame by frame, as the reference asks (gather_frames_like_reference)
-        const int r = gather_frames_like_reference(signal, w.h_x, nf, frame_len, stride, m.dsp.pre_shift);
+        const int r = gather_frames_like_reference(signal, w.h_x, nf, frame_len, stride, gather_shift(h));
         if (r != 0) { ei_printf("ERR: Failed to run DSP process (%d)\n", r); return fail(EI_IMPULSE_DSP_ERROR, "signal->get_data returned %d", r); }
     }
     w.h_s[0] = eos;                                                              // staged through pinned memory

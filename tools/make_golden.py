@@ -197,12 +197,50 @@ def get_data_trace(ref):
         print(k, len(out[k]), "calls; total_length after, error:", out[k + "_meta"].tolist(), "first:", out[k][:3].tolist())
 
 
+OTHER_LENGTHS = (16319, 16001, 15999, 15681, 15680, 15679, 8000, 1280, 960, 641, 640)
+
+
+def other_length(ref, synth, cfg):
+    """run_classifier on windows of another length than the model's 16 000 samples (ei_run_dsp.h:277-284 refuses only a feature matrix that
+    would not fit): per clip and length the compiled reference's return value and scores, the feature matrix it classified (its
+    extract_mfcc_features on that window, the rest at the calloc'd zeros) and the float32 twin's scores for that matrix through the
+    reference's op registrations.  Only lengths with 1 .. 49 frames (640 .. 16 319 samples): there the compiled reference is deterministic and
+    memory-safe (checked per length in processes of their own under MALLOC_CHECK_=3 with two MALLOC_PERTURB_ patterns).  A window with more
+    frames or none has no defined result in the reference: EIDSP_ERR is printf + assert(false) (dsp/config.hpp:65-67, EIDSP_USE_ASSERTS = 1 --
+    this SDK copy does not compile with 0), so it aborts, or under NDEBUG runs on: 16 320 / 16 321 / 16 640 / 17 000 samples overflow its
+    feature matrix (glibc: "free(): invalid next size"), 639 crashes after printing EIDSP_INPUT_MATRIX_EMPTY."""
+    clips = synth.synth(9, 0, 6).reshape(3, 32000)[:, :max(OTHER_LENGTHS)]
+    from kws_testlib import MODELS
+    twin = open(os.path.join(MODELS, "l476_no_yes_f32.kwsm"), "rb").read()
+    F = ref.n_features
+    rc = np.zeros((len(clips), len(OTHER_LENGTHS)), np.int32)
+    scores = np.zeros(rc.shape + (ref.n_labels,), np.float32)
+    twin_scores = np.zeros_like(scores)
+    feats = np.zeros(rc.shape + (F,), np.float32)
+    calls = np.zeros(rc.shape, np.int32)
+    for i, c in enumerate(clips):
+        for j, L in enumerate(OTHER_LENGTHS):
+            r, s, tl, gc = ref.run_classifier(c[:L])
+            assert tl == L
+            rc[i, j], scores[i, j], calls[i, j] = r, s, gc
+            if r == 0:
+                f = ref.extract_mfcc(c[:L], cfg)
+                feats[i, j, :f.size] = f
+                twin_scores[i, j] = ref.graph_run(twin, feats[i, j])[0]
+    np.savez_compressed(os.path.join(GOLDEN, "other_length_l476.npz"), clips=clips, lengths=np.int64(OTHER_LENGTHS), rc=rc, scores=scores, features=feats,
+                        twin_scores=twin_scores, get_data_calls=calls)
+    print("other_length_l476.npz", os.path.getsize(os.path.join(GOLDEN, "other_length_l476.npz")), "bytes; rc per length:", dict(zip(OTHER_LENGTHS, rc[0].tolist())),
+          "calls:", calls[0].tolist())
+
+
 def main():
     if "--only-qfb" in sys.argv:
         return qfb(Oracle(), L476_CONFIG())
     ref = Reference()
     if "--only-trace" in sys.argv:
         return get_data_trace(ref)
+    if "--only-other-length" in sys.argv:
+        return other_length(ref, Oracle(), L476_CONFIG())
     if "--only-mfcc40" in sys.argv:
         return mfcc40(ref, Oracle(), L476_CONFIG())
     if "--only-mfe-block" in sys.argv:
