@@ -331,3 +331,20 @@ def test_quantized_filterbank_option_pinned(oracle):
         for c in clips:
             assert (bits(oracle.extract_mfcc(c, cfg)) == bits(ref.extract_mfcc(c, cfg))).all(), kw
     assert changed >= 1
+
+def test_random_general_shape_configurations(oracle, reference):
+    """The random GENERAL-SHAPE configurations of tests/generic_soak.py (other fft lengths incl. non powers of two, 8 .. 64 filters, other frame
+    lengths / strides, 0.25 .. 2 s clips -- what csrc/kws_generic.hip serves): the reference's extract_mfcc_features == the restatement, bit for
+    bit.  The soak replays the same seeds on the GPU against the restatement (profiles/r04_generic_soak.txt)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("generic_soak", os.path.join(ROOT, "tests", "generic_soak.py"))
+    gs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gs)
+    sp = special_clips()
+    for seed in range(40, 440):
+        cfg_kw, _, n = gs.random_general_spec(seed)
+        cfg = L476_CONFIG().copy(**cfg_kw)
+        rnd = oracle.synth(1000 + seed, 0, 2).reshape(32000)[:n]
+        for c in (rnd, np.concatenate([sp["alternating_fullscale"]] * 2)[:n]):
+            a, b = oracle.extract_mfcc(c, cfg), reference.extract_mfcc(c, cfg)
+            assert a.shape == b.shape and (bits(a) == bits(b)).all(), (seed, cfg_kw)
