@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from kws_testlib import L476_CONFIG, Reference, bits, special_clips
+from kws_testlib import L476_CONFIG, ROOT, Reference, bits, special_clips
 
 pytestmark = pytest.mark.skipif(
     not __import__("kws_testlib").have_reference(), reason="oracle/_ref not built")
