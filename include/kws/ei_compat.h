@@ -48,7 +48,9 @@ typedef enum {
 
 /* dsp/numpy_types.h:234-253 with EIDSP_SIGNAL_C_FN_POINTER=1: 16 bytes on x86-64.
  * get_data(offset, length, out) must write `length` floats starting at sample `offset`,
- * returns 0 on success; it is never asked for data beyond total_length.
+ * returns 0 on success; it is never asked for data beyond total_length.  It is asked what the reference's DSP block asks, in that order
+ * (dsp/speechpy/processing.hpp:68, 86-94 under feature.hpp:263-281): the window's last sample, then per frame the sample before it and the
+ * frame -- 98 calls for the shipped 49-frame window; an MFE block: its frames only (tests/golden/get_data_trace_l476.npz).
  * The SDK's DEFAULT in C++ is the other form (get_data is a std::function, 40 bytes with libstdc++): a C++ application written for
  * that form defines KWS_SIGNAL_STD_FUNCTION before including this header -- signal_t is then that class, the C structure is called
  * kws_c_signal_t, and inline overloads at the end of this header bridge the two (nothing in the library's ABI changes). */
@@ -113,7 +115,11 @@ typedef struct {
 } ei_impulse_maf;
 
 /* classifier/ei_run_classifier.h:650  -- DSP blocks + run_inference on one window of audio.
- * `debug` prints the features and per-class scores through ei_printf, as the reference does. */
+ * `debug` prints the features and per-class scores through ei_printf, as the reference does.
+ * signal->total_length is normally the model's window; as in the reference (classifier/ei_run_dsp.h:277-286) a window of another length with
+ * at least one and at most the model's number of frames is classified from the frames that fit, the rest of the network's input at zero
+ * (MFCC blocks; tests/golden/other_length_l476.npz).  More frames, or none: EI_IMPULSE_DSP_ERROR -- the library's contract; the reference's
+ * default build asserts there (dsp/config.hpp:65-67) and has no result to match.  A non-zero get_data return: EI_IMPULSE_DSP_ERROR. */
 EI_IMPULSE_ERROR run_classifier(KWS_C_SIGNAL_T *signal, ei_impulse_result_t *result, bool debug);
 
 /* classifier/ei_run_classifier.h:293  -- quantise, run the network, dequantise */
