@@ -58,6 +58,7 @@ void kws_destroy(kws_handle *h)
     if (h->d_flags2) (void)hipFree(h->d_flags2);
     if (h->d_flags3) (void)hipFree(h->d_flags3);
     if (h->s_cep) (void)hipFree(h->s_cep);
+    for (hipEvent_t ev : h->gen_tune.ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &g : h->g_sets) for (void *p : { (void *)g.ws, (void *)g.mfcc, (void *)g.feat }) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         for (void *p : { (void *)h->pipe.pcm[k], (void *)h->pipe.s[k], (void *)h->pipe.f[k], (void *)h->pipe.q[k] }) if (p) (void)hipFree(p);
@@ -223,6 +224,53 @@ int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 
 // Buffers of the general MFCC kernels for a batch of B windows on stream s (B = 0: the transform scratch only).  A stream keeps
 // its set; when more than kGenericSets streams have been seen, the oldest set is handed on after the device has drained.
+// Which chunk length kws_spectral_lds_kernel runs with (8 or 4 frames, csrc/kws_generic.hip): measured, not guessed -- 4 is 15 - 22 % faster on
+// some shapes and 8 % slower on others and no rule here predicts which (profiles/r04_generic_rate.txt).  The first calls of a handle that bring
+// at least kGenTuneMinClips clips are timed between two events on their own stream -- 8, 4, 8, 4 -- and the one with the smaller time per clip is
+// used from then on.  Both are bit-exact: nothing but the time depends on the choice.  While it is being measured a call waits for the previous
+// timed call's kernel before it starts (four host waits in a handle's life).  KWS_DEV_GENERIC_LCH=4|8 pins the choice (A/B runs, tests).
+static const size_t kGenTuneMinClips = 2048;
+static int generic_chunk_begin(kws_handle *h, size_t B, hipStream_t s)
+{
+    const char *fe = getenv("KWS_DEV_GENERIC_LCH");          // (read per call: a test toggles it between handles)
+    const int forced = fe ? atoi(fe) : 0;
+    if (forced == 4 || forced == 8) return forced;
+    std::lock_guard<std::mutex> lk(h->g_mu);
+    kws_handle::GenericTune &T = h->gen_tune;
+    if (T.choice) return T.choice;
+    if (T.armed == 1) return 8;                               // another thread's timed call is in flight: do not disturb it
+    if (T.armed == 2) {                                       // collect what the previous timed call measured
+        float ms = 0.0f;
+        if (hipEventSynchronize(T.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, T.ev[0], T.ev[1]) == hipSuccess && T.clips) {
+            T.ms_per_clip[T.phase & 1] += (double)ms / (double)T.clips;
+            T.phase++;
+        }
+        T.armed = 0;
+        if (T.phase >= 4) { T.choice = T.ms_per_clip[0] <= T.ms_per_clip[1] ? 8 : 4; return T.choice; }
+    }
+    if (B < kGenTuneMinClips) return 8;                       // too small to time: the default, not a measurement
+    if (!T.ev[0] && (hipEventCreate(&T.ev[0]) != hipSuccess || hipEventCreate(&T.ev[1]) != hipSuccess)) { T.choice = 8; return 8; }
+    T.armed = 1;
+    T.clips = B;
+    (void)hipEventRecord(T.ev[0], s);
+    return (T.phase & 1) ? 4 : 8;
+}
+static void generic_chunk_end(kws_handle *h, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(h->g_mu);
+    if (h->gen_tune.armed == 1) { (void)hipEventRecord(h->gen_tune.ev[1], s); h->gen_tune.armed = 2; }
+}
+// the general-shape spectral launch with the handle's chunk length (the scratch kernel ignores it)
+static int launch_spectral_generic_for(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc, const float *wrap,
+                                       int out_stride, float *ws, hipStream_t s)
+{
+    const bool lds = kws_generic_uses_lds(P);
+    const int lch = lds ? generic_chunk_begin(h, B, s) : 8;
+    const int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, ws, grid_cap_mfcc(h), lch, s);
+    if (lds) generic_chunk_end(h, s);
+    return rc;
+}
+
 EI_IMPULSE_ERROR generic_for(kws_handle *h, hipStream_t s, size_t B, kws_handle::GenericBuf **out)
 {
     std::lock_guard<std::mutex> lk(h->g_mu);
@@ -270,7 +318,7 @@ EI_IMPULSE_ERROR spectral_device(kws_handle *h, const KwsDspPlan &P, const void 
         kws_handle::GenericBuf *g = nullptr;
         EI_IMPULSE_ERROR e = generic_for(h, s, 0, &g);
         if (e) return e;
-        int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, g->ws, grid_cap_mfcc(h), s);
+        int rc = launch_spectral_generic_for(h, P, pcm, is_float, B, mfcc, wrap, out_stride, g->ws, s);
         if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
     }
@@ -300,7 +348,7 @@ EI_IMPULSE_ERROR mfcc_fused_device_plan(kws_handle *h, const KwsDspPlan &P, cons
         kws_handle::GenericBuf *g = nullptr;
         EI_IMPULSE_ERROR e = generic_for(h, s, B, &g);
         if (e) return e;
-        int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, g->mfcc, nullptr, 0, g->ws, grid_cap_mfcc(h), s);
+        int rc = launch_spectral_generic_for(h, P, pcm, is_float, B, g->mfcc, nullptr, 0, g->ws, s);
         if (!rc) rc = kws_launch_cmvn_generic(P, g->mfcc, (int)B, features, q, h->nn.in_scale, h->nn.in_zp, s);
         if (rc) return fail(KWS_ERROR_HIP, "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;
@@ -517,6 +565,9 @@ EI_IMPULSE_ERROR kws_extract_mfcc_batch_device(kws_handle *h, const int16_t *pcm
     if (h->mode == KWS_MODE_FAST) return classify_fast_device(h, pcm, B, nullptr, features, true, q_in, (hipStream_t)stream);
     return mfcc_fused_device(h, pcm, 0, B, features, q_in, (hipStream_t)stream);
 }
+
+// development / test aid (not in the public headers): kws_spectral_lds_kernel's chunk length on this handle: 0 while it is being measured
+int kws_dev_generic_chunk(const kws_handle *h) { return h ? h->gen_tune.choice : 0; }
 
 // development aid (not in the public headers): per-phase shader-clock totals of wave 0 of the float network kernel
 extern long long *kws_dev_f32_prof;

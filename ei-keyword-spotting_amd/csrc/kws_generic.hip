@@ -246,13 +246,15 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
 //    * per chunk: frame energies (a lane per frame: numpy::sum is a sequential sum), the mel filterbank ((frame, filter) items over the
 //      lanes, ascending-bin dot products), log, and the DCT of all the chunk's frames at once ((frame, butterfly) items over the lanes),
 //      c0 <- log(energy), cepstra to HBM.
-//  LDS: complex buffer 2 (ncfft + ncfft/16) floats, the frame's samples fft_len, the leaf-order table ncfft ints, LCH power rows of
-//  n_bins | 1 floats, LCH mel rows, the DCT's arrays 3 NF + 2 per frame: 27 KB for fft 512 / 32 filters (LCH = 16), i.e. five waves per
-//  CU instead of a scratch that lived in L2.
+//  LDS (lds_layout): complex buffer 2 (ncfft + ncfft/16) floats, the leaf-order table ncfft ints, LCH power rows of n_bins | 1 floats, LCH mel
+//  rows, the DCT's arrays per frame, and the model's tables: 20 - 22 KB for fft 512 / 32 filters at LCH = 8 (14 - 16 KB at 4), i.e. seven or
+//  eight waves per CU, instead of a scratch that lived in L2.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef LCH
-#define LCH 8                                     // frames per chunk (measured, 8 192 clips of fft 512 x 49 frames: 16 -> 2.29 ms, 8 -> 1.29 / 1.30 ms in two calls, 4 -> 1.30 ms; 4 is faster on fft 1024 and on 98 frames, slower on fft 128: profiles/r04_generic_rate.txt.  The LDS per wave bounds how many waves a CU holds)
-#endif
+// frames per chunk: a template parameter, 8 or 4 (16: 2.29 ms for 8 192 clips of fft 512 x 49 frames, 8: 1.29 / 1.30 ms in two calls, 4: 1.30 ms; 4 is
+// 22 % / 15 % faster on 98-frame windows and on fft 1024, 8 % slower on fft 128: profiles/r04_generic_rate.txt).  The LDS per wave bounds how many
+// waves a CU holds, the per-chunk phases favour longer chunks: no rule here predicts the winner, so kws_api.cpp measures it per handle on the
+// handle's own first large calls (generic_chunk_begin) and passes the choice to kws_launch_spectral_generic.
+constexpr int KWS_LCH_DEFAULT = 8;
 // development aid: shader-clock totals per phase of workgroup 0 (kws_dev_generic_prof; tools/gpu_generic_rate.py --prof)
 __device__ long long g_gen_prof[8];
 #define GPH(i) do { const long long now_ = clock64(); if (blockIdx.x == 0 && lane == 0) g_gen_prof[i] += now_ - tlast_; tlast_ = now_; } while (0)
@@ -322,7 +324,7 @@ __device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstrid
 // + the model's tables, staged once per workgroup (every read of them sits on a lane's serial path: from L2 a tap of a mel filter or a
 // twiddle costs a round trip of ~1 us; measured: the first version, tables in L2, ran at 9.9 ns per frame against the scratch kernel's 12.4)
 struct LdsLayout { int z, y, perm, ps, ps_stride, mel, mel_stride, dct, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, total; };
-__host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int nnz)
+__host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int nnz, int LCH)
 {
     LdsLayout L;
     const int ncfft = fft / 2;
@@ -346,7 +348,7 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int 
     return L;
 }
 
-template <bool F32IN>
+template <bool F32IN, int LCH>
 __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips, float *__restrict__ mfcc_out,
                                                                const float *__restrict__ wrap, int out_stride)
 {
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
     const int lane = threadIdx.x;
     const int nfr = P.n_frames, NF = P.n_filters, ncep = P.n_cepstral, fft = P.fft_len, nbins = P.n_bins, ncfft = fft >> 1;
     const int nnz = P.filt_nnz;
-    const LdsLayout L = lds_layout(fft, NF, nbins, nnz);
+    const LdsLayout L = lds_layout(fft, NF, nbins, nnz, LCH);
     float *Z = glds + L.z, *PS = glds + L.ps, *MEL = glds + L.mel, *DCT = glds + L.dct;
     int *perm = (int *)(glds + L.perm);
     float2 *l_tw = (float2 *)(glds + L.tw), *l_stw = (float2 *)(glds + L.stw), *l_dtw = (float2 *)(glds + L.dtw), *l_dstw = (float2 *)(glds + L.dstw);
@@ -634,7 +636,7 @@ __global__ void kws_cmvn_generic_kernel(KwsDspPlan P, const float *__restrict__ 
 bool kws_generic_uses_lds(const KwsDspPlan &P)
 {
     static const bool forced_scratch = getenv("KWS_DEV_GENERIC_SCRATCH") != nullptr;
-    return !forced_scratch && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz).total * sizeof(float) <= 72 * 1024;
+    return !forced_scratch && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, KWS_LCH_DEFAULT).total * sizeof(float) <= 72 * 1024;
 }
 
 // development aid (not in the public headers): read and clear the phase clocks of kws_spectral_lds_kernel's workgroup 0
@@ -647,34 +649,42 @@ extern "C" __attribute__((visibility("default"))) int kws_dev_generic_prof(long 
 
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid) { if (kws_generic_uses_lds(P)) return 64; return (size_t)grid * g_ws_floats(P.fft_len, P.n_filters) * GL * sizeof(float); }
 
+template <int LCH>
+static int launch_spectral_lds(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap, int out_stride,
+                               int grid, hipStream_t stream)
+{
+    const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH).total * sizeof(float);
+    static std::atomic<unsigned long long> attr_done{ 0 };      // (one per instantiation pair)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<true, LCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<false, LCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return (int)hipGetLastError();
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    const long litems = (long)n_clips * ((P.n_frames + LCH - 1) / LCH);
+    // persistent-ish grid: as many one-wave workgroups as the LDS lets a CU hold (up to 8), times the CUs (grid = 8 x CUs from the caller)
+    int lgrid = grid * 2;
+    if (litems < lgrid) lgrid = (int)litems;
+    if (pcm_is_float)
+        hipLaunchKernelGGL((kws_spectral_lds_kernel<true, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
+    else
+        hipLaunchKernelGGL((kws_spectral_lds_kernel<false, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
+    return (int)hipGetLastError();
+}
+
+// lch: frames per chunk of the LDS kernel, 4 or 8 (anything else: 8); ignored by the scratch kernel
 int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
-                                int out_stride, float *ws, int grid, hipStream_t stream)
+                                int out_stride, float *ws, int grid, int lch, hipStream_t stream)
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
     if (out_stride == 0) out_stride = P.n_frames * (P.mfe_mel ? P.n_filters : P.n_cepstral);
-    if (kws_generic_uses_lds(P)) {
-        const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz).total * sizeof(float);
-        static std::atomic<unsigned long long> attr_done{ 0 };
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            if (hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return (int)hipGetLastError();
-            attr_done.fetch_or(bit, std::memory_order_release);
-        }
-        const long litems = (long)n_clips * ((P.n_frames + LCH - 1) / LCH);
-        // persistent-ish grid: as many one-wave workgroups as the LDS lets a CU hold (up to 8), times the CUs (grid = 8 x CUs from the caller)
-        int lgrid = grid * 2;
-        if (litems < lgrid) lgrid = (int)litems;
-        if (pcm_is_float)
-            hipLaunchKernelGGL(kws_spectral_lds_kernel<true>, dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
-        else
-            hipLaunchKernelGGL(kws_spectral_lds_kernel<false>, dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
-        return (int)hipGetLastError();
-    }
+    if (kws_generic_uses_lds(P))
+        return lch == 4 ? launch_spectral_lds<4>(P, pcm, pcm_is_float, n_clips, mfcc_out, wrap, out_stride, grid, stream)
+                        : launch_spectral_lds<8>(P, pcm, pcm_is_float, n_clips, mfcc_out, wrap, out_stride, grid, stream);
     const long items = (long)n_clips * ((P.n_frames + GL - 1) / GL);
     if (items < grid) grid = (int)items;
     if (pcm_is_float)

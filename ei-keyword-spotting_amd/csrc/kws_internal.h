@@ -58,7 +58,7 @@ int kws_launch_resample(const float *in, size_t n_in, float *out, size_t n_out, 
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid);
 bool kws_generic_uses_lds(const KwsDspPlan &P);       // the LDS-resident cooperative kernel serves this configuration (else: the scratch-in-HBM kernel)
 int kws_launch_spectral_generic(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap,
-                                int out_stride, float *ws, int grid, hipStream_t stream);
+                                int out_stride, float *ws, int grid, int lch /* frames per chunk of the LDS kernel: 4 or 8 */, hipStream_t stream);
 int kws_launch_cmvn_generic(const KwsDspPlan &P, const float *mfcc, int n_clips, float *features, int8_t *q_out, float in_scale, int in_zp,
                             hipStream_t stream);
 int kws_launch_synth(uint32_t seed, uint32_t first_clip, uint32_t n_clips, uint32_t clip_len, int16_t *out, hipStream_t stream);
@@ -159,6 +159,8 @@ struct kws_handle {
     const KwsNnPlanF32 *d_nnf = nullptr;   // the same plan in device memory (the float kernel reads it from there)
     int pooled_tap_bytes = 0;
     std::vector<void *> dev_allocs;
+    // kws_spectral_lds_kernel's frames per chunk, measured per handle on its own first large calls (kws_api.cpp generic_chunk_begin / _end)
+    struct GenericTune { int choice = 0, phase = 0, armed = 0; size_t clips = 0; hipEvent_t ev[2] = { nullptr, nullptr }; double ms_per_clip[2] = { 0.0, 0.0 }; } gen_tune;
     std::map<int, const int *> pad_maps_by_rows;     // kws_plan_for_length: cmvnw pad maps for other row counts than the model's (device, in dev_allocs)
     // scratch for the combined entry points (grown on demand)
     float *s_mfcc = nullptr;      // cepstra before CMVN, [B][n_features]

@@ -172,3 +172,50 @@ def test_quantized_filterbank_models_on_gpu(name, pkg, oracle, tmp_path):
     so, fo, qo = om.run_batch(clips, want_features=True)
     assert (bits(f) == bits(fo)).all() and (q == qo).all() and (bits(s) == bits(so)).all(), name
     gm.close()
+
+@pytest.mark.parametrize("name", ["fft1024_filters36", "stride10ms_win31", "fft128_win51"])
+def test_chunk_length_is_measured_per_handle_and_never_changes_a_bit(name, pkg, oracle, tmp_path, monkeypatch):
+    """kws_spectral_lds_kernel runs with eight or four frames per chunk (csrc/kws_generic.hip); which is faster depends on the shape, so a handle
+    measures it on its own first large calls (kws_api.cpp generic_chunk_begin).  Both pinned values and the measured path give the oracle's bits."""
+    import ctypes
+    import torch
+    kw = dict(BLOCKS, **CASES[name])
+    blob = synth_model_blob(seed=3, **kw)
+    path = str(tmp_path / "m.kwsm")
+    open(path, "wb").write(blob)
+    om = OracleModel(oracle, path)
+    n = om.raw_sample_count
+    B = 4096
+    clips = np.ascontiguousarray(np.tile(oracle.synth(6, 0, 64, n), (B // 64, 1)))
+    _, fo, _ = om.run_batch(clips[:64], want_features=True)
+    d = torch.from_numpy(clips).to("cuda:0")
+    L = pkg.lib()
+    L.kws_dev_generic_chunk.argtypes = [ctypes.c_void_p]
+
+    def features(gm):
+        ft = torch.zeros((B, gm.n_features), dtype=torch.float32, device="cuda:0")
+        gm.extract_mfcc_batch_device(d.data_ptr(), B, ft.data_ptr())
+        torch.cuda.synchronize()
+        f = ft.cpu().numpy()
+        assert (bits(f[:64]) == bits(fo)).all() and (bits(f[64:128]) == bits(fo)).all() and (bits(f[-64:]) == bits(fo)).all()
+
+    for pinned in ("8", "4"):
+        monkeypatch.setenv("KWS_DEV_GENERIC_LCH", pinned)
+        gm = pkg.Model(blob=blob)
+        assert gm.mfcc_kernel == "kws_spectral_lds_kernel"
+        features(gm)
+        assert L.kws_dev_generic_chunk(gm.h) == 0                      # pinned from outside: the handle has not measured anything
+        gm.close()
+    monkeypatch.delenv("KWS_DEV_GENERIC_LCH")
+    gm = pkg.Model(blob=blob)
+    for k in range(6):
+        assert L.kws_dev_generic_chunk(gm.h) == 0 or k >= 5
+        features(gm)
+    assert L.kws_dev_generic_chunk(gm.h) in (4, 8)
+    features(gm)
+    # a small batch is never timed and runs with the default
+    gm2 = pkg.Model(blob=blob)
+    s, f, _ = gm2.run_classifier_batch(clips[:64], want_features=True)
+    assert (bits(f) == bits(fo)).all() and L.kws_dev_generic_chunk(gm2.h) == 0
+    gm.close()
+    gm2.close()

@@ -43,7 +43,7 @@ def child(n):
         ft = torch.zeros((n, gm.n_features), dtype=torch.float32, device="cuda:0")
         res = []
         for fn in (lambda: gm.mfcc_batch_device(pcm.data_ptr(), n, mf.data_ptr()), lambda: gm.extract_mfcc_batch_device(pcm.data_ptr(), n, ft.data_ptr())):
-            for _ in range(2):
+            for _ in range(6):                                   # (the handle measures its chunk length on its first five large calls)
                 fn()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -52,7 +52,12 @@ def child(n):
                 fn()
             torch.cuda.synchronize()
             res.append((time.perf_counter() - t0) / reps)
-        print("RATE|%s|%s|%d|%.6f|%.6f" % (name, gm.mfcc_kernel, gm.n_frames, res[0], res[1]), flush=True)
+        chunk = 0
+        if hasattr(pkg.lib(), "kws_dev_generic_chunk"):
+            import ctypes
+            pkg.lib().kws_dev_generic_chunk.argtypes = [ctypes.c_void_p]
+            chunk = pkg.lib().kws_dev_generic_chunk(gm.h)
+        print("RATE|%s|%s|%d|%.6f|%.6f|%d" % (name, gm.mfcc_kernel, gm.n_frames, res[0], res[1], chunk), flush=True)
         if gm.mfcc_kernel == "kws_spectral_lds_kernel" and hasattr(pkg.lib(), "kws_dev_generic_prof"):
             import ctypes
             buf = (ctypes.c_longlong * 8)()
@@ -70,7 +75,7 @@ def main():
         return child(int(sys.argv[2]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     rows = {}
-    for tag, env in (("lds", {}), ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"})):
+    for tag, env in (("lds", {}), ("lds8", {"KWS_DEV_GENERIC_LCH": "8"}), ("lds4", {"KWS_DEV_GENERIC_LCH": "4"}), ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"})):
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if out.returncode != 0:
             print(tag, "FAILED", out.stderr[-1500:])
@@ -78,16 +83,21 @@ def main():
             if ln.startswith("PROF|") and tag == "lds":
                 print(ln)
             if ln.startswith("RATE|"):
-                _, name, kern, nfr, t_spec, t_all = ln.split("|")
-                rows.setdefault(name, {})[tag] = (kern, int(nfr), float(t_spec), float(t_all))
+                _, name, kern, nfr, t_spec, t_all, chunk = (ln.split("|") + ["0"])[:7]
+                rows.setdefault(name, {})[tag] = (kern, int(nfr), float(t_spec), float(t_all), int(chunk))
     print("# %d clips per call; speechpy::feature::mfcc (cepstra before cmvnw) and extract_mfcc_features (with cmvnw); ns per frame = time / (clips x frames)" % n)
+    print("# lds = the handle's own measured chunk length (the number in brackets; 0 = not settled), lds8 / lds4 = pinned with KWS_DEV_GENERIC_LCH, scratch = round 1's kernel")
     for name, r in rows.items():
         parts = []
-        for tag in ("lds", "scratch"):
+        for tag in ("lds", "lds8", "lds4", "scratch"):
             if tag in r:
-                kern, nfr, ts, ta = r[tag]
-                parts.append("%s [%s]: mfcc %.3f ms (%.1f ns/frame), extract %.3f ms (%.1f ns/frame)" % (tag, kern, ts * 1e3, ts / (n * nfr) * 1e9, ta * 1e3, ta / (n * nfr) * 1e9))
-        print("%-40s %s" % (name, "  |  ".join(parts)))
+                kern, nfr, ts, ta, chunk = r[tag]
+                parts.append("%s%s %.3f | %.3f ms" % (tag, (" [chunk %d]" % chunk) if tag == "lds" else "", ts * 1e3, ta * 1e3))
+        kern, nfr = r.get("lds", next(iter(r.values())))[:2]
+        print("%-40s %3d frames  %-26s %s" % (name, nfr, kern, "   ".join(parts)))
+        if all(t in r for t in ("lds", "lds8", "lds4")) and r["lds"][0] == "kws_spectral_lds_kernel":
+            best = min(r["lds8"][2], r["lds4"][2])
+            print("%-40s             measured choice within %.1f %% of the better pinned one (cepstra)" % ("", 100.0 * (r["lds"][2] / best - 1.0)))
 
 
 if __name__ == "__main__":
