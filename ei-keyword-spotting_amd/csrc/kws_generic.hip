@@ -630,6 +630,48 @@ __global__ void kws_cmvn_generic_kernel(KwsDspPlan P, const float *__restrict__ 
     }
 }
 
+// processing::cmvnw (processing.hpp:326-389) with the clip's PADDED cepstra matrix in LDS (round 4): the kernel above asks global memory for the
+// pad map's entry and then for the cepstrum it names, twice per window term -- two dependent round trips where the arithmetic is three
+// instructions.  Here one wave stages rows pad_map[0 .. nfr + 2 pad) of its clip once (numpy::pad_1d_symmetric, numpy.hpp:479-541, as an index map),
+// and the window of output row r is then padded rows r .. r + win - 1: one LDS read per term, lanes on consecutive elements (consecutive
+// addresses: no bank conflict), the sums in the reference's order term by term as before -- the same expressions on the same values.
+__global__ __launch_bounds__(64) void kws_cmvn_lds_kernel(KwsDspPlan P, const float *__restrict__ mfcc, int n_clips, float *__restrict__ features,
+                                                          int8_t *__restrict__ q_out, float in_scale, int in_zp)
+{
+    extern __shared__ __attribute__((aligned(16))) float cpm[];
+    const int nfr = P.n_frames, ncep = P.n_cepstral, win = P.win_size, lane = threadIdx.x;
+    const int per_clip = nfr * ncep, padded = (nfr + 2 * P.pad) * ncep;
+    const float fwin = (float)win;
+    for (int clip = blockIdx.x; clip < n_clips; clip += gridDim.x) {
+        const float *src = mfcc + (size_t)clip * per_clip;
+        for (int i = lane; i < padded; i += 64) {
+            const int row = i / ncep, c = i - row * ncep;
+            cpm[i] = src[P.pad_map[row] * ncep + c];
+        }
+        WAVE_SYNC();
+        for (int e = lane; e < per_clip; e += 64) {
+            const float *w0 = cpm + e;                                  // padded row r, column c of element e = r ncep + c
+            float sum = 0.0f;
+#pragma unroll 8
+            for (int j = 0; j < win; j++) sum += w0[j * ncep];
+            const float mean = sum / fwin;
+            float sd = 0.0f;
+#pragma unroll 8
+            for (int j = 0; j < win; j++) {
+                const float d = w0[j * ncep] - mean;
+                const double dd = (double)d;
+                sd = (float)__fma_rn(dd, dd, (double)sd);
+            }
+            const float dev = sqrtf(sd / fwin);
+            const float o = (w0[P.pad * ncep] - mean) / (dev + FLT_EPSILON);      // the row itself: padded row r + pad
+            const size_t out = (size_t)clip * per_clip + e;
+            if (features) features[out] = o;
+            if (q_out) q_out[out] = quantize_feature(o, in_scale, in_zp);
+        }
+        WAVE_SYNC();                                                    // the next clip overwrites the matrix
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // the LDS-resident kernel serves every general configuration whose arrays fit a CU's LDS twice over (fft up to 2048 with 64 filters);
 // KWS_DEV_GENERIC_SCRATCH=1 keeps the round-1 kernel with its scratch in HBM (same-box comparisons)
@@ -699,6 +741,17 @@ int kws_launch_cmvn_generic(const KwsDspPlan &P, const float *mfcc, int n_clips,
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
+    // the padded matrix of one clip in LDS when it fits 64 KB (199 x 13 floats = 10 KB for a 2 s window; 342 x 64 would be 87 KB); KWS_DEV_CMVN_GLOBAL=1
+    // keeps the one-thread-per-element kernel (same-box comparisons)
+    const size_t smem = (size_t)(P.n_frames + 2 * P.pad) * P.n_cepstral * sizeof(float);
+    static const bool forced_global = getenv("KWS_DEV_CMVN_GLOBAL") != nullptr;
+    if (smem <= 64 * 1024 && !forced_global) {
+        // one-wave workgroups, as many as the LDS lets a CU hold (up to 16), over 256 CUs' worth
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(smem, 1)));
+        const int grid = std::min(n_clips, 256 * per_cu);
+        hipLaunchKernelGGL(kws_cmvn_lds_kernel, dim3(grid), dim3(64), smem, stream, P, mfcc, n_clips, features, q_out, in_scale, in_zp);
+        return (int)hipGetLastError();
+    }
     const size_t n = (size_t)n_clips * P.n_frames * P.n_cepstral;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 65536);
     hipLaunchKernelGGL(kws_cmvn_generic_kernel, dim3(grid), dim3(256), 0, stream, P, mfcc, n, features, q_out, in_scale, in_zp);
