@@ -397,6 +397,16 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         lv_fs[l] = fsv;
         lv_inv[l] = (int)((1u << 20) / (unsigned)lv_m[l] + 1u);
     }
+    // the first trip's frame-independent parts (see the load phase): destination in Z (-1: beyond the fft length), clamped sample index, "is a used sample"
+    int dst0[8], ncl0[8];
+    unsigned used0 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int n = 64 * j + lane;
+        dst0[j] = n < fft ? 2 * zpad(perm[min(n, fft - 1) >> 1]) + (n & 1) : -1;
+        ncl0[j] = min(n, used - 1);
+        used0 |= (unsigned)(n < used) << j;
+    }
     long long tlast_ = clock64();
     for (int item = blockIdx.x; item < n_clips * chunks; item += gridDim.x) {
         const int clip = item / chunks, f0 = (item - clip * chunks) * LCH;
@@ -407,10 +417,29 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         };
         for (int fi = 0; fi < nfc; fi++) {
             // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing.  Eight samples
-            //      per lane and trip, all sixteen loads (sample, predecessor) requested before the first is used, no branch per sample: the
-            //      first version's loop waited for two dependent round trips per sample (16 per fft-512 frame: 40 % of the kernel)
+            //      per lane and trip, requested together (the first version's loop waited for two dependent round trips per sample: 40 % of
+            //      the kernel).  First trip (a whole frame up to fft 512): where a sample goes (dst0) and which one a lane reads (ncl0) do not
+            //      depend on the frame and are set up once per workgroup; the predecessor of sample n is what the neighbouring lane has just
+            //      loaded -- lane 0's is lane 63's of the slot before, or one more load for the frame's first sample.
             const int off = (f0 + fi) * P.frame_stride;
-            for (int n0 = 0; n0 < fft; n0 += 8 * 64) {
+            {
+                float xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) xv[j] = sample(off + ncl0[j]);
+                float first_prev = sample(off == 0 ? P.n_samples - 1 : off - 1);
+                if (wrap && off == 0) first_prev = wrap[clip];
+                float carry = first_prev;                                // sample 64 j - 1: lane 63 of the slot before
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float up = __shfl_up(xv[j], 1, KWS_WAVE);
+                    const float prev = lane == 0 ? carry : up;
+                    carry = __shfl(xv[j], KWS_WAVE - 1, KWS_WAVE);
+                    const float pl = P.pre_cof * prev;
+                    // sample n is the real (n even) or imaginary (n odd) part of kiss_fftr's input point n / 2, which sits at leaf perm[n / 2]
+                    if (dst0[j] >= 0) Z[dst0[j]] = ((used0 >> j) & 1) ? xv[j] - pl : 0.0f;
+                }
+            }
+            for (int n0 = 8 * 64; n0 < fft; n0 += 8 * 64) {
                 float xv[8], pv[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -424,7 +453,6 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                     const int n = n0 + 64 * j + lane;
                     const float prev = (wrap && off + n == 0) ? wrap[clip] : pv[j];
                     const float pl = P.pre_cof * prev;
-                    // sample n is the real (n even) or imaginary (n odd) part of kiss_fftr's input point n / 2, which sits at leaf perm[n / 2]
                     if (n < fft) Z[2 * zpad(perm[n >> 1]) + (n & 1)] = n < used ? xv[j] - pl : 0.0f;
                 }
             }
