@@ -77,8 +77,17 @@ static void walk(kws_handle *h)
     ei_impulse_result_t res;
     memset(&res, 0, sizeof res);
     (void)run_classifier(&sig, &res, false);
+    // windows of another length (kws_plan_for_length: a plan per frame count, cached pad maps; the gather with fewer frames), and the refused ones
+    for (size_t len : { n - 1, n + 1, n / 2, n / 2 + 7, (size_t)640, (size_t)641, (size_t)639, (size_t)1, (size_t)0, n + n / 16, 2 * n, n - 1 }) {
+        g_audio.assign(len + 4, 0.125f);
+        sig.total_length = len;
+        (void)run_classifier(&sig, &res, false);              // (debug = true would print to stdout, which the test parses line by line)
+    }
+    g_audio.assign(n, 0.25f);
     run_classifier_init();
     sig.total_length = n / 4;
+    (void)run_classifier_continuous(&sig, &res, false);
+    sig.total_length = n / 8;                                    // a shorter slice: fewer frames per call
     (void)run_classifier_continuous(&sig, &res, false);
 }
 
