@@ -377,13 +377,13 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     // Outside that range the reference has no result to match: its check for a matrix that does not fit (ei_run_dsp.h:279-284) and
     // feature.hpp's EIDSP_INPUT_MATRIX_EMPTY end in EIDSP_ERR = printf + assert(false) (dsp/config.hpp:65-67; the return-code form does not
     // compile for this SDK copy) -- an abort, or under NDEBUG a run into the overflow (observed: 16 320, 16 321, 16 640, 17 000 samples) or
-    // a crash (639).  The library returns EI_IMPULSE_DSP_ERROR there with the message run_classifier prints for a failed DSP block.  Also
-    // refused: other lengths for an MFE block (the same rule in the L432 copy's text, ei_run_dsp.h:381-386, but that copy's run_classifier
-    // cannot be compiled here to pin it).
+    // a crash (639).  The library returns EI_IMPULSE_DSP_ERROR there with the message run_classifier prints for a failed DSP block.  An MFE
+    // block follows the same rule (L432 ei_run_dsp.h:379-389; that copy's run_classifier cannot be compiled here, so its case is pinned by
+    // the copy's compiled leaves: tests/golden/mfe_other_length_l432.npz).
     const size_t n2 = signal->total_length;
     const int shift = gather_shift(h);
     const int nfr2 = n2 == n ? h->dsp.n_frames : kws_frames_for_length(h, n2);
-    if (n2 != n && (nfr2 > h->dsp.n_frames || nfr2 < 1 || h->model.dsp.block == DSP_BLOCK_MFE)) {
+    if (n2 != n && (nfr2 > h->dsp.n_frames || nfr2 < 1)) {
         float eos_unused = 0.0f;                                                 // the pre-emphasis object exists by then: its call has been made
         gather_constructor_call(signal, n2, shift, &eos_unused);
         if (nfr2 > h->dsp.n_frames) {                                            // ei_run_dsp.h:280-282
@@ -442,6 +442,19 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     memcpy(scores.data(), w.h_s, C * sizeof(float));
     fill_result(h, result, scores.data(), debug, nn_ms);
     if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+    return EI_IMPULSE_OK;
+}
+
+// development / test aid (not in the public headers): the feature matrix the last run_classifier() call of the default model classified
+// (the DSP block's output with the zero tail of a shorter window), copied from the device
+EI_IMPULSE_ERROR kws_dev_oneshot_features(float *out, size_t n)
+{
+    kws_handle *h = kws_default_model();
+    if (!h || !out) return fail(KWS_ERROR_BAD_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> sdk_lk(h->sdk_mu);
+    if (!h->ws.d_f || n != h->model.nn_input_frame_size) return fail(KWS_ERROR_BAD_ARGUMENT, "no one-shot call yet, or %zu is not the model's feature count", n);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(out, h->ws.d_f, n * sizeof(float), hipMemcpyDeviceToHost));
     return EI_IMPULSE_OK;
 }
 

@@ -118,7 +118,7 @@ typedef struct {
  * `debug` prints the features and per-class scores through ei_printf, as the reference does.
  * signal->total_length is normally the model's window; as in the reference (classifier/ei_run_dsp.h:277-286) a window of another length with
  * at least one and at most the model's number of frames is classified from the frames that fit, the rest of the network's input at zero
- * (MFCC blocks; tests/golden/other_length_l476.npz).  More frames, or none: EI_IMPULSE_DSP_ERROR -- the library's contract; the reference's
+ * (tests/golden/other_length_l476.npz; an MFE block: mfe_other_length_l432.npz).  More frames, or none: EI_IMPULSE_DSP_ERROR -- the library's contract; the reference's
  * default build asserts there (dsp/config.hpp:65-67) and has no result to match.  A non-zero get_data return: EI_IMPULSE_DSP_ERROR. */
 EI_IMPULSE_ERROR run_classifier(KWS_C_SIGNAL_T *signal, ei_impulse_result_t *result, bool debug);
 

@@ -65,6 +65,15 @@ def _sdk_call(pkg, clip, n_claimed, n_labels=4):
     return rc, np.float32([res.classification[i].value for i in range(n_labels)]), sig.total_length
 
 
+def _oneshot_features(pkg, n):
+    """the feature matrix the last run_classifier() call classified (kws_dev_oneshot_features: a test aid outside the public headers)"""
+    out = np.zeros(n, np.float32)
+    L = pkg.lib()
+    L.kws_dev_oneshot_features.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    assert L.kws_dev_oneshot_features(out.ctypes.data_as(ctypes.c_void_p), n) == 0
+    return out
+
+
 @pytest.mark.gpu
 def test_run_classifier_on_other_lengths_matches_the_reference(gold):
     from __graft_entry__ import load_package
@@ -76,6 +85,7 @@ def test_run_classifier_on_other_lengths_matches_the_reference(gold):
             for j, L in enumerate(gold["lengths"]):
                 rc, s, tl = _sdk_call(pkg, clip[:L], int(L))
                 assert rc == 0 and tl == L, (name, int(L), rc)
+                assert (bits(_oneshot_features(pkg, 637)) == bits(gold["features"][i, j])).all(), (name, i, int(L))     # the matrix it classified
                 if tol == 0.0:
                     assert (bits(s) == bits(gold[key][i, j])).all(), (name, i, int(L), s, gold[key][i, j])
                 else:
@@ -89,3 +99,53 @@ def test_run_classifier_on_other_lengths_matches_the_reference(gold):
             rc, s, tl = _sdk_call(pkg, clip[:L], L)
             assert rc == -5 and tl == L and (s == 0).all(), (name, L, rc)
         m.close()
+
+
+# ---- a model whose DSP block is MFE (L432 copy): the same rule (ei_run_dsp.h:379-389), no pre-emphasis object, cmvnw(win, false, true) + normalize
+#      over the rows that fit.  That copy's run_classifier cannot be compiled here: tests/golden/mfe_other_length_l432.npz is composed from its
+#      compiled leaves (tools/make_golden.py --only-mfe-other-length), as tests/golden/mfe_model_l432.npz is.
+def _mfe_blob():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from kws_testlib import synth_model_blob
+    from make_golden import MFE_MODEL_KW
+    return synth_model_blob(**MFE_MODEL_KW)
+
+
+def test_oracle_composition_matches_the_leaves_for_an_mfe_block(oracle, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "mfe_other_length_l432.npz"))
+    path = str(tmp_path / "mfe.kwsm")
+    open(path, "wb").write(_mfe_blob())
+    om = OracleModel(oracle, path)
+    cfg = L476_CONFIG().copy(pre_cof=0.0)
+    F = 49 * cfg.num_filters
+    for i, clip in enumerate(g["clips"]):
+        for j, L in enumerate(g["lengths"]):
+            f = oracle.extract_mfe(clip[:L], cfg)
+            padded = np.zeros(F, np.float32)
+            padded[:f.size] = f
+            assert f.size == cfg.num_filters * ((int(L) - 320) // 320)
+            assert (bits(padded) == bits(g["features"][i, j])).all(), (i, int(L))
+            assert (om.quantize_input(padded) == g["q"][i, j]).all(), (i, int(L))
+            assert (bits(om.run_inference(padded)) == bits(g["scores"][i, j])).all(), (i, int(L))
+    assert (g["q"][0, 2] != g["q"][0, 0]).sum() > 50 and (g["q"][0, 5] != g["q"][0, 0]).sum() > 1000      # the fixture tells the lengths apart
+
+
+@pytest.mark.gpu
+def test_run_classifier_on_other_lengths_for_an_mfe_block():
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    g = np.load(os.path.join(GOLDEN, "mfe_other_length_l432.npz"))
+    m = pkg.Model(blob=_mfe_blob())
+    m.set_default()
+    F = m.n_features
+    for i, clip in enumerate(g["clips"]):
+        for j, L in enumerate(g["lengths"]):
+            rc, s, tl = _sdk_call(pkg, clip[:L], int(L), n_labels=m.n_labels)
+            assert rc == 0 and tl == L, (int(L), rc)
+            assert (bits(_oneshot_features(pkg, F)) == bits(g["features"][i, j])).all(), (i, int(L))
+            assert (bits(s) == bits(g["scores"][i, j])).all(), (i, int(L), s, g["scores"][i, j])
+    for L in (16320, 17000, 639, 0):
+        rc, s, tl = _sdk_call(pkg, g["clips"][0][:L], L, n_labels=m.n_labels)
+        assert rc == -5 and (s == 0).all(), (L, rc)
+    m.close()

@@ -198,6 +198,41 @@ def get_data_trace(ref):
 
 
 OTHER_LENGTHS = (16319, 16001, 15999, 15681, 15680, 15679, 8000, 1280, 960, 641, 640)
+MFE_OTHER_LENGTHS = (16319, 16001, 15999, 15680, 15679, 8000, 1280, 641, 640)
+
+
+def mfe_other_length(ref, synth, cfg):
+    """The MFE-block model (mfe_model above) on one-shot windows of another length, composed from the reference's leaves the way mfe_model is:
+    extract_mfe_features sizes its matrix from signal->total_length with the same rule as the MFCC block (L432 ei_run_dsp.h:379-389: only a
+    matrix that does not fit is an error), feature::mfe on the frames that fit (the L476 build's leaf), cmvnw(win, false, true) + normalize over
+    those rows only (the L432 headers, compiled), the rest of the calloc'd feature matrix (L432 dsp/numpy_types.h:91) at zero, input
+    quantisation, the graph through the reference's op registrations.  The L432 copy's run_classifier itself cannot be compiled here: this row
+    is pinned by its leaves, not by an end-to-end run."""
+    from kws_testlib import OracleModel, ReferenceL432Dsp, synth_model_blob
+    r432 = ReferenceL432Dsp()
+    blob = synth_model_blob(**MFE_MODEL_KW)
+    tmp = os.path.join(GOLDEN, "_mfe_model_tmp.kwsm")
+    open(tmp, "wb").write(blob)
+    om = OracleModel(synth, tmp)
+    os.remove(tmp)
+    c = cfg.copy(pre_cof=0.0)
+    F = 49 * c.num_filters
+    clips = synth.synth(19, 0, 6).reshape(3, 32000)[:, :max(MFE_OTHER_LENGTHS)]
+    feats = np.zeros((len(clips), len(MFE_OTHER_LENGTHS), F), np.float32)
+    qs = np.zeros(feats.shape, np.int8)
+    scores = np.zeros((len(clips), len(MFE_OTHER_LENGTHS), om.n_labels), np.float32)
+    for i, x in enumerate(clips):
+        for j, L in enumerate(MFE_OTHER_LENGTHS):
+            mel, _ = ref.mfe(x[:L], c)
+            f = r432.cmvnw(mel, c.win_size, False, True).reshape(-1)
+            assert f.size == c.num_filters * ((L - 320) // 320) <= F
+            feats[i, j, :f.size] = f
+            qs[i, j] = om.quantize_input(feats[i, j])
+            out, _ = ref.graph_run(blob, qs[i, j])
+            scores[i, j] = om.dequantize(out)
+    np.savez_compressed(os.path.join(GOLDEN, "mfe_other_length_l432.npz"), clips=clips, lengths=np.int64(MFE_OTHER_LENGTHS), features=feats, q=qs, scores=scores)
+    print("mfe_other_length_l432.npz", os.path.getsize(os.path.join(GOLDEN, "mfe_other_length_l432.npz")), "bytes;", scores[0, :3].round(4).tolist())
+
 
 
 def other_length(ref, synth, cfg):
@@ -241,6 +276,8 @@ def main():
         return get_data_trace(ref)
     if "--only-other-length" in sys.argv:
         return other_length(ref, Oracle(), L476_CONFIG())
+    if "--only-mfe-other-length" in sys.argv:
+        return mfe_other_length(ref, Oracle(), L476_CONFIG())
     if "--only-mfcc40" in sys.argv:
         return mfcc40(ref, Oracle(), L476_CONFIG())
     if "--only-mfe-block" in sys.argv:
