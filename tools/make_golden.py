@@ -7,6 +7,16 @@ the hand-made edge-case clips of tests/kws_testlib.special_clips) and the values
 returned for them at each stage of run_classifier():
   pre-emphasised frames, power spectrum, mel energies, frame energies, MFCC before CMVN,
   features (after CMVN), int8 input tensor, every int8 op output, final scores.
+
+Without arguments: leaves_l476, e2e_l476, deep_l476, continuous_l476, f32_twin_l476.  One fixture at a time:
+  --only-mfcc40            mfcc40_l476.npz          the 40-filter MFCC configurations
+  --only-mfe-block         mfe_block_l432.npz       the MFE block's leaves (L432 headers compiled in place)
+  --only-mfe-model         mfe_model_l432.npz       a model whose DSP block is MFE, composed from the reference's leaves
+  --only-graphs            graphs_l476.npz          synthetic graphs through the reference's op registrations
+  --only-qfb               qfb_l476.npz             EIDSP_QUANTIZE_FILTERBANK = 1 (the second build of the compiled reference)
+  --only-trace             get_data_trace_l476.npz  what the reference asks the application's callback, call by call (FIRST user of continuous mode in its process)
+  --only-other-length      other_length_l476.npz    run_classifier on windows of another length (1 .. 49 frames)
+  --only-mfe-other-length  mfe_other_length_l432.npz  the same for the MFE-block model, composed from the L432 copy's leaves
 """
 import os
 import sys
