@@ -66,6 +66,8 @@ def build(force=False):
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+    # the development build (KWS_DEV_* switches compiled in): what the tests that force a tier / a layout and the A/B tools load
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "dev"])
     return LIB_PATH
 
 

@@ -232,7 +232,7 @@ int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 static const size_t kGenTuneMinClips = 2048;
 static int generic_chunk_begin(kws_handle *h, size_t B, hipStream_t s)
 {
-    const char *fe = getenv("KWS_DEV_GENERIC_LCH");          // (read per call: a test toggles it between handles)
+    const char *fe = KWS_DEV_ENV("KWS_DEV_GENERIC_LCH");          // (read per call: a test toggles it between handles)
     const int forced = fe ? atoi(fe) : 0;
     if (forced == 4 || forced == 8) return forced;
     std::lock_guard<std::mutex> lk(h->g_mu);
@@ -649,7 +649,7 @@ EI_IMPULSE_ERROR kws_run_inference_batch_device(kws_handle *h, const float *feat
 // the exact cmvnw + network and comes out with the exact mode's bits.  A clip costs its tiers: ~0.4 x the exact path for the second.
 static EI_IMPULSE_ERROR rerun_flagged_device(kws_handle *h, const int16_t *pcm, size_t B, float *scores, float *fx, bool want_f, int8_t *q, hipStream_t s)
 {
-    static const bool skip = getenv("KWS_DEV_FAST_NO_RERUN") != nullptr;     // development aid: what the (usually empty) re-run launches cost; results are wrong when set
+    static const bool skip = KWS_DEV_ENV("KWS_DEV_FAST_NO_RERUN") != nullptr;     // development aid: what the (usually empty) re-run launches cost; results are wrong when set
     if (skip) return EI_IMPULSE_OK;
     const size_t F = h->model.nn_input_frame_size;
     if (B > h->cep_cap) {

@@ -48,6 +48,19 @@ struct KwsFastBlock {
     int dw, mult;                 // DEPTHWISE_CONV_2D (reference/depthwiseconv_float.h:25): output channel n reads input channel n / mult; its taps run on
                                   // the vector ALU from the LDS image (fast_dwconv), weights [tap][out_c] at w_off
     float conv_min, conv_max, add_min, add_max, pool_min, pool_max;
+    // ---- the contraction on v_mfma_f32_16x16x32_f16 (round 5; DESIGN.md 4.4: "split operands").  An fp32 value is carried as two
+    //      halves, x s = hi + lo (s a power of two, hi = half(x s), lo = half(x s - hi): 22 significant bits), and a product as
+    //      hi hi + hi lo + lo hi in an fp32 accumulator -- what is dropped is 2^-22 of a product, the size of fp32's own rounding of it --
+    //      at sixteen times the rate of the fp32 matrix instruction.  K is walked in groups of eight channels of one tap
+    //      (g = tap * in_cp / 8 + cg), four groups (one per lane / 16) to a k-step.
+    int hconv;                    // 1: this block's contraction runs on split halves (CONV_2D blocks whose image fits the in-place split)
+    int h_ks;                     // k-steps = ceil(taps * (in_cp / 8) / 4)
+    int h_tab_off;                // shared LDS (floats): [h_ks + 2][4] x int2 { byte offset of the group's 16 bytes inside the image relative to
+                                  // the lane's row 0 (tap * row bytes + 16 cg), tap } ; groups past the last one: tap = 1 << 20 (reads the zero block)
+    int h_b_off;                  // shared LDS (floats) of the weight fragments [h_ks][2 (hi, lo)][n_tiles][64 lanes] x 16 bytes, or -1: they are
+                                  // read from h_b_global (the LDS block is full)
+    const void *h_b_global;       // the same fragments in device memory (always present)
+    float h_inv_wscale;           // 1 / (the power of two the weights were multiplied by before the split)
 };
 
 struct KwsFastPlan {
@@ -88,6 +101,7 @@ struct KwsFastPlan {
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;
+    int zero_off;                 // shared LDS (floats): 16 bytes of zeros, 16-byte aligned -- what an operand fetch outside an image reads (split-operand blocks)
     int sink_off;                 // F + sink_off + lane: where a lane's stores that fall outside an image go (no branch per value)
     int stash_off;                // F + stash_off: 48 floats that survive from one clip of a wave to its next (the paired tail pass)
     const float *shared_init;     // global image of the workgroup's shared LDS block (weights, biases, cmvnw tables)

@@ -84,6 +84,89 @@ __device__ __forceinline__ float oct_sum(float v)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+//  What follows a block's contraction, whichever matrix instruction ran it: the accumulators acc[MT][NT] (tile mt, nt: rows
+//  16 mt + 4 (lane / 16) + i, channel 16 nt + lane % 16) and the vector-ALU rows vout hold  sum x w / scale  (scale = 1 for the fp32
+//  instruction; the split-operand form carries the two powers of two its operands were multiplied by).
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__device__ __forceinline__ void fast_conv_finish(const KwsFastBlock &k, v4f (&acc)[MT][NT], const float (&vout)[2], float *__restrict__ stage, int sstride,
+                                                 const float *__restrict__ shared, int lane, float *__restrict__ sink, float scale)
+{
+    const int lm = lane & 15, lq = lane >> 4;
+    const int out_c = k.out_c;
+    const int out_w = k.out_w;
+    if (k.fpool) {
+        // ---- MAX_POOL_2D with non-overlapping windows, taken on the raw accumulators: bias, the activation clamps and the ADD are
+        //      non-decreasing in the accumulator, so max and epilogue commute (same values, bit for bit) and only pool_w x out_c
+        //      values go through the epilogue (fast_pool_finish).  A lane folds its four rows of a tile into at most two window
+        //      maxima in registers and merges them into pm[window][32] (the dead input image) with LDS float-max atomics.
+        float *pm = stage;
+        WAVE_SYNC();                                                  // every lane has read its last operands from the image
+        for (int i = lane; i < k.pool_w * 32; i += KWS_WAVE) pm[i] = -FLT_MAX;
+        WAVE_SYNC();
+        const unsigned pinv = (1u << 16) / (unsigned)k.pool + 1u;      // r / pool for r < 64
+        const int pool_w = k.pool_w;
+        float *const psink = pm + pool_w * 32 + lane;                  // windows past the last one (VALID pooling), channels past out_c
+        auto merge = [&](int p, int n, float m, bool ok) {
+            __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)((ok && p < pool_w && n < out_c) ? pm + p * 32 + n : psink), m, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);
+        };
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = 16 * nt + lm;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r0 = 16 * mt + 4 * lq;
+                int pw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[i] = (int)(((unsigned)(r0 + i) * pinv) >> 16);
+                float mlo = acc[mt][nt][0], mhi = acc[mt][nt][3];      // pool >= 4: the four rows touch at most two windows
+#pragma unroll
+                for (int i = 1; i < 4; ++i) {
+                    const bool row_ok = r0 + i < out_w;
+                    mlo = (row_ok && pw[i] == pw[0]) ? fmaxf(mlo, acc[mt][nt][i]) : mlo;
+                    if (i < 3) mhi = (row_ok && pw[i] == pw[3]) ? fmaxf(mhi, acc[mt][nt][i]) : mhi;
+                }
+                merge(pw[0], n, mlo, r0 < out_w);
+                merge(pw[3], n, mhi, r0 + 3 < out_w && pw[3] != pw[0]);
+            }
+        }
+        for (int vr = 0; vr < k.vrows; ++vr) {
+            const int r = 16 * MT + vr;
+            merge((int)(((unsigned)r * pinv) >> 16), lane & 31, vout[vr], lane < 32);
+        }
+        return;
+    }
+    // ---- epilogue: bias, fused activation, ADD(constant) + activation (conv.h:88-93, add.h:200-212) ---------------------
+    const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max;
+    const bool has_add = k.has_add != 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * nt + lm;
+        const int nc = min(n, out_c - 1);
+        const float bias = shared[k.bias_off + nc], addc = shared[k.addc_off + nc];
+        float *sp = stage + n;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * mt + 4 * lq + i;
+                float v = acc[mt][nt][i] * scale + bias;
+                v = fminf(fmaxf(v, cmin), cmax);
+                if (has_add) { v = v + addc; v = fminf(fmaxf(v, amin), amax); }
+                *((row < out_w && n < out_c) ? sp + row * sstride : sink) = v;
+            }
+        }
+    }
+    for (int vr = 0; vr < k.vrows; ++vr) {
+        const int n = lane & 31, nc = min(n, out_c - 1);
+        float v = vout[vr] * scale + shared[k.bias_off + nc];
+        v = fminf(fmaxf(v, cmin), cmax);
+        if (has_add) { v = v + shared[k.addc_off + nc]; v = fminf(fmaxf(v, amin), amax); }
+        if (lane < 32 && n < out_c) stage[(16 * MT + vr) * sstride + n] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 //  One CONV_2D block on the matrix cores: out[m][n] = sum_{tap, c} in[m + tap - pad_left][c] * w[n][tap][c].  The image holds the
 //  in_w real rows only: an operand whose row falls outside it (SAME padding, or the rows a 16-row tile has beyond the image) is
 //  replaced by zero in the register -- padding rows in LDS would cost 1 KB per wave.  Tiles of 16 rows x 16 channels, k-steps of
@@ -95,7 +178,7 @@ __device__ __forceinline__ float oct_sum(float v)
 //  step it are issued.
 // ---------------------------------------------------------------------------------------------------------
 template <int MT, int NT>
-__device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ stage,
+__device__ __forceinline__ float fast_conv_tiles(const KwsFastBlock &k, const float *__restrict__ in, float *__restrict__ stage,
                                                 int sstride, const float *__restrict__ shared, int lane, float *__restrict__ sink,
                                                 long long *t_loop = nullptr, long long *t_pre = nullptr)
 {
@@ -220,83 +303,212 @@ __device__ __forceinline__ void fast_conv_tiles(const KwsFastBlock &k, const flo
     }
     __builtin_amdgcn_s_setprio(0);
     if (t_loop) *t_loop = clock64();
-    const int out_w = k.out_w;
-    if (k.fpool) {
-        // ---- MAX_POOL_2D with non-overlapping windows, taken on the raw accumulators: bias, the activation clamps and the ADD are
-        //      non-decreasing in the accumulator, so max and epilogue commute (same values, bit for bit) and only pool_w x out_c
-        //      values go through the epilogue (fast_pool_finish).  A lane folds its four rows of a tile into at most two window
-        //      maxima in registers and merges them into pm[window][32] (the dead input image) with LDS float-max atomics.
-        float *pm = stage;
-        WAVE_SYNC();                                                  // every lane has read its last operands from the image
-        for (int i = lane; i < k.pool_w * 32; i += KWS_WAVE) pm[i] = -FLT_MAX;
-        WAVE_SYNC();
-        const unsigned pinv = (1u << 16) / (unsigned)k.pool + 1u;      // r / pool for r < 64
-        const int pool_w = k.pool_w;
-        float *const psink = pm + pool_w * 32 + lane;                  // windows past the last one (VALID pooling), channels past out_c
-        auto merge = [&](int p, int n, float m, bool ok) {
-            __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)((ok && p < pool_w && n < out_c) ? pm + p * 32 + n : psink), m, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);
-        };
+    fast_conv_finish<MT, NT>(k, acc, vout, stage, sstride, shared, lane, sink, 1.0f);
+    return 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+//  The same contraction on v_mfma_f32_16x16x32_f16 with SPLIT OPERANDS (KwsFastBlock::hconv).  An fp32 value x is carried as two
+//  halves of x s (s a power of two): hi = half(x s), lo = half(x s - hi) -- 22 significant bits --, and a product as
+//  hi hi + hi lo + lo hi, each term exact in the fp32 accumulator: what is dropped (lo lo, and the 2^-22 the two halves miss) is the
+//  size of fp32's own rounding of the product, and the matrix pipe runs the three instructions in 3/16 of the time one
+//  v_mfma_f32_16x16x4_f32 sequence of the same depth takes (tools/split_operand_study.py: the scores of the shipped float graphs move
+//  by <= 6e-7, less than the reference's own summation order does).
+//    fast_split_image  converts a block's input image IN PLACE: row r = [in_cp halves hi][in_cp halves lo] inside the row's
+//                      in_stride floats; s = 2^14 / 2^ceil(log2 max|x|) of this clip's image (values below 2^-10 s^-1 would land in
+//                      half's subnormals: with max|x| s >= 2^13 they are 2^-23 of the largest operand -- nothing).
+//    the weights       are split once on the host (kws_fast_plan.cpp) into per-lane fragments [k-step][hi, lo][n tile][lane] x 16 bytes.
+//  K runs over groups of eight channels of one tap, g = tap * (in_cp / 8) + cg; k-step s gives group 4 s + (lane / 16) to the lanes
+//  with that quotient: A = the eight halves at image row (16 mt + lane % 16 + tap - pad_left), channels 8 cg .. 8 cg + 7 (one
+//  ds_read_b128; rows outside the image read a block of zeros instead), B = this lane's 16 bytes of the fragment.  With eight
+//  output tiles in registers a 49-row image runs its fourth row tile for one row: 72 of 216 instructions of 16 cycles -- the fp32
+//  form paid 140 of 560 of 32 cycles for it, or a vector-ALU row (KwsFastBlock::vrows: 4.9 k clocks per clip).
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+#define KWS_FAST_HP 16            // channel pairs a lane converts: images of up to 64 x 16 pairs (the plan checks)
+
+// returns 1 / s
+__device__ __forceinline__ float fast_split_image(float *__restrict__ img, int in_w, int in_c, int in_cp, int in_stride, int lane)
+{
+    const int ppr = in_cp >> 1, items = in_w * ppr;
+    const unsigned inv = (1u << 20) / (unsigned)ppr + 1u;           // i / ppr for i < 1024, ppr <= 32
+    float2 v[KWS_FAST_HP];
+    int off[KWS_FAST_HP];                                           // byte offset of the pair's hi halves (kept: the second loop needs no division)
+    float mx = 0.0f;
+    // whole trips of the wave only (the trip count is wave-uniform: a small image -- a later block's -- takes one or two)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = 16 * nt + lm;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r0 = 16 * mt + 4 * lq;
-                int pw[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pw[i] = (int)(((unsigned)(r0 + i) * pinv) >> 16);
-                float mlo = acc[mt][nt][0], mhi = acc[mt][nt][3];      // pool >= 4: the four rows touch at most two windows
-#pragma unroll
-                for (int i = 1; i < 4; ++i) {
-                    const bool row_ok = r0 + i < out_w;
-                    mlo = (row_ok && pw[i] == pw[0]) ? fmaxf(mlo, acc[mt][nt][i]) : mlo;
-                    if (i < 3) mhi = (row_ok && pw[i] == pw[3]) ? fmaxf(mhi, acc[mt][nt][i]) : mhi;
-                }
-                merge(pw[0], n, mlo, r0 < out_w);
-                merge(pw[3], n, mhi, r0 + 3 < out_w && pw[3] != pw[0]);
-            }
+    for (int u = 0; u < KWS_FAST_HP; ++u) {
+        if (KWS_WAVE * u < items) {                                 // (no break: the loop must unroll, or the arrays go to scratch)
+            const int i = min(lane + KWS_WAVE * u, items - 1);
+            const int r = (int)(((unsigned)i * inv) >> 20), p2 = 2 * (i - r * ppr);
+            v[u] = *(const float2 *)(img + r * in_stride + p2);
+            off[u] = r * (in_stride * 4) + 2 * p2;
+            // the k-padding channels (in_c .. in_cp - 1) meet zero weights, but what sits there need not survive the scaling: zeros
+            v[u].x = p2 < in_c ? v[u].x : 0.0f;
+            v[u].y = p2 + 1 < in_c ? v[u].y : 0.0f;
+            mx = fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y)));
         }
-        for (int vr = 0; vr < k.vrows; ++vr) {
-            const int r = 16 * MT + vr;
-            merge((int)(((unsigned)r * pinv) >> 16), lane & 31, vout[vr], lane < 32);
-        }
-        return;
     }
-    // ---- epilogue: bias, fused activation, ADD(constant) + activation (conv.h:88-93, add.h:200-212) ---------------------
-    const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max;
-    const bool has_add = k.has_add != 0;
+    mx = wave_max(mx);
+    // max|x| < 2^e; e kept where both s and 1 / s are normal numbers whatever the image holds
+    const int e = __builtin_amdgcn_readfirstlane(min(max(__builtin_amdgcn_frexp_expf(mx), -100), 100));
+    const float s = ldexpf(1.0f, 14 - e);
+    WAVE_SYNC();                                                    // every lane has read its values: the rows may be overwritten
+    char *const ib = (char *)img;
+    const int lo_off = 2 * in_cp;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = 16 * nt + lm;
-        const int nc = min(n, out_c - 1);
-        const float bias = shared[k.bias_off + nc], addc = shared[k.addc_off + nc];
-        float *sp = stage + n;
+    for (int u = 0; u < KWS_FAST_HP; ++u) {
+        if (KWS_WAVE * u < items) {
+            const float y0 = v[u].x * s, y1 = v[u].y * s;
+            const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+            const float d0 = y0 - (float)h0, d1 = y1 - (float)h1;   // exact: the difference has at most 13 significant bits
+            const v2h hi = { h0, h1 }, lo = { (_Float16)d0, (_Float16)d1 };
+            // (the last trip's surplus lanes hold copies of the last pair: they store the same halves to the same place)
+            *(v2h *)(ib + off[u]) = hi;
+            *(v2h *)(ib + off[u] + lo_off) = lo;
+        }
+    }
+    WAVE_SYNC();
+    return ldexpf(1.0f, e - 14);
+}
+
+// A small block whose weight fragments did not fit the workgroup's LDS block (one output-channel tile, at most eight k-steps): every
+// fragment is requested from device memory BEFORE the image is split -- the round trips hide behind the conversion -- and the loop
+// then only reads the image.
+template <int MT>
+__device__ __forceinline__ float fast_conv_small_h(const KwsFastBlock &k, float *__restrict__ in, float *__restrict__ stage, int sstride,
+                                                   const float *__restrict__ shared, int zero_off, int lane, float *__restrict__ sink)
+{
+    constexpr int KSM = 8;
+    const int lm = lane & 15, lq = lane >> 4, n_ks = k.h_ks;
+    const char *const bg = (const char *)k.h_b_global + lane * 16;
+    v8h bh[KSM], blo[KSM];
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+        const int kc = min(ks, n_ks - 1);
+        bh[ks] = *(const v8h *)(bg + (kc * 2) * (KWS_WAVE * 16));
+        blo[ks] = *(const v8h *)(bg + (kc * 2 + 1) * (KWS_WAVE * 16));
+    }
+    const float inv_s = fast_split_image(in, k.in_w, k.in_c, k.in_cp, k.in_stride, lane);
+    v4f acc[MT][1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = v4f{ 0.f, 0.f, 0.f, 0.f };
+    const int rowb = k.in_stride * 4, in_w = k.in_w, lo_off = 2 * k.in_cp;
+    const int row0 = lm - k.pad_left;
+    const char *const abase = (const char *)in + row0 * rowb;
+    const char *const zb = (const char *)(shared + zero_off);
+    const int2 *const tab = (const int2 *)(shared + k.h_tab_off) + lq;
+    // every operand of the image in one batch too (2 MT reads per k-step)
+    v8h ah[KSM][MT], al[KSM][MT];
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+        const int2 d = tab[4 * min(ks, n_ks)];                            // row n_ks: zeros
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 16 * mt + 4 * lq + i;
-                float v = acc[mt][nt][i] + bias;
-                v = fminf(fmaxf(v, cmin), cmax);
-                if (has_add) { v = v + addc; v = fminf(fmaxf(v, amin), amax); }
-                *((row < out_w && n < out_c) ? sp + row * sstride : sink) = v;
-            }
+            const bool in_img = (unsigned)(row0 + d.y + 16 * mt) < (unsigned)in_w;
+            const char *p = in_img ? abase + d.x + mt * (16 * rowb) : zb;
+            ah[ks][mt] = *(const v8h *)p;
+            al[ks][mt] = *(const v8h *)(p + lo_off);
         }
     }
-    for (int vr = 0; vr < k.vrows; ++vr) {
-        const int n = lane & 31, nc = min(n, out_c - 1);
-        float v = vout[vr] + shared[k.bias_off + nc];
-        v = fminf(fmaxf(v, cmin), cmax);
-        if (has_add) { v = v + shared[k.addc_off + nc]; v = fminf(fmaxf(v, amin), amax); }
-        if (lane < 32 && n < out_c) stage[(16 * MT + vr) * sstride + n] = v;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+        if (ks < n_ks) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks][mt], bh[ks], acc[mt][0], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][mt], blo[ks], acc[mt][0], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][mt], bh[ks], acc[mt][0], 0, 0, 0);
+        }
     }
+    __builtin_amdgcn_s_setprio(0);
+    const float scale = inv_s * k.h_inv_wscale;
+    const float vout[2] = { 0.0f, 0.0f };
+    fast_conv_finish<MT, 1>(k, acc, vout, stage, sstride, shared, lane, sink, scale);
+    return scale;
+}
+
+// BG: the weight fragments are read from device memory (the workgroup's LDS block has no room for them) instead of LDS
+template <int MT, int NT, bool BG>
+__device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float *__restrict__ in, float *__restrict__ stage, int sstride,
+                                                   const float *__restrict__ shared, int zero_off, int lane, float *__restrict__ sink)
+{
+    const int lm = lane & 15, lq = lane >> 4;
+    const float inv_s = fast_split_image(in, k.in_w, k.in_c, k.in_cp, k.in_stride, lane);
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{ 0.f, 0.f, 0.f, 0.f };
+    const int rowb = k.in_stride * 4, in_w = k.in_w, lo_off = 2 * k.in_cp, n_ks = k.h_ks;
+    const int row0 = lm - k.pad_left;                       // image row of this lane's operand for tile 0, tap 0
+    const char *const abase = (const char *)in + row0 * rowb;
+    const char *const zb = (const char *)(shared + zero_off);          // 16 bytes of zeros, and again lo_off bytes further
+    const int2 *const tab = (const int2 *)(shared + k.h_tab_off) + lq;  // [k-step][lane / 16] { byte offset of the group, tap }
+    const char *const bl = (const char *)(shared + (BG ? 0 : k.h_b_off)) + lane * 16;
+    const char *const bg = (const char *)k.h_b_global + lane * 16;
+    auto fetch = [&](int ks, const int2 &d, v8h (&ah)[MT], v8h (&al)[MT], v8h (&bh)[NT], v8h (&blo)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int off = ((ks * 2) * NT + nt) * (KWS_WAVE * 16);
+            if constexpr (BG) { bh[nt] = *(const v8h *)(bg + off); blo[nt] = *(const v8h *)(bg + off + NT * (KWS_WAVE * 16)); }
+            else { bh[nt] = *(const v8h *)(bl + off); blo[nt] = *(const v8h *)(bl + off + NT * (KWS_WAVE * 16)); }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool in_img = (unsigned)(row0 + d.y + 16 * mt) < (unsigned)in_w;
+            const char *p = in_img ? abase + d.x + mt * (16 * rowb) : zb;
+            ah[mt] = *(const v8h *)p;
+            al[mt] = *(const v8h *)(p + lo_off);
+        }
+    };
+    auto mfmas = [&](const v8h (&ah)[MT], const v8h (&al)[MT], const v8h (&bh)[NT], const v8h (&blo)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], blo[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+    };
+    // two operand sets, the loop unrolled by two: a set's operands are requested before the other set's matrix instructions are issued
+    v8h ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
+    int2 d0 = tab[0], d1 = tab[4];
+    fetch(0, d0, ah0, al0, bh0, bl0);
+    __builtin_amdgcn_s_setprio(1);
+    for (int ks = 0; ks < n_ks; ks += 2) {
+        d0 = tab[4 * (ks + 2)];                                           // n_ks + 2 rows: the rows past the last one read zeros
+        fetch(ks + 1 < n_ks ? ks + 1 : ks, d1, ah1, al1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 >= n_ks) break;                                        // odd step count
+        d1 = tab[4 * (ks + 3)];
+        fetch(ks + 2 < n_ks ? ks + 2 : ks, d0, ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(ah1, al1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    const float scale = inv_s * k.h_inv_wscale;
+    const float vout[2] = { 0.0f, 0.0f };
+    fast_conv_finish<MT, NT>(k, acc, vout, stage, sstride, shared, lane, sink, scale);
+    return scale;
 }
 
 // Pooled-in-flight blocks (KwsFastBlock::fpool): the window maxima of the raw accumulators sit in pm[pool_w][32]; bias, activation,
 // ADD + activation, pooling clamp -- the reference's order per value (conv.h:88-93, add.h:200-212, pooling.h:231-233) -- and the
 // zeroed k-padding channels of the next image.
 __device__ __forceinline__ void fast_pool_finish(const KwsFastBlock &k, const float *__restrict__ pm, float *__restrict__ img,
-                                                 const float *__restrict__ shared, int lane, int out_stride, int out_cp)
+                                                 const float *__restrict__ shared, int lane, int out_stride, int out_cp, float scale)
 {
     const int items = k.pool_w * out_cp, out_c = k.out_c;
     const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;
@@ -304,7 +516,7 @@ __device__ __forceinline__ void fast_pool_finish(const KwsFastBlock &k, const fl
     const bool has_add = k.has_add != 0;
     for (int i = lane; i < items; i += KWS_WAVE) {
         const int p = (int)(((unsigned)i * inv) >> 20), c = i - p * out_cp, cc = min(c, out_c - 1);
-        float v = pm[p * 32 + cc] + shared[k.bias_off + cc];
+        float v = pm[p * 32 + cc] * scale + shared[k.bias_off + cc];
         v = fminf(fmaxf(v, cmin), cmax);
         if (has_add) { v = v + shared[k.addc_off + cc]; v = fminf(fmaxf(v, amin), amax); }
         v = fminf(fmaxf(v, pmin), pmax);
@@ -1290,6 +1502,22 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                 FPH(6 + (b > 0));
                 continue;
             }
+            float cscale = 1.0f;                                         // what the accumulators still carry (split operands: two powers of two)
+            if (k.hconv) {
+                // split operands on v_mfma_f32_16x16x32_f16: row tiles 1 / 2 / 4 (an idle tile costs 16 cycles per instruction there)
+                const int zo = FP.zero_off;
+                const bool bgl = k.h_b_off < 0;
+                if (bgl && k.n_tiles == 1 && k.m_tiles == 1 && k.h_ks <= 8) cscale = fast_conv_small_h<1>(k, cur, stage, sstride, shared, zo, lane_n, wsink);
+                else
+                switch ((k.m_tiles > 2 ? 4 : k.m_tiles) * 4 + k.n_tiles) {
+                case 4 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<4, 2, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<4, 2, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
+                case 4 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<4, 1, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<4, 1, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
+                case 2 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<2, 2, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<2, 2, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
+                case 2 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<2, 1, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<2, 1, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
+                case 1 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<1, 2, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<1, 2, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
+                default: cscale = bgl ? fast_conv_tiles_h<1, 1, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<1, 1, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
+                }
+            } else
             switch (k.m_tiles * 4 + k.n_tiles) {
             case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n, wsink, tl, tp); break;
             case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
@@ -1302,7 +1530,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
             }
             WAVE_SYNC();
             if (PROF && b == 0) { ph[9] += t_loop - t_pre; ph[10] += clock64() - t_loop; ph[11] += t_pre - tlast; }
-            if (k.fpool) fast_pool_finish(k, stage, oth, shared, lane_n, o_stride, o_cp);
+            if (k.fpool) fast_pool_finish(k, stage, oth, shared, lane_n, o_stride, o_cp, cscale);
             else fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
             WAVE_SYNC();
             float *tmp = cur; cur = oth; oth = tmp;

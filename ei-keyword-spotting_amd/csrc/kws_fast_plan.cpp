@@ -8,6 +8,42 @@ static const int kLdsBytes = 160 * 1024;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// IEEE binary16 of a float, round to nearest even (the conversion v_cvt_f16_f32 performs); finite inputs below 65520 in magnitude
+static uint16_t f32_to_f16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, sizeof u);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x47800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));       // overflow / NaN (the plan never produces them)
+    if (u < 0x38800000u) {                                                                           // subnormal half (or zero)
+        if (u < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(u >> 23);                                                      // 14 .. 24
+        const uint32_t m = (u & 0x7fffffu) | 0x800000u;
+        uint32_t h = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((u - 0x38000000u) >> 13);
+    const uint32_t rem = u & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+static float f16_to_f32(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    float f;
+    if (e == 0) f = ldexpf((float)m, -24);
+    else if (e == 31) f = m ? NAN : INFINITY;
+    else f = ldexpf((float)(m | 0x400u), (int)e - 25);
+    uint32_t u;
+    memcpy(&u, &f, sizeof u);
+    u |= sign;
+    memcpy(&f, &u, sizeof f);
+    return f;
+}
+
 // The guard (kws_fast.h): which clips the fast kernel may keep.  Round 4: the tolerance is a
 // property of the LOADED MODEL.  cmvnw turns a cepstral coefficient x into (x - mean) / (deviation + eps) over a window of its column, so
 // whatever the fast arithmetic moved in x or in the window's mean comes out divided by the deviation; the graph then carries a feature
@@ -48,14 +84,16 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
     const float e0 = kAbs0, kappa_s = kKappaStale;
     // development aids (tests/gain_study.py runs with the guard off).  They put KWS_MODE_FAST outside its documented tolerance, so the handle
     // remembers (kws_fast_tolerance::dev_overrides: bench.py refuses to report a number then) and the library says so once on stderr
-    if (const char *ev = getenv("KWS_DEV_FAST_GUARD_SCALE")) { scale = (float)atof(ev); h->fast_dev_overrides |= 1; }
-    if (const char *ev = getenv("KWS_DEV_FAST_GUARD")) { (void)sscanf(ev, "%f,%f,%f,%f", &a0, &ad, &as, &kappa); h->fast_dev_overrides |= 2; }
-    if (getenv("KWS_DEV_FAST_NO_RERUN")) h->fast_dev_overrides |= 4;
+    if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_GUARD_SCALE")) { scale = (float)atof(ev); h->fast_dev_overrides |= 1; }
+    if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_GUARD")) { (void)sscanf(ev, "%f,%f,%f,%f", &a0, &ad, &as, &kappa); h->fast_dev_overrides |= 2; }
+    if (KWS_DEV_ENV("KWS_DEV_FAST_NO_RERUN")) h->fast_dev_overrides |= 4;
+#ifdef KWS_DEV_SWITCHES
     if (h->fast_dev_overrides) {
         static std::atomic<bool> said{ false };
         if (!said.exchange(true))
             fprintf(stderr, "libkws_mi355x: a KWS_DEV_FAST_* development switch is set: KWS_MODE_FAST results are OUTSIDE the documented tolerance\n");
     }
+#endif
     std::vector<float> gain((size_t)ncep, 0.0f);
     if (h->is_float && h->gain.calibrated) gain = h->gain.col;
     else for (float &g : gain) g = 4.0f / (kGuardLin * sqrtf((float)(nfr * ncep)));
@@ -112,7 +150,7 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
             }
             if (v * (double)std::max(F.g_c1 / 16.0f, F.g_c2) <= 1.0) entry = tier + 1;
         }
-        if (const char *ev = getenv("KWS_DEV_FAST_ENTRY")) entry = std::max(1, std::min(3, atoi(ev)));      // development / test aid: the tier's kernels whatever the routing
+        if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_ENTRY")) entry = std::max(1, std::min(3, atoi(ev)));      // development / test aid: the tier's kernels whatever the routing
         h->fast_entry_tier = entry;
     }
     // numpy::pad_1d_symmetric's row order, for the replayed window means of column 0
@@ -287,6 +325,18 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     return EI_IMPULSE_OK;
 }
 
+// per-wave LDS: the two image regions (kws_fast.h)
+static void fast_wave_floats(const kws_handle *h, KwsFastPlan &F, int need_f, int need_r1)
+{
+    const int nfr = h->dsp.n_frames;
+    // image + log energies (or a later block's image), then one slot per lane: the sink of stores that fall outside an image
+    F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4) + KWS_FAST_WAVE + 48;
+    F.sink_off = F.f_floats - KWS_FAST_WAVE - 48;
+    F.stash_off = F.f_floats - 48;
+    F.r1_floats = round_up(std::max(std::max(KWS_FAST_MEL_CHUNK * KWS_FAST_XS, KWS_FAST_MEL_CHUNK * F.pstride), need_r1), 4);
+    F.wave_floats = F.f_floats + F.r1_floats;
+}
+
 static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vector<float> &shared, int need_f, int need_r1)
 {
     const KwsDspPlan &P = h->dsp;
@@ -308,16 +358,11 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
             }
     while (shared.size() & 3) shared.push_back(0.0f);
     F.shared_floats = (int)shared.size();
-    // image + log energies (or a later block's image), then one slot per lane: the sink of stores that fall outside an image
-    F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4) + KWS_FAST_WAVE + 48;
-    F.sink_off = F.f_floats - KWS_FAST_WAVE - 48;
-    F.stash_off = F.f_floats - 48;
-    F.r1_floats = round_up(std::max(std::max(KWS_FAST_MEL_CHUNK * KWS_FAST_XS, KWS_FAST_MEL_CHUNK * F.pstride), need_r1), 4);
-    F.wave_floats = F.f_floats + F.r1_floats;
+    fast_wave_floats(h, F, need_f, need_r1);
     const int avail = kLdsBytes / 4 - F.shared_floats - F.q_floats;
     F.n_waves = std::min(8, avail / F.wave_floats);
-    if (const char *ev = getenv("KWS_DEV_FAST_WAVES")) F.n_waves = std::max(1, std::min(F.n_waves, atoi(ev)));   // development aid (occupancy experiments)
-    if (F.n_waves < 4 && !getenv("KWS_DEV_FAST_WAVES")) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
+    if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_WAVES")) F.n_waves = std::max(1, std::min(F.n_waves, atoi(ev)));   // development aid (occupancy experiments)
+    if (F.n_waves < 4 && !KWS_DEV_ENV("KWS_DEV_FAST_WAVES")) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
                                    F.shared_floats * 4, F.wave_floats * 4);
     EI_IMPULSE_ERROR e = h->upload(shared, &F.shared_init);
     if (e) return e;
@@ -388,6 +433,12 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
     // and the 4-row x 16-column writes of the DCT tiles fall into distinct LDS banks
     F.fs = h->dsp.n_filters + 4;
     int need[2] = { 0, 0 };                     // floats each image region must hold beyond its first use
+    // split-operand blocks (KwsFastBlock::hconv): their weight fragments, placed in LDS once everything else has its place
+    std::vector<uint16_t> hfrag[KWS_FAST_MAX_BLOCKS];
+    const bool hconv_on = !KWS_DEV_ENV("KWS_DEV_FAST_F32_CONV");          // development aid: the fp32 matrix instruction for every block (A/B runs)
+    while (shared.size() & 3) shared.push_back(0.0f);
+    F.zero_off = (int)shared.size();
+    shared.resize(shared.size() + 64, 0.0f);      // 16 bytes of zeros and 16 more up to 240 bytes further (the lo halves of a row sit 2 in_cp bytes behind the hi halves)
     for (int b = 0; b < N.n_blocks; b++) {
         const KwsConvBlockF32 &s = N.blk[b];
         KwsFastBlock &k = F.blk[b];
@@ -411,7 +462,50 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         k.pool_min = s.pool_min; k.pool_max = s.pool_max;
         const std::vector<float> &w = h->hostf.w[b];
         k.st_off = 0;
-        if (k.dw) {
+        k.hconv = 0; k.h_ks = 0; k.h_tab_off = 0; k.h_b_off = -1; k.h_b_global = nullptr; k.h_inv_wscale = 1.0f;
+        // split operands: the image is converted in place by one pass of at most KWS_FAST_HP channel pairs per lane
+        if (hconv_on && !k.dw && s.in_w * (k.in_cp / 2) <= 16 * KWS_FAST_WAVE && k.in_cp <= 64 && (s.out_w + 15) / 16 <= 4 && k.n_tiles <= 2) {
+            k.hconv = 1;
+            k.m_tiles = (s.out_w + 15) / 16; k.vrows = 0;
+            const int ncg = k.in_cp / 8, G = k.taps * ncg, NT = k.n_tiles;
+            k.h_ks = (G + 3) / 4;
+            float maxw = 0.0f;
+            for (float v : w) maxw = std::max(maxw, fabsf(v));
+            int e = 0;
+            if (maxw > 0.0f && std::isfinite(maxw)) (void)frexpf(maxw, &e);             // maxw < 2^e
+            e = std::max(-100, std::min(100, e));
+            const float sw = ldexpf(1.0f, 14 - e);
+            k.h_inv_wscale = ldexpf(1.0f, e - 14);
+            std::vector<uint16_t> &fr = hfrag[b];
+            fr.assign((size_t)k.h_ks * 2 * NT * KWS_FAST_WAVE * 8, 0);
+            for (int ks = 0; ks < k.h_ks; ks++)
+                for (int nt = 0; nt < NT; nt++)
+                    for (int lane = 0; lane < KWS_FAST_WAVE; lane++) {
+                        const int g = 4 * ks + (lane >> 4), n = 16 * nt + (lane & 15);
+                        if (g >= G || n >= k.out_c) continue;
+                        const int tap = g / ncg, cg = g % ncg;
+                        for (int j = 0; j < 8; j++) {
+                            const int ch = 8 * cg + j;
+                            if (ch >= k.in_c) continue;
+                            const float v = w[((size_t)n * k.taps + tap) * k.in_c + ch] * sw;
+                            const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                            fr[((((size_t)ks * 2 + 0) * NT + nt) * KWS_FAST_WAVE + lane) * 8 + j] = hi;
+                            fr[((((size_t)ks * 2 + 1) * NT + nt) * KWS_FAST_WAVE + lane) * 8 + j] = lo;
+                        }
+                    }
+            // operand table [h_ks + 2][4] x { byte offset of the group inside the image, tap }
+            while (shared.size() & 1) shared.push_back(0.0f);
+            k.h_tab_off = (int)shared.size();
+            for (int ks = 0; ks < k.h_ks + 2; ks++)
+                for (int lq = 0; lq < 4; lq++) {
+                    const int g = 4 * ks + lq;
+                    const int ent[2] = { g < G ? (g / ncg) * k.in_stride * 4 + 16 * (g % ncg) : 0, g < G ? g / ncg : (1 << 20) };
+                    for (int j = 0; j < 2; j++) { float f; memcpy(&f, &ent[j], sizeof f); shared.push_back(f); }
+                }
+        }
+        if (k.hconv) {
+            k.w_off = 0;
+        } else if (k.dw) {
             // depthwise filter [1][1][taps][out_c] as it is: a lane reads the taps of its own channel
             k.w_off = (int)shared.size();
             shared.insert(shared.end(), w.begin(), w.end());
@@ -425,7 +519,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
                     shared[(size_t)k.w_off + (((size_t)tap * (k.in_cp / 2) + ch / 2) * k.out_c + n) * 2 + (ch & 1)] =
                         w[((size_t)n * k.taps + tap) * k.in_c + ch];
         }
-        if (!k.dw) {   // k-step table: step it = tap * (in_cp / 8) + cg reads the image at tap * in_stride + 8 cg and the weights at it * 8 out_c
+        if (!k.dw && !k.hconv) {   // k-step table: step it = tap * (in_cp / 8) + cg reads the image at tap * in_stride + 8 cg and the weights at it * 8 out_c
             while (shared.size() & 3) shared.push_back(0.0f);
             k.st_off = (int)shared.size();
             const int ncg = k.in_cp / 8, n_it = k.taps * ncg;
@@ -451,6 +545,23 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
     shared.insert(shared.end(), h->hostf.fc_w.begin(), h->hostf.fc_w.end());
     F.fc_b_off = (int)shared.size();
     shared.insert(shared.end(), h->hostf.fc_b.begin(), h->hostf.fc_b.end());
+    // the split-operand blocks' weight fragments: always in device memory; a copy in the workgroup's LDS block while eight waves still fit
+    // (first block first: it is the largest contraction)
+    fast_wave_floats(h, F, need[0], need[1]);
+    for (int b = 0; b < N.n_blocks; b++) {
+        KwsFastBlock &k = F.blk[b];
+        if (!k.hconv) continue;
+        const uint16_t *dev = nullptr;
+        if ((e = h->upload(hfrag[b], &dev))) return e;
+        k.h_b_global = dev;
+        while (shared.size() & 3) shared.push_back(0.0f);
+        const size_t fl = hfrag[b].size() / 2;
+        if ((shared.size() + fl + 4) + (size_t)8 * F.wave_floats <= (size_t)kLdsBytes / 4 && !KWS_DEV_ENV("KWS_DEV_FAST_B_GLOBAL")) {
+            k.h_b_off = (int)shared.size();
+            shared.resize(shared.size() + fl);
+            memcpy(&shared[(size_t)k.h_b_off], hfrag[b].data(), fl * sizeof(float));
+        }
+    }
     return finish_fast_plan(h, F, shared, need[0], need[1]);
 }
 

@@ -14,8 +14,8 @@
 // bound through |W| row sums is ~100x larger and would switch the fast mode off for every model): tests/test_gain_calibration.py
 // holds it to Jacobians of the shipped graphs on real clips' features, and the guard multiplies it by k standard deviations.
 //
-// sigma_net: what the fused network's own re-ordering (MFMA accumulation instead of the reference's sequential total += x * w) moves in
-// a logit difference -- the same graph evaluated in float32 with two summation orders on the calibration set.
+// sigma_net: what the fused network's own arithmetic (matrix-core accumulation of split 22-bit operands instead of the reference's
+// sequential total += x * w) moves in a logit difference -- the same graph evaluated in float32 both ways on the calibration set.
 #include "kws_internal.h"
 
 #include <random>
@@ -117,12 +117,49 @@ void block_backward(const KwsConvBlockF32 &k, const std::vector<float> &w, const
 
 // the graph in float32 with the reference's summation order (blocked = false: total += x * w, tap outer, channel inner) or with partial
 // sums over groups of four products added pairwise (blocked = true: the shape of a matrix-core k-step); logits only
+// x s as a 22-bit number: the sum of the two halves the split-operand contraction carries (kws_fast.hip: fast_split_image; kws_fast_plan.cpp
+// splits the weights the same way); s = 2^14 / 2^ceil(log2 max|v|)
+float half_rn(float v)
+{
+    if (!(fabsf(v) < 65520.0f)) return v;
+    if (fabsf(v) < 6.103515625e-5f) return ldexpf(nearbyintf(ldexpf(v, 24)), -24);       // subnormal halves: multiples of 2^-24
+    int e;
+    const float m = frexpf(v, &e);                                                      // v = m 2^e, 0.5 <= |m| < 1: 11 bits = multiples of 2^-11
+    return ldexpf(nearbyintf(ldexpf(m, 11)), e - 11);
+}
+void split22(const std::vector<float> &v, std::vector<float> &out, float *scale)
+{
+    float mx = 0.0f;
+    for (float a : v) mx = std::max(mx, fabsf(a));
+    int e = 0;
+    if (mx > 0.0f && std::isfinite(mx)) (void)frexpf(mx, &e);
+    e = std::max(-100, std::min(100, e));
+    const float s = ldexpf(1.0f, 14 - e);
+    out.resize(v.size());
+    for (size_t i = 0; i < v.size(); i++) {
+        const float y = v[i] * s, hi = half_rn(y), lo = half_rn(y - hi);
+        out[i] = hi + lo;                                                               // exact in fp32: 22 significant bits
+    }
+    *scale = ldexpf(1.0f, e - 14);
+}
+
 void forward_f32(const KwsNnPlanF32 &N, const kws_handle::HostF32 &W, const std::vector<float> &x, bool blocked, std::vector<float> &logits)
 {
-    std::vector<float> cur = x, nxt, val;
+    std::vector<float> cur = x, nxt, val, cs, ws;
     for (int b = 0; b < N.n_blocks; b++) {
         const KwsConvBlockF32 &k = N.blk[b];
-        const std::vector<float> &w = W.w[b];
+        const std::vector<float> *wp = &W.w[b];
+        float unscale = 1.0f;
+        if (blocked && !k.depthwise) {
+            // the fused kernel's contraction: both operands as 22-bit numbers (the dropped lo x lo term is below the accumulator's own rounding)
+            float s1, s2;
+            split22(cur, cs, &s1);
+            split22(W.w[b], ws, &s2);
+            cur.swap(cs);
+            wp = &ws;
+            unscale = s1 * s2;
+        }
+        const std::vector<float> &w = *wp;
         val.assign((size_t)k.out_w * k.out_c, 0.0f);
         for (int r = 0; r < k.out_w; r++)
             for (int n = 0; n < k.out_c; n++) {
@@ -140,7 +177,7 @@ void forward_f32(const KwsNnPlanF32 &N, const kws_handle::HostF32 &W, const std:
                     else for (int c = 0; c < k.in_c; c++) add(cur[(size_t)row * k.in_c + c], w[((size_t)n * k.taps + tap) * k.in_c + c]);
                 }
                 if (blocked && (cnt & 3)) total = total + ((part[0] + part[1]) + (part[2] + part[3]));
-                float v = total + W.bias[b][n];
+                float v = total * unscale + W.bias[b][n];
                 v = std::min(std::max(v, k.conv_min), k.conv_max);
                 if (k.has_add) { v = v + W.addc[b][n]; v = std::min(std::max(v, k.add_min), k.add_max); }
                 val[(size_t)r * k.out_c + n] = v;

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64) void kws_cmvn_lds_kernel(KwsDspPlan P, const fl
 // KWS_DEV_GENERIC_SCRATCH=1 keeps the round-1 kernel with its scratch in HBM (same-box comparisons)
 bool kws_generic_uses_lds(const KwsDspPlan &P)
 {
-    static const bool forced_scratch = getenv("KWS_DEV_GENERIC_SCRATCH") != nullptr;
+    static const bool forced_scratch = KWS_DEV_ENV("KWS_DEV_GENERIC_SCRATCH") != nullptr;
     return !forced_scratch && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, KWS_LCH_DEFAULT).total * sizeof(float) <= 72 * 1024;
 }
 
@@ -772,7 +772,7 @@ int kws_launch_cmvn_generic(const KwsDspPlan &P, const float *mfcc, int n_clips,
     // the padded matrix of one clip in LDS when it fits 64 KB (199 x 13 floats = 10 KB for a 2 s window; 342 x 64 would be 87 KB); KWS_DEV_CMVN_GLOBAL=1
     // keeps the one-thread-per-element kernel (same-box comparisons)
     const size_t smem = (size_t)(P.n_frames + 2 * P.pad) * P.n_cepstral * sizeof(float);
-    static const bool forced_global = getenv("KWS_DEV_CMVN_GLOBAL") != nullptr;
+    static const bool forced_global = KWS_DEV_ENV("KWS_DEV_CMVN_GLOBAL") != nullptr;
     if (smem <= 64 * 1024 && !forced_global) {
         // one-wave workgroups, as many as the LDS lets a CU hold (up to 16), over 256 CUs' worth
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(smem, 1)));

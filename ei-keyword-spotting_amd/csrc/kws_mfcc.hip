@@ -1092,9 +1092,9 @@ static int launch_mfcc_t(const KwsDspPlan &P, const void *pcm, int n_clips, floa
     // Short windows (the 250 ms slices of continuous mode: 12 frames) stay with kws_mfcc_kernel: two passes cannot amortise what
     // kws_mfcc8_kernel re-derives per window (measured: 65 536 streams advance a slice in 0.790 vs 0.814 ms); KWS_DEV_MFCC8_MIN_FRAMES moves
     // the threshold (tests: 1 = every frame count on the new layout)
-    const char *const min_env = getenv("KWS_DEV_MFCC8_MIN_FRAMES");
+    const char *const min_env = KWS_DEV_ENV("KWS_DEV_MFCC8_MIN_FRAMES");
     const int min_frames8 = min_env ? atoi(min_env) : 16;
-    const bool old_layout = getenv("KWS_DEV_MFCC_OLD_LAYOUT") != nullptr || P.n_frames < min_frames8;
+    const bool old_layout = KWS_DEV_ENV("KWS_DEV_MFCC_OLD_LAYOUT") != nullptr || P.n_frames < min_frames8;
     const MfccVariant table[] = {
         // latency shape first (float samples + cmvnw only): run_classifier() and other calls of at most KWS_LAT_MAX_CLIPS windows
         { 40, 8, 0, true, (F32IN && WITH_CMVN && !PROF) ? mfcc_launch<KWS_LAT_CHP, true, true, 8, 40, false, false, KWS_LAT_WAVES> : nullptr },

@@ -509,7 +509,7 @@ int kws_launch_nn(const KwsNnPlan &N, const int8_t *q_in, int n_clips, float *sc
     // share the weights and tables), up to twelve
     int nw = KWS_NN_WAVES_MAX, per_cu = 1;
     while (nw > KWS_NN_WAVES && kws_nn_smem_bytes(N, nw) > 158 * 1024) --nw;
-    if (const char *ev = getenv("KWS_DEV_NN_WAVES")) { int a = 0, b2 = 0; if (sscanf(ev, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= KWS_NN_WAVES_MAX && b2 >= 1) { nw = a; per_cu = b2; } }   // development aid (occupancy experiments)
+    if (const char *ev = KWS_DEV_ENV("KWS_DEV_NN_WAVES")) { int a = 0, b2 = 0; if (sscanf(ev, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= KWS_NN_WAVES_MAX && b2 >= 1) { nw = a; per_cu = b2; } }   // development aid (occupancy experiments)
     const size_t smem = kws_nn_smem_bytes(N, nw);
     grid = (n_clips + nw - 1) / nw;
     if (grid > (grid_cap / 4) * per_cu) grid = (grid_cap / 4) * per_cu;          // grid_cap = 4 workgroups per CU

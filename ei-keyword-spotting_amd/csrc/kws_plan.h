@@ -3,6 +3,16 @@
 // All tables are built ONCE on the host, in the same precision and order the reference builds them per clip
 // ("batch-first, table-once, fused"), uploaded to HBM, and referenced from these structs.
 #pragma once
+#include <stdlib.h>
+
+// Development switches (environment variables KWS_DEV_*: occupancy experiments, A/B runs, forcing a tier in a test) exist only in a library
+// built with -DKWS_DEV_SWITCHES (make dev -> libkws_mi355x_dev.so); the product library does not read the environment and does not
+// contain their names.
+#ifdef KWS_DEV_SWITCHES
+#define KWS_DEV_ENV(name) getenv(name)
+#else
+#define KWS_DEV_ENV(name) ((const char *)nullptr)
+#endif
 #include <stdint.h>
 
 struct KwsDspPlan {

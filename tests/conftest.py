@@ -25,6 +25,17 @@ def host_exe(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def dev_pkg():
+    """The binding over libkws_mi355x_dev.so (built with -DKWS_DEV_SWITCHES): the product library does not read the KWS_DEV_* environment
+    switches, so tests that force a tier or a kernel layout run on this build of the same sources."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch  # noqa: F401
+    from __graft_entry__ import load_package
+    return load_package(dev=True)
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from kws_testlib import Oracle
     return Oracle()

@@ -274,7 +274,7 @@ FUSED_DW_GRAPHS = {
 
 
 @pytest.mark.parametrize("key", sorted(FUSED_DW_GRAPHS))
-def test_fast_mode_fused_depthwise_separable_graphs(key, pkg, oracle, tmp_path, monkeypatch):
+def test_fast_mode_fused_depthwise_separable_graphs(key, dev_pkg, oracle, tmp_path, monkeypatch):
     """Depthwise-separable float graphs in the fused fast kernel: depthwise first block, depth multiplier 2, VALID pooling with a
     dropped tail, ragged SAME windows, 40-channel inputs, eight blocks -- each against the restated float kernels
     (reference/depthwiseconv_float.h:25, reference/conv.h:28-99) within the fast mode's score tolerance, incl. the special clips."""
@@ -285,7 +285,9 @@ def test_fast_mode_fused_depthwise_separable_graphs(key, pkg, oracle, tmp_path, 
     from kws_testlib import synth_model_blob
     blob = dequantize(synth_model_blob(**FUSED_DW_GRAPHS[key]))
     # these random-weight graphs have whatever logit gain their draws gave them: most would be routed past the first tier (round 4).  This
-    # test is about the fused kernel's arithmetic: start every batch call in it (the guards still decide which clips it keeps)
+    # test is about the fused kernel's arithmetic: start every batch call in it (the guards still decide which clips it keeps) -- a
+    # development switch, so the development build of the library (conftest.py: dev_pkg)
+    pkg = dev_pkg
     monkeypatch.setenv("KWS_DEV_FAST_ENTRY", "1")
     p = tmp_path / ("%s.kwsm" % key)
     p.write_bytes(blob)

@@ -174,9 +174,10 @@ def test_quantized_filterbank_models_on_gpu(name, pkg, oracle, tmp_path):
     gm.close()
 
 @pytest.mark.parametrize("name", ["fft1024_filters36", "stride10ms_win31", "fft128_win51"])
-def test_chunk_length_is_measured_per_handle_and_never_changes_a_bit(name, pkg, oracle, tmp_path, monkeypatch):
+def test_chunk_length_is_measured_per_handle_and_never_changes_a_bit(name, dev_pkg, oracle, tmp_path, monkeypatch):
     """kws_spectral_lds_kernel runs with eight or four frames per chunk (csrc/kws_generic.hip); which is faster depends on the shape, so a handle
     measures it on its own first large calls (kws_api.cpp generic_chunk_begin).  Both pinned values and the measured path give the oracle's bits."""
+    pkg = dev_pkg            # KWS_DEV_GENERIC_LCH is a development switch: the development build of the library (conftest.py)
     import ctypes
     import torch
     kw = dict(BLOCKS, **CASES[name])

@@ -28,8 +28,9 @@ def pkg():
 
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
-def test_every_frame_count_on_both_layouts(shape, pkg, oracle, tmp_path):
+def test_every_frame_count_on_both_layouts(shape, dev_pkg, oracle, tmp_path):
     import torch
+    pkg = dev_pkg            # the layout switches are development switches: the development build of the library (conftest.py)
     ran = []
     for nfr in FRAMES:
         if nfr > 50 and SHAPES[shape]["num_filters"] == 40:
