@@ -725,6 +725,22 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
         // the graph's gain leaves the first tier no room (build_guard): every clip's cepstra come from the exact kernels, then the fast
         // cmvnw + network with the second tier's guard and the exact kernels for what that hands on (the continuous mode's path) -- or,
         // entry tier 3, the exact kernels throughout
+        if (h->is_float && h->fast_fused_ok) {
+            // float32 graph of the fused shapes: the DSP block by the exact kernels -- extract_mfcc_features' matrix, bit for bit: no feature
+            // error, whatever the graph's gain -- and the network on the matrix cores from that matrix (kws_fast_kernel's feat_in form).
+            // What is left of the guard is the network's own arithmetic (split 22-bit operands, KwsFastPlan::v_net_feat) against the clip's
+            // own scores; a clip it does not clear is listed and goes through the exact network.  (configs[4].)
+            HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));
+            if ((e = mfcc_fused_device(h, pcm, 0, B, fx, nullptr, s))) return e;
+            if (!scores) return EI_IMPULSE_OK;                               // extract_mfcc_features only
+            rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, fx, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
+                                              h->d_flags, h->d_flags + 1, h->n_cu, s, nullptr, h->tap_logits, 1);
+            if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, h->tap_logits, h->n_cu, s, h->d_flags);
+            if (rc) return fail(KWS_ERROR_HIP, "NN kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            HIP_TRY(hipMemcpyAsync(h->d_flags2, h->d_flags, sizeof(int), hipMemcpyDeviceToDevice, s));      // those clips carry the exact mode's scores
+            return EI_IMPULSE_OK;
+        }
         if (h->fast_entry_tier >= 3) {
             HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));
             if (!scores) return mfcc_fused_device(h, pcm, 0, B, fx, q, s);

@@ -93,6 +93,7 @@ struct KwsFastPlan {
     // g_c1 = (k sigma x margin / score tolerance)^2, g_c2 = (k sigma / largest logit error the linearisation is trusted for)^2.
     int guard_off;                // shared LDS: [n_cepstral rounded up to cg] x float4 { abs, lev, rel, alternative rel: column 0 with its means replayed; the other columns for a clip with digitally silent frames }
     int guard_cep_off;            // the same for windows that arrive as the exact kernels' cepstra (no spectral terms): continuous mode, second tier
+    float v_net_feat;             // V of a window that arrives as the exact kernels' FEATURES (kws_fast_kernel's feat_in): the network's own arithmetic only
     float g_c1, g_c2, v_net, lvl_inv;   // lvl_inv = 1 / (n_frames x sqrt(filters)): level = lvl_inv x sum over the frames of |the DCT's coefficient 0|
     float c0_factor, c0_abs, c0_rel, c0_inv_rows;   // column 0: the exact window means are only computed when c0_factor x (plain deviation of
                                   // the column) < c0_abs + c0_rel x (its largest magnitude); c0_factor = sqrt(c0_mult n_frames / win_size),

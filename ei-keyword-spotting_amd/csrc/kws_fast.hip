@@ -827,7 +827,9 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
 // ---------------------------------------------------------------------------------------------------------
 // NZ: taps of mel filters 0..31 kept in registers (filters 32..39, when there are 40, keep KWS_FAST_NZ2); DG: DCT k-groups = filters / 8
 // FROM_CEP: the windows arrive as cepstra before cmvnw [n_frames][n_cepstral] (continuous mode: the rolling buffers of kws_streams_*,
-// ring-indexed per KwsDspPlan::ring_*) instead of PCM: the kernel starts at cmvnw.
+// ring-indexed per KwsDspPlan::ring_*) instead of PCM: the kernel starts at cmvnw.  feat_in (run-time, FROM_CEP forms): what arrives is
+// extract_mfcc_features' matrix itself -- the exact kernels' bits --: cmvnw and its guard are skipped and only the network runs (the
+// guard that is left is the network's own arithmetic, KwsFastPlan::v_net_feat).
 // NET: the float32 network follows in the same launch (no feature / int8 outputs); !NET: the features / the int8 tensor leave for
 // HBM and no network code is compiled in.  Two instantiations instead of run-time flags: each form's cmvnw stores are written
 // for what it does (with a branch per value only where a global store hangs on it).
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,
                                                           long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr,
                                                           const KwsNnPlan *__restrict__ QNp = nullptr, const int *__restrict__ sel = nullptr,
-                                                          float *__restrict__ tap_logits = nullptr)
+                                                          float *__restrict__ tap_logits = nullptr, int feat_in = 0)
 {
     static_assert(QCP == 0 || !NET, "the int8 network follows the feature-emitting form");
     static_assert(!MFE || (!NET && QCP == 0 && !FROM_CEP && !PROF), "the MFE form is the spectral prefix: mel energies to HBM");
@@ -1367,7 +1369,8 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // guard at the column's largest magnitude, the running-sum mean is good enough for every window (error kappa |mean| / deviation
         // below the feature tolerance) and the pass is skipped -- the usual case for audio whose loudness changes over the second.
         bool c0_exact = false, silent = false;
-        if constexpr (!MFE) {
+        const bool feats_given = FROM_CEP && feat_in != 0;              // wave-uniform
+        if constexpr (!MFE) if (!feats_given) {
             const bool on = lane_m < nfr;
             const float x0 = img[min(lane_m, nfr - 1) * fs];
             // a frame without any energy: zero handling put FLT_EPSILON there, and its log (bit-identical in both tiers: the reference's own
@@ -1429,10 +1432,13 @@ __global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const Kw
         // the guard (kws_fast.h): V = variance estimate of a logit difference's error; the clip stays iff V max(c1 P^2, c2) <= 1
         float gV = 0.0f;
         if constexpr (!MFE) {                             // (MFE: nothing is divided by a deviation: the mel energies leave as they are)
+          if (feats_given) gV = FP.v_net_feat;
+          else {
             const float level = FROM_CEP ? 0.0f : wave_sum(lvl_sum) * FP.lvl_inv;
             if (cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
+          }
         }
         if constexpr (!NET) {
             // the scores are another kernel's (or an int8 network's): P = 1/4, the largest p (1 - p) there is.  !(x <= 1): a NaN hands the clip on
@@ -1580,7 +1586,7 @@ template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true, int
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
                          long long *prof_out, hipStream_t stream, const float *cep = nullptr, const KwsNnPlan *d_nn = nullptr, const int *sel = nullptr,
-                         float *tap_logits = nullptr)
+                         float *tap_logits = nullptr, int feat_in = 0)
 {
     const size_t smem = ((size_t)FP.shared_floats + FP.q_floats + (size_t)FP.n_waves * FP.wave_floats) * sizeof(float);
     // the opt-in for more than 64 KB of dynamic LDS is per device (and this instantiation): one bit per device, set once
@@ -1597,7 +1603,7 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
     hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
-                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel, tap_logits);
+                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel, tap_logits, feat_in);
     return (int)hipGetLastError();
 }
 
@@ -1652,13 +1658,14 @@ size_t kws_fast_qnet_bytes(int qcp)
 // cmvnw + (fused float network | features / int8 tensor) from cepstra in HBM, ring-indexed per P.ring_* (continuous mode)
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
                                  float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
-                                 const int *sel, float *tap_logits)
+                                 const int *sel, float *tap_logits, int feat_in)
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
+    if (feat_in && !FP.fuse) return (int)hipErrorInvalidValue;          // features in: only the fused network is left to run
     // mel taps / DCT are not part of this variant: one instantiation serves every model
     return FP.fuse ? launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list,
-                                                      n_cu, nullptr, stream, cep, nullptr, sel, tap_logits)
+                                                      n_cu, nullptr, stream, cep, nullptr, sel, tap_logits, feat_in)
                    : launch_fast_t<4, 4, false, true, false>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count,
                                                              flag_list, n_cu, nullptr, stream, cep, nullptr, sel);
 }

@@ -104,6 +104,7 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
     for (float g : gain) tot2 += (double)g * (double)g * (double)nfr;
     F.v_net = (float)((double)kRhoDev * (double)kRhoDev * tot2) + ((h->is_float && h->gain.calibrated) ? h->gain.sigma_net * h->gain.sigma_net : 0.0f);
     F.v_net *= scale * scale;
+    F.v_net_feat = ((h->is_float && h->gain.calibrated) ? h->gain.sigma_net * h->gain.sigma_net : 0.0f) * scale * scale;
     F.lvl_inv = 1.0f / ((float)nfr * sqrtf((float)NF));      // level = mean over the frames of |mean over the filters of the log-mel energies|
     while (shared.size() & 3) shared.push_back(0.0f);
     for (int tier = 0; tier < 2; tier++) {

@@ -36,7 +36,7 @@ int kws_launch_cmvn_nn(const KwsDspPlan &P, const KwsNnPlan &N, const float *mfc
                        int *ran_nn, hipStream_t stream, const int *sel = nullptr);
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
                                  float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
-                                 const int *sel = nullptr, float *tap_logits = nullptr);
+                                 const int *sel = nullptr, float *tap_logits = nullptr, int feat_in = 0);
 int kws_launch_nn_f32(const KwsNnPlanF32 &N, const KwsNnPlanF32 *d_plan, const float *features, int n_clips, float *scores,
                       float *tap_logits, int n_cu, hipStream_t stream, const int *sel = nullptr);
 size_t kws_nn_f32_smem_bytes(const KwsNnPlanF32 &N, int n_waves);

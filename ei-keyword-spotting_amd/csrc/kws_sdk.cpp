@@ -254,6 +254,14 @@ static void fill_result(const kws_handle *h, ei_impulse_result_t *result, const 
         cls[ix].value = scores[ix];
     }
 }
+// run_inference polls the cancellation hook twice once the result is written: behind the classifier (ei_run_classifier.h:489-491) and at
+// its end (:636-638, behind the -- absent -- anomaly block); the second poll is not made when the first one cancels.
+static EI_IMPULSE_ERROR inference_polls(void)
+{
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+    return EI_IMPULSE_OK;
+}
 static ei_impulse_result_timing_t *result_timing(const kws_handle *h, ei_impulse_result_t *result)
 {
     const size_t C = h->model.labels.size();
@@ -283,8 +291,7 @@ EI_IMPULSE_ERROR run_inference(ei_matrix_t *fmatrix, ei_impulse_result_t *result
     if (e) return e;
     memcpy(scores.data(), w.h_s, C * sizeof(float));
     fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t0));
-    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;     // ei_run_classifier.h:489-491
-    return EI_IMPULSE_OK;
+    return inference_polls();
 }
 
 // run_classifier's device work on the workspace stream: H2D of the window, extract_mfcc_features, the network, D2H of the
@@ -426,7 +433,8 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     if (e == EI_IMPULSE_CANCELED) return e;
     if (!e && hipStreamSynchronize(w.st) != hipSuccess) e = fail(KWS_ERROR_HIP, "run_classifier: device work failed");
     if (e) return e;
-    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
+    // (with debug the poll behind the DSP block has been made where the SDK makes it, before the features are printed: oneshot_enqueue)
+    if (!debug && ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
     // timing.dsp / timing.classification (ei_run_classifier.h:669, 696: the SDK reads its millisecond timer around each stage).  Both
     // stages are queued before the host waits once, so the split comes from events on the stream: the callback gather (host) + H2D +
     // DSP block kernels, and the network + D2H.  With debug the host drained the stream between the stages and its own timer is used.
@@ -441,8 +449,7 @@ EI_IMPULSE_ERROR run_classifier(signal_t *signal, ei_impulse_result_t *result, b
     std::vector<float> scores(C);
     memcpy(scores.data(), w.h_s, C * sizeof(float));
     fill_result(h, result, scores.data(), debug, nn_ms);
-    if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
-    return EI_IMPULSE_OK;
+    return inference_polls();
 }
 
 // development / test aid (not in the public headers): the feature matrix the last run_classifier() call of the default model classified
@@ -584,12 +591,14 @@ EI_IMPULSE_ERROR run_classifier_continuous(signal_t *signal, ei_impulse_result_t
         memcpy(scores.data(), w.h_s, C * sizeof(float));
         timing->dsp += (int)(t1 - dsp_start_ms);
         fill_result(h, result, scores.data(), debug, (int)(ei_read_timer_ms() - t1));
+        // run_inference's return value is only handed on at the end: a cancelled call still filters the scores and shifts the buffer
+        // (ei_run_classifier.h:268-281)
+        const EI_IMPULSE_ERROR polled = inference_polls();
         ei_impulse_result_classification_t *cls = (ei_impulse_result_classification_t *)result;
         for (size_t ix = 0; ix < C; ix++) cls[ix].value = run_moving_average_filter(&h->maf[ix], cls[ix].value);
         // shift the feature buffer for new data (ei_run_classifier.h:277-279)
         for (size_t i = 0; i < F - feature_size; i++) h->cont_features[i] = h->cont_features[i + feature_size];
-        if (ei_run_impulse_check_canceled() == EI_IMPULSE_CANCELED) return EI_IMPULSE_CANCELED;
-        return EI_IMPULSE_OK;
+        return polled;
     }
     return EI_IMPULSE_OK;
 }

@@ -43,7 +43,16 @@ using namespace ei;
 
 /* ---- porting hooks (SDK/porting/ei_classifier_porting.h:45-76) ---------- */
 static int g_print = 0;
-EI_IMPULSE_ERROR ei_run_impulse_check_canceled() { return EI_IMPULSE_OK; }
+/* boundary fixtures (tools/make_golden.py --only-debug-cancel): the text the reference prints with debug = true is captured instead of
+ * going to stdout, and the cancellation hook the reference polls (ei_run_classifier.h:221, 489, 689) answers EI_IMPULSE_CANCELED on its
+ * g_cancel_at-th call (1-based; 0 = never) */
+static char *g_cap = NULL;
+static size_t g_cap_size = 0, g_cap_len = 0;
+static int g_cancel_at = 0, g_cancel_polls = 0;
+EI_IMPULSE_ERROR ei_run_impulse_check_canceled() {
+    g_cancel_polls++;
+    return (g_cancel_at > 0 && g_cancel_polls == g_cancel_at) ? EI_IMPULSE_CANCELED : EI_IMPULSE_OK;
+}
 EI_IMPULSE_ERROR ei_sleep(int32_t) { return EI_IMPULSE_OK; }
 uint64_t ei_read_timer_us() {
     struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -51,8 +60,18 @@ uint64_t ei_read_timer_us() {
 }
 uint64_t ei_read_timer_ms() { return ei_read_timer_us() / 1000; }
 void ei_printf(const char *format, ...) {
+    va_list a;
+    if (g_cap) {
+        va_start(a, format);
+        if (g_cap_len + 1 < g_cap_size) {
+            const int n = vsnprintf(g_cap + g_cap_len, g_cap_size - g_cap_len, format, a);
+            if (n > 0) g_cap_len = g_cap_len + (size_t)n < g_cap_size ? g_cap_len + (size_t)n : g_cap_size - 1;
+        }
+        va_end(a);
+        return;
+    }
     if (!g_print) return;
-    va_list a; va_start(a, format); vprintf(format, a); va_end(a);
+    va_start(a, format); vprintf(format, a); va_end(a);
 }
 void ei_printf_float(float f) { ei_printf("%f", f); }
 void DebugLog(const char *s) { ei_printf("%s", s); }
@@ -126,6 +145,51 @@ int eiref_continuous(const int16_t *slice, size_t n, float *scores, int *produce
     return (int)r;
 }
 int eiref_slice_size(void) { return EI_CLASSIFIER_SLICE_SIZE; }
+
+/* ---- boundary behaviour: debug text and the cancellation hook -------------------------------------------------------------
+ * eiref_capture(buf, cap): ei_printf appends to buf (NULL: back to stdout / silence); eiref_capture_len() = bytes written so far.
+ * eiref_cancel_at(n): the hook's n-th call from now on answers EI_IMPULSE_CANCELED (0: never); eiref_cancel_polls() = calls seen since.
+ * The *_full entry points hand the caller's ei_impulse_result_t back byte for byte, pre-filled with 0xA5 so that what the reference
+ * leaves untouched can be seen; labels[i] = 1 when classification[i].label points at the model's i-th category string. */
+void eiref_capture(char *buf, size_t cap) { g_cap = buf; g_cap_size = cap; g_cap_len = 0; if (buf && cap) buf[0] = 0; }
+size_t eiref_capture_len(void) { return g_cap_len; }
+void eiref_cancel_at(int n) { g_cancel_at = n; g_cancel_polls = 0; }
+int eiref_cancel_polls(void) { return g_cancel_polls; }
+int eiref_result_size(void) { return (int)sizeof(ei_impulse_result_t); }
+static void result_out(const ei_impulse_result_t &r, unsigned char *bytes, int *labels) {
+    memcpy(bytes, &r, sizeof r);
+    for (int i = 0; i < EI_CLASSIFIER_LABEL_COUNT; i++) labels[i] = r.classification[i].label == ei_classifier_inferencing_categories[i];
+}
+int eiref_run_classifier_full(const int16_t *pcm, size_t n, int debug, unsigned char *result_bytes, int *labels) {
+    g_pcm = pcm; g_pcm_len = n; g_get_data_calls = 0;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    ei_impulse_result_t result;
+    memset(&result, 0xA5, sizeof(result));
+    EI_IMPULSE_ERROR r = run_classifier(&signal, &result, debug != 0);
+    result_out(result, result_bytes, labels);
+    return (int)r;
+}
+int eiref_run_inference_full(const float *features, int debug, unsigned char *result_bytes, int *labels) {
+    matrix_t fm(1, EI_CLASSIFIER_NN_INPUT_FRAME_SIZE, (float *)features);
+    ei_impulse_result_t result;
+    memset(&result, 0xA5, sizeof(result));
+    EI_IMPULSE_ERROR r = run_inference(&fm, &result, debug != 0);
+    result_out(result, result_bytes, labels);
+    return (int)r;
+}
+int eiref_continuous_full(const int16_t *slice, size_t n, int debug, unsigned char *result_bytes, int *labels) {
+    g_pcm = slice; g_pcm_len = n; g_get_data_calls = 0;
+    signal_t signal;
+    signal.total_length = n;
+    signal.get_data = &pcm_get_data;
+    ei_impulse_result_t result;
+    memset(&result, 0xA5, sizeof(result));
+    EI_IMPULSE_ERROR r = run_classifier_continuous(&signal, &result, debug != 0);
+    result_out(result, result_bytes, labels);
+    return (int)r;
+}
 /* arm (buf != NULL) / disarm the get_data trace; eiref_trace_count = calls seen since it was armed (may exceed cap) */
 void eiref_trace_get_data(long long *buf /*[3 * cap]*/, int cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
 int eiref_trace_count(void) { return g_trace_n; }

@@ -20,7 +20,8 @@ def host_exe(tmp_path_factory):
     if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") and shutil.which("gcc")):
         pytest.skip("needs ROCm's clang++ and gcc")
     out = str(tmp_path_factory.mktemp("kws_host_stub"))
-    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "sanitize"), "OUT=" + out, os.path.join(out, "kws_host_san")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "sanitize"), "OUT=" + out, os.path.join(out, "kws_host_san"),
+                           os.path.join(out, "kws_boundary_san")])
     return os.path.join(out, "kws_host_san")
 
 

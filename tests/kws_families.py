@@ -19,12 +19,16 @@ re-ordering moved in the cepstra is amplified by 1 / deviation.  The synthetic b
                  recording at its default volumes (word 1.0, background 0.1: 0.5 word + 0.05 background, lines 134-135, 167-181) --
                  a word shorter than the window over white / pink / amplitude-modulated noise (the test mixes it with
                  kws_mix_audio_device)
+  word_noise_gain  the same mix with BOTH volumes drawn per clip (word 0.05 .. 1, background 0.01 .. 1: a quiet word over a loud floor up to a
+                 loud word over a barely audible one): 0.5 word_vol word + 0.5 bg_vol background (dataset-curation.py:133-135) -- bench.py's
+                 mix_audio-shaped input family
 """
 import numpy as np
 
 CLIP_LEN = 16000
 FS = 16000.0
-FAMILIES = ("amp_sweep", "word_silence", "dc_tone", "clipped", "pure_tone", "bursts", "quiet_noise", "near_constant", "detuned_tone", "word_background")
+FAMILIES = ("amp_sweep", "word_silence", "dc_tone", "clipped", "pure_tone", "bursts", "quiet_noise", "near_constant", "detuned_tone", "word_background",
+            "word_noise_gain")
 
 
 def _to_pcm(x):
@@ -94,6 +98,14 @@ def family(name, n, seed=0):
         start = rng.integers(0, track.size - CLIP_LEN + 1, n)
         noise = np.stack([track[st:st + CLIP_LEN] for st in start])
         return _to_pcm((0.5 * w.astype(np.float64) + (np.float32(0.05) * noise).astype(np.float64)) * 32767.0)
+    if name == "word_noise_gain":
+        w, _ = word_waveforms(n, seed)
+        track = background_track(seed)
+        start = rng.integers(0, track.size - CLIP_LEN + 1, n)
+        noise = np.stack([track[st:st + CLIP_LEN] for st in start])
+        wv = np.exp(rng.uniform(np.log(0.05), np.log(1.0), (n, 1)))
+        bv = np.exp(rng.uniform(np.log(0.01), np.log(1.0), (n, 1)))
+        return _to_pcm((0.5 * wv * w.astype(np.float64) + 0.5 * bv * noise.astype(np.float64)) * 32767.0)
     if name == "dc_tone":
         dc = rng.choice([-1.0, 1.0], (n, 1)) * np.exp(rng.uniform(np.log(50.0), np.log(20000.0), (n, 1)))
         amp = np.exp(rng.uniform(np.log(20.0), np.log(10000.0), (n, 1)))

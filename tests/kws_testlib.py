@@ -411,6 +411,33 @@ class Reference:
         assert t >= 0, t
         return t
 
+    # ---- boundary behaviour (debug text, the cancellation hook): oracle/ref_driver.cpp eiref_*_full -------------------------
+    def boundary_call(self, kind, data, debug=False, cancel_at=0):
+        """kind: 'oneshot' (int16 window) | 'inference' (float features) | 'continuous' (int16 slice).  Returns (rc, polls of the
+        cancellation hook, the caller's ei_impulse_result_t byte for byte -- pre-filled with 0xA5 --, label flags, printed text)."""
+        L = self.L
+        L.eiref_capture.argtypes = [C.c_void_p, C.c_size_t]
+        L.eiref_capture_len.restype = C.c_size_t
+        fn = {"oneshot": L.eiref_run_classifier_full, "inference": L.eiref_run_inference_full, "continuous": L.eiref_continuous_full}[kind]
+        buf = C.create_string_buffer(1 << 16)
+        res = np.zeros(L.eiref_result_size(), np.uint8)
+        lab = np.zeros(self.n_labels, np.int32)
+        L.eiref_capture(buf, len(buf))
+        L.eiref_cancel_at(int(cancel_at))
+        if kind == "inference":
+            x = np.ascontiguousarray(data, np.float32)
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+            rc = fn(_ptr(x), int(debug), _ptr(res), _ptr(lab))
+        else:
+            x = np.ascontiguousarray(data, np.int16)
+            fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            rc = fn(_ptr(x), x.size, int(debug), _ptr(res), _ptr(lab))
+        n = L.eiref_capture_len()
+        polls = L.eiref_cancel_polls()
+        L.eiref_capture(None, 0)
+        L.eiref_cancel_at(0)
+        return rc, polls, res, lab, buf.raw[:n]
+
     def run_classifier(self, pcm):
         pcm = np.ascontiguousarray(pcm, np.int16)
         s = np.zeros(self.n_labels, np.float32)

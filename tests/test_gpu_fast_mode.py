@@ -244,7 +244,8 @@ def test_fast_mode_depthwise_separable_graph_is_fused_and_extract_mfcc(pkg, orac
     host = oracle.synth(77, 0, B)
     pcm = torch.from_numpy(host).to("cuda:0")
     # round 4: this graph's logit gain (~42 per unit of rms feature error x sqrt(features); the headline graph: 8) leaves the first tier
-    # no room -- its batch calls start from the exact kernels' cepstra and run the fast cmvnw + the fused network from there
+    # no room.  Round 5: such a float graph gets the exact kernels' feature matrix (bit for bit) and the fused network on the matrix cores
+    # from it (kws_fast_kernel's feat_in form): no clip depends on a cmvnw guard any more
     assert gm.fast_tolerance()["entry_tier"] == 2
     s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm)
     n_fb = gm.fast_fallback_count()
@@ -253,8 +254,8 @@ def test_fast_mode_depthwise_separable_graph_is_fused_and_extract_mfcc(pkg, orac
     so, fo, _ = om.run_batch(host, want_features=True)
     print("\ncfg5 fp32 in fast mode (entry tier 2), %d clips: max |score - oracle| = %.3g, %d clips finished by the exact kernels (%d when only the scores are asked for)"
           % (B, np.abs(s2 - so).max(), n_fb, n_fb2))
-    assert np.abs(s - so).max() <= FAST_SCORE_TOL and np.abs(f - fo).max() <= FAST_FEATURE_TOL
-    assert np.abs(s2 - so).max() <= FAST_SCORE_TOL and n_fb2 <= n_fb
+    assert np.abs(s - so).max() <= FAST_SCORE_TOL and (bits(f) == bits(fo)).all()
+    assert np.abs(s2 - so).max() <= FAST_SCORE_TOL and n_fb2 <= n_fb <= B // 100
     f2 = torch.zeros((B, gm.n_features), dtype=torch.float32, device="cuda:0")
     gm.extract_mfcc_batch_device(pcm.data_ptr(), B, f2.data_ptr())
     torch.cuda.synchronize()
@@ -513,7 +514,12 @@ def test_fast_mode_guard_follows_the_model_gain(pkg, oracle, tmp_path):
                         dz=float(pair_error(z_t.cpu().numpy(), zo)[~exact].max(initial=0.0)), pq=float(np.median((so * (1 - so)).max(axis=1))))
         assert (bits(fe) == bits(fo)).all()
         assert res[tag]["ds"] <= FAST_SCORE_TOL, res
-        assert (bits(s[exact]) == bits(se[exact])).all()
+        if res[tag]["entry"] == 1:
+            assert (bits(s[exact]) == bits(se[exact])).all()            # a clip the exact kernels finished carries their bits
+        else:
+            # round 5: a float graph whose gain leaves the fast DSP tiers no room gets the exact kernels' feature matrix for EVERY clip (bit for
+            # bit) and the network on the matrix cores from it: the scores are the exact mode's up to the network's own arithmetic
+            assert exact.all() and np.abs(s - se).max() <= FAST_SCORE_TOL / 4
         gm.close()
     print("\nfirst convolution x 8 on %d clips: %s" % (B, res))
     assert 5.0 <= res["hot"]["gain"] / res["base"]["gain"] <= 12.0

@@ -15,6 +15,7 @@ Without arguments: leaves_l476, e2e_l476, deep_l476, continuous_l476, f32_twin_l
   --only-graphs            graphs_l476.npz          synthetic graphs through the reference's op registrations
   --only-qfb               qfb_l476.npz             EIDSP_QUANTIZE_FILTERBANK = 1 (the second build of the compiled reference)
   --only-trace             get_data_trace_l476.npz  what the reference asks the application's callback, call by call (FIRST user of continuous mode in its process)
+  --only-debug-cancel      debug_cancel_l476.npz    the text debug = true prints and what the cancellation polls do (FIRST user of continuous mode in its process)
   --only-other-length      other_length_l476.npz    run_classifier on windows of another length (1 .. 49 frames)
   --only-mfe-other-length  mfe_other_length_l432.npz  the same for the MFE-block model, composed from the L432 copy's leaves
 """
@@ -207,6 +208,62 @@ def get_data_trace(ref):
         print(k, len(out[k]), "calls; total_length after, error:", out[k + "_meta"].tolist(), "first:", out[k][:3].tolist())
 
 
+# the boundary scenarios, in the order every implementation must run them in a FRESH process (the reference's function-static
+# first_run makes the process's first continuous call special): (name, kind, what, debug, cancel_at)
+#   what: ("clip", i) = window i of the seed-9 clips; ("features", i) = extract_mfcc_features of window i; ("slice", k) = slice k of the
+#   2 s stream made of windows 2 and 3; "init" = run_classifier_init()
+BOUNDARY_SCENARIOS = (
+    ("oneshot_dbg_a", "oneshot", ("clip", 0), 1, 0), ("oneshot_dbg_b", "oneshot", ("clip", 1), 1, 0),
+    ("inference_dbg_a", "inference", ("features", 0), 1, 0),
+    ("oneshot_cancel1", "oneshot", ("clip", 0), 0, 1), ("oneshot_cancel2", "oneshot", ("clip", 0), 0, 2), ("oneshot_cancel1_dbg", "oneshot", ("clip", 0), 1, 1),
+    ("oneshot_cancel2_dbg", "oneshot", ("clip", 0), 1, 2), ("inference_cancel1", "inference", ("features", 0), 0, 1),
+    ("init0", "init", None, 0, 0),
+    ("cont_dbg_0", "continuous", ("slice", 0), 1, 0), ("cont_dbg_1", "continuous", ("slice", 1), 1, 0), ("cont_dbg_2", "continuous", ("slice", 2), 1, 0),
+    ("cont_dbg_3", "continuous", ("slice", 3), 1, 0), ("cont_dbg_4", "continuous", ("slice", 4), 1, 0),
+    ("init1", "init", None, 0, 0),
+    ("cont_cancel1_first", "continuous", ("slice", 0), 0, 1),          # cancelled after the DSP block: the slice is not committed
+    ("cont_after_0", "continuous", ("slice", 0), 0, 0), ("cont_after_1", "continuous", ("slice", 1), 0, 0), ("cont_after_2", "continuous", ("slice", 2), 0, 0),
+    ("cont_after_3", "continuous", ("slice", 3), 0, 0),
+    ("cont_cancel2_full", "continuous", ("slice", 4), 0, 2),           # buffer full: cancelled inside run_inference, the filter and the shift still happen
+    ("cont_after_5", "continuous", ("slice", 5), 0, 0),
+    ("cont_cancel1_full", "continuous", ("slice", 6), 1, 1),           # buffer full, cancelled after the DSP block (debug on: nothing printed yet)
+    ("cont_after_7", "continuous", ("slice", 7), 0, 0),
+)
+
+
+def debug_cancel(ref, synth, cfg):
+    """What the reference prints with debug = true (ei_run_classifier.h:698-705, 463-479; continuous :242-253) and what its cancellation
+    polls do (:689, :489; continuous :221) -- return code, number of polls, the caller's result struct byte for byte (pre-filled with 0xA5:
+    what stays 0xA5 the reference did not touch) -- for BOUNDARY_SCENARIOS.  Run as  make_golden.py --only-debug-cancel  (fresh process)."""
+    clips = synth.synth(9, 0, 4)
+    stream = clips[2:4].reshape(-1)
+    out = {"clips": clips, "names": np.array([x[0] for x in BOUNDARY_SCENARIOS])}
+    feats = {}
+    for name, kind, what, debug, cancel_at in BOUNDARY_SCENARIOS:
+        if kind == "init":
+            ref.continuous_init()
+            continue
+        if what[0] == "clip":
+            data = clips[what[1]]
+        elif what[0] == "features":
+            if what[1] not in feats:
+                feats[what[1]] = ref.extract_mfcc(clips[what[1]], cfg).reshape(-1)
+            data = feats[what[1]]
+        else:
+            data = stream[what[1] * 4000:(what[1] + 1) * 4000]
+        rc, polls, res, lab, text = ref.boundary_call(kind, data, debug, cancel_at)
+        out[name + "_meta"] = np.int64([rc, polls])
+        out[name + "_result"] = res
+        out[name + "_labels"] = lab
+        out[name + "_text"] = np.frombuffer(text, np.uint8)
+        print("%-22s rc %2d polls %d touched %2d of %d bytes, text %5d bytes: %s" % (name, rc, polls, int((res != 0xA5).sum()), res.size, len(text),
+                                                                                  text[:60].decode(errors="replace").replace("\n", "|")))
+    out["features_a"] = feats[0]
+    out["labels"] = np.array(ref.labels)
+    np.savez_compressed(os.path.join(GOLDEN, "debug_cancel_l476.npz"), **out)
+    print("debug_cancel_l476.npz", os.path.getsize(os.path.join(GOLDEN, "debug_cancel_l476.npz")), "bytes")
+
+
 OTHER_LENGTHS = (16319, 16001, 15999, 15681, 15680, 15679, 8000, 1280, 960, 641, 640)
 MFE_OTHER_LENGTHS = (16319, 16001, 15999, 15680, 15679, 8000, 1280, 641, 640)
 
@@ -284,6 +341,8 @@ def main():
     ref = Reference()
     if "--only-trace" in sys.argv:
         return get_data_trace(ref)
+    if "--only-debug-cancel" in sys.argv:
+        return debug_cancel(ref, Oracle(), L476_CONFIG())
     if "--only-other-length" in sys.argv:
         return other_length(ref, Oracle(), L476_CONFIG())
     if "--only-mfe-other-length" in sys.argv:

@@ -68,6 +68,20 @@ def main():
                                     "MFMA_busy_cycles_per_clip": round(cs.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / batch, 1),
                                     "LDS_bank_conflict_share": round(cs.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, cs.get("SQ_LDS_IDX_ACTIVE", 1.0)), 4),
                                     "source": "rocprofv3 --pmc, one pass per counter set (tools/pmc_sets.sh)"}
+                # fractions of the pipes' ceilings over the launch (bench.py: roofline.compute).  GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the
+                # launch's shader cycles; 256 CUs x 4 SIMDs; a plain fp32 vector instruction occupies a SIMD's issue for 2.34 cycles (1.05e12 wave-instructions/s
+                # at 2.4 GHz, tools/ubench/valu_throughput.hip); SQ_VALU_MFMA_BUSY_CYCLES is in cycles per SIMD; SQ_LDS_IDX_ACTIVE in cycles per CU.
+                if cs.get("GRBM_GUI_ACTIVE"):
+                    cyc = cs["GRBM_GUI_ACTIVE"] / 8.0
+                    valu_plain = cs["SQ_INSTS_VALU"] - cs.get("SQ_INSTS_MFMA", 0.0)
+                    res["sq"][short]["compute"] = {
+                        "valu_issue_frac": round(valu_plain * 2.34 / (1024.0 * cyc), 4),
+                        "mfma_busy_frac": round(cs.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc), 4),
+                        "lds_busy_frac": round(cs.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256.0 * cyc), 4),
+                        "waves_per_simd": round(cs["SQ_WAVES"] / 1024.0, 2) if cs.get("SQ_WAVES") else None,
+                        "shader_cycles_per_launch": round(cyc),
+                        "ceilings": "vector ALU: 1.05e12 plain fp32 wave-instructions/s = 2.34 cycles per instruction per SIMD (tools/ubench/valu_throughput.hip, measured on MI355X); "
+                                    "matrix pipe: busy cycles / (1024 SIMDs x launch cycles); LDS: index-active cycles / (256 CUs x launch cycles); launch cycles = GRBM_GUI_ACTIVE / 8 XCDs"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["kernels"], indent=1))
 
