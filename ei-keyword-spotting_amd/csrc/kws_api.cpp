@@ -168,6 +168,7 @@ EI_IMPULSE_ERROR kws_fast_tolerance_info(const kws_handle *h, kws_fast_tolerance
     out->n_frames = h->dsp.n_frames;
     out->entry_tier = h->fast_entry_tier;
     out->dev_overrides = h->fast_dev_overrides;
+    out->k_sigma_worst_column = (h->is_float && h->gain.calibrated) ? out->k_sigma / 1.3f : out->k_sigma;
     out->sigma_net = sqrtf(F.v_net);       // the terms of V that do not depend on the clip: the fused network's re-ordering noise, the deviation's own error
     // sum of gain^2 over every feature: a feature error of rms size t on every feature gives V = sigma_net^2 + t^2 x this
     double g2 = 0.0;
@@ -765,6 +766,20 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s (is the gfx950 code object present?)", hipGetErrorString((hipError_t)rc));
         return rerun_flagged_device(h, pcm, B, scores, fx, want_f, q, s);
     }
+#ifdef KWS_DEV_SWITCHES
+    if (fused && KWS_DEV_ENV("KWS_DEV_FAST_SPLIT")) {
+        // development prototype ("build the two-kernel split and time it"): the spectral half + cmvnw as the
+        // feature-emitting form, the features through HBM, the network half as the feat_in form of the from-cepstra kernel.  Timing only: the
+        // first launch's guard assumes P = 1/4 and its list is not re-run here.
+        rc = kws_launch_fast(h->dsp, h->fast_plain, h->d_fast_plain, pcm, (int)B, nullptr, fx, nullptr, h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        HIP_TRY(hipMemsetAsync(h->d_flags3, 0, sizeof(int), s));
+        rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, fx, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
+                                          h->d_flags3, h->d_flags3 + 1, h->n_cu, s, nullptr, h->tap_logits, 1);
+        if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return EI_IMPULSE_OK;
+    }
+#endif
     if (fused && want_f) {
         // the fused kernel keeps the feature matrix on chip: a caller who also wants it gets it from the feature-emitting form first
         // (that launch knows no scores: its guard assumes the largest p (1 - p) there is, and its list decides for features and scores)

@@ -167,6 +167,8 @@ EI_IMPULSE_ERROR kws_resample_device_ex(const float *in, size_t n_in, int sr_in,
         tb = slot;
     }
     const double ratio = (double)sr_out / (double)sr_in;
+    // resampy's index_step = int(min(1, ratio) x precision): below 1 / precision it is 0 and the kernel would divide by it
+    if ((int)(std::min(1.0, ratio) * (double)kResPrecision) < 1) return fail(KWS_ERROR_BAD_ARGUMENT, "kws_resample_device: ratio %g is below 1/%d", ratio, kResPrecision);
     const bool exact = (flags & KWS_RESAMPLE_EXACT_POSITIONS) != 0;
     // the reference's length: resampy writes int(n ratio) samples, librosa's fix_length pads with zeros up to ceil(n ratio)
     const size_t n_valid = exact ? n_out : std::min(n_out, (size_t)((double)n_in * ratio));

@@ -270,7 +270,8 @@ struct ScratchUse {
 EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h);
 EI_IMPULSE_ERROR build_nn_plan(kws_handle *h);
 EI_IMPULSE_ERROR build_fast_plans(kws_handle *h);     // kws_fast_plan.cpp; never fatal: sets fast_*_ok
-#define KWS_GAIN_INPUTS 16
+#define KWS_GAIN_INPUTS 48
+#define KWS_GAIN_HEADROOM 1.25f        // the calibrated per-column gain is the largest value over the calibration matrices x this (kws_gain.cpp)
 void kws_calibrate_gain(kws_handle *h);               // kws_gain.cpp
 
 // kws_api.cpp: stage launchers shared with the stream / SDK entry points (kws_sdk.cpp); internal, not exported

@@ -174,6 +174,9 @@ static EI_IMPULSE_ERROR ensure_ws(kws_handle *h, size_t n_x)
         if (hipMalloc((void **)&w.d_x, n_x * sizeof(float)) != hipSuccess ||
             hipHostMalloc((void **)&w.h_x, n_x * sizeof(float), hipHostMallocDefault) != hipSuccess)
             return oom();
+        // (the one-shot path fills the window frame by frame: samples no frame covers -- the tail behind the last frame, the slack -- are
+        //  copied to the device with the rest and must not be whatever the allocator left there: ADVICE round 4)
+        memset(w.h_x, 0, n_x * sizeof(float));
         w.cap_x = n_x;
     }
     return EI_IMPULSE_OK;

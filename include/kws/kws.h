@@ -77,6 +77,10 @@ int kws_fast_is_fused(const kws_handle *h);
  *                            (bit-identical to the reference's), then the fast cmvnw + network from those -- about 0.4 x the exact path;
  *   kws_fast_exact_count     clips the second tier handed back in turn: they were finished by the exact kernels and carry the exact
  *                            mode's bits.
+ * A float32 graph whose gain leaves the fast DSP tiers no room (entry_tier >= 2) takes another route since round 5: EVERY clip's feature
+ * matrix comes from the exact kernels (bit for bit) and the fused network runs from it on the matrix cores; what is left to guard is the
+ * network's own arithmetic against the clip's own scores.  Both counts then are the (normally zero) clips that guard sent through the
+ * exact network as well.
  * When a tier hands a clip back -- the rule follows from the LOADED MODEL: cmvnw divides whatever the fast arithmetic
  * moved in a cepstral coefficient, or in a window's mean, by the window's deviation; the graph carries a feature error into its logits with
  * a gain that depends on its weights.  kws_create measures that gain per cepstral column (reverse differentiation of the float graph on a
@@ -91,6 +95,12 @@ int kws_fast_is_fused(const kws_handle *h);
  * error, through the clip's own softmax, must stay below the score tolerance of 1e-4.  A calibrated statistical estimate, not a bound
  * (a worst-case bound through the weights' row sums would refuse every model); tests/test_gpu_fast_families.py re-evaluates the rule
  * from the oracle's cepstra and holds scores AND logits to it on eleven input families.
+ * How many standard deviations k_sigma is worth depends on how well the calibrated gain covers the clip at hand: gain[c] is the largest value
+ * over 48 calibration matrices x 1.25.  On real clips' Jacobians (tests/test_gain_calibration.py) no clip's total gain exceeds the calibrated
+ * one -- the full 4.5 sigma for an error spread over the columns -- and a single column's gain reaches at most 1.3 x the calibrated value:
+ * 4.5 / 1.3 = 3.4 sigma for a clip whose whole error sat in that column (kws_fast_tolerance::k_sigma_worst_column).  For a graph whose
+ * activation patterns on its real inputs differ from anything the calibration set reaches, nothing bounds the underestimate: the numbers
+ * are what was measured on the shipped graphs.
  * int8 graphs have no float logits to protect (the network is bit-exact from its int8 input tensor on): gain[c] is the constant for which
  * the rule reads "k_sigma x the rms of the clip's feature error estimates <= 1e-4", calibrated = 0.
  *   kws_fast_guard   coef [4][n_columns]: abs, lev, rel, and the alternative rel: column 0 -- when its window means were replayed in the reference's
@@ -105,11 +115,15 @@ typedef struct {
     float total_gain;                                  /* sqrt(sum over all features of gain^2) */
     float uniform_feature_tol;                         /* the feature error of random sign, the same size on every feature, that exactly meets the rule at P = 1/4 */
     int calibrated, n_columns, n_frames;
-    int entry_tier;                                    /* where kws_run_classifier_batch_device starts in KWS_MODE_FAST: 1 the fast kernel; 2 exact cepstra for
-                                                          every clip, then the fast cmvnw + network (a graph whose gain leaves tier 1 no room: a typical
-                                                          clip would be handed on anyway); 3 the exact kernels.  Routing only: every tier applies its guard */
+    int entry_tier;                                    /* where kws_run_classifier_batch_device starts in KWS_MODE_FAST: 1 the fast kernel; 2 / 3: the graph's gain
+                                                          leaves tier 1 (and tier 2) no room -- a typical clip would be handed on anyway.  float32 graphs of the
+                                                          fused shapes then get the exact kernels' feature matrix + the network on the matrix cores; other graphs:
+                                                          2 = exact cepstra for every clip, then the fast cmvnw + network; 3 = the exact kernels.  Routing only:
+                                                          every tier applies its guard */
     int dev_overrides;                                 /* non-zero: a KWS_DEV_FAST_* development switch (guard off / scaled, no re-run) was set in the environment when
                                                           the model was created -- KWS_MODE_FAST results are then outside the documented tolerance */
+    float k_sigma_worst_column;                        /* k_sigma / 1.3: what k_sigma is worth for a clip whose whole error sits in the column where a real clip's gain was
+                                                          measured furthest above the calibrated one (see above); = k_sigma for int8 graphs (no gain is calibrated) */
 } kws_fast_tolerance;
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
 EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);

@@ -109,11 +109,13 @@ def test_calibrated_gain_against_jacobians_on_real_clips(name, host_exe):
     ratios = np.array(ratios)
     print("\n%s: real clips' column gain / calibrated: median %.2f, p90 %.2f, max %.2f; total gain of a clip: median %.3g, max %.3g, calibrated %.3g"
           % (name, np.median(ratios), np.quantile(ratios, 0.9), ratios.max(), np.median(totals), max(totals), info["total"]))
-    # the calibration keeps the largest value per column over its inputs: a typical clip sits below it, none far above, and it is not
-    # a loose bound either.  (k_sigma = 4.5 absorbs a clip whose gain is above the calibrated one: 4.5 / 2.2 is still two sigma.)
-    assert 0.4 <= np.median(ratios) <= 1.1
-    assert ratios.max() <= 2.2
-    assert max(totals) <= 1.5 * info["total"] and np.median(totals) >= 0.4 * info["total"]
+    # the calibration keeps the largest value per column over its 48 inputs x 1.25 (16 inputs without headroom left real
+    # clips' columns up to 1.7 x above it): a typical clip sits below it, no column more than 1.3 x above, no clip's TOTAL gain -- what a
+    # clip's summed variance scales with -- above it, and it is not a loose bound either.  k_sigma = 4.5 against the calibrated gain is
+    # then >= 4.5 / 1.3 = 3.4 sigma even for a clip whose whole error sat in its worst column (kws.h says so next to k_sigma).
+    assert 0.4 <= np.median(ratios) <= 1.0
+    assert ratios.max() <= 1.3
+    assert max(totals) <= 1.0 * info["total"] and np.median(totals) >= 0.4 * info["total"]
 
 
 def test_high_gain_model_gets_a_tighter_tolerance(host_exe, tmp_path):
@@ -129,7 +131,9 @@ def test_high_gain_model_gets_a_tighter_tolerance(host_exe, tmp_path):
     # the tighter tolerance is what the hotter graph needs: at ITS tolerance the bar holds, at the base model's it does not
     om = OracleModel(o, hot)
     assert perturbation_experiment(om, o, i1["uniform_tol"], n=128, seeds=(0,)) <= 1e-4
-    assert perturbation_experiment(om, o, i0["uniform_tol"], n=128, seeds=(0,)) > 1e-4
+    # (the calibrated gain carries 1.25 x headroom and is a maximum over its inputs: the stated tolerance is ~2 x tighter than a typical
+    # clip needs -- twice the base model's tolerance is still eight times too loose for the hot graph)
+    assert perturbation_experiment(om, o, 2.0 * i0["uniform_tol"], n=128, seeds=(0,)) > 1e-4
 
 
 def test_int8_models_use_the_feature_level_rule(host_exe):
