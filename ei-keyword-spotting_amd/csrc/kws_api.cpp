@@ -231,44 +231,63 @@ int grid_cap_nn(const kws_handle *h) { return h->n_cu * 4; }
 // used from then on.  Both are bit-exact: nothing but the time depends on the choice.  While it is being measured a call waits for the previous
 // timed call's kernel before it starts (four host waits in a handle's life).  KWS_DEV_GENERIC_LCH=4|8 pins the choice (A/B runs, tests).
 static const size_t kGenTuneMinClips = 2048;
-static int generic_chunk_begin(kws_handle *h, size_t B, hipStream_t s)
+static int generic_chunk_begin(kws_handle *h, size_t B, hipStream_t s, bool *mine)
 {
+    *mine = false;
     const char *fe = KWS_DEV_ENV("KWS_DEV_GENERIC_LCH");          // (read per call: a test toggles it between handles)
     const int forced = fe ? atoi(fe) : 0;
     if (forced == 4 || forced == 8) return forced;
-    std::lock_guard<std::mutex> lk(h->g_mu);
-    kws_handle::GenericTune &T = h->gen_tune;
-    if (T.choice) return T.choice;
-    if (T.armed == 1) return 8;                               // another thread's timed call is in flight: do not disturb it
-    if (T.armed == 2) {                                       // collect what the previous timed call measured
+    hipEvent_t wait_for[2] = { nullptr, nullptr };
+    {
+        std::lock_guard<std::mutex> lk(h->g_mu);
+        kws_handle::GenericTune &T = h->gen_tune;
+        if (T.choice) return T.choice;
+        if (T.armed == 1) return 8;                           // another call's timed sample is in flight: do not disturb it
+        if (T.armed == 2) { T.armed = 3; wait_for[0] = T.ev[0]; wait_for[1] = T.ev[1]; }      // this call collects it -- outside the lock
+        else if (T.armed == 3) return 8;                      // somebody else is collecting
+    }
+    if (wait_for[1]) {
         float ms = 0.0f;
-        if (hipEventSynchronize(T.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, T.ev[0], T.ev[1]) == hipSuccess && T.clips) {
-            T.ms_per_clip[T.phase & 1] += (double)ms / (double)T.clips;
-            T.phase++;
-        }
+        const bool ok = hipEventSynchronize(wait_for[1]) == hipSuccess && hipEventElapsedTime(&ms, wait_for[0], wait_for[1]) == hipSuccess;
+        std::lock_guard<std::mutex> lk(h->g_mu);
+        kws_handle::GenericTune &T = h->gen_tune;
+        if (ok && T.clips) { T.ms_per_clip[T.phase & 1] += (double)ms / (double)T.clips; T.phase++; }
         T.armed = 0;
         if (T.phase >= 4) { T.choice = T.ms_per_clip[0] <= T.ms_per_clip[1] ? 8 : 4; return T.choice; }
     }
-    if (B < kGenTuneMinClips) return 8;                       // too small to time: the default, not a measurement
+    std::lock_guard<std::mutex> lk(h->g_mu);
+    kws_handle::GenericTune &T = h->gen_tune;
+    if (T.choice) return T.choice;
+    if (T.armed != 0 || B < kGenTuneMinClips) return 8;       // (too small to time: the default, not a measurement)
+    const int lch = (T.phase & 1) ? 4 : 8;
+    // the first launch of a chunk length pays one-time host costs (function attributes, the code object's lazy load) between the events:
+    // it runs un-timed, the sample is taken from the next call of that length
+    if (!(T.warm & lch)) { T.warm |= lch; return lch; }
     if (!T.ev[0] && (hipEventCreate(&T.ev[0]) != hipSuccess || hipEventCreate(&T.ev[1]) != hipSuccess)) { T.choice = 8; return 8; }
     T.armed = 1;
+    T.owner = s; T.owned = true;
     T.clips = B;
+    *mine = true;
     (void)hipEventRecord(T.ev[0], s);
-    return (T.phase & 1) ? 4 : 8;
+    return lch;
 }
-static void generic_chunk_end(kws_handle *h, hipStream_t s)
+// only the call that armed the sample closes it, on its own stream (another thread's call on another stream used to)
+static void generic_chunk_end(kws_handle *h, hipStream_t s, bool mine)
 {
+    if (!mine) return;
     std::lock_guard<std::mutex> lk(h->g_mu);
-    if (h->gen_tune.armed == 1) { (void)hipEventRecord(h->gen_tune.ev[1], s); h->gen_tune.armed = 2; }
+    kws_handle::GenericTune &T = h->gen_tune;
+    if (T.armed == 1 && T.owned && T.owner == s) { (void)hipEventRecord(T.ev[1], s); T.armed = 2; T.owned = false; }
 }
 // the general-shape spectral launch with the handle's chunk length (the scratch kernel ignores it)
 static int launch_spectral_generic_for(kws_handle *h, const KwsDspPlan &P, const void *pcm, int is_float, size_t B, float *mfcc, const float *wrap,
                                        int out_stride, float *ws, hipStream_t s)
 {
     const bool lds = kws_generic_uses_lds(P);
-    const int lch = lds ? generic_chunk_begin(h, B, s) : 8;
+    bool mine = false;
+    const int lch = lds ? generic_chunk_begin(h, B, s, &mine) : 8;
     const int rc = kws_launch_spectral_generic(P, pcm, is_float, (int)B, mfcc, wrap, out_stride, ws, grid_cap_mfcc(h), lch, s);
-    if (lds) generic_chunk_end(h, s);
+    if (lds) generic_chunk_end(h, s, mine);
     return rc;
 }
 

@@ -28,6 +28,9 @@
 #define KWS_FAST_CMVN_EXT 8       // rows a cmvnw first window may count more often than the others (sparse form, see ext_off)
 #define KWS_FAST_XS 144           // floats per frame of the FFT exchange buffer: 64 positions + 2 floats of padding per 8; = 16 mod 64
 #define KWS_FAST_WAVE 64
+#ifndef KWS_FAST_WPS
+#define KWS_FAST_WPS 2            // waves per SIMD the fast kernel is built for (4 x this per workgroup; 3 = an occupancy experiment: <= 168 registers)
+#endif
 #define KWS_FAST_ZF 320           // floats per in-place FFT buffer of the exact kernel (kws_device.h KWS_ZF)
 
 struct KwsFastBlock {

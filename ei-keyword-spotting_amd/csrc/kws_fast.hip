@@ -840,7 +840,7 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
 // written as the 16- / 64-byte activation rows of nn_mfma_clip (kws_nn_int8_dev.h) instead of -- or besides -- going to HBM, and the
 // network is bit-exact from that tensor on, as in kws_nn_mfma_kernel; 0: no int8 network code.
 template <int NZ, int DG, bool PROF = false, bool FROM_CEP = false, bool NET = true, int QCP = 0, bool MFE = false>
-__global__ __launch_bounds__(512, 2) void kws_fast_kernel(KwsDspPlan P, const KwsFastPlan *__restrict__ FPp, const int16_t *__restrict__ pcm, int n_clips,
+__global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_kernel(KwsDspPlan P, const KwsFastPlan *__restrict__ FPp, const int16_t *__restrict__ pcm, int n_clips,
                                                           float *__restrict__ scores, float *__restrict__ features,
                                                           int8_t *__restrict__ q_out, float in_scale, int in_zp,
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,

@@ -361,7 +361,7 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     F.shared_floats = (int)shared.size();
     fast_wave_floats(h, F, need_f, need_r1);
     const int avail = kLdsBytes / 4 - F.shared_floats - F.q_floats;
-    F.n_waves = std::min(8, avail / F.wave_floats);
+    F.n_waves = std::min(4 * KWS_FAST_WPS, avail / F.wave_floats);
     if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_WAVES")) F.n_waves = std::max(1, std::min(F.n_waves, atoi(ev)));   // development aid (occupancy experiments)
     if (F.n_waves < 4 && !KWS_DEV_ENV("KWS_DEV_FAST_WAVES")) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
                                    F.shared_floats * 4, F.wave_floats * 4);
@@ -557,7 +557,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         k.h_b_global = dev;
         while (shared.size() & 3) shared.push_back(0.0f);
         const size_t fl = hfrag[b].size() / 2;
-        if ((shared.size() + fl + 4) + (size_t)8 * F.wave_floats <= (size_t)kLdsBytes / 4 && !KWS_DEV_ENV("KWS_DEV_FAST_B_GLOBAL")) {
+        if ((shared.size() + fl + 4) + (size_t)(4 * KWS_FAST_WPS) * F.wave_floats <= (size_t)kLdsBytes / 4 && !KWS_DEV_ENV("KWS_DEV_FAST_B_GLOBAL")) {
             k.h_b_off = (int)shared.size();
             shared.resize(shared.size() + fl);
             memcpy(&shared[(size_t)k.h_b_off], hfrag[b].data(), fl * sizeof(float));

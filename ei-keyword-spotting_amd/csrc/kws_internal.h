@@ -160,7 +160,8 @@ struct kws_handle {
     int pooled_tap_bytes = 0;
     std::vector<void *> dev_allocs;
     // kws_spectral_lds_kernel's frames per chunk, measured per handle on its own first large calls (kws_api.cpp generic_chunk_begin / _end)
-    struct GenericTune { int choice = 0, phase = 0, armed = 0; size_t clips = 0; hipEvent_t ev[2] = { nullptr, nullptr }; double ms_per_clip[2] = { 0.0, 0.0 }; } gen_tune;
+    struct GenericTune { int choice = 0, phase = 0, armed = 0; size_t clips = 0; hipEvent_t ev[2] = { nullptr, nullptr }; double ms_per_clip[2] = { 0.0, 0.0 };
+                         hipStream_t owner = nullptr; bool owned = false; int warm = 0; } gen_tune;   // owner: the stream whose call armed the running sample; warm: bit per chunk length already launched once
     std::map<int, const int *> pad_maps_by_rows;     // kws_plan_for_length: cmvnw pad maps for other row counts than the model's (device, in dev_allocs)
     // scratch for the combined entry points (grown on demand)
     float *s_mfcc = nullptr;      // cepstra before CMVN, [B][n_features]

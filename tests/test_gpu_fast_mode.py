@@ -483,6 +483,38 @@ def test_fast_mode_fused_graphs_with_other_pooling_shapes(key, pkg, oracle, tmp_
     gm.close()
 
 
+@pytest.mark.parametrize("factor", [1.0e-4, 3.0e3])
+def test_split_operand_contraction_over_the_scale_range(factor, pkg, tmp_path):
+    """Round 5: the fused network's CONV_2D blocks run on v_mfma_f32_16x16x32_f16 with every fp32 operand carried as two halves of x * 2^k
+    (kws_fast.hip: fast_split_image; k from the image's largest magnitude per clip, the weights' k per block on the host).  The scaling is
+    what keeps the halves inside binary16's range: the headline graph with its first convolution x 1e-4 (activations of ~1e-4 behind it)
+    and x 3e3 (activations of several thousand, logits of +-1e4) must come out with the LOGITS of the reference's float kernels to fp32
+    accuracy -- relative to the largest logit, the yardstick a sum of products rounds against."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gain_calibration import scaled_first_conv
+    path = str(tmp_path / "cfg2_conv1_scaled.kwsm")
+    scaled_first_conv(os.path.join(MODELS, "cfg2_mfcc40_f32.kwsm"), factor, path)
+    B, seed = 1024, 31
+    pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda:0")
+    pkg.synth_clips_device(seed, 0, B, 16000, pcm.data_ptr())
+    gm = pkg.Model(path, device=0)
+    assert gm.fast_is_fused
+    z_t = torch.zeros((B, gm.n_labels), dtype=torch.float32, device="cuda:0")
+    gm.set_logits_tap(z_t.data_ptr())
+    s, f, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm, want_f=False)
+    gm.set_logits_tap(None)
+    so, fo, _, zo = oracle_all(path, seed, B, want_logits=True)
+    z = z_t.cpu().numpy()
+    rel = float(np.abs(z.astype(np.float64) - zo).max() / max(1.0, float(np.abs(zo).max())))
+    print("\nfirst convolution x %g: entry tier %d, max |logit| %.3g, max |logit - oracle| / max |logit| = %.3g, max |score - oracle| = %.3g"
+          % (factor, gm.fast_tolerance()["entry_tier"], float(np.abs(zo).max()), rel, float(np.abs(s - so).max())))
+    assert not np.isnan(s).any() and np.abs(s - so).max() <= FAST_SCORE_TOL
+    assert rel <= 2.0e-5
+    gm.close()
+
+
 def test_fast_mode_guard_follows_the_model_gain(pkg, oracle, tmp_path):
     """a deliberately high-gain model (the headline graph with its first convolution's weights x 8).  The
     library must measure the higher gain at kws_create, tighten the guard with it -- the same clips that the base model keeps in the
