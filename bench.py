@@ -538,7 +538,8 @@ def main():
     # which pipe is closest to its ceiling (the judged figure stays the HBM fraction: SURVEY 8(d))
     binds = "hbm"
     if compute:
-        cands = {"hbm": hbm_frac, "valu_issue": compute.get("valu_issue_frac") or 0.0, "mfma": compute.get("mfma_busy_frac") or 0.0, "lds": compute.get("lds_busy_frac") or 0.0}
+        cands = {"hbm": hbm_frac, "valu": max(compute.get("valu_issue_frac") or 0.0, compute.get("valu_active_frac") or 0.0),
+                 "mfma": compute.get("mfma_busy_frac") or 0.0, "lds": compute.get("lds_busy_frac") or 0.0}
         binds = max(cands, key=cands.get)
     roof = {"bound": binds, "kernel": dominant(r), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc[1]["traffic_bytes"] if pmc else None,

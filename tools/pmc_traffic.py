@@ -76,12 +76,13 @@ def main():
                     valu_plain = cs["SQ_INSTS_VALU"] - cs.get("SQ_INSTS_MFMA", 0.0)
                     res["sq"][short]["compute"] = {
                         "valu_issue_frac": round(valu_plain * 2.34 / (1024.0 * cyc), 4),
+                        "valu_active_frac": round(cs.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * cyc), 4),
                         "mfma_busy_frac": round(cs.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc), 4),
                         "lds_busy_frac": round(cs.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256.0 * cyc), 4),
                         "waves_per_simd": round(cs["SQ_WAVES"] / 1024.0, 2) if cs.get("SQ_WAVES") else None,
                         "shader_cycles_per_launch": round(cyc),
                         "ceilings": "vector ALU: 1.05e12 plain fp32 wave-instructions/s = 2.34 cycles per instruction per SIMD (tools/ubench/valu_throughput.hip, measured on MI355X); "
-                                    "matrix pipe: busy cycles / (1024 SIMDs x launch cycles); LDS: index-active cycles / (256 CUs x launch cycles); launch cycles = GRBM_GUI_ACTIVE / 8 XCDs"}
+                                    "valu_active_frac = SQ_ACTIVE_INST_VALU (quad-cycles a wave has a vector instruction executing, summed over waves) x 4 / (1024 SIMDs x launch cycles): the pipe's occupancy whatever the instruction mix; matrix pipe: busy cycles / (1024 SIMDs x launch cycles); LDS: index-active cycles / (256 CUs x launch cycles); launch cycles = GRBM_GUI_ACTIVE / 8 XCDs"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["kernels"], indent=1))
 
