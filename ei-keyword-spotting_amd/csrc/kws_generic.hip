@@ -323,13 +323,15 @@ __device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstrid
 
 // + the model's tables, staged once per workgroup (every read of them sits on a lane's serial path: from L2 a tap of a mel filter or a
 // twiddle costs a round trip of ~1 us; measured: the first version, tables in L2, ran at 9.9 ns per frame against the scratch kernel's 12.4)
-struct LdsLayout { int z, y, perm, ps, ps_stride, mel, mel_stride, dct, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, total; };
-__host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int nnz, int LCH)
+struct LdsLayout { int z, zs, y, perm, ps, ps_stride, mel, mel_stride, dct, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, total; };
+// fb: frames of a chunk transformed TOGETHER (round 5): fb work buffers, the butterflies of a level dealt over (frame, butterfly) items
+__host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int nnz, int LCH, int fb = 1)
 {
     LdsLayout L;
     const int ncfft = fft / 2;
     L.z = 0;
-    L.y = L.z + 2 * (ncfft + (ncfft >> 4) + 1);
+    L.zs = 2 * (ncfft + (ncfft >> 4) + 1);
+    L.y = L.z + fb * L.zs;
     L.perm = L.y;                                         // (the sample buffer of the first version is gone: samples go straight to their leaves)
     L.ps = L.perm + ncfft;
     L.ps_stride = nbins | 1;
@@ -350,13 +352,13 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int 
 
 template <bool F32IN, int LCH>
 __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips, float *__restrict__ mfcc_out,
-                                                               const float *__restrict__ wrap, int out_stride)
+                                                               const float *__restrict__ wrap, int out_stride, int fb)
 {
     extern __shared__ __attribute__((aligned(16))) float glds[];
     const int lane = threadIdx.x;
     const int nfr = P.n_frames, NF = P.n_filters, ncep = P.n_cepstral, fft = P.fft_len, nbins = P.n_bins, ncfft = fft >> 1;
     const int nnz = P.filt_nnz;
-    const LdsLayout L = lds_layout(fft, NF, nbins, nnz, LCH);
+    const LdsLayout L = lds_layout(fft, NF, nbins, nnz, LCH, fb);
     float *Z = glds + L.z, *PS = glds + L.ps, *MEL = glds + L.mel, *DCT = glds + L.dct;
     int *perm = (int *)(glds + L.perm);
     float2 *l_tw = (float2 *)(glds + L.tw), *l_stw = (float2 *)(glds + L.stw), *l_dtw = (float2 *)(glds + L.dtw), *l_dstw = (float2 *)(glds + L.dstw);
@@ -415,28 +417,40 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         auto sample = [&](int n) -> float {
             return F32IN ? ((const float *)pcm_v)[cbase + n] : (float)((const int16_t *)pcm_v)[cbase + n] * (1.0f / 32768.0f);     // numpy::int16_to_float
         };
-        for (int fi = 0; fi < nfc; fi++) {
-            // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing.  Eight samples
-            //      per lane and trip, requested together (the first version's loop waited for two dependent round trips per sample: 40 % of
-            //      the kernel).  First trip (a whole frame up to fft 512): where a sample goes (dst0) and which one a lane reads (ncl0) do not
-            //      depend on the frame and are set up once per workgroup; the predecessor of sample n is what the neighbouring lane has just
-            //      loaded -- lane 0's is lane 63's of the slot before, or one more load for the frame's first sample.
+        for (int fb0 = 0; fb0 < nfc; fb0 += fb) {
+          const int nbf = min(fb, nfc - fb0);                        // frames of this sub-batch: transformed together
+          // the first trip (a whole frame up to fft 512) of EVERY frame of the sub-batch is requested before any of it is used (round 5: one
+          // exposed round trip to HBM per sub-batch instead of one per frame)
+          float xq[4][8], fpq[4];
+#pragma unroll
+          for (int fj = 0; fj < 4; fj++) if (fj < nbf) {
+              const int off = (f0 + fb0 + fj) * P.frame_stride;
+#pragma unroll
+              for (int j = 0; j < 8; j++) xq[fj][j] = sample(off + ncl0[j]);
+              fpq[fj] = sample(off == 0 ? P.n_samples - 1 : off - 1);
+          }
+#pragma unroll
+          for (int fj = 0; fj < 4; fj++) if (fj < nbf) {
+            const int fi = fb0 + fj;
+            float *Zf = Z + fj * L.zs;
+            // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing.  Where a sample
+            //      goes (dst0) and which one a lane reads (ncl0) do not depend on the frame and are set up once per workgroup; the predecessor of
+            //      sample n is what the neighbouring lane has just loaded -- lane 0's is lane 63's of the slot before, or one more load for the
+            //      frame's first sample.
             const int off = (f0 + fi) * P.frame_stride;
             {
-                float xv[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) xv[j] = sample(off + ncl0[j]);
-                float first_prev = sample(off == 0 ? P.n_samples - 1 : off - 1);
+                float first_prev = fpq[fj];
                 if (wrap && off == 0) first_prev = wrap[clip];
                 float carry = first_prev;                                // sample 64 j - 1: lane 63 of the slot before
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float up = __shfl_up(xv[j], 1, KWS_WAVE);
+                    const float xvj = xq[fj][j];
+                    const float up = __shfl_up(xvj, 1, KWS_WAVE);
                     const float prev = lane == 0 ? carry : up;
-                    carry = __shfl(xv[j], KWS_WAVE - 1, KWS_WAVE);
+                    carry = __shfl(xvj, KWS_WAVE - 1, KWS_WAVE);
                     const float pl = P.pre_cof * prev;
                     // sample n is the real (n even) or imaginary (n odd) part of kiss_fftr's input point n / 2, which sits at leaf perm[n / 2]
-                    if (dst0[j] >= 0) Z[dst0[j]] = ((used0 >> j) & 1) ? xv[j] - pl : 0.0f;
+                    if (dst0[j] >= 0) Zf[dst0[j]] = ((used0 >> j) & 1) ? xvj - pl : 0.0f;
                 }
             }
             for (int n0 = 8 * 64; n0 < fft; n0 += 8 * 64) {
@@ -453,54 +467,96 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                     const int n = n0 + 64 * j + lane;
                     const float prev = (wrap && off + n == 0) ? wrap[clip] : pv[j];
                     const float pl = P.pre_cof * prev;
-                    if (n < fft) Z[2 * zpad(perm[n >> 1]) + (n & 1)] = n < used ? xv[j] - pl : 0.0f;
+                    if (n < fft) Zf[2 * zpad(perm[n >> 1]) + (n & 1)] = n < used ? xv[j] - pl : 0.0f;
                 }
             }
+          }
             WAVE_SYNC();
             GPH(0);
-            // ---- kf_work's levels, innermost first; the butterflies of a level are independent of each other ------------------
+            // ---- kf_work's levels, innermost first.  The butterflies of a level are independent of each other, and so are the frames of the
+            //      sub-batch: (frame, butterfly) items over the lanes.  Radix-4 levels (every level of a power-of-two length but one) take four
+            //      items per lane at a time -- sixteen points and twelve twiddles requested together, then the four butterflies, then the
+            //      stores: one LDS round trip per four butterflies instead of one per butterfly (round 5).
 #pragma unroll
             for (int l = MAXLEV - 1; l >= 0; l--) {
                 if (l >= P.fft_levels) continue;
                 const int p = lv_p[l], m = lv_m[l], fstride = lv_fs[l];
-                const int nb = ncfft / p;
-                for (int b = lane; b < nb; b += 64) {
-                    const int g = (int)(((unsigned)b * (unsigned)lv_inv[l]) >> 20), k = b - g * m;
-                    z_bfly_one(Z, g * p * m, k, fstride, m, p, l_tw);
+                const int nb = ncfft / p, items = nbf * nb;
+                const unsigned inv_nb = (1u << 20) / (unsigned)nb + 1u;          // it / nb for it < 4096
+                if (p == 4) {
+                    for (int it0 = lane; it0 - lane < items; it0 += 4 * 64) {
+                        cf f[4][4], t1[4], t2[4], t3[4];
+                        int zo[4], kk[4];
+                        const int slot0 = it0 - lane;                     // wave-uniform: slots past the last item are skipped whole
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (slot0 + 64 * u < items) {
+                            const int it = min(it0 + 64 * u, items - 1);
+                            const int fj = (int)(((unsigned)it * inv_nb) >> 20), b = it - fj * nb;
+                            const int g = (int)(((unsigned)b * (unsigned)lv_inv[l]) >> 20), k = b - g * m;
+                            zo[u] = fj * L.zs; kk[u] = g * 4 * m + k;
+                            const float *Zf = Z + zo[u];
+                            f[u][0] = z_ld(Zf, kk[u]); f[u][1] = z_ld(Zf, kk[u] + m); f[u][2] = z_ld(Zf, kk[u] + 2 * m); f[u][3] = z_ld(Zf, kk[u] + 3 * m);
+                            t1[u] = to_cf(l_tw[k * fstride]); t2[u] = to_cf(l_tw[k * fstride * 2]); t3[u] = to_cf(l_tw[k * fstride * 3]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (slot0 + 64 * u < items) bfly4(f[u][0], f[u][1], f[u][2], f[u][3], t1[u], t2[u], t3[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (it0 + 64 * u < items) {                  // (a lane past the last item re-did the last butterfly: not stored)
+                                float *Zf = Z + zo[u];
+                                z_st(Zf, kk[u], f[u][0]); z_st(Zf, kk[u] + m, f[u][1]); z_st(Zf, kk[u] + 2 * m, f[u][2]); z_st(Zf, kk[u] + 3 * m, f[u][3]);
+                            }
+                        }
+                    }
+                } else {
+                    for (int it = lane; it < items; it += 64) {
+                        const int fj = (int)(((unsigned)it * inv_nb) >> 20), b = it - fj * nb;
+                        const int g = (int)(((unsigned)b * (unsigned)lv_inv[l]) >> 20), k = b - g * m;
+                        z_bfly_one(Z + fj * L.zs, g * p * m, k, fstride, m, p, l_tw);
+                    }
                 }
                 WAVE_SYNC();
             }
             GPH(2);
-            // ---- kiss_fftr's split (kiss_fftr.cpp:84-119) + power spectrum: sqrt(re^2 + im^2) in double, (1/fft) * mag^2 ---------
-            float *ps = PS + fi * L.ps_stride;
+            // ---- kiss_fftr's split (kiss_fftr.cpp:84-119) + power spectrum: sqrt(re^2 + im^2) in double, (1/fft) * mag^2; (frame, bin pair)
+            //      items over the lanes ---------
             auto power = [&](cf v) -> float {
                 const double re = (double)v.r, im = (double)v.i;
                 const float mag = (float)g_dsqrt(__fma_rn(re, re, im * im));
                 const float sq = mag * mag;
                 return (float)(inv_fft * (double)sq);
             };
-            if (lane == 0) {
-                const cf t0 = z_ld(Z, 0);
+            if (lane < nbf) {
+                const cf t0 = z_ld(Z + lane * L.zs, 0);
+                float *ps = PS + (fb0 + lane) * L.ps_stride;
                 cf dc, ny;
                 dc.r = t0.r + t0.i; dc.i = 0.0f;
                 ny.r = t0.r - t0.i; ny.i = 0.0f;
                 ps[0] = power(dc);
                 ps[ncfft] = power(ny);
             }
-            for (int k = 1 + lane; k <= ncfft / 2; k += 64) {
-                const cf fpk = z_ld(Z, k);
-                cf fpnk = z_ld(Z, ncfft - k);
-                fpnk.i = -fpnk.i;
-                const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
-                const cf twv = cmul(f2k, to_cf(l_stw[k - 1]));
-                cf lo, hi;
-                lo.r = (f1k.r + twv.r) * 0.5f;
-                lo.i = (f1k.i + twv.i) * 0.5f;
-                hi.r = (f1k.r - twv.r) * 0.5f;
-                hi.i = (twv.i - f1k.i) * 0.5f;
-                // bin ncfft / 2 is written twice by the reference (k == ncfft - k): the second store wins -- the same value pair here
-                ps[k] = power(lo);
-                ps[ncfft - k] = power(hi);
+            {
+                const int hb = ncfft / 2, items = nbf * hb;
+                const unsigned inv_hb = (1u << 20) / (unsigned)hb + 1u;
+                for (int it = lane; it < items; it += 64) {
+                    const int fj = (int)(((unsigned)it * inv_hb) >> 20), k = 1 + (it - fj * hb);
+                    const float *Zf = Z + fj * L.zs;
+                    float *ps = PS + (fb0 + fj) * L.ps_stride;
+                    const cf fpk = z_ld(Zf, k);
+                    cf fpnk = z_ld(Zf, ncfft - k);
+                    fpnk.i = -fpnk.i;
+                    const cf f1k = cadd(fpk, fpnk), f2k = csub(fpk, fpnk);
+                    const cf twv = cmul(f2k, to_cf(l_stw[k - 1]));
+                    cf lo, hi;
+                    lo.r = (f1k.r + twv.r) * 0.5f;
+                    lo.i = (f1k.i + twv.i) * 0.5f;
+                    hi.r = (f1k.r - twv.r) * 0.5f;
+                    hi.i = (twv.i - f1k.i) * 0.5f;
+                    // bin ncfft / 2 is written twice by the reference (k == ncfft - k): the second store wins -- the same value pair here
+                    const float plo = power(lo), phi = power(hi);
+                    ps[k] = plo;
+                    ps[ncfft - k] = phi;
+                }
             }
             WAVE_SYNC();
             GPH(3);
@@ -510,7 +566,14 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         if (lane < nfc) {
             const float *ps = PS + lane * L.ps_stride;
             int k = 0;
-            for (; k + 8 <= nbins; k += 8) {                       // eight reads in flight, then the eight ordered additions
+            for (; k + 32 <= nbins; k += 32) {                     // thirty-two reads in flight, then the thirty-two ordered additions
+                float v[32];
+#pragma unroll
+                for (int e = 0; e < 32; e++) v[e] = ps[k + e];
+#pragma unroll
+                for (int e = 0; e < 32; e++) energy += v[e];
+            }
+            for (; k + 8 <= nbins; k += 8) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = ps[k + e];
@@ -719,11 +782,25 @@ extern "C" __attribute__((visibility("default"))) int kws_dev_generic_prof(long 
 
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid) { if (kws_generic_uses_lds(P)) return 64; return (size_t)grid * g_ws_floats(P.fft_len, P.n_filters) * GL * sizeof(float); }
 
+// frames of a chunk that are transformed together: as many (4, 2, 1; at most the chunk) as keep a workgroup at 32 KB of LDS -- five one-wave
+// workgroups per CU --; one frame at a time (the layout of round 4) always fits
+static int pick_fb(const KwsDspPlan &P, int LCH)
+{
+    // measured (profiles/r05_generic_rate.txt, 8 192 clips): four frames together are 18 - 19 % faster than round 4's schedule for fft 512, 6 % for
+    // fft 128, and 11 % SLOWER for fft 1024 (its work buffers alone are 4.3 KB per frame: the workgroups a CU holds drop): one at a time there
+    if (P.fft_len > 512) return 1;
+    for (int fb = 4; fb > 1; fb >>= 1)
+        if (fb <= LCH && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH, fb).total * sizeof(float) <= 32 * 1024) return fb;
+    return 1;
+}
+
 template <int LCH>
 static int launch_spectral_lds(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap, int out_stride,
                                int grid, hipStream_t stream)
 {
-    const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH).total * sizeof(float);
+    static const char *fb_env = KWS_DEV_ENV("KWS_DEV_GENERIC_FB");          // development aid: 1 = one frame at a time (round 4's schedule)
+    const int fb = fb_env ? std::max(1, std::min(std::min(LCH, 4), atoi(fb_env))) : pick_fb(P, LCH);
+    const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH, fb).total * sizeof(float);
     static std::atomic<unsigned long long> attr_done{ 0 };      // (one per instantiation pair)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
@@ -739,9 +816,9 @@ static int launch_spectral_lds(const KwsDspPlan &P, const void *pcm, int pcm_is_
     int lgrid = grid * 2;
     if (litems < lgrid) lgrid = (int)litems;
     if (pcm_is_float)
-        hipLaunchKernelGGL((kws_spectral_lds_kernel<true, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
+        hipLaunchKernelGGL((kws_spectral_lds_kernel<true, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, fb);
     else
-        hipLaunchKernelGGL((kws_spectral_lds_kernel<false, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride);
+        hipLaunchKernelGGL((kws_spectral_lds_kernel<false, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, fb);
     return (int)hipGetLastError();
 }
 

@@ -43,7 +43,7 @@ def child(n):
         ft = torch.zeros((n, gm.n_features), dtype=torch.float32, device="cuda:0")
         res = []
         for fn in (lambda: gm.mfcc_batch_device(pcm.data_ptr(), n, mf.data_ptr()), lambda: gm.extract_mfcc_batch_device(pcm.data_ptr(), n, ft.data_ptr())):
-            for _ in range(6):                                   # (the handle measures its chunk length on its first five large calls)
+            for _ in range(8):                                   # (the handle measures its chunk length on its first seven large calls)
                 fn()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -75,8 +75,11 @@ def main():
         return child(int(sys.argv[2]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     rows = {}
-    for tag, env in (("lds", {}), ("lds8", {"KWS_DEV_GENERIC_LCH": "8"}), ("lds4", {"KWS_DEV_GENERIC_LCH": "4"}), ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"})):
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # the switches are development switches: the children load the development build of the library (KWS_LIB); "fb1" = round 4's schedule (one frame at a time)
+    dev_lib = os.path.join(ROOT, "ei-keyword-spotting_amd", "libkws_mi355x_dev.so")
+    for tag, env in (("lds", {}), ("lds8", {"KWS_DEV_GENERIC_LCH": "8"}), ("lds4", {"KWS_DEV_GENERIC_LCH": "4"}), ("fb1_8", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "1"}),
+                     ("fb1_4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "1"}), ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"})):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=dict(os.environ, KWS_LIB=dev_lib, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if out.returncode != 0:
             print(tag, "FAILED", out.stderr[-1500:])
         for ln in out.stdout.splitlines():
@@ -89,7 +92,7 @@ def main():
     print("# lds = the handle's own measured chunk length (the number in brackets; 0 = not settled), lds8 / lds4 = pinned with KWS_DEV_GENERIC_LCH, scratch = round 1's kernel")
     for name, r in rows.items():
         parts = []
-        for tag in ("lds", "lds8", "lds4", "scratch"):
+        for tag in ("lds", "lds8", "lds4", "fb1_8", "fb1_4", "scratch"):
             if tag in r:
                 kern, nfr, ts, ta, chunk = r[tag]
                 parts.append("%s%s %.3f | %.3f ms" % (tag, (" [chunk %d]" % chunk) if tag == "lds" else "", ts * 1e3, ta * 1e3))
