@@ -114,7 +114,12 @@ EI_IMPULSE_ERROR settle(kws_comm *c, const char *what, hipStream_t stream)
         }
         const hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) return EI_IMPULSE_OK;
-        if (q != hipErrorNotReady) return fail(KWS_ERROR_HIP, "%s: %s", what, hipGetErrorString(q));
+        if (q != hipErrorNotReady) {
+            // the stream itself failed: a later ncclCommDestroy would wait on it -- abort here too
+            (void)g_rccl.CommAbort(c->comm);
+            c->aborted = true;
+            return fail(KWS_ERROR_HIP, "%s: %s; communicator aborted", what, hipGetErrorString(q));
+        }
         if (std::chrono::steady_clock::now() > deadline) {
             (void)g_rccl.CommAbort(c->comm);
             c->aborted = true;
@@ -129,6 +134,7 @@ struct InitJob {
     std::mutex mu;
     std::condition_variable cv;
     bool done = false;
+    bool abandoned = false;        // the caller gave up at its deadline: a communicator that still comes into being belongs to nobody
     ncclResult_t result = ncclSuccess;
     ncclComm_t comm = nullptr;
 };
@@ -168,11 +174,15 @@ EI_IMPULSE_ERROR kws_comm_create(const void *id, size_t nbytes, int world_size, 
             ncclResult_t r = hipSetDevice(device) == hipSuccess ? g_rccl.CommInitRank(&comm, world_size, u, rank) : ncclUnhandledCudaError;
             std::lock_guard<std::mutex> lk(job->mu);
             job->result = r; job->comm = comm; job->done = true;
+            // a peer that joins after the caller's deadline completes the initialisation into a communicator nobody holds: abort it here
+            // instead of leaking it
+            if (job->abandoned && r == ncclSuccess && comm) { (void)g_rccl.CommAbort(comm); job->comm = nullptr; }
             job->cv.notify_all();
         }).detach();
         std::unique_lock<std::mutex> lk(job->mu);
         if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms()), [&] { return job->done; })) {
-            delete c;       // the helper stays blocked inside RCCL (it holds its own reference to the job): the caller is expected to give up
+            job->abandoned = true;      // (under job->mu) the helper stays blocked inside RCCL and holds its own reference to the job
+            delete c;
             return fail(KWS_ERROR_HIP, "ncclCommInitRank(rank %d of %d): not every rank joined within %d ms", rank, world_size, timeout_ms());
         }
         if (job->result != ncclSuccess) { const ncclResult_t r = job->result; delete c; return fail(KWS_ERROR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world_size, g_rccl.GetErrorString(r)); }

@@ -961,13 +961,41 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         for (int n = 0; n < NZ; ++n) w1[n] = FP.tap_w1[lane_c * KWS_FAST_NZ_MAX + n];
     #pragma unroll
         for (int n = 0; n < NZ2; ++n) w2[n] = FP.tap_w2[lane_c * KWS_FAST_NZ2 + n];
+        int touched_a = 0, touched_b = 0;                                   // (FROM_CEP) the next window's cache lines, see below
         if constexpr (FROM_CEP) {
+            // the window's matrix in batches of requests (round 5: a loop of load -> store pairs exposed a round trip per trip); windows of up to
+            // 52 x 40 values: 33 per lane
             const float *src = cep + (size_t)clip * (nfr * ncep);
+            const int n_val = nfr * ncep;
             const unsigned inv = (1u << 20) / (unsigned)ncep + 1u;           // i / ncep for i < 4096
-            for (int i = lane; i < nfr * ncep; i += KWS_WAVE) {
-                const int r = (int)(((unsigned)i * inv) >> 20), c = i - r * ncep;
-                img[r * fs + c] = src[ring_in_row(P, r) * ncep + c];
+            // (a rolled loop, four requests per trip: the fully unrolled forms -- 33 or 3 x 11 words per lane -- cost this kernel 150 - 180 spilled registers)
+            const int rr = P.ring_rows, rh = P.ring_head;
+            auto ring = [&](int r) { const int t = r + rh; return (rr != 0 && r < rr) ? (t >= rr ? t - rr : t) : r; };     // ring_in_row without its division
+            auto trips = [&](int i_from, int i_to) {
+                for (int i0 = i_from + lane; i0 - lane < i_to; i0 += 4 * KWS_WAVE) {
+                    float v[4];
+                    int dst[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = min(i0 + KWS_WAVE * u, n_val - 1);
+                        const int r = (int)(((unsigned)i * inv) >> 20), c = i - r * ncep;
+                        v[u] = src[ring(r) * ncep + c];
+                        dst[u] = r * fs + c;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (i0 + KWS_WAVE * u < n_val) img[dst[u]] = v[u];
+                }
+            };
+            trips(0, 4 * KWS_WAVE);
+            // ... and the NEXT window of this wave: one touch per 64-byte line (two per lane cover 8 KB), so that its requests find their lines
+            // in the cache a window later; the values are only handed to an empty asm statement at the end of this window
+            if (ci + clip_stride < n_sel) {
+                const char *nsrc = (const char *)(cep + (size_t)sel_clip(sel, ci + clip_stride) * n_val);
+                const int nbytes = n_val * 4 - 4;
+                touched_a = *(const int *)(nsrc + (min(128 * lane, nbytes) & ~3));
+                touched_b = *(const int *)(nsrc + (min(128 * lane + 64, nbytes) & ~3));
             }
+            trips(4 * KWS_WAVE, n_val);
             WAVE_SYNC();
         } else {
         const int16_t *xbase = pcm + (size_t)clip * n_samples;
@@ -1482,6 +1510,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             __builtin_amdgcn_s_setprio(0);
             WAVE_SYNC();
         }
+        if constexpr (FROM_CEP) asm volatile("" : : "v"(touched_a), "v"(touched_b));
         if constexpr (!NET) continue;
         else {
 

@@ -98,3 +98,15 @@ def test_generated_dct_tables_are_current(tmp_path):
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     with open(os.path.join(ROOT, "ei-keyword-spotting_amd", "csrc", "kws_dct_tables.h")) as f:
         assert f.read() == out
+
+
+def test_product_library_carries_no_development_switches(pkg):
+    """the KWS_DEV_* environment switches (guard off / scaled, no re-run, forced tiers and layouts) exist only in the
+    development build (csrc/Makefile: `make dev`, -DKWS_DEV_SWITCHES -> libkws_mi355x_dev.so).  The product library does not contain
+    their names -- so no environment can put KWS_MODE_FAST outside its tolerance -- and the development build, when present, does."""
+    blob = open(pkg.LIB_PATH, "rb").read()
+    assert b"KWS_DEV_" not in blob
+    dev = os.path.join(os.path.dirname(pkg.LIB_PATH), "libkws_mi355x_dev.so")
+    if os.path.exists(dev):
+        names = set(re.findall(rb"KWS_DEV_[A-Z0-9_]+", open(dev, "rb").read()))
+        assert {b"KWS_DEV_FAST_ENTRY", b"KWS_DEV_FAST_GUARD_SCALE", b"KWS_DEV_FAST_NO_RERUN", b"KWS_DEV_GENERIC_LCH", b"KWS_DEV_MFCC_OLD_LAYOUT"} <= names, names
