@@ -526,7 +526,12 @@ def main():
         return "kws_fast_kernel" if x["mode"] == "fast" else "kws_mfcc8_kernel"
 
     def dtype(x):
-        return ("f32 (MFCC, KissFFT-order FFT) / %s (CNN)" if x["mode"] == "fast" else "f32+f64 (MFCC) / %s (CNN)") % ("f32" if x["is_float"] else "i8")
+        # the fused float network's contractions run on v_mfma_f32_16x16x32_f16 with every f32 operand carried as two f16 halves (22 bits) and three
+        # products per pair, accumulated in f32: fp32-grade (scores within 6e-7 of a float64 evaluation, tools/split_operand_study.py), not an f16 network
+        if x["mode"] == "fast":
+            cnn = ("f32 (contractions: f32 operands as split f16 pairs on the matrix cores, f32 accumulate)" if x.get("fused") else "f32") if x["is_float"] else "i8"
+            return "f32 (MFCC, KissFFT-order FFT) / %s (CNN)" % cnn
+        return "f32+f64 (MFCC) / %s (CNN)" % ("f32" if x["is_float"] else "i8")
 
     algo_bytes = CLIP_LEN * 2 + r["labels"] * 4          # int16 PCM in + C float scores out, per clip
     achieved = algo_bytes * B / (r["ms_path"] * 1e-3) / 1e9
