@@ -257,7 +257,15 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
 constexpr int KWS_LCH_DEFAULT = 8;
 // development aid: shader-clock totals per phase of workgroup 0 (kws_dev_generic_prof; tools/gpu_generic_rate.py --prof)
 __device__ long long g_gen_prof[8];
-#define GPH(i) do { const long long now_ = clock64(); if (blockIdx.x == 0 && lane == 0) g_gen_prof[i] += now_ - tlast_; tlast_ = now_; } while (0)
+#ifdef KWS_DEV_SWITCHES
+#ifdef KWS_DEV_SWITCHES
+#define GPH(i) do { const long long now_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_gen_prof[i] += now_ - tlast_; tlast_ = now_; } while (0)
+#else
+#define GPH(i) do { } while (0)          // (a clock read drains the wave's outstanding LDS and scalar requests: development build only)
+#endif
+#else
+#define GPH(i) do { } while (0)          // (a clock read drains the wave's outstanding LDS and scalar requests: development build only)
+#endif
 __device__ __forceinline__ int zpad(int p) { return p + (p >> 4); }             // complex index -> padded complex index
 __device__ __forceinline__ cf z_ld(const float *z, int p) { const float2 v = *(const float2 *)(z + 2 * zpad(p)); cf c; c.r = v.x; c.i = v.y; return c; }
 __device__ __forceinline__ void z_st(float *z, int p, cf v) { *(float2 *)(z + 2 * zpad(p)) = make_float2(v.r, v.i); }
@@ -323,22 +331,17 @@ __device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstrid
 
 // + the model's tables, staged once per workgroup (every read of them sits on a lane's serial path: from L2 a tap of a mel filter or a
 // twiddle costs a round trip of ~1 us; measured: the first version, tables in L2, ran at 9.9 ns per frame against the scratch kernel's 12.4)
-struct LdsLayout { int z, zs, y, perm, ps, ps_stride, mel, mel_stride, dct, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, total; };
-// fb: frames of a chunk transformed TOGETHER (round 5): fb work buffers, the butterflies of a level dealt over (frame, butterfly) items
+// shared: the tables, one copy per workgroup (offsets from the start of the dynamic LDS); wave: each wave's own buffers (offsets from its block at
+// shared + wave index * wave)
+struct LdsLayout { int z, zs, ps, ps_stride, mel, mel_stride, dct, wave, perm, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, shared, total; };
+// fb: frames of a chunk transformed TOGETHER (round 5): fb work buffers, the butterflies of a level dealt over (frame, butterfly) items.
+// total = the tables + ONE wave's buffers
 __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int nnz, int LCH, int fb = 1)
 {
     LdsLayout L;
     const int ncfft = fft / 2;
-    L.z = 0;
-    L.zs = 2 * (ncfft + (ncfft >> 4) + 1);
-    L.y = L.z + fb * L.zs;
-    L.perm = L.y;                                         // (the sample buffer of the first version is gone: samples go straight to their leaves)
-    L.ps = L.perm + ncfft;
-    L.ps_stride = nbins | 1;
-    L.mel = L.ps + LCH * L.ps_stride;
-    L.mel_stride = nf | 1;
-    L.dct = L.mel + LCH * L.mel_stride;
-    L.tw = (L.dct + (2 * (nf / 2 + (nf >> 5) + 1) + 2 * (nf / 2 + 1)) * LCH + 1) & ~1;       // (the DCT's buffers per frame); float2 tables: 8-byte aligned
+    L.perm = 0;                                           // (the sample buffer of the first version is gone: samples go straight to their leaves)
+    L.tw = (L.perm + ncfft + 1) & ~1;                     // float2 tables: 8-byte aligned
     L.stw = L.tw + 2 * ncfft;
     L.dtw = L.stw + 2 * (ncfft / 2 + 1);
     L.dstw = L.dtw + 2 * (nf / 2 + 1);
@@ -346,36 +349,49 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int 
     L.fstart = L.dcs + 2 * (nf / 2 + 1);
     L.fbin = L.fstart + nf + 1;
     L.fw = L.fbin + nnz + 4;                              // (+4: the mel loop reads whole batches of four taps)
-    L.total = L.fw + nnz + 4;
+    L.shared = (L.fw + nnz + 4 + 3) & ~3;
+    L.z = 0;
+    L.zs = 2 * (ncfft + (ncfft >> 4) + 1);
+    L.ps = L.z + fb * L.zs;
+    L.ps_stride = nbins | 1;
+    L.mel = L.ps + LCH * L.ps_stride;
+    L.mel_stride = nf | 1;
+    L.dct = (L.mel + LCH * L.mel_stride + 1) & ~1;        // (the DCT's buffers per frame hold float2 points)
+    L.wave = (L.dct + (2 * (nf / 2 + (nf >> 5) + 1) + 2 * (nf / 2 + 1)) * LCH + 3) & ~3;
+    L.total = L.shared + L.wave;
     return L;
 }
 
-template <bool F32IN, int LCH>
-__global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips, float *__restrict__ mfcc_out,
-                                                               const float *__restrict__ wrap, int out_stride, int fb)
+// WPS: waves per SIMD the registers are budgeted for (2: up to 256 VGPRs)
+template <bool F32IN, int LCH, int WPS>
+__global__ __launch_bounds__(256, WPS) void kws_spectral_lds_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips, float *__restrict__ mfcc_out,
+                                                                    const float *__restrict__ wrap, int out_stride, int fb)
 {
     extern __shared__ __attribute__((aligned(16))) float glds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = threadIdx.x / KWS_WAVE, n_waves = blockDim.x / KWS_WAVE, tid = threadIdx.x, nthr = blockDim.x;
     const int nfr = P.n_frames, NF = P.n_filters, ncep = P.n_cepstral, fft = P.fft_len, nbins = P.n_bins, ncfft = fft >> 1;
     const int nnz = P.filt_nnz;
+    // batch depths: radix-4 butterflies per lane and LDS round trip, frames whose samples are requested together, ordered additions per read batch
+    constexpr int UB = WPS >= 3 ? 2 : 4, FBMAX = WPS >= 3 ? 2 : 4, EB = WPS >= 3 ? 16 : 32;
     const LdsLayout L = lds_layout(fft, NF, nbins, nnz, LCH, fb);
-    float *Z = glds + L.z, *PS = glds + L.ps, *MEL = glds + L.mel, *DCT = glds + L.dct;
+    float *wbase = glds + L.shared + wave * L.wave;
+    float *Z = wbase + L.z, *PS = wbase + L.ps, *MEL = wbase + L.mel, *DCT = wbase + L.dct;
     int *perm = (int *)(glds + L.perm);
     float2 *l_tw = (float2 *)(glds + L.tw), *l_stw = (float2 *)(glds + L.stw), *l_dtw = (float2 *)(glds + L.dtw), *l_dstw = (float2 *)(glds + L.dstw);
     float *l_dcos = glds + L.dcs, *l_dsin = l_dcos + NF / 2 + 1, *l_fw = glds + L.fw;
     int *l_fstart = (int *)(glds + L.fstart), *l_fbin = (int *)(glds + L.fbin);
-    for (int i = lane; i < ncfft; i += 64) l_tw[i] = P.tw[i];
-    for (int i = lane; i < ncfft / 2; i += 64) l_stw[i] = P.stw[i];
-    for (int i = lane; i < NF / 2; i += 64) l_dtw[i] = P.dct_tw[i];
-    for (int i = lane; i < NF / 4; i += 64) l_dstw[i] = P.dct_stw[i];
-    for (int i = lane; i <= NF / 2; i += 64) { l_dcos[i] = P.dct_cos[i]; l_dsin[i] = P.dct_sin[i]; }
-    for (int i = lane; i <= NF; i += 64) l_fstart[i] = P.filt_start[i];
-    for (int i = lane; i < nnz + 4; i += 64) { l_fbin[i] = i < nnz ? P.filt_bin[i] : 0; l_fw[i] = i < nnz ? P.filt_w[i] : 0.0f; }
+    for (int i = tid; i < ncfft; i += nthr) l_tw[i] = P.tw[i];
+    for (int i = tid; i < ncfft / 2; i += nthr) l_stw[i] = P.stw[i];
+    for (int i = tid; i < NF / 2; i += nthr) l_dtw[i] = P.dct_tw[i];
+    for (int i = tid; i < NF / 4; i += nthr) l_dstw[i] = P.dct_stw[i];
+    for (int i = tid; i <= NF / 2; i += nthr) { l_dcos[i] = P.dct_cos[i]; l_dsin[i] = P.dct_sin[i]; }
+    for (int i = tid; i <= NF; i += nthr) l_fstart[i] = P.filt_start[i];
+    for (int i = tid; i < nnz + 4; i += nthr) { l_fbin[i] = i < nnz ? P.filt_bin[i] : 0; l_fw[i] = i < nnz ? P.filt_w[i] : 0.0f; }
     const int chunks = (nfr + LCH - 1) / LCH;
     const int used = P.frame_len < fft ? P.frame_len : fft;      // numpy::rfft: truncate to fft_length or zero-pad (numpy.hpp:1097-1111)
     const double inv_fft = 1.0 / (double)(float)fft;             // processing.hpp:306-309
     // kf_work's leaf order (kiss_fft.cpp:232-296): output position o of the strided copies reads input point i; perm[i] = o
-    for (int o = lane; o < ncfft; o += 64) {
+    for (int o = tid; o < ncfft; o += nthr) {
         int rem = o, i = 0, stride = 1;
         for (int l = 0; l < P.fft_levels; l++) {
             const int p = P.fft_fac[2 * l], m = P.fft_fac[2 * l + 1];
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         }
         perm[i] = o;                                               // inverse: input point i is leaf o
     }
-    WAVE_SYNC();
+    __syncthreads();                                               // the tables are the workgroup's; from here on every wave is on its own
     // the levels' parameters, once: (p, m, twiddle stride, butterflies, 2^20 / m + 1 for b / m with b < 4096)
     constexpr int MAXLEV = 8;
     int lv_p[MAXLEV], lv_m[MAXLEV], lv_fs[MAXLEV], lv_inv[MAXLEV];
@@ -409,8 +425,12 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         ncl0[j] = min(n, used - 1);
         used0 |= (unsigned)(n < used) << j;
     }
+#ifdef KWS_DEV_SWITCHES
+#ifdef KWS_DEV_SWITCHES
     long long tlast_ = clock64();
-    for (int item = blockIdx.x; item < n_clips * chunks; item += gridDim.x) {
+#endif
+#endif
+    for (int item = blockIdx.x * n_waves + wave; item < n_clips * chunks; item += gridDim.x * n_waves) {
         const int clip = item / chunks, f0 = (item - clip * chunks) * LCH;
         const int nfc = min(LCH, nfr - f0);
         const size_t cbase = (size_t)clip * P.n_samples;
@@ -421,16 +441,16 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
           const int nbf = min(fb, nfc - fb0);                        // frames of this sub-batch: transformed together
           // the first trip (a whole frame up to fft 512) of EVERY frame of the sub-batch is requested before any of it is used (round 5: one
           // exposed round trip to HBM per sub-batch instead of one per frame)
-          float xq[4][8], fpq[4];
+          float xq[FBMAX][8], fpq[FBMAX];
 #pragma unroll
-          for (int fj = 0; fj < 4; fj++) if (fj < nbf) {
+          for (int fj = 0; fj < FBMAX; fj++) if (fj < nbf) {
               const int off = (f0 + fb0 + fj) * P.frame_stride;
 #pragma unroll
               for (int j = 0; j < 8; j++) xq[fj][j] = sample(off + ncl0[j]);
               fpq[fj] = sample(off == 0 ? P.n_samples - 1 : off - 1);
           }
 #pragma unroll
-          for (int fj = 0; fj < 4; fj++) if (fj < nbf) {
+          for (int fj = 0; fj < FBMAX; fj++) if (fj < nbf) {
             const int fi = fb0 + fj;
             float *Zf = Z + fj * L.zs;
             // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing.  Where a sample
@@ -484,12 +504,12 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                 const int nb = ncfft / p, items = nbf * nb;
                 const unsigned inv_nb = (1u << 20) / (unsigned)nb + 1u;          // it / nb for it < 4096
                 if (p == 4) {
-                    for (int it0 = lane; it0 - lane < items; it0 += 4 * 64) {
-                        cf f[4][4], t1[4], t2[4], t3[4];
-                        int zo[4], kk[4];
+                    for (int it0 = lane; it0 - lane < items; it0 += UB * 64) {
+                        cf f[UB][4], t1[UB], t2[UB], t3[UB];
+                        int zo[UB], kk[UB];
                         const int slot0 = it0 - lane;                     // wave-uniform: slots past the last item are skipped whole
 #pragma unroll
-                        for (int u = 0; u < 4; u++) if (slot0 + 64 * u < items) {
+                        for (int u = 0; u < UB; u++) if (slot0 + 64 * u < items) {
                             const int it = min(it0 + 64 * u, items - 1);
                             const int fj = (int)(((unsigned)it * inv_nb) >> 20), b = it - fj * nb;
                             const int g = (int)(((unsigned)b * (unsigned)lv_inv[l]) >> 20), k = b - g * m;
@@ -499,9 +519,9 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
                             t1[u] = to_cf(l_tw[k * fstride]); t2[u] = to_cf(l_tw[k * fstride * 2]); t3[u] = to_cf(l_tw[k * fstride * 3]);
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) if (slot0 + 64 * u < items) bfly4(f[u][0], f[u][1], f[u][2], f[u][3], t1[u], t2[u], t3[u]);
+                        for (int u = 0; u < UB; u++) if (slot0 + 64 * u < items) bfly4(f[u][0], f[u][1], f[u][2], f[u][3], t1[u], t2[u], t3[u]);
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
+                        for (int u = 0; u < UB; u++) {
                             if (it0 + 64 * u < items) {                  // (a lane past the last item re-did the last butterfly: not stored)
                                 float *Zf = Z + zo[u];
                                 z_st(Zf, kk[u], f[u][0]); z_st(Zf, kk[u] + m, f[u][1]); z_st(Zf, kk[u] + 2 * m, f[u][2]); z_st(Zf, kk[u] + 3 * m, f[u][3]);
@@ -566,12 +586,12 @@ __global__ __launch_bounds__(64) void kws_spectral_lds_kernel(KwsDspPlan P, cons
         if (lane < nfc) {
             const float *ps = PS + lane * L.ps_stride;
             int k = 0;
-            for (; k + 32 <= nbins; k += 32) {                     // thirty-two reads in flight, then the thirty-two ordered additions
-                float v[32];
+            for (; k + EB <= nbins; k += EB) {                     // thirty-two (sixteen) reads in flight, then the ordered additions
+                float v[EB];
 #pragma unroll
-                for (int e = 0; e < 32; e++) v[e] = ps[k + e];
+                for (int e = 0; e < EB; e++) v[e] = ps[k + e];
 #pragma unroll
-                for (int e = 0; e < 32; e++) energy += v[e];
+                for (int e = 0; e < EB; e++) energy += v[e];
             }
             for (; k + 8 <= nbins; k += 8) {
                 float v[8];
@@ -782,44 +802,83 @@ extern "C" __attribute__((visibility("default"))) int kws_dev_generic_prof(long 
 
 size_t kws_generic_ws_bytes(const KwsDspPlan &P, int grid) { if (kws_generic_uses_lds(P)) return 64; return (size_t)grid * g_ws_floats(P.fft_len, P.n_filters) * GL * sizeof(float); }
 
-// frames of a chunk that are transformed together: as many (4, 2, 1; at most the chunk) as keep a workgroup at 32 KB of LDS -- five one-wave
-// workgroups per CU --; one frame at a time (the layout of round 4) always fits
-static int pick_fb(const KwsDspPlan &P, int LCH)
+// How a launch of kws_spectral_lds_kernel is shaped: fb = frames of a chunk transformed together (4, 2, 1; at most the chunk), waves = waves per
+// workgroup (they share one copy of the tables), per_cu = workgroups a CU holds.  The registers allow two waves per SIMD (eight per CU); the LDS
+// decides how many of them a CU gets: the tables once per workgroup + each wave's buffers.
+struct GenericLaunch { int fb, waves, per_cu; size_t smem; };
+static GenericLaunch pick_launch(const KwsDspPlan &P, int LCH, int force_fb, int force_waves, int wps = 2)
 {
-    // measured (profiles/r05_generic_rate.txt, 8 192 clips): four frames together are 18 - 19 % faster than round 4's schedule for fft 512, 6 % for
-    // fft 128, and 11 % SLOWER for fft 1024 (its work buffers alone are 4.3 KB per frame: the workgroups a CU holds drop): one at a time there
-    if (P.fft_len > 512) return 1;
-    for (int fb = 4; fb > 1; fb >>= 1)
-        if (fb <= LCH && (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH, fb).total * sizeof(float) <= 32 * 1024) return fb;
-    return 1;
+    const size_t cu_lds = 160 * 1024;
+    GenericLaunch best = { 1, 1, 1, 0 };
+    double best_score = -1.0;
+    for (int fb = 4; fb >= 1; fb >>= 1) {
+        if (fb > LCH || (force_fb && fb != force_fb) || (wps >= 3 && fb > 2)) continue;          // (the three-wave build requests two frames' samples together)
+        const LdsLayout L = lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH, fb);
+        for (int w = 4; w >= 1; w >>= 1) {
+            if (force_waves && w != force_waves) continue;
+            const size_t smem = ((size_t)(L.shared + w * L.wave) * sizeof(float) + 1023) & ~(size_t)1023;      // (allocation granularity: assumed 1 KB at most)
+            if (smem > cu_lds) continue;
+            const int per_cu = (int)std::min<size_t>(4 * wps / w, cu_lds / smem);
+            // measured (profiles/r05_generic_rate.txt): frames transformed together are worth more than the same factor in resident waves up to
+            // four, and resident waves are worth their number
+            const double score = (double)(per_cu * w) * (fb == 4 ? 1.3 : fb == 2 ? 1.15 : 1.0);
+            if (score > best_score) { best_score = score; best = GenericLaunch{ fb, w, per_cu, smem }; }
+        }
+    }
+    if (best_score < 0.0) {                                   // nothing fits (kws_generic_uses_lds admits only layouts that do): one wave, one frame
+        const LdsLayout L = lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH, 1);
+        best = GenericLaunch{ 1, 1, 1, (size_t)L.total * sizeof(float) };
+    }
+    return best;
+}
+
+// one instantiation pair's launch: its dynamic-LDS ceiling is raised once per device
+template <int LCH, int WPS>
+static int launch_spectral_lds_at(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap, int out_stride,
+                                  dim3 gd, dim3 bd, const GenericLaunch &G, hipStream_t stream)
+{
+    static std::atomic<unsigned long long> attr_done{ 0 };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<true, LCH, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<false, LCH, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return (int)hipGetLastError();
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    if (pcm_is_float)
+        hipLaunchKernelGGL((kws_spectral_lds_kernel<true, LCH, WPS>), gd, bd, G.smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, G.fb);
+    else
+        hipLaunchKernelGGL((kws_spectral_lds_kernel<false, LCH, WPS>), gd, bd, G.smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, G.fb);
+    return (int)hipGetLastError();
 }
 
 template <int LCH>
 static int launch_spectral_lds(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap, int out_stride,
                                int grid, hipStream_t stream)
 {
-    static const char *fb_env = KWS_DEV_ENV("KWS_DEV_GENERIC_FB");          // development aid: 1 = one frame at a time (round 4's schedule)
-    const int fb = fb_env ? std::max(1, std::min(std::min(LCH, 4), atoi(fb_env))) : pick_fb(P, LCH);
-    const size_t smem = (size_t)lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH, fb).total * sizeof(float);
-    static std::atomic<unsigned long long> attr_done{ 0 };      // (one per instantiation pair)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<true, LCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<false, LCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return (int)hipGetLastError();
-        attr_done.fetch_or(bit, std::memory_order_release);
-    }
+    // development aids: KWS_DEV_GENERIC_FB = frames together (1 = round 4's schedule), KWS_DEV_GENERIC_WAVES = waves per workgroup (1 = tables per wave)
+    static const char *fb_env = KWS_DEV_ENV("KWS_DEV_GENERIC_FB"), *w_env = KWS_DEV_ENV("KWS_DEV_GENERIC_WAVES");
+    const int force_fb = fb_env ? std::max(1, std::min(std::min(LCH, 4), atoi(fb_env))) : 0;
+    const int force_w = w_env ? std::max(1, std::min(4, atoi(w_env))) : 0;
+    int wps = 2;
+#ifdef KWS_DEV_SWITCHES
+    // KWS_DEV_GENERIC_WPS=3: the same source compiled for three waves per SIMD (168 registers: the compiler spills) -- an occupancy experiment
+    static const char *wps_env = KWS_DEV_ENV("KWS_DEV_GENERIC_WPS");
+    if (wps_env && atoi(wps_env) == 3) wps = 3;
+#endif
+    const GenericLaunch G = pick_launch(P, LCH, force_fb == 3 ? 2 : force_fb, force_w == 3 ? 2 : force_w, wps);
     const long litems = (long)n_clips * ((P.n_frames + LCH - 1) / LCH);
-    // persistent-ish grid: as many one-wave workgroups as the LDS lets a CU hold (up to 8), times the CUs (grid = 8 x CUs from the caller)
-    int lgrid = grid * 2;
-    if (litems < lgrid) lgrid = (int)litems;
-    if (pcm_is_float)
-        hipLaunchKernelGGL((kws_spectral_lds_kernel<true, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, fb);
-    else
-        hipLaunchKernelGGL((kws_spectral_lds_kernel<false, LCH>), dim3(lgrid), dim3(64), smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, fb);
-    return (int)hipGetLastError();
+    // persistent-ish grid: twice the workgroups the chip holds at once (grid = 8 x CUs from the caller), at most one wave per item
+    long lgrid = (long)(grid / 8) * G.per_cu * 2;
+    if (lgrid * G.waves > litems) lgrid = (litems + G.waves - 1) / G.waves;
+    if (lgrid < 1) lgrid = 1;
+    const dim3 gd((unsigned)lgrid), bd(KWS_WAVE * G.waves);
+#ifdef KWS_DEV_SWITCHES
+    if (wps == 3) return launch_spectral_lds_at<LCH, 3>(P, pcm, pcm_is_float, n_clips, mfcc_out, wrap, out_stride, gd, bd, G, stream);
+#endif
+    return launch_spectral_lds_at<LCH, 2>(P, pcm, pcm_is_float, n_clips, mfcc_out, wrap, out_stride, gd, bd, G, stream);
 }
 
 // lch: frames per chunk of the LDS kernel, 4 or 8 (anything else: 8); ignored by the scratch kernel

@@ -218,7 +218,8 @@ int kws_launch_mix_audio(const float *words, const int *word_len, size_t word_st
 //  EXACT = false (the default of kws_resample_device: the REFERENCE's behaviour): the published loop of resampy's
 //  resample_f as librosa.load ran it in the reference's day -- a wing walks the table in steps of the truncated integer
 //  int(scale x precision) from offset int(frac x precision), with ONE interpolation factor eta per wing; at most (nwin - offset) / step
-//  taps; the output is a float32 array, so every `y[t] += weight * x` rounds to float32; resampy produces floor(n ratio) samples and
+//  taps with nwin = the table's 32 769 entries (len(interp_win)); the output is a float32 array, so every `y[t] += weight * x` rounds to
+//  float32; resampy produces floor(n ratio) samples and
 //  librosa's fix_length pads with zeros up to ceil(n ratio): n_valid.  resampy advances its time register by repeated addition
 //  (time_register += time_increment): at the output samples whose time is an integer number of input samples -- every 160th for 44.1 -> 16
 //  kHz -- the accumulated value can sit one ulp below it and the loop then starts one input sample earlier with a fraction just under 1, so
@@ -259,7 +260,11 @@ __global__ void kws_resample_kernel(const float *__restrict__ x, int n_in, float
                 const int count = min(avail, (nwin - offset) / index_step);
                 for (int i = 0; i < count; ++i) {
                     const int k = offset + i * index_step;
-                    const double weight = scale * win[k] + eta * (scale * delta[k]);       // resampy scales the table itself: interp_win *= ratio, delta = diff
+                    // resampy scales the table itself (interp_win *= ratio) and takes the differences of the SCALED table: the same two
+                    // roundings here; the table's last entry has no successor (interp_delta's last entry is 0)
+                    const double wk = scale * win[k];
+                    const double dk = k + 1 < nwin ? scale * win[k + 1] - wk : 0.0;
+                    const double weight = wk + eta * dk;
                     acc = (float)((double)acc + weight * (double)x[first + dir * i]);
                 }
             };
@@ -277,6 +282,6 @@ int kws_launch_resample(const float *in, size_t n_in, float *out, size_t n_out, 
     if (n_out == 0) return 0;
     const int grid = (int)std::min<size_t>((n_out + 255) / 256, 65536);
     if (exact) hipLaunchKernelGGL(kws_resample_kernel<true>, dim3(grid), dim3(256), 0, stream, in, (int)n_in, out, n_out, n_valid, ratio, win, delta, nwin, precision, nullptr);
-    else hipLaunchKernelGGL(kws_resample_kernel<false>, dim3(grid), dim3(256), 0, stream, in, (int)n_in, out, n_out, n_valid, ratio, win, delta, nwin, precision, treg);
+    else hipLaunchKernelGGL(kws_resample_kernel<false>, dim3(grid), dim3(256), 0, stream, in, (int)n_in, out, n_out, n_valid, ratio, win, delta, nwin + 1, precision, treg);   // len(interp_win) = zeros x precision + 1
     return (int)hipGetLastError();
 }

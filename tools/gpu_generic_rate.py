@@ -70,37 +70,56 @@ def child(n):
         gm.close()
 
 
+VARIANTS = (
+    # tag, environment; "product" = the shipped library (no switches, no phase clocks), everything else the development build
+    ("product", None),
+    ("auto", {}),
+    ("L4 fb4 w4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "4"}),
+    ("L4 fb4 w1", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "1"}),
+    ("L4 fb2 w4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "2", "KWS_DEV_GENERIC_WAVES": "4"}),
+    ("L4 fb1 w4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "1", "KWS_DEV_GENERIC_WAVES": "4"}),
+    ("L8 fb4 w4", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "4"}),
+    ("L8 fb4 w2", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "2"}),
+    ("L8 fb2 w4", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "2", "KWS_DEV_GENERIC_WAVES": "4"}),
+    ("L8 fb1 w4", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "1", "KWS_DEV_GENERIC_WAVES": "4"}),
+    ("L4 wps3", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_WPS": "3"}),
+    ("L8 wps3", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_WPS": "3"}),
+    ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"}),
+)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         return child(int(sys.argv[2]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None
     rows = {}
-    # the switches are development switches: the children load the development build of the library (KWS_LIB); "fb1" = round 4's schedule (one frame at a time)
     dev_lib = os.path.join(ROOT, "ei-keyword-spotting_amd", "libkws_mi355x_dev.so")
-    for tag, env in (("lds", {}), ("lds8", {"KWS_DEV_GENERIC_LCH": "8"}), ("lds4", {"KWS_DEV_GENERIC_LCH": "4"}), ("fb1_8", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "1"}),
-                     ("fb1_4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "1"}), ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"})):
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=dict(os.environ, KWS_LIB=dev_lib, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    tags = []
+    for tag, env in VARIANTS:
+        if only and tag not in only:
+            continue
+        tags.append(tag)
+        cenv = dict(os.environ) if env is None else dict(os.environ, KWS_LIB=dev_lib, **env)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=cenv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if out.returncode != 0:
             print(tag, "FAILED", out.stderr[-1500:])
         for ln in out.stdout.splitlines():
-            if ln.startswith("PROF|") and tag == "lds":
+            if ln.startswith("PROF|") and tag == "auto":
                 print(ln)
             if ln.startswith("RATE|"):
                 _, name, kern, nfr, t_spec, t_all, chunk = (ln.split("|") + ["0"])[:7]
                 rows.setdefault(name, {})[tag] = (kern, int(nfr), float(t_spec), float(t_all), int(chunk))
-    print("# %d clips per call; speechpy::feature::mfcc (cepstra before cmvnw) and extract_mfcc_features (with cmvnw); ns per frame = time / (clips x frames)" % n)
-    print("# lds = the handle's own measured chunk length (the number in brackets; 0 = not settled), lds8 / lds4 = pinned with KWS_DEV_GENERIC_LCH, scratch = round 1's kernel")
+    print("# %d clips per call; ms per call of speechpy::feature::mfcc (cepstra before cmvnw) | of extract_mfcc_features (with cmvnw)" % n)
+    print("# product = the shipped library; auto = the development build without switches (the handle's measured chunk length in brackets); Lx fby wz = chunk")
+    print("# length x, y frames transformed together, z waves per workgroup; wps3 = compiled for three waves per SIMD; scratch = round 1's kernel")
     for name, r in rows.items():
-        parts = []
-        for tag in ("lds", "lds8", "lds4", "fb1_8", "fb1_4", "scratch"):
+        kern, nfr = next(iter(r.values()))[:2]
+        print("%s  (%d frames, %s)" % (name, nfr, kern))
+        for tag in tags:
             if tag in r:
                 kern, nfr, ts, ta, chunk = r[tag]
-                parts.append("%s%s %.3f | %.3f ms" % (tag, (" [chunk %d]" % chunk) if tag == "lds" else "", ts * 1e3, ta * 1e3))
-        kern, nfr = r.get("lds", next(iter(r.values())))[:2]
-        print("%-40s %3d frames  %-26s %s" % (name, nfr, kern, "   ".join(parts)))
-        if all(t in r for t in ("lds", "lds8", "lds4")) and r["lds"][0] == "kws_spectral_lds_kernel":
-            best = min(r["lds8"][2], r["lds4"][2])
-            print("%-40s             measured choice within %.1f %% of the better pinned one (cepstra)" % ("", 100.0 * (r["lds"][2] / best - 1.0)))
+                print("    %-12s %8.3f | %8.3f ms   %6.2f ns per frame%s" % (tag, ts * 1e3, ta * 1e3, ts * 1e9 / (n * nfr), (" [chunk %d]" % chunk) if tag in ("product", "auto") else ""))
 
 
 if __name__ == "__main__":
