@@ -352,27 +352,44 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int 
     L.shared = (L.fw + nnz + 4 + 3) & ~3;
     L.z = 0;
     L.zs = 2 * (ncfft + (ncfft >> 4) + 1);
-    L.ps = L.z + fb * L.zs;
-    L.ps_stride = nbins | 1;
-    L.mel = L.ps + LCH * L.ps_stride;
+    // the mel rows and the DCT's buffers are written after the chunk's last transform: they lie over the (then dead) work buffers
+    L.mel = 0;
     L.mel_stride = nf | 1;
     L.dct = (L.mel + LCH * L.mel_stride + 1) & ~1;        // (the DCT's buffers per frame hold float2 points)
-    L.wave = (L.dct + (2 * (nf / 2 + (nf >> 5) + 1) + 2 * (nf / 2 + 1)) * LCH + 3) & ~3;
+    const int tail = L.dct + (2 * (nf / 2 + (nf >> 5) + 1) + 2 * (nf / 2 + 1)) * LCH;
+    L.ps = ((fb * L.zs > tail ? fb * L.zs : tail) + 1) & ~1;
+    L.ps_stride = nbins | 1;
+    L.wave = (L.ps + LCH * L.ps_stride + 3) & ~3;
     L.total = L.shared + L.wave;
     return L;
 }
 
-// WPS: waves per SIMD the registers are budgeted for (2: up to 256 VGPRs)
-template <bool F32IN, int LCH, int WPS>
-__global__ __launch_bounds__(256, WPS) void kws_spectral_lds_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips, float *__restrict__ mfcc_out,
-                                                                    const float *__restrict__ wrap, int out_stride, int fb)
+// WPS: waves per SIMD the registers are budgeted for -- 2: up to 256 VGPRs, deep batches; 4: 128 VGPRs, shallow batches (experiment knobs:
+// -DKWS_GEN_UB / _FB / _EB = radix-4 butterflies per lane and LDS round trip, frames whose samples are requested together, ordered additions
+// per read batch of the four-wave build)
+#ifndef KWS_GEN_UB
+#define KWS_GEN_UB 1
+#endif
+#ifndef KWS_GEN_FB
+#define KWS_GEN_FB 2
+#endif
+#ifndef KWS_GEN_EB
+#define KWS_GEN_EB 8
+#endif
+template <bool F32IN, int LCH, int WPS, bool PK>
+__global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_kernel(KwsDspPlan P, const void *__restrict__ pcm_v, int n_clips, float *__restrict__ mfcc_out,
+                                                                    const float *__restrict__ wrap, int out_stride, int fb_arg)
 {
     extern __shared__ __attribute__((aligned(16))) float glds[];
-    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = threadIdx.x / KWS_WAVE, n_waves = blockDim.x / KWS_WAVE, tid = threadIdx.x, nthr = blockDim.x;
+    const int fb = fb_arg & 255;
+#ifdef KWS_DEV_SWITCHES
+    const bool fine_prof = (fb_arg & 256) != 0;          // KWS_DEV_GENERIC_PROF: a forced wait for the samples, so that the phase clocks tell arrival from dealing
+#endif
+    const int lane = threadIdx.x & (KWS_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / KWS_WAVE), n_waves = blockDim.x / KWS_WAVE, tid = threadIdx.x, nthr = blockDim.x;
     const int nfr = P.n_frames, NF = P.n_filters, ncep = P.n_cepstral, fft = P.fft_len, nbins = P.n_bins, ncfft = fft >> 1;
     const int nnz = P.filt_nnz;
     // batch depths: radix-4 butterflies per lane and LDS round trip, frames whose samples are requested together, ordered additions per read batch
-    constexpr int UB = WPS >= 3 ? 2 : 4, FBMAX = WPS >= 3 ? 2 : 4, EB = WPS >= 3 ? 16 : 32;
+    constexpr int UB = WPS >= 3 ? KWS_GEN_UB : 4, FBMAX = WPS >= 3 ? KWS_GEN_FB : 4, EB = WPS >= 3 ? KWS_GEN_EB : 32;
     const LdsLayout L = lds_layout(fft, NF, nbins, nnz, LCH, fb);
     float *wbase = glds + L.shared + wave * L.wave;
     float *Z = wbase + L.z, *PS = wbase + L.ps, *MEL = wbase + L.mel, *DCT = wbase + L.dct;
@@ -415,22 +432,36 @@ __global__ __launch_bounds__(256, WPS) void kws_spectral_lds_kernel(KwsDspPlan P
         lv_fs[l] = fsv;
         lv_inv[l] = (int)((1u << 20) / (unsigned)lv_m[l] + 1u);
     }
-    // the first trip's frame-independent parts (see the load phase): destination in Z (-1: beyond the fft length), clamped sample index, "is a used sample"
-    int dst0[8], ncl0[8];
-    unsigned used0 = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int n = 64 * j + lane;
-        dst0[j] = n < fft ? 2 * zpad(perm[min(n, fft - 1) >> 1]) + (n & 1) : -1;
-        ncl0[j] = min(n, used - 1);
-        used0 |= (unsigned)(n < used) << j;
-    }
-#ifdef KWS_DEV_SWITCHES
 #ifdef KWS_DEV_SWITCHES
     long long tlast_ = clock64();
 #endif
-#endif
-    for (int item = blockIdx.x * n_waves + wave; item < n_clips * chunks; item += gridDim.x * n_waves) {
+    // ---- the samples of a sub-batch.  int16 input whose frames start on even samples (PK, decided by the launch): PAIRS -- lane l of slot j
+    //      loads the dword that holds samples 2 i, 2 i + 1 of kiss_fftr's input point i = 64 j + l, so a lane owns a whole complex point: one
+    //      8-byte LDS store per point, the even sample's predecessor one lane down (a DPP wave shift), the odd sample's in the lane itself.
+    //      The requests run one sub-batch AHEAD: as soon as a sub-batch's samples have been dealt into their leaves, the same registers are
+    //      asked for the next sub-batch's (of this chunk, or the first of the wave's next chunk) and the transform hides the round trip to HBM
+    //      -- measured before: 40 % of the wave's clocks were spent waiting for samples (profiles/r05_generic_rate.txt).
+    constexpr int SLOTS = WPS >= 4 ? 4 : 8;                          // dwords per lane and frame: fft <= 128 SLOTS
+    const int total_items = n_clips * chunks, item_step = gridDim.x * n_waves;
+    unsigned pk[PK ? FBMAX : 1][PK ? SLOTS : 1];
+    float pk_prev[PK ? FBMAX : 1];
+    auto issue = [&](int clip_n, int frame_n) {
+      if constexpr (PK) {
+        const int16_t *src = (const int16_t *)pcm_v + (size_t)clip_n * P.n_samples;
+#pragma unroll
+        for (int fj = 0; fj < FBMAX; fj++) {
+            const int off = min(frame_n + fj, nfr - 1) * P.frame_stride;     // (frames past the clip's last: re-read, never used)
+#pragma unroll
+            for (int j = 0; j < SLOTS; j++) pk[fj][j] = *(const unsigned *)(src + off + 2 * min(64 * j + lane, (used >> 1) - 1));
+            pk_prev[fj] = (float)src[off == 0 ? P.n_samples - 1 : off - 1] * (1.0f / 32768.0f);
+        }
+      }
+    };
+    int item = blockIdx.x * n_waves + wave;
+    if constexpr (PK) {
+        if (item < total_items) issue(item / chunks, (item % chunks) * LCH);
+    }
+    for (; item < total_items; item += item_step) {
         const int clip = item / chunks, f0 = (item - clip * chunks) * LCH;
         const int nfc = min(LCH, nfr - f0);
         const size_t cbase = (size_t)clip * P.n_samples;
@@ -439,38 +470,80 @@ __global__ __launch_bounds__(256, WPS) void kws_spectral_lds_kernel(KwsDspPlan P
         };
         for (int fb0 = 0; fb0 < nfc; fb0 += fb) {
           const int nbf = min(fb, nfc - fb0);                        // frames of this sub-batch: transformed together
+          if constexpr (PK) {
+            {
+              // where point i = 64 j + lane goes: its leaf (frame-independent; worked out per sub-batch from the table rather than held in registers)
+              int dpt[SLOTS];
+#pragma unroll
+              for (int j = 0; j < SLOTS; j++) dpt[j] = 2 * zpad(perm[min(64 * j + lane, ncfft - 1)]);
+#ifdef KWS_DEV_SWITCHES
+              if (fine_prof) { __builtin_amdgcn_s_waitcnt(0x0F70); GPH(1); }      // phase clocks: "the samples have arrived" apart from "dealt into their leaves"
+#endif
+#pragma unroll
+              for (int fj = 0; fj < FBMAX; fj++) if (fj < nbf) {
+                  float *Zf = Z + fj * L.zs;
+                  const int off = (f0 + fb0 + fj) * P.frame_stride;
+                  // pre-emphasis (processing.hpp:52-138): x[-1] = the window's last sample, or the caller's override
+                  float carry = (wrap && off == 0) ? wrap[clip] : pk_prev[fj];        // the sample before point 64 j: lane 63's odd sample of the slot before
+#pragma unroll
+                  for (int j = 0; j < SLOTS; j++) if (64 * j < ncfft) {
+                      const unsigned w = pk[fj][j];
+                      const float x0 = (float)(int)(short)(w & 0xffffu) * (1.0f / 32768.0f), x1 = (float)((int)w >> 16) * (1.0f / 32768.0f);   // numpy::int16_to_float
+                      const float p0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(x1), 0x138, 0xf, 0xf, false));   // wave_shr:1, lane 0 keeps carry
+                      carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), KWS_WAVE - 1));
+                      const float pl0 = P.pre_cof * p0, pl1 = P.pre_cof * x0;
+                      const int i = 64 * j + lane;
+                      const bool in = 2 * i < used;                            // (used is even here: both samples of a point or neither)
+                      const float y0 = in ? x0 - pl0 : 0.0f, y1 = in ? x1 - pl1 : 0.0f;
+                      if (i < ncfft) *(float2 *)(Zf + dpt[j]) = make_float2(y0, y1);
+                  }
+              }
+              // the next sub-batch's samples: this chunk's next frames, or the first frames of the wave's next chunk
+              if (fb0 + fb < nfc) issue(clip, f0 + fb0 + fb);
+              else if (item + item_step < total_items) { const int nx = item + item_step; issue(nx / chunks, (nx % chunks) * LCH); }
+            }
+          }
+          if constexpr (!PK) {
           // the first trip (a whole frame up to fft 512) of EVERY frame of the sub-batch is requested before any of it is used (round 5: one
-          // exposed round trip to HBM per sub-batch instead of one per frame)
+          // exposed round trip to HBM per sub-batch instead of one per frame).  A sample's destination in Z (-1: beyond the fft length) is
+          // frame-independent: worked out per sub-batch from the leaf table rather than held in registers for the life of the wave
+          int dst0[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+              const int n = 64 * j + lane;
+              dst0[j] = n < fft ? 2 * zpad(perm[min(n, fft - 1) >> 1]) + (n & 1) : -1;
+          }
           float xq[FBMAX][8], fpq[FBMAX];
 #pragma unroll
           for (int fj = 0; fj < FBMAX; fj++) if (fj < nbf) {
               const int off = (f0 + fb0 + fj) * P.frame_stride;
 #pragma unroll
-              for (int j = 0; j < 8; j++) xq[fj][j] = sample(off + ncl0[j]);
+              for (int j = 0; j < 8; j++) xq[fj][j] = sample(off + min(64 * j + lane, used - 1));      // (unconditional: a guard per request serialises them)
               fpq[fj] = sample(off == 0 ? P.n_samples - 1 : off - 1);
           }
+#ifdef KWS_DEV_SWITCHES
+          if (fine_prof) { __builtin_amdgcn_s_waitcnt(0x0F70); GPH(1); }
+#endif
 #pragma unroll
           for (int fj = 0; fj < FBMAX; fj++) if (fj < nbf) {
             const int fi = fb0 + fj;
             float *Zf = Z + fj * L.zs;
-            // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing.  Where a sample
-            //      goes (dst0) and which one a lane reads (ncl0) do not depend on the frame and are set up once per workgroup; the predecessor of
-            //      sample n is what the neighbouring lane has just loaded -- lane 0's is lane 63's of the slot before, or one more load for the
-            //      frame's first sample.
+            // ---- pre-emphasis (processing.hpp:52-138; x[-1] = the window's last sample, or the caller's override) + framing: the predecessor of
+            //      sample n is what the neighbouring lane has just loaded (a DPP wave shift) -- lane 0's is lane 63's of the slot before, or
+            //      one more load for the frame's first sample.
             const int off = (f0 + fi) * P.frame_stride;
             {
                 float first_prev = fpq[fj];
                 if (wrap && off == 0) first_prev = wrap[clip];
                 float carry = first_prev;                                // sample 64 j - 1: lane 63 of the slot before
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < 8; j++) if (64 * j < fft) {
                     const float xvj = xq[fj][j];
-                    const float up = __shfl_up(xvj, 1, KWS_WAVE);
-                    const float prev = lane == 0 ? carry : up;
-                    carry = __shfl(xvj, KWS_WAVE - 1, KWS_WAVE);
+                    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(xvj), 0x138, 0xf, 0xf, false));   // wave_shr:1, lane 0 keeps carry
+                    carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xvj), KWS_WAVE - 1));
                     const float pl = P.pre_cof * prev;
                     // sample n is the real (n even) or imaginary (n odd) part of kiss_fftr's input point n / 2, which sits at leaf perm[n / 2]
-                    if (dst0[j] >= 0) Zf[dst0[j]] = ((used0 >> j) & 1) ? xvj - pl : 0.0f;
+                    if (dst0[j] >= 0) Zf[dst0[j]] = 64 * j + lane < used ? xvj - pl : 0.0f;
                 }
             }
             for (int n0 = 8 * 64; n0 < fft; n0 += 8 * 64) {
@@ -490,6 +563,7 @@ __global__ __launch_bounds__(256, WPS) void kws_spectral_lds_kernel(KwsDspPlan P
                     if (n < fft) Zf[2 * zpad(perm[n >> 1]) + (n & 1)] = n < used ? xv[j] - pl : 0.0f;
                 }
             }
+          }
           }
             WAVE_SYNC();
             GPH(0);
@@ -812,9 +886,9 @@ static GenericLaunch pick_launch(const KwsDspPlan &P, int LCH, int force_fb, int
     GenericLaunch best = { 1, 1, 1, 0 };
     double best_score = -1.0;
     for (int fb = 4; fb >= 1; fb >>= 1) {
-        if (fb > LCH || (force_fb && fb != force_fb) || (wps >= 3 && fb > 2)) continue;          // (the three-wave build requests two frames' samples together)
+        if (fb > LCH || (force_fb && fb != force_fb) || (wps >= 3 && fb > KWS_GEN_FB)) continue;          // (the four-wave build requests fewer frames' samples together)
         const LdsLayout L = lds_layout(P.fft_len, P.n_filters, P.n_bins, P.filt_nnz, LCH, fb);
-        for (int w = 4; w >= 1; w >>= 1) {
+        for (int w = wps >= 4 ? 8 : 4; w >= 1; w >>= 1) {
             if (force_waves && w != force_waves) continue;
             const size_t smem = ((size_t)(L.shared + w * L.wave) * sizeof(float) + 1023) & ~(size_t)1023;      // (allocation granularity: assumed 1 KB at most)
             if (smem > cu_lds) continue;
@@ -832,25 +906,21 @@ static GenericLaunch pick_launch(const KwsDspPlan &P, int LCH, int force_fb, int
     return best;
 }
 
-// one instantiation pair's launch: its dynamic-LDS ceiling is raised once per device
-template <int LCH, int WPS>
-static int launch_spectral_lds_at(const KwsDspPlan &P, const void *pcm, int pcm_is_float, int n_clips, float *mfcc_out, const float *wrap, int out_stride,
-                                  dim3 gd, dim3 bd, const GenericLaunch &G, hipStream_t stream)
+// one instantiation's launch: its dynamic-LDS ceiling is raised once per device
+template <bool F32IN, int LCH, int WPS, bool PK>
+static int launch_spectral_lds_at(const KwsDspPlan &P, const void *pcm, int n_clips, float *mfcc_out, const float *wrap, int out_stride,
+                                  dim3 gd, dim3 bd, size_t smem, int fb_arg, hipStream_t stream)
 {
     static std::atomic<unsigned long long> attr_done{ 0 };
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<true, LCH, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<false, LCH, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)kws_spectral_lds_kernel<F32IN, LCH, WPS, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return (int)hipGetLastError();
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    if (pcm_is_float)
-        hipLaunchKernelGGL((kws_spectral_lds_kernel<true, LCH, WPS>), gd, bd, G.smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, G.fb);
-    else
-        hipLaunchKernelGGL((kws_spectral_lds_kernel<false, LCH, WPS>), gd, bd, G.smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, G.fb);
+    hipLaunchKernelGGL((kws_spectral_lds_kernel<F32IN, LCH, WPS, PK>), gd, bd, smem, stream, P, pcm, n_clips, mfcc_out, wrap, out_stride, fb_arg);
     return (int)hipGetLastError();
 }
 
@@ -861,24 +931,38 @@ static int launch_spectral_lds(const KwsDspPlan &P, const void *pcm, int pcm_is_
     // development aids: KWS_DEV_GENERIC_FB = frames together (1 = round 4's schedule), KWS_DEV_GENERIC_WAVES = waves per workgroup (1 = tables per wave)
     static const char *fb_env = KWS_DEV_ENV("KWS_DEV_GENERIC_FB"), *w_env = KWS_DEV_ENV("KWS_DEV_GENERIC_WAVES");
     const int force_fb = fb_env ? std::max(1, std::min(std::min(LCH, 4), atoi(fb_env))) : 0;
-    const int force_w = w_env ? std::max(1, std::min(4, atoi(w_env))) : 0;
-    int wps = 2;
-#ifdef KWS_DEV_SWITCHES
-    // KWS_DEV_GENERIC_WPS=3: the same source compiled for three waves per SIMD (168 registers: the compiler spills) -- an occupancy experiment
-    static const char *wps_env = KWS_DEV_ENV("KWS_DEV_GENERIC_WPS");
-    if (wps_env && atoi(wps_env) == 3) wps = 3;
-#endif
-    const GenericLaunch G = pick_launch(P, LCH, force_fb == 3 ? 2 : force_fb, force_w == 3 ? 2 : force_w, wps);
+    const int force_w = w_env ? std::max(1, std::min(8, atoi(w_env))) : 0;
+    const int fw = (force_w == 3 || (force_w > 4 && force_w < 8)) ? 4 : force_w, ffb = force_fb == 3 ? 2 : force_fb;
+    // Two builds of the kernel: registers for FOUR waves per SIMD with shallow batches (one radix-4 butterfly per lane and round trip, two
+    // frames' samples requested together), and for TWO with deep ones (four and four).  Measured on five shapes (profiles/r05_generic_rate.txt):
+    // the kernel is bound by latency, not by any pipe -- sixteen resident waves with shallow batches beat eight with deep ones by 9 - 20 %
+    // wherever the LDS lets a CU hold more than eight (fft <= 512); where it does not (fft 1024: 12.6 KB per wave), the deep build is 8 % ahead.
+    int wps = 4;
+    {
+        const GenericLaunch G4 = pick_launch(P, LCH, ffb > KWS_GEN_FB ? 0 : ffb, fw, 4);
+        if (G4.per_cu * G4.waves <= 8 || P.fft_len > 512) wps = 2;          // (the four-wave build holds four sample dwords per lane and frame: fft <= 512)
+    }
+    const char *wps_env = KWS_DEV_ENV("KWS_DEV_GENERIC_WPS");              // development aid: 2 or 4 pins the build (read per call: a test toggles it)
+    if (wps_env && (atoi(wps_env) == 2 || atoi(wps_env) == 4)) wps = atoi(wps_env);
+    const GenericLaunch G = pick_launch(P, LCH, (wps == 4 && ffb > KWS_GEN_FB) ? 0 : ffb, fw, wps);
     const long litems = (long)n_clips * ((P.n_frames + LCH - 1) / LCH);
     // persistent-ish grid: twice the workgroups the chip holds at once (grid = 8 x CUs from the caller), at most one wave per item
     long lgrid = (long)(grid / 8) * G.per_cu * 2;
     if (lgrid * G.waves > litems) lgrid = (litems + G.waves - 1) / G.waves;
     if (lgrid < 1) lgrid = 1;
     const dim3 gd((unsigned)lgrid), bd(KWS_WAVE * G.waves);
-#ifdef KWS_DEV_SWITCHES
-    if (wps == 3) return launch_spectral_lds_at<LCH, 3>(P, pcm, pcm_is_float, n_clips, mfcc_out, wrap, out_stride, gd, bd, G, stream);
-#endif
-    return launch_spectral_lds_at<LCH, 2>(P, pcm, pcm_is_float, n_clips, mfcc_out, wrap, out_stride, gd, bd, G, stream);
+    static const char *prof_env = KWS_DEV_ENV("KWS_DEV_GENERIC_PROF");
+    const int fb_arg = G.fb | (prof_env ? 256 : 0);
+    // pair loads (see the kernel's item loop): int16 input whose frames start on even samples and use an even number of them
+    const int used = std::min(P.frame_len, P.fft_len);
+    const char *nopairs_env = KWS_DEV_ENV("KWS_DEV_GENERIC_NOPAIRS");             // development aid: the sample-by-sample loads (A/B runs, tests; read per call)
+    const bool pairs = !pcm_is_float && !nopairs_env && P.n_samples % 2 == 0 && P.frame_stride % 2 == 0 && used % 2 == 0 && used >= 2 && ((uintptr_t)pcm & 3) == 0 &&
+                       P.fft_len <= (wps == 4 ? 512 : 1024);
+#define KWS_GEN_GO(F, W, K) launch_spectral_lds_at<F, LCH, W, K>(P, pcm, n_clips, mfcc_out, wrap, out_stride, gd, bd, G.smem, fb_arg, stream)
+    if (pcm_is_float) return wps == 4 ? KWS_GEN_GO(true, 4, false) : KWS_GEN_GO(true, 2, false);
+    if (pairs) return wps == 4 ? KWS_GEN_GO(false, 4, true) : KWS_GEN_GO(false, 2, true);
+    return wps == 4 ? KWS_GEN_GO(false, 4, false) : KWS_GEN_GO(false, 2, false);
+#undef KWS_GEN_GO
 }
 
 // lch: frames per chunk of the LDS kernel, 4 or 8 (anything else: 8); ignored by the scratch kernel

@@ -200,14 +200,24 @@ def test_chunk_length_is_measured_per_handle_and_never_changes_a_bit(name, dev_p
         f = ft.cpu().numpy()
         assert (bits(f[:64]) == bits(fo)).all() and (bits(f[64:128]) == bits(fo)).all() and (bits(f[-64:]) == bits(fo)).all()
 
+    # ... and so do both builds of the kernel (registers for two waves per SIMD with deep batches, for four with shallow ones), pinned with
+    # KWS_DEV_GENERIC_WPS; left alone the launch picks the build by how many waves the LDS lets a CU hold
+    # ... and the two ways the int16 samples are fetched (dword pairs requested one sub-batch ahead; sample by sample: KWS_DEV_GENERIC_NOPAIRS)
     for pinned in ("8", "4"):
-        monkeypatch.setenv("KWS_DEV_GENERIC_LCH", pinned)
-        gm = pkg.Model(blob=blob)
-        assert gm.mfcc_kernel == "kws_spectral_lds_kernel"
-        features(gm)
-        assert L.kws_dev_generic_chunk(gm.h) == 0                      # pinned from outside: the handle has not measured anything
-        gm.close()
+        for build in ("2", "4"):
+            for nopairs in (False, True):
+                monkeypatch.setenv("KWS_DEV_GENERIC_LCH", pinned)
+                monkeypatch.setenv("KWS_DEV_GENERIC_WPS", build)
+                if nopairs:
+                    monkeypatch.setenv("KWS_DEV_GENERIC_NOPAIRS", "1")
+                gm = pkg.Model(blob=blob)
+                assert gm.mfcc_kernel == "kws_spectral_lds_kernel"
+                features(gm)
+                assert L.kws_dev_generic_chunk(gm.h) == 0              # pinned from outside: the handle has not measured anything
+                gm.close()
+                monkeypatch.delenv("KWS_DEV_GENERIC_NOPAIRS", raising=False)
     monkeypatch.delenv("KWS_DEV_GENERIC_LCH")
+    monkeypatch.delenv("KWS_DEV_GENERIC_WPS")
     gm = pkg.Model(blob=blob)
     for k in range(8):                                              # two un-timed first launches (one per chunk length) + four timed samples, collected by the next call
         assert L.kws_dev_generic_chunk(gm.h) == 0 or k >= 7

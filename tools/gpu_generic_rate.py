@@ -66,26 +66,29 @@ def child(n):
             torch.cuda.synchronize()
             pkg.lib().kws_dev_generic_prof(buf)
             tot = float(sum(buf)) or 1.0
-            print("PROF|%s|" % name + " ".join("%s %.0f%%" % (nm, 100.0 * v / tot) for nm, v in zip(("load", "perm", "levels", "split+power", "energy", "mel", "dct+out", "-"), buf)) + " | clocks per frame of workgroup 0: %.0f" % (tot / max(1, (n * ((gm.n_frames + 15) // 16) // 4096)) / 16), flush=True)
+            print("PROF|%s|" % name + " ".join("%s %.0f%%" % (nm, 100.0 * v / tot) for nm, v in zip(("load", "samples arrive", "levels", "split+power", "energy", "mel", "dct+out", "-"), buf)) + " | clocks per frame of workgroup 0: %.0f" % (tot / max(1, (n * ((gm.n_frames + 15) // 16) // 4096)) / 16), flush=True)
         gm.close()
 
 
-VARIANTS = (
-    # tag, environment; "product" = the shipped library (no switches, no phase clocks), everything else the development build
-    ("product", None),
-    ("auto", {}),
-    ("L4 fb4 w4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "4"}),
-    ("L4 fb4 w1", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "1"}),
-    ("L4 fb2 w4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "2", "KWS_DEV_GENERIC_WAVES": "4"}),
-    ("L4 fb1 w4", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_FB": "1", "KWS_DEV_GENERIC_WAVES": "4"}),
-    ("L8 fb4 w4", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "4"}),
-    ("L8 fb4 w2", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "4", "KWS_DEV_GENERIC_WAVES": "2"}),
-    ("L8 fb2 w4", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "2", "KWS_DEV_GENERIC_WAVES": "4"}),
-    ("L8 fb1 w4", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_FB": "1", "KWS_DEV_GENERIC_WAVES": "4"}),
-    ("L4 wps3", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_WPS": "3"}),
-    ("L8 wps3", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_WPS": "3"}),
-    ("scratch", {"KWS_DEV_GENERIC_SCRATCH": "1"}),
-)
+VARIANTS = [
+    # tag, environment (None: the shipped library, no switches, no phase clocks), library (None: the development build)
+    ("product", None, None),
+    ("auto", {}, None),
+    ("auto, sample wait", {"KWS_DEV_GENERIC_PROF": "1"}, None),
+    ("L4 deep", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_WPS": "2"}, None),
+    ("L8 deep", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_WPS": "2"}, None),
+    ("L4 shallow", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_WPS": "4"}, None),
+    ("L8 shallow", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_WPS": "4"}, None),
+    ("L4 deep, by sample", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_WPS": "2", "KWS_DEV_GENERIC_NOPAIRS": "1"}, None),
+    ("L4 shallow, by sample", {"KWS_DEV_GENERIC_LCH": "4", "KWS_DEV_GENERIC_WPS": "4", "KWS_DEV_GENERIC_NOPAIRS": "1"}, None),
+    ("L8 shallow, by sample", {"KWS_DEV_GENERIC_LCH": "8", "KWS_DEV_GENERIC_WPS": "4", "KWS_DEV_GENERIC_NOPAIRS": "1"}, None),
+]
+# experiment builds (tools/build_generic_variants.sh): libkws_var_<tag>.so = the four-wave build at other batch depths
+import glob
+for lib in sorted(glob.glob(os.path.join(ROOT, "ei-keyword-spotting_amd", "libkws_var_*.so"))):
+    vt = os.path.basename(lib)[len("libkws_var_"):-3]
+    for lch in ("4", "8"):
+        VARIANTS.append(("L%s %s" % (lch, vt), {"KWS_DEV_GENERIC_LCH": lch, "KWS_DEV_GENERIC_WPS": "4"}, lib))
 
 
 def main():
@@ -96,30 +99,31 @@ def main():
     rows = {}
     dev_lib = os.path.join(ROOT, "ei-keyword-spotting_amd", "libkws_mi355x_dev.so")
     tags = []
-    for tag, env in VARIANTS:
+    for tag, env, lib in VARIANTS:
         if only and tag not in only:
             continue
         tags.append(tag)
-        cenv = dict(os.environ) if env is None else dict(os.environ, KWS_LIB=dev_lib, **env)
+        cenv = dict(os.environ) if env is None else dict(os.environ, KWS_LIB=lib or dev_lib, **env)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n)], env=cenv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if out.returncode != 0:
             print(tag, "FAILED", out.stderr[-1500:])
         for ln in out.stdout.splitlines():
-            if ln.startswith("PROF|") and tag == "auto":
-                print(ln)
+            if ln.startswith("PROF|") and tag.startswith("auto"):
+                print(ln.replace("PROF|", "PROF %s|" % tag, 1))
             if ln.startswith("RATE|"):
                 _, name, kern, nfr, t_spec, t_all, chunk = (ln.split("|") + ["0"])[:7]
                 rows.setdefault(name, {})[tag] = (kern, int(nfr), float(t_spec), float(t_all), int(chunk))
     print("# %d clips per call; ms per call of speechpy::feature::mfcc (cepstra before cmvnw) | of extract_mfcc_features (with cmvnw)" % n)
-    print("# product = the shipped library; auto = the development build without switches (the handle's measured chunk length in brackets); Lx fby wz = chunk")
-    print("# length x, y frames transformed together, z waves per workgroup; wps3 = compiled for three waves per SIMD; scratch = round 1's kernel")
+    print("# product = the shipped library; auto = the development build without switches (the handle's measured chunk length in brackets); Lx = chunk length x;")
+    print("# deep = the build for two waves per SIMD (4 butterflies per lane and round trip, 4 frames requested together), shallow = the build for four (1 and 2);")
+    print("# by sample = 2-byte loads requested at the start of the sub-batch (round 4's way) instead of dword pairs requested one sub-batch ahead")
     for name, r in rows.items():
         kern, nfr = next(iter(r.values()))[:2]
         print("%s  (%d frames, %s)" % (name, nfr, kern))
         for tag in tags:
             if tag in r:
                 kern, nfr, ts, ta, chunk = r[tag]
-                print("    %-12s %8.3f | %8.3f ms   %6.2f ns per frame%s" % (tag, ts * 1e3, ta * 1e3, ts * 1e9 / (n * nfr), (" [chunk %d]" % chunk) if tag in ("product", "auto") else ""))
+                print("    %-22s %8.3f | %8.3f ms   %6.2f ns per frame%s" % (tag, ts * 1e3, ta * 1e3, ts * 1e9 / (n * nfr), (" [chunk %d]" % chunk) if tag in ("product", "auto") else ""))
 
 
 if __name__ == "__main__":
