@@ -51,6 +51,13 @@ struct KwsFastBlock {
     int dw, mult;                 // DEPTHWISE_CONV_2D (reference/depthwiseconv_float.h:25): output channel n reads input channel n / mult; its taps run on
                                   // the vector ALU from the LDS image (fast_dwconv), weights [tap][out_c] at w_off
     float conv_min, conv_max, add_min, add_max, pool_min, pool_max;
+    // reciprocals for the kernel's item -> (row, channel) splits, worked out once by the plan: a 32-bit division costs a wave ~35 vector
+    // instructions even when every lane divides the same two numbers.  o_cp = the next block's in_cp (the last block's: its own out_c).
+    unsigned inv_pool16;          // 2^16 / pool + 1:            r / pool for r < 64
+    unsigned inv_ppr20;           // 2^20 / (in_cp / 2) + 1:     i / (in_cp / 2) for i < 1024
+    unsigned inv_ocp20;           // 2^20 / o_cp + 1:            i / o_cp for i < 4096
+    unsigned inv_npad20;          // 2^20 / max(o_cp - out_c, 1) + 1
+    int dw_nseg, dw_seg_rows;     // un-pooled depthwise blocks: max(1, 64 / o_cp) segments of the time axis, rows per segment
     // ---- the contraction on v_mfma_f32_16x16x32_f16 (round 5; DESIGN.md 4.4: "split operands").  An fp32 value is carried as two
     //      halves, x s = hi + lo (s a power of two, hi = half(x s), lo = half(x s - hi): 22 significant bits), and a product as
     //      hi hi + hi lo + lo hi in an fp32 accumulator -- what is dropped is 2^-22 of a product, the size of fp32's own rounding of it --

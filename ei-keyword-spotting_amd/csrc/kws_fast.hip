@@ -104,7 +104,7 @@ __device__ __forceinline__ void fast_conv_finish(const KwsFastBlock &k, v4f (&ac
         WAVE_SYNC();                                                  // every lane has read its last operands from the image
         for (int i = lane; i < k.pool_w * 32; i += KWS_WAVE) pm[i] = -FLT_MAX;
         WAVE_SYNC();
-        const unsigned pinv = (1u << 16) / (unsigned)k.pool + 1u;      // r / pool for r < 64
+        const unsigned pinv = k.inv_pool16;                             // r / pool for r < 64 (the plan's reciprocal)
         const int pool_w = k.pool_w;
         float *const psink = pm + pool_w * 32 + lane;                  // windows past the last one (VALID pooling), channels past out_c
         auto merge = [&](int p, int n, float m, bool ok) {
@@ -329,10 +329,10 @@ typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 #define KWS_FAST_HP 16            // channel pairs a lane converts: images of up to 64 x 16 pairs (the plan checks)
 
 // returns 1 / s
-__device__ __forceinline__ float fast_split_image(float *__restrict__ img, int in_w, int in_c, int in_cp, int in_stride, int lane)
+__device__ __forceinline__ float fast_split_image(float *__restrict__ img, int in_w, int in_c, int in_cp, int in_stride, int lane, unsigned ppr_inv20)
 {
     const int ppr = in_cp >> 1, items = in_w * ppr;
-    const unsigned inv = (1u << 20) / (unsigned)ppr + 1u;           // i / ppr for i < 1024, ppr <= 32
+    const unsigned inv = ppr_inv20;                                 // i / ppr for i < 1024, ppr <= 32 (the plan's reciprocal)
     float2 v[KWS_FAST_HP];
     int off[KWS_FAST_HP];                                           // byte offset of the pair's hi halves (kept: the second loop needs no division)
     float mx = 0.0f;
@@ -390,7 +390,7 @@ __device__ __forceinline__ float fast_conv_small_h(const KwsFastBlock &k, float 
         bh[ks] = *(const v8h *)(bg + (kc * 2) * (KWS_WAVE * 16));
         blo[ks] = *(const v8h *)(bg + (kc * 2 + 1) * (KWS_WAVE * 16));
     }
-    const float inv_s = fast_split_image(in, k.in_w, k.in_c, k.in_cp, k.in_stride, lane);
+    const float inv_s = fast_split_image(in, k.in_w, k.in_c, k.in_cp, k.in_stride, lane, k.inv_ppr20);
     v4f acc[MT][1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = v4f{ 0.f, 0.f, 0.f, 0.f };
@@ -437,7 +437,7 @@ __device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float 
                                                    const float *__restrict__ shared, int zero_off, int lane, float *__restrict__ sink)
 {
     const int lm = lane & 15, lq = lane >> 4;
-    const float inv_s = fast_split_image(in, k.in_w, k.in_c, k.in_cp, k.in_stride, lane);
+    const float inv_s = fast_split_image(in, k.in_w, k.in_c, k.in_cp, k.in_stride, lane, k.inv_ppr20);
     v4f acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -511,7 +511,7 @@ __device__ __forceinline__ void fast_pool_finish(const KwsFastBlock &k, const fl
                                                  const float *__restrict__ shared, int lane, int out_stride, int out_cp, float scale)
 {
     const int items = k.pool_w * out_cp, out_c = k.out_c;
-    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;
+    const unsigned inv = k.inv_ocp20;
     const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max, pmin = k.pool_min, pmax = k.pool_max;
     const bool has_add = k.has_add != 0;
     for (int i = lane; i < items; i += KWS_WAVE) {
@@ -531,14 +531,14 @@ __device__ __forceinline__ void fast_pool(const KwsFastBlock &k, const float *__
                                           int out_stride, int out_cp, bool pooled)
 {
     const int items = k.pool_w * out_cp;
-    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;        // i / out_cp == (i * inv) >> 20 for i < 4096, out_cp <= 64
+    const unsigned inv = k.inv_ocp20;                               // i / out_cp == (i * inv) >> 20 for i < 4096, out_cp <= 64
     const int sstride = k.stage_stride, out_w = k.out_w, out_c = k.out_c, pool = k.pool, pstr = k.pool_stride;
     const float pmin = k.pool_min, pmax = k.pool_max;
     if (!pooled) {
         // the tiles were written straight into the next image: only its k-padding channels (at most seven per row) are left
         const int npad = out_cp - out_c;
         if (npad == 0) return;
-        const unsigned pinv = (1u << 20) / (unsigned)npad + 1u;
+        const unsigned pinv = k.inv_npad20;
         for (int i = lane; i < k.pool_w * npad; i += KWS_WAVE) {
             const int p = (int)(((unsigned)i * pinv) >> 20), c = out_c + (i - p * npad);
             img[p * out_stride + c] = 0.0f;
@@ -589,10 +589,10 @@ __device__ __forceinline__ void fast_dw_t(const KwsFastBlock &k, const float *__
 {
     const int out_c = k.out_c, in_w = k.in_w, out_w = k.out_w, pad_left = k.pad_left, in_stride = k.in_stride, mult = k.mult;
     const bool pooled = k.pool > 1 || k.pool_stride > 1;
-    const int n_seg = pooled ? k.pool_w : max(1, KWS_WAVE / out_cp);
-    const int seg_rows = pooled ? k.pool : (out_w + n_seg - 1) / n_seg, seg_step = pooled ? k.pool_stride : seg_rows;
+    const int n_seg = pooled ? k.pool_w : k.dw_nseg;                // (max(1, 64 / out_cp), from the plan)
+    const int seg_rows = pooled ? k.pool : k.dw_seg_rows, seg_step = pooled ? k.pool_stride : seg_rows;
     const int items = n_seg * out_cp;
-    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;        // i / out_cp for i < 4096, out_cp <= 64
+    const unsigned inv = k.inv_ocp20;                               // i / out_cp for i < 4096, out_cp <= 64
     const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max, pmin = k.pool_min, pmax = k.pool_max;
     const bool has_add = k.has_add != 0;
     const float *wt = shared + k.w_off;
@@ -639,7 +639,7 @@ __device__ __forceinline__ void fast_dwconv_any(const KwsFastBlock &k, const flo
 {
     const int items = k.pool_w * out_cp, out_c = k.out_c, in_w = k.in_w, out_w = k.out_w, taps = k.taps, pad_left = k.pad_left;
     const int in_stride = k.in_stride, pool = k.pool, pstr = k.pool_stride, mult = k.mult;
-    const unsigned inv = (1u << 20) / (unsigned)out_cp + 1u;        // i / out_cp for i < 4096, out_cp <= 64
+    const unsigned inv = k.inv_ocp20;                               // i / out_cp for i < 4096, out_cp <= 64
     const float cmin = k.conv_min, cmax = k.conv_max, amin = k.add_min, amax = k.add_max, pmin = k.pool_min, pmax = k.pool_max;
     const bool has_add = k.has_add != 0;
     const float *wt = shared + k.w_off;

@@ -563,6 +563,16 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
             memcpy(&shared[(size_t)k.h_b_off], hfrag[b].data(), fl * sizeof(float));
         }
     }
+    for (int b = 0; b < N.n_blocks; b++) {
+        KwsFastBlock &k = F.blk[b];
+        const int o_cp = b + 1 == N.n_blocks ? k.out_c : F.blk[b + 1].in_cp;
+        k.inv_pool16 = (1u << 16) / (unsigned)std::max(k.pool, 1) + 1u;
+        k.inv_ppr20 = (1u << 20) / (unsigned)std::max(k.in_cp >> 1, 1) + 1u;
+        k.inv_ocp20 = (1u << 20) / (unsigned)std::max(o_cp, 1) + 1u;
+        k.inv_npad20 = (1u << 20) / (unsigned)std::max(o_cp - k.out_c, 1) + 1u;
+        k.dw_nseg = std::max(1, 64 / std::max(o_cp, 1));
+        k.dw_seg_rows = (k.out_w + k.dw_nseg - 1) / k.dw_nseg;
+    }
     return finish_fast_plan(h, F, shared, need[0], need[1]);
 }
 

@@ -255,6 +255,8 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
 // waves a CU holds, the per-chunk phases favour longer chunks: no rule here predicts the winner, so kws_api.cpp measures it per handle on the
 // handle's own first large calls (generic_chunk_begin) and passes the choice to kws_launch_spectral_generic.
 constexpr int KWS_LCH_DEFAULT = 8;
+// a 24 x 24-bit multiply (full rate; v_mul_lo_u32 is a quarter-rate instruction): LDS offsets, item indices and their reciprocals all fit
+#define M24(a, b) __mul24((int)(a), (int)(b))
 // development aid: shader-clock totals per phase of workgroup 0 (kws_dev_generic_prof; tools/gpu_generic_rate.py --prof)
 __device__ long long g_gen_prof[8];
 #ifdef KWS_DEV_SWITCHES
@@ -274,20 +276,21 @@ __device__ __forceinline__ void z_st(float *z, int p, cf v) { *(float2 *)(z + 2 
 // g_bfly's loops, operation for operation
 __device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstride, int m, int p, const float2 *__restrict__ tw)
 {
+    const int kf = M24(k, fstride), fm = M24(fstride, m);        // (24-bit multiplies: table indices)
     if (p == 2) {
-        const cf t = cmul(z_ld(Z, base + k + m), to_cf(tw[k * fstride]));
+        const cf t = cmul(z_ld(Z, base + k + m), to_cf(tw[kf]));
         const cf a = z_ld(Z, base + k);
         z_st(Z, base + k + m, csub(a, t));
         z_st(Z, base + k, cadd(a, t));
     } else if (p == 4) {
         cf f0 = z_ld(Z, base + k), f1 = z_ld(Z, base + k + m), f2 = z_ld(Z, base + k + 2 * m), f3 = z_ld(Z, base + k + 3 * m);
-        bfly4(f0, f1, f2, f3, to_cf(tw[k * fstride]), to_cf(tw[k * fstride * 2]), to_cf(tw[k * fstride * 3]));
+        bfly4(f0, f1, f2, f3, to_cf(tw[kf]), to_cf(tw[2 * kf]), to_cf(tw[3 * kf]));
         z_st(Z, base + k, f0); z_st(Z, base + k + m, f1); z_st(Z, base + k + 2 * m, f2); z_st(Z, base + k + 3 * m, f3);
     } else if (p == 3) {
-        const cf epi3 = to_cf(tw[fstride * m]);
+        const cf epi3 = to_cf(tw[fm]);
         cf f0 = z_ld(Z, base + k);
-        const cf s1 = cmul(z_ld(Z, base + k + m), to_cf(tw[k * fstride]));
-        const cf s2 = cmul(z_ld(Z, base + k + 2 * m), to_cf(tw[k * fstride * 2]));
+        const cf s1 = cmul(z_ld(Z, base + k + m), to_cf(tw[kf]));
+        const cf s2 = cmul(z_ld(Z, base + k + 2 * m), to_cf(tw[2 * kf]));
         const cf s3 = cadd(s1, s2);
         cf s0 = csub(s1, s2);
         cf f1, f2;
@@ -302,12 +305,12 @@ __device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstrid
         f1.i += s0.r;
         z_st(Z, base + k, f0); z_st(Z, base + k + m, f1); z_st(Z, base + k + 2 * m, f2);
     } else {    // 5
-        const cf ya = to_cf(tw[fstride * m]), yb = to_cf(tw[fstride * 2 * m]);
+        const cf ya = to_cf(tw[fm]), yb = to_cf(tw[2 * fm]);
         const int u = k;
         cf F0 = z_ld(Z, base + u), F1 = z_ld(Z, base + u + m), F2 = z_ld(Z, base + u + 2 * m), F3 = z_ld(Z, base + u + 3 * m), F4 = z_ld(Z, base + u + 4 * m);
         const cf s0 = F0;
-        const cf s1 = cmul(F1, to_cf(tw[u * fstride])), s2 = cmul(F2, to_cf(tw[2 * u * fstride]));
-        const cf s3 = cmul(F3, to_cf(tw[3 * u * fstride])), s4 = cmul(F4, to_cf(tw[4 * u * fstride]));
+        const cf s1 = cmul(F1, to_cf(tw[kf])), s2 = cmul(F2, to_cf(tw[2 * kf]));
+        const cf s3 = cmul(F3, to_cf(tw[3 * kf])), s4 = cmul(F4, to_cf(tw[4 * kf]));
         const cf s7 = cadd(s1, s4), s10 = csub(s1, s4), s8 = cadd(s2, s3), s9 = csub(s2, s3);
         float tt, a, b;
         tt = s7.r + s8.r; F0.r = F0.r + tt;
@@ -333,7 +336,7 @@ __device__ __forceinline__ void z_bfly_one(float *Z, int base, int k, int fstrid
 // twiddle costs a round trip of ~1 us; measured: the first version, tables in L2, ran at 9.9 ns per frame against the scratch kernel's 12.4)
 // shared: the tables, one copy per workgroup (offsets from the start of the dynamic LDS); wave: each wave's own buffers (offsets from its block at
 // shared + wave index * wave)
-struct LdsLayout { int z, zs, ps, ps_stride, mel, mel_stride, dct, wave, perm, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, shared, total; };
+struct LdsLayout { int z, zs, ps, ps_stride, mel, mel_stride, dct, wave, perm, tw, stw, dtw, dstw, dcs, fstart, fbin, fw, dperm, shared, total; };
 // fb: frames of a chunk transformed TOGETHER (round 5): fb work buffers, the butterflies of a level dealt over (frame, butterfly) items.
 // total = the tables + ONE wave's buffers
 __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int nnz, int LCH, int fb = 1)
@@ -349,7 +352,8 @@ __host__ __device__ inline LdsLayout lds_layout(int fft, int nf, int nbins, int 
     L.fstart = L.dcs + 2 * (nf / 2 + 1);
     L.fbin = L.fstart + nf + 1;
     L.fw = L.fbin + nnz + 4;                              // (+4: the mel loop reads whole batches of four taps)
-    L.shared = (L.fw + nnz + 4 + 3) & ~3;
+    L.dperm = L.fw + nnz + 4;                             // the DCT's leaf order (nf / 2 ints)
+    L.shared = (L.dperm + nf / 2 + 3) & ~3;
     L.z = 0;
     L.zs = 2 * (ncfft + (ncfft >> 4) + 1);
     // the mel rows and the DCT's buffers are written after the chunk's last transform: they lie over the (then dead) work buffers
@@ -419,7 +423,24 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
         }
         perm[i] = o;                                               // inverse: input point i is leaf o
     }
+    // the DCT's leaf order likewise (kf_work on NF / 2 points): leaf o reads input point dperm[o]
+    int *dperm = (int *)(glds + L.dperm);
+    for (int o = tid; o < NF / 2; o += nthr) {
+        int rem = o, i = 0, stride = 1;
+        for (int l = 0; l < P.dct_levels; l++) {
+            const int p = P.dct_fac[2 * l], m = P.dct_fac[2 * l + 1];
+            const int k = rem / m;
+            rem -= k * m;
+            i += k * stride;
+            stride *= p;
+        }
+        dperm[o] = i;
+    }
     __syncthreads();                                               // the tables are the workgroup's; from here on every wave is on its own
+    // x / d for the small item counts of the per-chunk phases (x d < 2^20): (x * (2^20 / d + 1)) >> 20 -- an integer division costs ~35 instructions
+    auto recip20 = [](int d) -> unsigned { return (1u << 20) / (unsigned)d + 1u; };
+    auto div20 = [](int x, unsigned r) -> int { return (int)(__umul24((unsigned)x, r) >> 20); };
+    const unsigned r_nf = recip20(NF), r_nc = recip20(max(NF >> 1, 1)), r_half = recip20((NF >> 2) + 1), r_ncep = recip20(ncep);
     // the levels' parameters, once: (p, m, twiddle stride, butterflies, 2^20 / m + 1 for b / m with b < 4096)
     constexpr int MAXLEV = 8;
     int lv_p[MAXLEV], lv_m[MAXLEV], lv_fs[MAXLEV], lv_inv[MAXLEV];
@@ -458,11 +479,14 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
       }
     };
     int item = blockIdx.x * n_waves + wave;
+    // (clip, chunk) of the wave's item, advanced by the stride's own (clips, chunks): three integer divisions per wave instead of three per chunk
+    int clip = item / chunks, ck = item - clip * chunks;
+    const int step_clips = item_step / chunks, step_ck = item_step - step_clips * chunks;
     if constexpr (PK) {
-        if (item < total_items) issue(item / chunks, (item % chunks) * LCH);
+        if (item < total_items) issue(clip, ck * LCH);
     }
-    for (; item < total_items; item += item_step) {
-        const int clip = item / chunks, f0 = (item - clip * chunks) * LCH;
+    for (; item < total_items; item += item_step, clip += step_clips + (ck + step_ck >= chunks ? 1 : 0), ck = ck + step_ck >= chunks ? ck + step_ck - chunks : ck + step_ck) {
+        const int f0 = ck * LCH;
         const int nfc = min(LCH, nfr - f0);
         const size_t cbase = (size_t)clip * P.n_samples;
         auto sample = [&](int n) -> float {
@@ -482,7 +506,7 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
 #pragma unroll
               for (int fj = 0; fj < FBMAX; fj++) if (fj < nbf) {
                   float *Zf = Z + fj * L.zs;
-                  const int off = (f0 + fb0 + fj) * P.frame_stride;
+                  const int off = M24(f0 + fb0 + fj, P.frame_stride);
                   // pre-emphasis (processing.hpp:52-138): x[-1] = the window's last sample, or the caller's override
                   float carry = (wrap && off == 0) ? wrap[clip] : pk_prev[fj];        // the sample before point 64 j: lane 63's odd sample of the slot before
 #pragma unroll
@@ -500,7 +524,10 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
               }
               // the next sub-batch's samples: this chunk's next frames, or the first frames of the wave's next chunk
               if (fb0 + fb < nfc) issue(clip, f0 + fb0 + fb);
-              else if (item + item_step < total_items) { const int nx = item + item_step; issue(nx / chunks, (nx % chunks) * LCH); }
+              else if (item + item_step < total_items) {
+                  const bool carry_ck = ck + step_ck >= chunks;
+                  issue(clip + step_clips + (carry_ck ? 1 : 0), (carry_ck ? ck + step_ck - chunks : ck + step_ck) * LCH);
+              }
             }
           }
           if constexpr (!PK) {
@@ -585,12 +612,13 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
 #pragma unroll
                         for (int u = 0; u < UB; u++) if (slot0 + 64 * u < items) {
                             const int it = min(it0 + 64 * u, items - 1);
-                            const int fj = (int)(((unsigned)it * inv_nb) >> 20), b = it - fj * nb;
-                            const int g = (int)(((unsigned)b * (unsigned)lv_inv[l]) >> 20), k = b - g * m;
-                            zo[u] = fj * L.zs; kk[u] = g * 4 * m + k;
+                            const int fj = (int)(__umul24((unsigned)it, inv_nb) >> 20), b = it - M24(fj, nb);
+                            const int g = (int)(__umul24((unsigned)b, (unsigned)lv_inv[l]) >> 20), k = b - M24(g, m);
+                            zo[u] = M24(fj, L.zs); kk[u] = M24(g, 4 * m) + k;
                             const float *Zf = Z + zo[u];
                             f[u][0] = z_ld(Zf, kk[u]); f[u][1] = z_ld(Zf, kk[u] + m); f[u][2] = z_ld(Zf, kk[u] + 2 * m); f[u][3] = z_ld(Zf, kk[u] + 3 * m);
-                            t1[u] = to_cf(l_tw[k * fstride]); t2[u] = to_cf(l_tw[k * fstride * 2]); t3[u] = to_cf(l_tw[k * fstride * 3]);
+                            const int kf = M24(k, fstride);
+                            t1[u] = to_cf(l_tw[kf]); t2[u] = to_cf(l_tw[2 * kf]); t3[u] = to_cf(l_tw[3 * kf]);
                         }
 #pragma unroll
                         for (int u = 0; u < UB; u++) if (slot0 + 64 * u < items) bfly4(f[u][0], f[u][1], f[u][2], f[u][3], t1[u], t2[u], t3[u]);
@@ -604,9 +632,9 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
                     }
                 } else {
                     for (int it = lane; it < items; it += 64) {
-                        const int fj = (int)(((unsigned)it * inv_nb) >> 20), b = it - fj * nb;
-                        const int g = (int)(((unsigned)b * (unsigned)lv_inv[l]) >> 20), k = b - g * m;
-                        z_bfly_one(Z + fj * L.zs, g * p * m, k, fstride, m, p, l_tw);
+                        const int fj = (int)(__umul24((unsigned)it, inv_nb) >> 20), b = it - M24(fj, nb);
+                        const int g = (int)(__umul24((unsigned)b, (unsigned)lv_inv[l]) >> 20), k = b - M24(g, m);
+                        z_bfly_one(Z + M24(fj, L.zs), M24(g, p * m), k, fstride, m, p, l_tw);
                     }
                 }
                 WAVE_SYNC();
@@ -621,8 +649,8 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
                 return (float)(inv_fft * (double)sq);
             };
             if (lane < nbf) {
-                const cf t0 = z_ld(Z + lane * L.zs, 0);
-                float *ps = PS + (fb0 + lane) * L.ps_stride;
+                const cf t0 = z_ld(Z + M24(lane, L.zs), 0);
+                float *ps = PS + M24(fb0 + lane, L.ps_stride);
                 cf dc, ny;
                 dc.r = t0.r + t0.i; dc.i = 0.0f;
                 ny.r = t0.r - t0.i; ny.i = 0.0f;
@@ -633,9 +661,9 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
                 const int hb = ncfft / 2, items = nbf * hb;
                 const unsigned inv_hb = (1u << 20) / (unsigned)hb + 1u;
                 for (int it = lane; it < items; it += 64) {
-                    const int fj = (int)(((unsigned)it * inv_hb) >> 20), k = 1 + (it - fj * hb);
-                    const float *Zf = Z + fj * L.zs;
-                    float *ps = PS + (fb0 + fj) * L.ps_stride;
+                    const int fj = (int)(__umul24((unsigned)it, inv_hb) >> 20), k = 1 + (it - M24(fj, hb));
+                    const float *Zf = Z + M24(fj, L.zs);
+                    float *ps = PS + M24(fb0 + fj, L.ps_stride);
                     const cf fpk = z_ld(Zf, k);
                     cf fpnk = z_ld(Zf, ncfft - k);
                     fpnk.i = -fpnk.i;
@@ -658,7 +686,7 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
         // ---- frame energies: numpy::sum, ascending (numpy.hpp:88-94): a lane per frame --------------------------------------
         float energy = 0.0f;
         if (lane < nfc) {
-            const float *ps = PS + lane * L.ps_stride;
+            const float *ps = PS + M24(lane, L.ps_stride);
             int k = 0;
             for (; k + EB <= nbins; k += EB) {                     // thirty-two (sixteen) reads in flight, then the ordered additions
                 float v[EB];
@@ -681,8 +709,8 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
         GPH(4);
         // ---- mel filterbank: dot_by_row over the non-zero weights in ascending bin order, zero handling, log ----------------
         for (int it = lane; it < nfc * NF; it += 64) {
-            const int fi = it / NF, j = it - fi * NF;
-            const float *ps = PS + fi * L.ps_stride;
+            const int fi = div20(it, r_nf), j = it - M24(fi, NF);
+            const float *ps = PS + M24(fi, L.ps_stride);
             float acc = 0.0f;
             const int n1 = l_fstart[j + 1];
             for (int n = l_fstart[j]; n < n1; n += 4) {            // four taps per trip (the tables are padded by four): bins, then their power values, then
@@ -700,7 +728,7 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
             }
             if (acc == 0.0f) acc = FLT_EPSILON;
             if (P.mfe_mel) P.mfe_mel[(size_t)clip * out_stride + (size_t)ring_out_row(P, f0 + fi) * NF + j] = acc;
-            MEL[fi * L.mel_stride + j] = fast_log(acc);
+            MEL[M24(fi, L.mel_stride) + j] = fast_log(acc);
         }
         WAVE_SYNC();
         GPH(5);
@@ -712,20 +740,13 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
             const int nc = NF >> 1, zs = 2 * (nc + (nc >> 4) + 1), ss = 2 * (nc + 1);      // floats per frame: transform buffer, spectrum
             float *DZ = DCT, *DS = DCT + LCH * zs;
             for (int it = lane; it < nfc * nc; it += 64) {
-                const int fi = it / nc, o = it - fi * nc;
-                int rem = o, i = 0, stride = 1;
-                for (int l = 0; l < P.dct_levels; l++) {
-                    const int p = P.dct_fac[2 * l], m = P.dct_fac[2 * l + 1];
-                    const int k = rem / m;
-                    rem -= k * m;
-                    i += k * stride;
-                    stride *= p;
-                }
+                const int fi = div20(it, r_nc), o = it - M24(fi, nc);
+                const int i = dperm[o];
                 // dct::transform's reorder: in[j] = v[2 j], in[NF - 1 - j] = v[2 j + 1] for j < NF / 2; kiss_fftr reads (in[2 i], in[2 i + 1])
-                const float *mel = MEL + fi * L.mel_stride;
+                const float *mel = MEL + M24(fi, L.mel_stride);
                 auto reord = [&](int q) { return q < nc ? mel[2 * q] : mel[2 * (NF - 1 - q) + 1]; };
                 cf v; v.r = reord(2 * i); v.i = reord(2 * i + 1);
-                z_st(DZ + fi * zs, o, v);
+                z_st(DZ + M24(fi, zs), o, v);
             }
             WAVE_SYNC();
             for (int l = P.dct_levels - 1; l >= 0; l--) {
@@ -733,17 +754,18 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
                 int fstride = 1;
                 for (int q = 0; q < l; q++) fstride *= P.dct_fac[2 * q];
                 const int nb = nc / p;
+                const unsigned r_nb = recip20(nb), r_m = recip20(m);
                 for (int it = lane; it < nfc * nb; it += 64) {
-                    const int fi = it / nb, b = it - fi * nb;
-                    const int g = b / m, k = b - g * m;
-                    z_bfly_one(DZ + fi * zs, g * p * m, k, fstride, m, p, l_dtw);
+                    const int fi = div20(it, r_nb), b = it - M24(fi, nb);
+                    const int g = div20(b, r_m), k = b - M24(g, m);
+                    z_bfly_one(DZ + M24(fi, zs), M24(g, p * m), k, fstride, m, p, l_dtw);
                 }
                 WAVE_SYNC();
             }
             for (int it = lane; it < nfc * (nc / 2 + 1); it += 64) {
-                const int fi = it / (nc / 2 + 1), k = it - fi * (nc / 2 + 1);
-                const float *Zf = DZ + fi * zs;
-                float *sp = DS + fi * ss;
+                const int fi = div20(it, r_half), k = it - M24(fi, nc / 2 + 1);
+                const float *Zf = DZ + M24(fi, zs);
+                float *sp = DS + M24(fi, ss);
                 if (k == 0) {
                     const cf t0 = z_ld(Zf, 0);
                     sp[0] = t0.r + t0.i; sp[1] = 0.0f;
@@ -765,8 +787,8 @@ __global__ __launch_bounds__(WPS >= 4 ? 512 : 256, WPS) void kws_spectral_lds_ke
             if (lane < nfc) DZ[lane] = energy;
             WAVE_SYNC();
             for (int it = lane; it < nfc * ncep; it += 64) {
-                const int fi = it / ncep, i = it - fi * ncep;
-                const float *mel = MEL + fi * L.mel_stride, *sp = DS + fi * ss;
+                const int fi = div20(it, r_ncep), i = it - M24(fi, ncep);
+                const float *mel = MEL + M24(fi, L.mel_stride), *sp = DS + M24(fi, ss);
                 float d;
                 if (i <= nc) {
                     const float a = sp[2 * i] * l_dcos[i];

@@ -31,12 +31,17 @@ __device__ __forceinline__ float act_clamp(float x, float lo, float hi)   // Act
 // node), or staged in Y for a separate pooling pass
 __host__ __device__ __forceinline__ bool nnf_direct(const KwsConvBlockF32 &k) { return k.pool == 1; }
 __host__ __device__ __forceinline__ bool nnf_staged(const KwsConvBlockF32 &k) { return !k.fused_pool && !nnf_direct(k); }
-__host__ __device__ __forceinline__ int nnf_ntb(const KwsConvBlockF32 &k) { return k.fused_pool ? k.pool_w : (k.out_w + k.tb - 1) / k.tb; }
-__host__ __device__ __forceinline__ int nnf_rows(const KwsConvBlockF32 &k)          // rows of the zero-padded input image
+__host__ __device__ __forceinline__ int nnf_ntb_of(const KwsConvBlockF32 &k) { return k.fused_pool ? k.pool_w : (k.out_w + k.tb - 1) / k.tb; }
+__host__ __device__ __forceinline__ int nnf_rows_of(const KwsConvBlockF32 &k)       // rows of the zero-padded input image
 {
-    const int a = k.pad_left + k.in_w, b = nnf_ntb(k) * k.tb + k.taps - 1;    // rows the blocked walk touches (k.tb is final)
+    const int a = k.pad_left + k.in_w, b = nnf_ntb_of(k) * k.tb + k.taps - 1;  // rows the blocked walk touches (k.tb is final)
     return a > b ? a : b;
 }
+// x / d for an item index: the plan's reciprocal where it is exact (x d < 2^20), a real division (~35 vector instructions) elsewhere
+__device__ __forceinline__ int nnf_div(int x, int d, unsigned inv20) { return inv20 ? (int)(((unsigned)x * inv20) >> 20) : x / d; }
+// ... as the plan holds them (kws_nn_f32_pick_blocking sets both with the blocking)
+__host__ __device__ __forceinline__ int nnf_ntb(const KwsConvBlockF32 &k) { return k.ntb; }
+__host__ __device__ __forceinline__ int nnf_rows(const KwsConvBlockF32 &k) { return k.rows; }
 __host__ __device__ __forceinline__ int nnf_ocp(const KwsConvBlockF32 &k) { return (k.out_c + 3) & ~3; }
 // LDS position of weight (step j, output channel oc) of a conv block: [j][oc] (a lane reads OB consecutive channels of one
 // step) for register-blocked blocks; [oc block][j][OB] for one-time-step blocks, whose lanes stream their own weights
@@ -57,7 +62,7 @@ __device__ __forceinline__ void nnf_conv(const KwsConvBlockF32 &k, const float *
     const int n_ob = (k.out_c + OB - 1) / OB, n_tb = nnf_ntb(k);
     const bool direct = nnf_direct(k);
     for (int item = lane; item < n_tb * n_ob; item += 64) {
-        const int tb = item / n_ob, ob = item - tb * n_ob;
+        const int tb = nnf_div(item, n_ob, k.inv_item20), ob = item - tb * n_ob;
         const int t0 = tb * TB, oc0 = ob * OB;
         float acc[TB][OB];
 #pragma unroll
@@ -206,9 +211,9 @@ __device__ __forceinline__ void nnf_dwconv(const KwsConvBlockF32 &k, const float
     const int ocp = nnf_ocp(k), n_tb = nnf_ntb(k);
     const bool direct = nnf_direct(k);
     for (int item = lane; item < n_tb * k.out_c; item += 64) {
-        const int tb = item / k.out_c, oc = item - tb * k.out_c;
+        const int tb = nnf_div(item, k.out_c, k.inv_outc20), oc = item - tb * k.out_c;
         const int t0 = tb * TB;
-        const float *xp = x + t0 * k.in_c + oc / k.depth_mult;
+        const float *xp = x + t0 * k.in_c + (k.depth_mult == 1 ? oc : oc / k.depth_mult);
         float acc[TB];
 #pragma unroll
         for (int i = 0; i < TB; ++i) acc[i] = 0.0f;
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(MAXT) void kws_nn_f32_kernel(const KwsNnPlanF32 *__
             if (nnf_staged(k)) {
                 // MAX_POOL_2D over time (pooling.h:189-237) from the staged conv output
                 for (int idx = lane; idx < n_out; idx += 64) {
-                    const int pw = idx / k.out_c, oc = idx - pw * k.out_c;
+                    const int pw = nnf_div(idx, k.out_c, k.inv_outc20), oc = idx - pw * k.out_c;
                     float mx = -FLT_MAX;
                     for (int q = 0; q < k.pool && pw * k.pool_stride + q < k.out_w; ++q) {      // the last window may be ragged (SAME)
                         const float v = Y[(pw * k.pool_stride + q) * k.out_c + oc];
@@ -505,6 +510,12 @@ void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k)
     k->fused_pool = (can_fuse && best[1] <= best[0]) ? 1 : 0;
     k->tb = btb[k->fused_pool];
     k->ob = bob[k->fused_pool];
+    k->ntb = nnf_ntb_of(*k);
+    k->rows = nnf_rows_of(*k);
+    // the kernel's item splits: items = time blocks x channel blocks (conv) or x out_c (depthwise, the pooling pass: out_w x out_c at most)
+    const long n_ob = k->depthwise ? k->out_c : (k->out_c + k->ob - 1) / k->ob;
+    k->inv_item20 = ((long)k->ntb * n_ob + 64) * n_ob < (1L << 20) ? (1u << 20) / (unsigned)n_ob + 1u : 0u;
+    k->inv_outc20 = ((long)std::max(k->ntb * std::max(k->tb, 1), k->out_w) * k->out_c + 64) * k->out_c < (1L << 20) ? (1u << 20) / (unsigned)k->out_c + 1u : 0u;
 }
 
 long long *kws_dev_f32_prof = nullptr;      // development aid: device buffer of KWS_MAX_BLOCKS + 2 phase counters, or NULL

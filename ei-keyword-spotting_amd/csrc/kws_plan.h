@@ -112,6 +112,9 @@ struct KwsConvBlockF32 {
     int depthwise, depth_mult;     // DEPTHWISE_CONV_2D (filter [1][1][taps][out_c]); else CONV_2D (filter [out_c][1][taps][in_c])
     int tb, ob;                    // register blocking of the conv: time steps x output channels per lane
     int fused_pool;                // tb == pool == pool_stride: the lane max-pools its own window, no staging of the conv output
+    unsigned inv_item20, inv_outc20;   // 2^20 / d + 1 for the kernel's item splits (d = channel blocks per time block, or out_c), 0 where items x d >= 2^20
+    int ntb, rows;                 // set with the blocking (kws_nn_f32_pick_blocking): time blocks per channel block, rows of the zero-padded input image
+                                   // -- derived values the kernel would otherwise divide for on every clip (a 32-bit division is ~35 vector instructions)
     float conv_min, conv_max;      // fused activation range of the convolution
     float add_min, add_max;        // fused activation range of the ADD (ReLU: [0, max])
     float pool_min, pool_max;
