@@ -118,7 +118,7 @@ __device__ __forceinline__ void fast_conv_finish(const KwsFastBlock &k, v4f (&ac
                 const int r0 = 16 * mt + 4 * lq;
                 int pw[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pw[i] = (int)(((unsigned)(r0 + i) * pinv) >> 16);
+                for (int i = 0; i < 4; ++i) pw[i] = (int)(__umul24((unsigned)(r0 + i), pinv) >> 16);
                 float mlo = acc[mt][nt][0], mhi = acc[mt][nt][3];      // pool >= 4: the four rows touch at most two windows
 #pragma unroll
                 for (int i = 1; i < 4; ++i) {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void fast_conv_finish(const KwsFastBlock &k, v4f (&ac
                 float v = acc[mt][nt][i] * scale + bias;
                 v = fminf(fmaxf(v, cmin), cmax);
                 if (has_add) { v = v + addc; v = fminf(fmaxf(v, amin), amax); }
-                *((row < out_w && n < out_c) ? sp + row * sstride : sink) = v;
+                *((row < out_w && n < out_c) ? sp + __mul24(row, sstride) : sink) = v;
             }
         }
     }
@@ -341,9 +341,11 @@ __device__ __forceinline__ float fast_split_image(float *__restrict__ img, int i
     for (int u = 0; u < KWS_FAST_HP; ++u) {
         if (KWS_WAVE * u < items) {                                 // (no break: the loop must unroll, or the arrays go to scratch)
             const int i = min(lane + KWS_WAVE * u, items - 1);
-            const int r = (int)(((unsigned)i * inv) >> 20), p2 = 2 * (i - r * ppr);
-            v[u] = *(const float2 *)(img + r * in_stride + p2);
-            off[u] = r * (in_stride * 4) + 2 * p2;
+            // (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction, and these four run sixteen times per image)
+            const int r = (int)(__umul24((unsigned)i, inv) >> 20), p2 = 2 * (i - __mul24(r, ppr));
+            const int ro = __mul24(r, in_stride);
+            v[u] = *(const float2 *)(img + ro + p2);
+            off[u] = 4 * ro + 2 * p2;
             // the k-padding channels (in_c .. in_cp - 1) meet zero weights, but what sits there need not survive the scaling: zeros
             v[u].x = p2 < in_c ? v[u].x : 0.0f;
             v[u].y = p2 + 1 < in_c ? v[u].y : 0.0f;
