@@ -533,7 +533,10 @@ def main():
         # DSP configurations OUTSIDE the tuned shape (fft 512 / 128 / 1024, 2 s windows): extract_mfcc_features on the general-shape kernels
         # (kws_spectral_lds_kernel + kws_cmvn_lds_kernel, bit-exact, exact mode only) -- not a BASELINE configuration, reported
         # because SURVEY 8(f)2's ingestion accepts such models
-        dsp_shapes = also_dsp(backend, pkg)
+        try:
+            dsp_shapes = also_dsp(backend, pkg)
+        except Exception as e:                                        # a side measurement must never cost the bench line
+            dsp_shapes = [{"error": "%s: %s" % (type(e).__name__, e)}]
 
     if not a.dry_run_cpu and backend.comm is not None:
         backend.comm.close()
