@@ -20,7 +20,8 @@ CASES = {
     "clip4000": dict(raw_samples=4000, blocks=((8, 3, 1), (4, 3, 1))),
     "clip640_one_frame": dict(raw_samples=640, blocks=((8, 3, 1), (4, 3, 1))),      # 1 frame (no pooling: SAME pooling of 1-2 rows
     "clip1000": dict(raw_samples=1000, blocks=((8, 3, 1), (4, 3, 1))),               # would need padding, which the network plan refuses)
-    "clip15999_unaligned": dict(raw_samples=15999),
+    "clip15999_unaligned": dict(raw_samples=15999),                  # (odd clip length: the int16 samples are fetched one by one, not as dword pairs)
+    "odd_stride_fft512": dict(fft_length=512, frame_length=0.0200625, frame_stride=0.0100625, win_size=31),   # 321-sample frames every 161: likewise
     "filters24": dict(num_filters=24, ncep=10),                      # DCT of 24 points: radix 4, 3
     "filters64_wide": dict(num_filters=64, ncep=20, high=0),         # 64 filters
     "filters20_0_8000": dict(num_filters=20, ncep=12, low=0, high=0),  # few, wide filters: more than 12 taps each

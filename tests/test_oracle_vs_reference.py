@@ -35,6 +35,7 @@ def test_dsp_stages_random_clips(oracle, reference):
     dict(fft_length=128, win_size=51),
     dict(frame_stride=0.01, win_size=31),                        # overlapping frames
     dict(pre_cof=0.0),
+    dict(fft_length=512, frame_length=0.0200625, frame_stride=0.0100625, win_size=31),   # 321-sample frames every 161 samples (odd both)
 ])
 def test_mfcc_configs(oracle, reference, kw):
     cfg = L476_CONFIG().copy(**kw)
