@@ -235,20 +235,21 @@ __global__ __launch_bounds__(GL) void kws_spectral_generic_kernel(KwsDspPlan P, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-//  kws_spectral_lds_kernel (round 4): the same function as kws_spectral_generic_kernel -- any factorisation, any
-//  frame / filter count, every operation in the reference's order -- without the lane-interleaved scratch in HBM.  One wave per workgroup
-//  owns a chunk of LCH consecutive frames of a clip:
-//    * per frame, the wave transforms it COOPERATIVELY: the frame's samples are loaded coalesced, pre-emphasised, and dealt into kf_work's
-//      leaf order (a mixed-radix digit reversal, tabulated once per workgroup); then level by level, innermost first, the butterflies of
-//      a level -- ncfft / p of them, all independent -- are spread over the 64 lanes (butterfly b = (sub-transform b / m, index b % m));
-//      each is kf_bfly2 / 3 / 4 / 5 exactly as g_bfly computes it.  kiss_fftr's split and the power spectrum (double-precision magnitude)
-//      run per bin pair, straight into the chunk's power rows in LDS.
+//  kws_spectral_lds_kernel (round 4; round 5: how it occupies the chip): the same function as
+//  kws_spectral_generic_kernel -- any factorisation, any frame / filter count, every operation in the reference's order -- without the
+//  lane-interleaved scratch in HBM.  A WAVE owns a chunk of LCH consecutive frames of a clip; the waves of a workgroup (up to eight) share
+//  one copy of the model's tables and nothing else:
+//    * per sub-batch of up to fb frames, the wave transforms them COOPERATIVELY: the samples are fetched (int16 on even sample offsets: as
+//      dword pairs, requested one sub-batch ahead), pre-emphasised, and dealt into kf_work's leaf order (a mixed-radix digit reversal,
+//      tabulated once per workgroup); then level by level, innermost first, the butterflies of a level -- ncfft / p per frame, all
+//      independent -- are spread over the 64 lanes as (frame, butterfly) items; each is kf_bfly2 / 3 / 4 / 5 exactly as g_bfly computes it.
+//      kiss_fftr's split and the power spectrum (double-precision magnitude) run per bin pair, straight into the chunk's power rows in LDS.
 //    * per chunk: frame energies (a lane per frame: numpy::sum is a sequential sum), the mel filterbank ((frame, filter) items over the
 //      lanes, ascending-bin dot products), log, and the DCT of all the chunk's frames at once ((frame, butterfly) items over the lanes),
 //      c0 <- log(energy), cepstra to HBM.
-//  LDS (lds_layout): complex buffer 2 (ncfft + ncfft/16) floats, the leaf-order table ncfft ints, LCH power rows of n_bins | 1 floats, LCH mel
-//  rows, the DCT's arrays per frame, and the model's tables: 20 - 22 KB for fft 512 / 32 filters at LCH = 8 (14 - 16 KB at 4), i.e. seven or
-//  eight waves per CU, instead of a scratch that lived in L2.
+//  LDS (lds_layout): per workgroup the tables (leaf orders, twiddles, filterbank: 8 - 13 KB); per wave fb complex work buffers of
+//  2 (ncfft + ncfft/16 + 1) floats -- the mel rows and the DCT's arrays lie over them once they are dead -- and LCH power rows of n_bins | 1
+//  floats: 8.5 KB for fft 512 at LCH = 4, fb = 2, i.e. sixteen waves per CU in the build for four waves per SIMD (see launch_spectral_lds).
 // ---------------------------------------------------------------------------------------------------------
 // frames per chunk: a template parameter, 8 or 4 (16: 2.29 ms for 8 192 clips of fft 512 x 49 frames, 8: 1.29 / 1.30 ms in two calls, 4: 1.30 ms; 4 is
 // 22 % / 15 % faster on 98-frame windows and on fft 1024, 8 % slower on fft 128: profiles/r04_generic_rate.txt).  The LDS per wave bounds how many
