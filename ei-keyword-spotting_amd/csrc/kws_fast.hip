@@ -328,29 +328,36 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 #define KWS_FAST_HP 16            // channel pairs a lane converts: images of up to 64 x 16 pairs (the plan checks)
 
-// returns 1 / s
-__device__ __forceinline__ float fast_split_image(float *__restrict__ img, int in_w, int in_c, int in_cp, int in_stride, int lane, unsigned ppr_inv20)
+// T trips of the wave, every one of them whole (pairs past the last one: the lane re-reads the last pair and stores the same halves to the same
+// place).  The reads of all T trips go out as ONE batch, with nothing conditional around them: a trip in a block of its own ("if this trip has
+// items: read") makes the compiler wait for every read before it issues the next one -- sixteen exposed LDS round trips, measured as 34 % of
+// the first convolution block's clocks (profiles/r05_fast_subphase.txt).
+template <int T>
+__device__ __forceinline__ float fast_split_trips(float *__restrict__ img, int items, int in_c, int in_cp, int in_stride, int lane, unsigned inv, int ppr)
 {
-    const int ppr = in_cp >> 1, items = in_w * ppr;
-    const unsigned inv = ppr_inv20;                                 // i / ppr for i < 1024, ppr <= 32 (the plan's reciprocal)
-    float2 v[KWS_FAST_HP];
-    int off[KWS_FAST_HP];                                           // byte offset of the pair's hi halves (kept: the second loop needs no division)
-    float mx = 0.0f;
-    // whole trips of the wave only (the trip count is wave-uniform: a small image -- a later block's -- takes one or two)
+    float2 v[T];
+    int off[T];                                                     // byte offset of the pair's hi halves (kept: the second loop needs no division)
+    int pc[T];                                                      // the pair's first channel
 #pragma unroll
-    for (int u = 0; u < KWS_FAST_HP; ++u) {
-        if (KWS_WAVE * u < items) {                                 // (no break: the loop must unroll, or the arrays go to scratch)
-            const int i = min(lane + KWS_WAVE * u, items - 1);
-            // (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction, and these four run sixteen times per image)
-            const int r = (int)(__umul24((unsigned)i, inv) >> 20), p2 = 2 * (i - __mul24(r, ppr));
-            const int ro = __mul24(r, in_stride);
-            v[u] = *(const float2 *)(img + ro + p2);
-            off[u] = 4 * ro + 2 * p2;
-            // the k-padding channels (in_c .. in_cp - 1) meet zero weights, but what sits there need not survive the scaling: zeros
-            v[u].x = p2 < in_c ? v[u].x : 0.0f;
-            v[u].y = p2 + 1 < in_c ? v[u].y : 0.0f;
-            mx = fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y)));
-        }
+    for (int u = 0; u < T; ++u) {
+        const int i = min(lane + KWS_WAVE * u, items - 1);
+        // (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction)
+        const int r = (int)(__umul24((unsigned)i, inv) >> 20), p2 = 2 * (i - __mul24(r, ppr));
+        const int ro = __mul24(r, in_stride);
+        v[u] = *(const float2 *)(img + ro + p2);
+        off[u] = 4 * ro + 2 * p2;
+        pc[u] = p2;
+    }
+    // (the values are pinned here: the selects below must not turn the reads above into predicated reads, which would wait one by one)
+#pragma unroll
+    for (int u = 0; u < T; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y));
+    float mx = 0.0f;
+#pragma unroll
+    for (int u = 0; u < T; ++u) {
+        // the k-padding channels (in_c .. in_cp - 1) meet zero weights, but what sits there need not survive the scaling: zeros
+        v[u].x = pc[u] < in_c ? v[u].x : 0.0f;
+        v[u].y = pc[u] + 1 < in_c ? v[u].y : 0.0f;
+        mx = fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y)));
     }
     mx = wave_max(mx);
     // max|x| < 2^e; e kept where both s and 1 / s are normal numbers whatever the image holds
@@ -360,19 +367,26 @@ __device__ __forceinline__ float fast_split_image(float *__restrict__ img, int i
     char *const ib = (char *)img;
     const int lo_off = 2 * in_cp;
 #pragma unroll
-    for (int u = 0; u < KWS_FAST_HP; ++u) {
-        if (KWS_WAVE * u < items) {
-            const float y0 = v[u].x * s, y1 = v[u].y * s;
-            const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
-            const float d0 = y0 - (float)h0, d1 = y1 - (float)h1;   // exact: the difference has at most 13 significant bits
-            const v2h hi = { h0, h1 }, lo = { (_Float16)d0, (_Float16)d1 };
-            // (the last trip's surplus lanes hold copies of the last pair: they store the same halves to the same place)
-            *(v2h *)(ib + off[u]) = hi;
-            *(v2h *)(ib + off[u] + lo_off) = lo;
-        }
+    for (int u = 0; u < T; ++u) {
+        const float y0 = v[u].x * s, y1 = v[u].y * s;
+        const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+        const float d0 = y0 - (float)h0, d1 = y1 - (float)h1;       // exact: the difference has at most 13 significant bits
+        const v2h hi = { h0, h1 }, lo = { (_Float16)d0, (_Float16)d1 };
+        *(v2h *)(ib + off[u]) = hi;
+        *(v2h *)(ib + off[u] + lo_off) = lo;
     }
     WAVE_SYNC();
     return ldexpf(1.0f, e - 14);
+}
+
+// returns 1 / s
+__device__ __forceinline__ float fast_split_image(float *__restrict__ img, int in_w, int in_c, int in_cp, int in_stride, int lane, unsigned ppr_inv20)
+{
+    const int ppr = in_cp >> 1, items = in_w * ppr;                 // i / ppr for i < 1024, ppr <= 32: the plan's reciprocal
+    // the trip count is wave-uniform: a later block's small image takes a few trips, the first block's up to sixteen
+    if (items <= 4 * KWS_WAVE) return fast_split_trips<4>(img, items, in_c, in_cp, in_stride, lane, ppr_inv20, ppr);
+    if (items <= 8 * KWS_WAVE) return fast_split_trips<8>(img, items, in_c, in_cp, in_stride, lane, ppr_inv20, ppr);
+    return fast_split_trips<KWS_FAST_HP>(img, items, in_c, in_cp, in_stride, lane, ppr_inv20, ppr);
 }
 
 // A small block whose weight fragments did not fit the workgroup's LDS block (one output-channel tile, at most eight k-steps): every
