@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development measurement: shader clocks of wave 0 of workgroup 0 inside the split-operand convolution of the headline graph -- image split,
 contraction loop, epilogue -- read from a scratch build of the library that carries the clock reads (KWS_LIB; built from a patched copy of
-csrc/kws_fast.hip, not part of the product: tools/round5/README.md, run28).
+csrc/kws_fast.hip by tools/round5/make_subprof_lib.sh, not part of the product).
 
     KWS_LIB=ab_tmp/libkws_subprof.so python tools/gpu_fast_subphase.py [steps]"""
 import ctypes
