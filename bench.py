@@ -50,6 +50,14 @@ WORKLOADS = {
     "cfg5_dscnn_mfcc40_int8.kwsm": "BASELINE configs[4] shape: 49x40 MFCC + 7-block depthwise-separable CNN, 12 labels, int8, synthetic weights",
     "cfg5_dscnn_mfcc40_f32.kwsm": "BASELINE configs[4] shape: 49x40 MFCC + 7-block depthwise-separable CNN, 12 labels, fp32, synthetic weights",
 }
+WORKLOADS_SHORT = {
+    "cfg2_mfcc40_f32.kwsm": "BASELINE configs[1]: 49x40 MFCC + 2-Conv CNN fp32, synthetic weights",
+    "cfg2_mfcc40_int8.kwsm": "configs[1] graph quantised to int8",
+    "l476_no_yes.kwsm": "BASELINE configs[3]: the shipped int8 impulse (49x13 MFCC + 2-Conv CNN)",
+    "l476_no_yes_f32.kwsm": "fp32 twin of the shipped impulse",
+    "cfg5_dscnn_mfcc40_int8.kwsm": "BASELINE configs[4] shape, int8",
+    "cfg5_dscnn_mfcc40_f32.kwsm": "BASELINE configs[4] shape, fp32",
+}
 CLIP_LEN = 16000
 # also_inputs: the headline graph on inputs that are not the bench's noise-floored synthetic clips (tests/kws_families.py)
 INPUT_FAMILIES = ("word_noise_gain", "word_background", "word_silence", "amp_sweep", "bursts")
@@ -158,6 +166,7 @@ def cpu_baseline(seconds=10.0, model_path=DEFAULT_MODEL, n_clips=2000):
     wall = time.time() - t0
     return {"value": round(sum(rates), 1), "unit": "clips/s", "cores": len(rates), "kind": kind, "cpu": cpu_model_name(),
             "per_core": round(sum(rates) / max(1, len(rates)), 1), "kwsm_file": os.path.basename(model_path),
+            "sample_short": "%d processes x %d distinct synthetic clips, >= %.0f s each, %d clips" % (len(rates), n_clips, seconds, clips),
             "sample": "%d concurrent processes (one per usable core), each running the reference's MFCC + network over its own %d "
                       "distinct seed-0 synthetic clips for >= %.0f s: %d clips in all (%.1f s wall incl. start-up)"
                       % (len(rates), n_clips, seconds, clips, wall)}
@@ -404,9 +413,10 @@ def measure(backend, model_path, mode, steps, warmup, barrier, max_over_ranks, g
     return res
 
 
-def pmc_for(kernel, model, batch):
-    """HBM traffic / SQ counters of `kernel` from rocprofv3 PMC passes of this same command (tools/profile_round.sh), used only
-    when they were taken with the library that is running now (SHA-256 of libkws_mi355x.so recorded next to them)."""
+def pmc_for(kernels, model, batch, mode="fast"):
+    """HBM traffic / SQ counters of the hot path's kernels (`kernels`: the dominant one first) from rocprofv3 PMC passes of this same
+    command (tools/profile_round.sh), used only when they were taken with the library that is running now (SHA-256 of libkws_mi355x.so
+    recorded next to them).  -> (directory, {traffic_bytes: summed over `kernels`, per_kernel}, SQ figures of the dominant kernel) or None"""
     sha = lib_sha256()
     best = None
     prof = os.path.join(ROOT, "profiles")
@@ -416,8 +426,10 @@ def pmc_for(kernel, model, batch):
             j = json.load(open(f))
         except Exception:
             continue
-        if j.get("lib_sha256") == sha and j.get("model") == model and j.get("batch") == batch and kernel in j.get("kernels", {}):
-            best = (os.path.join("profiles", d), j["kernels"][kernel], j.get("sq", {}).get(kernel))
+        ks = j.get("kernels", {})
+        if j.get("lib_sha256") == sha and j.get("model") == model and j.get("batch") == batch and j.get("mode", "fast") == mode and kernels[0] in ks:
+            per = {k: ks[k]["traffic_bytes"] for k in kernels if k in ks}
+            best = (os.path.join("profiles", d), {"traffic_bytes": sum(per.values()), "per_kernel": per}, j.get("sq", {}).get(kernels[0]))
     return best
 
 
@@ -567,7 +579,14 @@ def main():
                 else "bit-exact vs reference") + " -- tests/test_gpu_parity.py"
 
     def dominant(x):
-        return "kws_fast_kernel" if x["mode"] == "fast" else "kws_mfcc8_kernel"
+        return "kws_fast_kernel" if x["mode"] == "fast" and x.get("entry_tier", 0) in (None, 0, 1) else "kws_mfcc8_kernel"
+
+    def path_kernels(x):
+        """the kernels of x's hot path that move data, the dominant one first (bench.py sums their counter traffic)"""
+        if x["mode"] == "fast":
+            # a float graph whose gain leaves the fast MFCC no room (entry tier >= 2) takes the exact features + the fused network (DESIGN 4.6)
+            return ["kws_fast_kernel"] if dominant(x) == "kws_fast_kernel" else ["kws_mfcc8_kernel", "kws_fast_kernel"]
+        return ["kws_mfcc8_kernel", x["nn_kernel"].split("<")[0].split(" ")[0]]
 
     def dtype(x):
         # the fused float network's contractions run on v_mfma_f32_16x16x32_f16 with every f32 operand carried as two f16 halves (22 bits) and three
@@ -579,7 +598,7 @@ def main():
 
     algo_bytes = CLIP_LEN * 2 + r["labels"] * 4          # int16 PCM in + C float scores out, per clip
     achieved = algo_bytes * B / (r["ms_path"] * 1e-3) / 1e9
-    pmc = pmc_for(dominant(r), r["model"], B) if not a.dry_run_cpu else None
+    pmc = pmc_for(path_kernels(r), r["model"], B, r["mode"]) if not a.dry_run_cpu else None
     compute = None
     if pmc and pmc[2] and pmc[2].get("compute"):
         compute = dict(pmc[2]["compute"])
@@ -608,8 +627,10 @@ def main():
         "metric": "1s@16kHz clips/sec (MFCC+CNN)", "value": round(world * B * a.steps / r["dt"], 1), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(r["dt"] / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype(r),
+        "dtype_short": ("f32" if r["is_float"] else "f32 (MFCC) / i8 (CNN)") if r["mode"] == "fast" else ("f32+f64 (MFCC) / %s (CNN)" % ("f32" if r["is_float"] else "i8")),
         "data": "synthetic" + (" (DRY RUN ON CPU: oracle + gloo stand in for the GPU library + RCCL; not a measurement)" if a.dry_run_cpu else ""),
         "config": {"workload": workload(r["model"], r["mode"], r["is_float"]), "mode": r["mode"], "clips_per_gpu": B, "global_batch": world * B, "kwsm_file": r["model"],
+                   "workload_short": WORKLOADS_SHORT.get(r["model"], r["model"]) + "; %d clips of 1 s @ 16 kHz per GPU in HBM" % B,
                    "parity": parity(r), "network_fused_into_mfcc_kernel": r["fused"], "clips_handed_on_by_the_first_fast_tier_last_step": r["fallback"],
                    "clips_finished_by_exact_kernels_last_step": r["exact_count"],
                    "fast_fallback_rate": round(r["fallback"] / float(B), 6), "fast_entry_tier": r["entry_tier"], "fast_guard": r["guard"],
@@ -626,7 +647,9 @@ def main():
     }
 
     def line(x, steps):
-        return {"kwsm_file": x["model"], "mode": x["mode"], "workload": workload(x["model"], x["mode"], x["is_float"]), "value": round(B * steps / x["dt"], 1),
+        px = pmc_for(path_kernels(x), x["model"], B, x["mode"]) if not a.dry_run_cpu else None
+        return {"traffic": px[1]["traffic_bytes"] if px else None, "traffic_per_kernel": px[1]["per_kernel"] if px else None, "traffic_source": px[0] if px else None,
+                "kwsm_file": x["model"], "mode": x["mode"], "workload": workload(x["model"], x["mode"], x["is_float"]), "value": round(B * steps / x["dt"], 1),
                 "fast_fallback_rate": round(x["fallback"] / float(B), 6), "fast_exact_rate": round(x["exact_count"] / float(B), 6), "fast_entry_tier": x["entry_tier"],
                 "unit": "clips/s", "ms_per_step": round(x["dt"] / steps * 1e3, 4), "steps": steps, "dtype": dtype(x), "parity": parity(x),
                 "network_kernel": "fused into kws_fast_kernel" if x["fused"] else x["nn_kernel"],
@@ -658,12 +681,87 @@ def main():
         out["int8_exact"] = dict(line(x, st), configs="BASELINE configs[3]: int8-quantised weights/activations, bit-exact (the reference's own impulse; every MFCC feature, "
                                                      "int8 tensor and score identical to the reference's), batch 65 536, 1x MI355X",
                                  roofline={"bound": "hbm", "kernel": "kws_mfcc8_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": ab * B,
+                                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": ab * B,
                                            "hot_path_ms": round(x["ms_path"], 4),
                                            "hot_path_ms_note": "HIP events around the hot-path call: kws_mfcc8_kernel (MFCC -> int8 tensor) + kws_nn_mfma_kernel"})
+        out["int8_exact"]["roofline"].update(traffic=out["int8_exact"]["traffic"], traffic_source=out["int8_exact"]["traffic_source"],
+                                             traffic_per_kernel=out["int8_exact"]["traffic_per_kernel"])
     if cpu is not None:
         out["cpu_baseline"] = cpu
-    print(json.dumps(out))
+    emit(out, a)
+
+
+DETAIL_FILE = "bench_detail.json"
+LINE_LIMIT = 6000                # bytes: the driver keeps a bounded tail of stdout (round 5's 27 KB line was not parsed)
+
+
+def compact_line(out):
+    """The ONE stdout line: numbers and short names only (every prose field of `out` stays in bench_detail.json / stderr)."""
+    def short_row(x, extra=()):
+        row = {"kwsm": x["kwsm_file"].replace(".kwsm", ""), "mode": x["mode"], "value": x["value"], "ms_per_step": x["ms_per_step"],
+               "hbm_frac": x["hbm_frac"], "fallback": x["fast_fallback_rate"]}
+        if x.get("traffic"):
+            row["traffic"] = x["traffic"]
+        for k in extra:
+            row[k] = x[k]
+        return row
+
+    def short_roof(rf):
+        c = rf.get("compute") or None
+        return {"bound": "hbm", "limited_by": rf.get("bound"), "kernel": rf.get("kernel"), "achieved": rf.get("achieved"), "peak": rf.get("peak"),
+                "unit": rf.get("unit"), "frac": rf.get("frac"), "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
+                "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"), "hot_path_ms": rf.get("hot_path_ms"),
+                "compute": {k: c.get(k) for k in ("valu_issue_frac", "valu_active_frac", "mfma_busy_frac", "lds_busy_frac")} if c else None}
+
+    cfg = out["config"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")}
+    line["dtype"] = out["dtype_short"]
+    line["data"] = out["data"] if len(out["data"]) < 40 else "synthetic (dry run on CPU: not a measurement)"
+    line["config"] = {"workload": cfg["workload_short"], "mode": cfg["mode"], "clips_per_gpu": cfg["clips_per_gpu"], "global_batch": cfg["global_batch"],
+                      "kwsm_file": cfg["kwsm_file"], "fast_fallback_rate": cfg["fast_fallback_rate"], "collective": cfg["collective"].split(" (")[0],
+                      "lib_sha256": cfg["lib_sha256"]}
+    line["roofline"] = short_roof(out["roofline"])
+    if out.get("cpu_baseline"):
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "cpu": cb["cpu"],
+                                "sample": cb["sample_short"]}
+    col = out.get("collective")
+    line["collective"] = ({k: col.get(k) for k in ("allgather_ms_per_step", "inside_timed_region", "ranks", "ranks_seen_by_rccl", "rccl_version", "rank_time_skew_max_over_min",
+                                                      "per_rank_clips_per_s", "gloo_world_size")
+                           if k in col} if col else None)
+    rows = [short_row(x) for x in out.get("modes", [])[1:]] + [short_row(x) for x in out.get("also", [])]
+    if rows:
+        line["also"] = rows
+    if out.get("int8_exact"):
+        x = out["int8_exact"]
+        line["int8_exact"] = dict(short_row(x), roofline={k: v for k, v in short_roof(x["roofline"]).items() if k not in ("limited_by", "compute") or v})
+    if out.get("also_inputs"):
+        line["also_inputs"] = [{"family": x["family"], "mode": x["mode"], "value": x["value"], "handed_on": x["fast_fallback_rate"], "exact": x["fast_exact_rate"]}
+                               for x in out["also_inputs"] if x["mode"] == "fast"]
+    line["checksum"], line["checksum_class0"] = out["checksum"], out["checksum_class0"]
+    line["detail"] = DETAIL_FILE
+    return line
+
+
+def emit(out, a):
+    """bench_detail.json (next to this script) and stderr get everything; stdout gets one line of at most LINE_LIMIT bytes."""
+    detail = json.dumps(out, indent=1)
+    try:
+        with open(os.path.join(ROOT, DETAIL_FILE), "w") as f:
+            f.write(detail + "\n")
+    except OSError as e:                                            # a read-only tree must not cost the bench line
+        print("bench.py: could not write %s: %s" % (DETAIL_FILE, e), file=sys.stderr)
+    print(json.dumps(out), file=sys.stderr)
+    sys.stderr.flush()
+    line = compact_line(out)
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("also_inputs", "also"):                           # never reached with the shipped model list; the headline must survive
+        if len(text) >= LINE_LIMIT and drop in line:
+            del line[drop]
+            text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, "bench.py: the stdout line is %d bytes" % len(text)
+    print(text)
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@ Because the directory name carries a hyphen, import it through `__graft_entry__.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -68,7 +69,9 @@ def build(force=False):
         os.remove(LIB_PATH)
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
     # the development build (KWS_DEV_* switches compiled in): what the tests that force a tier / a layout and the A/B tools load
-    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "dev"])
+    # (best effort: a failure of the development build must not keep the product library from loading)
+    if subprocess.call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "dev"]) != 0:
+        print("ei-keyword-spotting_amd.build(): the development build (libkws_mi355x_dev.so) failed; the product library is built", file=sys.stderr)
     return LIB_PATH
 
 

@@ -101,7 +101,13 @@ def test_bench_spawns_its_own_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout
+    # round 6: the driver keeps a bounded tail of stdout (round 5's 27 KB line went unparsed): the line stays under 6 KB, the prose and the
+    # side measurements go to bench_detail.json / stderr
+    from bench import DETAIL_FILE, LINE_LIMIT
+    assert LINE_LIMIT <= 6000 and len(lines[0]) < 6000, len(lines[0])
     j = json.loads(lines[0])
+    assert j["detail"] == DETAIL_FILE and json.load(open(os.path.join(ROOT, DETAIL_FILE)))["value"] == j["value"]
+    assert j["roofline"]["bound"] in ("hbm", "mfma") and j["roofline"]["unit"] == "GB/s" and j["roofline"]["peak"] == 8000.0
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["collective"]["ranks"] == 2
     assert abs(j["checksum"] - 8.0) < 0.1                       # 8 softmax rows
     # round 4: the line carries every rank's own rate and the spread between the ranks, and what the communicator itself reports

@@ -23,6 +23,7 @@ def test_bench_force_collective_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout                                      # banners of gloo / RCCL are kept off stdout
+    assert len(lines[0]) < 6000
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["config"]["mode"] == "fast" and j["config"]["clips_per_gpu"] == 4096
     assert j["collective"]["ranks"] == 1 and j["collective"]["allgather_ms_per_step"] > 0
@@ -32,6 +33,34 @@ def test_bench_force_collective_on_one_gpu():
     assert "RCCL" in j["config"]["collective"]
     assert abs(j["checksum"] - 4096.0) < 0.05                               # the gathered scores: 4096 softmax rows
     assert j["value"] > 1e5 and j["roofline"]["kernel"] == "kws_fast_kernel"
+
+
+def test_bench_line_with_the_drivers_flags_is_compact_and_complete():
+    """The driver's own command (`python bench.py --gpus 1 --steps 20 --warmup 5`, everything on: the CPU baseline leg, the other modes / models /
+    input families): ONE stdout line under 6 KB (round 5's 27 KB line was not parsed by the driver) that carries the headline, its roofline
+    object, the CPU baseline, the exact-mode row of the headline graph and BASELINE configs[3] (int8_exact); the rest is in bench_detail.json."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 6000, (len(lines), [len(ln) for ln in lines])
+    j = json.loads(lines[0])
+    assert j["steps"] == 20 and j["warmup"] == 5 and j["n_gpus"] == 1 and j["unit"] == "clips/s" and j["value"] > 1e6
+    assert abs(j["value"] - 65536 / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] == "kws_fast_kernel" and rf["peak"] == 8000.0 and rf["algorithmic_bytes_per_launch"] == 65536 * 32016
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0 < rf["hot_path_ms"] <= j["ms_per_step"] * 1.02
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    rows = {(r["kwsm"], r["mode"]): r for r in j["also"]}
+    assert ("cfg2_mfcc40_f32", "exact") in rows and ("cfg5_dscnn_mfcc40_f32", "fast") in rows
+    assert j["int8_exact"]["kwsm"] == "l476_no_yes" and j["int8_exact"]["mode"] == "exact" and j["int8_exact"]["roofline"]["frac"] > 0
+    assert {r["family"] for r in j["also_inputs"]} >= {"word_silence", "amp_sweep", "bursts"}
+    detail = json.load(open(os.path.join(ROOT, j["detail"])))
+    assert detail["value"] == j["value"] and "also_dsp" in detail and len(detail["also_inputs"]) == 2 * len(j["also_inputs"])
 
 
 def test_allgather_scores_c_abi_world_size_one():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --output-format csv).
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <batch> <out.json> [model file name]
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <batch> <out.json> [model file name] [mode: fast | exact]
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): the counters report KiB; on gfx950 FETCH_SIZE counts half
 of the bytes of 16-byte-per-lane coalesced streaming reads, so it is doubled.  WRITE_SIZE is checked against
@@ -36,12 +36,13 @@ def per_kernel(path, counter):
 def main():
     fetch, write, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     model = sys.argv[5] if len(sys.argv) > 5 else "cfg2_mfcc40_f32.kwsm"
+    mode = sys.argv[6] if len(sys.argv) > 6 else "fast"
     (f, f_inst), (w, _) = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ei-keyword-spotting_amd", "libkws_mi355x.so")
     res = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
-           "command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
-                      "--no-cpu-baseline --no-also  (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
-           "batch": batch, "model": model, "unit": "bytes per launch",
+           "command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py --model models/%s --mode %s --steps 3 --warmup 1 "
+                      "--no-cpu-baseline --no-also  (one pass per counter: FETCH_SIZE, WRITE_SIZE)" % (model, mode),
+           "batch": batch, "model": model, "mode": mode, "unit": "bytes per launch",
            "correction": "counter values are KiB; FETCH_SIZE doubled (gfx950, 16-byte/lane coalesced streaming reads); "
                          "WRITE_SIZE checked on kws_synth_kernel (batch*32000 B written)",
            "kernels": {}}
