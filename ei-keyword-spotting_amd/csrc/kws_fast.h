@@ -109,6 +109,12 @@ struct KwsFastPlan {
                                   // the column) < c0_abs + c0_rel x (its largest magnitude); c0_factor = sqrt(c0_mult n_frames / win_size),
                                   // c0_mult = how often every window holds every row at least (0: always compute them)
     int pad_off;                  // shared LDS: [n_frames + 2 pad] ints, numpy::pad_1d_symmetric's row order (column 0's exact window means)
+    // Digitally silent frames (frame energy exactly 0: zero handling turns every mel energy into FLT_EPSILON) have ONE cepstral row in the
+    // reference -- the DCT of a constant vector, a handful of rounding residues -- which kws_create records from the exact kernels on an
+    // all-zero window (kws_fast_plan.cpp: record_silent_row).  The PCM forms write that row's DCT outputs over their own for such frames, so
+    // those rows carry no spectral error: the guard's absolute / per-level terms are scaled by sqrt(live rows / rows) and its level is the
+    // live rows' (round 6).  sil_off: shared LDS, 32 floats (columns 0 .. 31; only 1 .. NF/2 are read), or -1: not recorded
+    int sil_off;
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;

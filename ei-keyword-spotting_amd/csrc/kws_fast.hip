@@ -1,14 +1,16 @@
 // kws_fast.hip -- kws_fast_kernel: KWS_MODE_FAST, the tolerance-mode form of run_classifier()'s hot path (see kws_fast.h for
 // what is relaxed and what is not).  One wavefront owns one clip from the int16 PCM in HBM to its scores: extract_mfcc_features
-// (SDK/classifier/ei_run_dsp.h:256-308) with the FFT in KissFFT's order and everything behind it in plain fp32, then -- for a
-// float32 graph -- the CONV_2D / ADD / MAX_POOL_2D / FULLY_CONNECTED / SOFTMAX chain (TFL/kernels/internal/reference/conv.h:28-99,
-// add.h:179-215, pooling.h:189-237, fully_connected.h:26-60, softmax.h:31-63) with the convolutions on v_mfma_f32_16x16x4_f32.
+// (SDK/classifier/ei_run_dsp.h:256-308) with the FFT in KissFFT's order and everything behind it in plain fp32 (the DCT on
+// v_mfma_f32_16x16x4_f32), then -- for a float32 graph -- the CONV_2D / ADD / MAX_POOL_2D / FULLY_CONNECTED / SOFTMAX chain
+// (TFL/kernels/internal/reference/conv.h:28-99, add.h:179-215, pooling.h:189-237, fully_connected.h:26-60, softmax.h:31-63) with the
+// contractions on v_mfma_f32_16x16x32_f16: every fp32 operand carried as two fp16 halves (22 significant bits), three products per pair,
+// fp32 accumulation (fast_conv_tiles_h; blocks whose image does not fit the in-place split keep v_mfma_f32_16x16x4_f32, fast_conv_tiles).
 // Eight waves of a workgroup share the weights in LDS; nothing but the PCM and the scores crosses HBM.
 //
-// With 13 KB of LDS per wave next to the shared weights, and ~208 VGPRs, only two waves fit a SIMD, so every phase is written to
-// keep its own memory operations in flight: loads of a phase are issued as one batch before the arithmetic that consumes them,
-// tile counts are template parameters (no predicated code inside the contraction loops), and the convolution loops fetch one
-// k-step ahead.  DESIGN.md 4.4 has the phase table, the counters and what was tried and rejected.
+// With 13.6 KB of LDS per wave next to the shared 46 KB of weight fragments and tables, and 256 VGPRs, two waves fit a SIMD, so every
+// phase is written to keep its own memory operations in flight: loads of a phase are issued as one batch before the arithmetic that
+// consumes them, tile counts are template parameters (no predicated code inside the contraction loops), and the convolution loops
+// fetch their operands ahead of the matrix instructions.  DESIGN.md 4.4 has the phase table, the counters and what was tried and rejected.
 #include <atomic>
 
 #include "kws_device.h"
@@ -496,6 +498,7 @@ __device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float 
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
     };
     // two operand sets, the loop unrolled by two: a set's operands are requested before the other set's matrix instructions are issued
+    // (round 6: three sets with requests two steps ahead -- 48 more live registers -- measured 1.9 .. 3.9 % SLOWER same-box, profiles/r06_ab_variants.txt)
     v8h ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
     int2 d0 = tab[0], d1 = tab[4];
     fetch(0, d0, ah0, al0, bh0, bl0);
@@ -710,13 +713,13 @@ __device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *
 //  KWS_FAST_CMVN_EXT rows more, so it is m0 x (the column's plain sums, gathered from the row groups' own rows with
 //  ds_bpermute) + those few rows, instead of a walk over every row.
 //  Returns this lane's share of the guard's variance estimate (kws_fast.h): sum over its windows of
-//  ((g.abs + g.lev * level + g.rel * |mean|) / (deviation + eps))^2 -- the caller reduces it over the wave.
+//  ((abs_scale * (g.abs + g.lev * level) + g.rel * |mean|) / (deviation + eps))^2 -- the caller reduces it over the wave.
 //  DEFER: the guard's terms are kept in registers and summed in the store loop, under the predicate the stores need anyway -- a select
 //  of its own per window (compare, scalar and, conditional move: 17 x 2 per clip) costs 2.6 % of the whole kernel; the forms with the int8
 //  network behind them sit at 256 registers and would spill the CR extra values (+7 % there): they sum in place.
 template <int CR, int CG, bool DEFER>
 __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                           float inv_win, const float *__restrict__ guard_tab, float level, bool silent, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
+                                           float inv_win, const float *__restrict__ guard_tab, float level, float abs_scale, bool silent, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
                                            const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
@@ -742,15 +745,22 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
         const int c = cb + cl;
         const bool act = lane_on && c < ncep && r0 < nfr;
         float *col = img + min(c, ncep - 1);
-        // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name
-        const float piv = col[0];
+        // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name.
+        // The pivot is the median of three rows a third of the window apart (round 6): with the first row alone, a clip that STARTS with an
+        // outlier of the column -- a burst in otherwise silent audio -- had every d = x - pivot large, and var = Q/n - (S/n)^2 cancelled
+        // (pivot - mean)^2 / var digits away (profiles/r06_guard_fit.txt: a deviation off by 2e-6 relative, the largest logit errors of the family)
+        // A window shorter than the column (no ext_tab: every lane sums its own first window) takes a pivot of its own rows instead -- the row in
+        // the middle of the lane's group: a short window's mean follows the column's drift, and any clip-wide pivot leaves (pivot - mean)^2 / var
+        // of 1e3 .. 1e4 where the window itself is quiet (a random configuration with win_size 15: a deviation off by 5e-4 relative).
+        const float piv = ext_tab ? __builtin_amdgcn_fmed3f(col[0], col[min(16, nfr - 1) * fs], col[min(32, nfr - 1) * fs]) : col[min(r0 + CR / 2, nfr - 1) * fs];
         const float4 gcol = ((const float4 *)guard_tab)[cb + cl];   // (absolute, per level, per |window mean|, its alternative); padded to a multiple of CG columns
         // column 0 (the log frame energy, |mean| ~ 10): when its deviation is small against its level, its window means have been summed
         // in the reference's own order (c0_exact) and the window-mean part of its guard does not apply.  The other columns: a clip with
         // digitally silent frames has runs of identical values in every column, and the reference's sequential window sums then round
         // systematically instead of randomly: the alternative coefficient is the larger one measured on such clips.
         const bool is_c0 = c0_exact && cb + cl == 0;
-        const float g_abs = __fmaf_rn(gcol.y, level, gcol.x), g_rel = (cb + cl == 0 ? c0_exact : silent) ? gcol.w : gcol.z;
+        // (level arrives multiplied by abs_scale = sqrt(live rows / rows): the rows of digitally silent frames carry the reference's own values)
+        const float g_abs = __fmaf_rn(gcol.y, level, gcol.x * abs_scale), g_rel = (cb + cl == 0 ? c0_exact : silent) ? gcol.w : gcol.z;
         float mr[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) mr[i] = (c0_exact && cb == 0) ? mref[min(r0 + i, nfr - 1)] : 0.0f;
@@ -1158,6 +1168,8 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                 for (int qq = 0; qq < 8; ++qq) {
                     const int a = qq & 3, b = qq >> 2;
                     cf other;
+                    // (round 6: all sixteen requests of the loop issued before the first use -- sixteen more live registers -- measured 0.3 .. 1.3 % SLOWER
+                    // same-box, profiles/r06_ab_variants.txt)
                     other.r = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(u[3 - a][3 - b].r)));
                     other.i = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(u[3 - a][3 - b].i)));
                     cf fpk = u[a][b];
@@ -1413,18 +1425,37 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         // guard at the column's largest magnitude, the running-sum mean is good enough for every window (error kappa |mean| / deviation
         // below the feature tolerance) and the pass is skipped -- the usual case for audio whose loudness changes over the second.
         bool c0_exact = false, silent = false;
+        int n_silent = 0;                                               // frames whose rows were replaced by the reference's silent row (wave-uniform)
         const bool feats_given = FROM_CEP && feat_in != 0;              // wave-uniform
         if constexpr (!MFE) if (!feats_given) {
             const bool on = lane_m < nfr;
             const float x0 = img[min(lane_m, nfr - 1) * fs];
             // a frame without any energy: zero handling put FLT_EPSILON there, and its log (bit-identical in both tiers: the reference's own
             // polynomial) sits in column 0
-            silent = __any(on && x0 == fast_log(FLT_EPSILON));
+            const unsigned long long smask = __ballot(on && x0 == fast_log(FLT_EPSILON));      // bit r: frame r is silent (lane r looked at row r)
+            silent = smask != 0ull;
+            if constexpr (!FROM_CEP) {
+                // Those frames' DCT outputs are the reference's own (KwsFastPlan::sil_off): the transform of a constant row is a handful of
+                // rounding residues that the reference and the matrix cores do not share, and a column that is otherwise quiet would be decided
+                // by them.  A rare path (no clip of a noise-floored recording has such a frame): kept out of the way of the others.
+                if (silent && FP.sil_off >= 0) {
+                    const float *const srow = shared + FP.sil_off;
+                    const int half_nf = NF / 2;
+                    for (int i = lane_m; i < nfr * 32; i += KWS_WAVE) {
+                        const int r = i >> 5, c = i & 31;
+                        if (((smask >> r) & 1ull) && c >= 1 && c <= half_nf && c < ncep) img[r * fs + c] = srow[c];
+                    }
+                    n_silent = __popcll(smask);
+                    WAVE_SYNC();
+                }
+            }
             const float mu = wave_sum(on ? x0 : 0.0f) * FP.c0_inv_rows;
             const float d0 = on ? x0 - mu : 0.0f;
             const float sd0 = __builtin_amdgcn_sqrtf(wave_sum(d0 * d0) * FP.c0_inv_rows);
             const float top = wave_max(on ? fabsf(x0) : 0.0f);
-            c0_exact = !(FP.c0_factor * sd0 >= __fmaf_rn(FP.c0_rel, top, FP.c0_abs));
+            // ... and always for a clip with digitally silent frames: their runs of identical log energies make the reference's sequential
+            // window sums round the same way add after add (0.5e-6 .. 0.75e-6 |mean| measured), which no running sum reproduces
+            c0_exact = silent || !(FP.c0_factor * sd0 >= __fmaf_rn(FP.c0_rel, top, FP.c0_abs));
         }
         if (c0_exact) {
             // four copies of the padded column, copy s shifted by s rows: lane r's window pad[r ..] then starts at a 16-byte aligned slot
@@ -1478,9 +1509,17 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         if constexpr (!MFE) {                             // (MFE: nothing is divided by a deviation: the mel energies leave as they are)
           if (feats_given) gV = FP.v_net_feat;
           else {
-            const float level = FROM_CEP ? 0.0f : wave_sum(lvl_sum) * FP.lvl_inv;
-            if (cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
-            else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            // the level of the LIVE rows (a silent row's own level is |log FLT_EPSILON|, and it carries no spectral error), and the share of
+            // the rows that carry one: the absolute / per-level terms are an rms over a column's rows
+            float level = FROM_CEP ? 0.0f : wave_sum(lvl_sum) * FP.lvl_inv, abs_scale = 1.0f;
+            if (!FROM_CEP && n_silent > 0) {
+                const float live = (float)(nfr - n_silent), rows = (float)nfr;
+                level = live > 0.0f ? fmaxf(__fmaf_rn(level, rows, (float)n_silent * fast_log(FLT_EPSILON)), 0.0f) / live : 0.0f;     // (log FLT_EPSILON < 0)
+                abs_scale = __builtin_amdgcn_sqrtf(live / rows);
+                level *= abs_scale;
+            }
+            if (cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
           }
         }
@@ -1580,7 +1619,8 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
             }
             WAVE_SYNC();
-            if (PROF && b == 0) { ph[9] += t_loop - t_pre; ph[10] += clock64() - t_loop; ph[11] += t_pre - tlast; }
+            // (block 0's sub-phases: only the fp32-instruction form takes these clocks; the split-operand form's are tools/gpu_fast_subphase.py's)
+            if (PROF && b == 0 && t_loop != 0) { ph[9] += t_loop - t_pre; ph[10] += clock64() - t_loop; ph[11] += t_pre - tlast; }
             if (k.fpool) fast_pool_finish(k, stage, oth, shared, lane_n, o_stride, o_cp, cscale);
             else fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
             WAVE_SYNC();

@@ -229,6 +229,7 @@ struct kws_handle {
     std::vector<float> fast_guard_coef[2][4];
     int fast_dev_overrides = 0;                            // bit set: a KWS_DEV_FAST_* switch that changes results was read at kws_create
     int fast_entry_tier = 1;                               // 1: batch calls start in the fast kernel; 2: from exact cepstra; 3: exact kernels (build_guard)
+    std::vector<float> fast_sil_row;                       // the reference's cepstral row of a digitally silent frame (record_silent_row); empty: not recorded
     std::vector<float> fast_gain_used;                     // the per-column gain those coefficients were built with (float32 graph: gain.col)
     int mode = KWS_MODE_EXACT;
     int *d_flags = nullptr;       // [0] = count, [1 + i] = clip index: the clips the fast kernel handed back (first tier)

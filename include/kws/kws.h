@@ -88,7 +88,8 @@ int kws_fast_is_fused(const kws_handle *h);
  *     V = sigma_net^2 + sum over cmvnw windows (row r, column c) of ((abs[c] + lev[c] x level + rel[c] x |window mean|) / (deviation + eps))^2
  * -- an estimate of the variance of the error of a logit difference; abs / lev / rel = gain[c] x the rms error of a coefficient (absolute,
  * per unit of the clip's log-mel level = mean over its frames of |mean over the filters of the log-mel energies|, per unit of |mean|:
- * kws_fast_guard), level = 0 for tier 2.  The clip stays in its tier iff
+ * kws_fast_guard), level = 0 for tier 2.  Tier 1, clips with digitally silent frames (kws_fast_tolerance::silent_rows_exact): those frames' rows are
+ * the reference's own, so abs and lev are multiplied by sqrt(live frames / frames) and level is taken over the live frames.  The clip stays in its tier iff
  *     V x max(g_c1 x P^2, g_c2) <= 1,    g_c1 = (k_sigma x lin_margin / score_tol)^2,  g_c2 = (k_sigma / logit_cap)^2,
  * P = the largest p (1 - p) among the clip's own scores where the network runs in the same launch (|d score| <= p (1 - p) x the error of
  * a logit difference: a saturated softmax passes nothing on), 1/4 otherwise.  In words: k_sigma standard deviations of the estimated logit
@@ -124,6 +125,9 @@ typedef struct {
                                                           the model was created -- KWS_MODE_FAST results are then outside the documented tolerance */
     float k_sigma_worst_column;                        /* k_sigma / 1.3: what k_sigma is worth for a clip whose whole error sits in the column where a real clip's gain was
                                                           measured furthest above the calibrated one (see above); = k_sigma for int8 graphs (no gain is calibrated) */
+    int silent_rows_exact;                             /* 1 (round 6): the rows of digitally silent frames (frame energy exactly 0) carry the reference's own cepstral
+                                                          row in tier 1 -- recorded at kws_create from the exact kernels on an all-zero window --, so the rule's abs / lev
+                                                          terms are multiplied by sqrt(live frames / frames) and `level` is the mean over the LIVE frames only */
 } kws_fast_tolerance;
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
 EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);

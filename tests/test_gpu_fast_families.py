@@ -55,12 +55,17 @@ def _oracle_worker(args):
             _, taps = om.nn_invoke_f32(f[i], taps=True)
             z[i] = [t for t in taps if len(t) == om.n_labels][-2]            # the tensor SOFTMAX reads
     # the clip's log-mel level (what the fast kernel's rounding errors scale with): mean over the frames of |mean over the filters|
-    # ... and whether it has digitally silent frames (a frame energy of exactly 0, which zero handling turns into FLT_EPSILON)
-    lvl, sil = np.zeros(len(pcm), np.float32), np.zeros(len(pcm), bool)
+    # ... and which frames are digitally silent (a frame energy of exactly 0, which zero handling turns into FLT_EPSILON).  Round 6: tier 1
+    # writes the reference's own cepstral row into such frames, so the rule's level is the LIVE frames' and its absolute / per-level terms
+    # are scaled by sqrt(live frames / frames): lvl = [level over all frames, level over the live frames], sil = the number of silent frames
+    lvl, sil = np.zeros((len(pcm), 2), np.float32), np.zeros(len(pcm), np.int32)
     for i, p in enumerate(pcm):
         mel, en = o.mfe(p, om.cfg)
-        lvl[i] = np.abs(np.log(mel.astype(np.float64)).mean(axis=1)).mean()
-        sil[i] = (en == np.float32(1.1920929e-7)).any()
+        per_frame = np.abs(np.log(mel.astype(np.float64)).mean(axis=1))
+        dead = en == np.float32(1.1920929e-7)
+        lvl[i, 0] = per_frame.mean()
+        lvl[i, 1] = per_frame[~dead].mean() if (~dead).any() else 0.0
+        sil[i] = int(dead.sum())
     return s, f, q, sdw.astype(np.float32), mw.astype(np.float32), z, lvl, sil
 
 
@@ -120,16 +125,23 @@ def run_device(pkg, gm, mode, pcm_t):
 def guard_variance(gm, sdw, mw, lvl, sil, tier):
     """The guard's variance estimate V of that tier, re-evaluated from the oracle's windows (kws.h): (lo, hi) per clip -- column 0's
     window-mean term is dropped when the kernel replayed its means in the reference's order, a decision taken inside the kernel: lo assumes
-    it did, hi that it did not.  The other columns take the alternative coefficient for clips with digitally silent frames."""
+    it did, hi that it did not.  The other columns take the alternative coefficient for clips with digitally silent frames; in tier 1 those
+    frames' rows are the reference's own (kws_fast_tolerance::silent_rows_exact): the level is the live frames', the absolute and per-level
+    terms are scaled by sqrt(live frames / frames).  lvl [clips][2] = level over all / over the live frames, sil [clips] = silent frames."""
     coef = gm.fast_guard(tier).astype(np.float64)                     # [4][columns]: abs, per level, per |mean|, the alternative per |mean|
     tol = gm.fast_tolerance()
-    level = lvl.astype(np.float64)[:, None, None] if tier == 1 else 0.0
+    nfr = sdw.shape[1]
+    sil = np.asarray(sil)
+    exact_rows = bool(tol["silent_rows_exact"]) and tier == 1
+    live = (nfr - sil).astype(np.float64)
+    scale = np.sqrt(live / nfr)[:, None, None] if exact_rows else 1.0
+    level = (lvl[:, 1] if exact_rows else lvl[:, 0]).astype(np.float64)[:, None, None] if tier == 1 else 0.0
     rd = 1.0 / (sdw.astype(np.float64) + 1.1920929e-7)
-    base = coef[0][None, None, :] + coef[1][None, None, :] * level
-    rel = np.where(sil[:, None], coef[3][None, :], coef[2][None, :])    # [clips][columns]
+    base = (coef[0][None, None, :] + coef[1][None, None, :] * level) * scale
+    rel = np.where((sil > 0)[:, None], coef[3][None, :], coef[2][None, :])    # [clips][columns]
     v = []
     for rel0 in (coef[3][0], coef[2][0]):
-        rel[:, 0] = rel0
+        rel[:, 0] = np.where(sil > 0, coef[3][0], rel0)           # round 6: a clip with silent frames always has column 0's means replayed
         b = (base + rel[:, None, :] * np.abs(mw)) * rd
         v.append((b * b).reshape(len(sdw), -1).sum(axis=1) + tol["sigma_net"] ** 2)
     return v[0], v[1]

@@ -24,6 +24,8 @@ tot = p[:9].sum()
 nclips = max(1, B // (256 * int(os.environ.get("KWS_DEV_FAST_WAVES", "8"))))
 print(os.path.basename(path), "rc", rc, "clips by wave 0 ~", nclips, "total cycles", tot, "per clip", tot / nclips)
 for n, v in zip(names, p):
+    if n.startswith("(") and (v <= 0 or v > tot):      # block 0's sub-phase slots: only the fp32-instruction form of the convolution writes them
+        continue
     print("%-20s %12d  %5.1f%%  %8.0f cycles/clip" % (n, v, 100.0 * v / tot, v / nclips))
 for b in range(1, 8):
     if pa[12 + b]:

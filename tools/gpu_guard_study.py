@@ -95,8 +95,8 @@ def main():
                 fam, on_t2, on_ex, over, ("%.3f" % (over / on_t2)) if on_t2 else "-", np.nanmax(ds), np.nanmax(dzp), np.nanmax(r), np.nanquantile(r, 0.99),
                 np.nanmax(ds_on), int(np.isnan(s1).sum())))
             key = "%s/%s/" % (name, fam)
-            for k, v in dict(ds=ds, ds_on=ds_on, dzp=dzp, pq=pq, ecep=ecep, efeat=efeat, v_lo=v_lo, v_hi=v_hi, lvl=lvl, sil=sil,
-                             sd_mean=sdw.mean(axis=1), sd_min=sdw.min(axis=1), m_abs=np.abs(mw).mean(axis=1), on=np.int64([on_t2, on_ex])).items():
+            for k, v in dict(ds=ds, ds_on=ds_on, dzp=dzp, pq=pq, ecep=ecep, efeat=efeat, v_lo=v_lo, v_hi=v_hi, lvl=lvl[:, 0], sil=sil,
+                             lvl_live=lvl[:, 1], sd_mean=sdw.mean(axis=1), sd_min=sdw.min(axis=1), m_abs=np.abs(mw).mean(axis=1), on=np.int64([on_t2, on_ex])).items():
                 arrays[key + k] = np.asarray(v, np.float32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)
             sys.stdout.flush()
         gm.close()
