@@ -401,7 +401,7 @@ EI_IMPULSE_ERROR cmvn_nn_device(kws_handle *h, const float *mfcc, size_t B, floa
 {
     // ring_rows != 0: mfcc holds ring-indexed rolling buffers (continuous mode, kws_streams_*)
     KwsDspPlan PR = h->dsp;
-    PR.ring_rows = ring_rows; PR.ring_head = ring_head;
+    PR.ring_rows = ring_rows; PR.ring_head = ring_rows > 0 ? ((ring_head % ring_rows) + ring_rows) % ring_rows : 0;      // (the fast kernel's ring() wraps with one subtraction: head < rows)
     if (B > 0x7fffffff) return fail(KWS_ERROR_BAD_ARGUMENT, "batch too large");
     int ran_nn = 0;
     if (h->model.dsp.block == DSP_BLOCK_MFE) {
@@ -476,7 +476,7 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
     HIP_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(int), s));
     HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));      // kws_fast_exact_count describes the LAST fast call: this path has one fast tier
     KwsDspPlan PR = h->dsp;
-    PR.ring_rows = ring_rows; PR.ring_head = ring_head;
+    PR.ring_rows = ring_rows; PR.ring_head = ring_rows > 0 ? ((ring_head % ring_rows) + ring_rows) % ring_rows : 0;      // (the fast kernel's ring() wraps with one subtraction: head < rows)
     const bool fused = scores && h->is_float && h->fast_fused_ok;       // scores == NULL: features / int8 tensor only (extract_mfcc_features)
     float *fx = features ? features : h->s_mfcc;
     int8_t *q = h->is_float ? nullptr : (q_out ? q_out : h->s_q);

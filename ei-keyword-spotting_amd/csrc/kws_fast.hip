@@ -719,7 +719,7 @@ __device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *
 //  network behind them sit at 256 registers and would spill the CR extra values (+7 % there): they sum in place.
 template <int CR, int CG, bool DEFER>
 __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                           float inv_win, const float *__restrict__ guard_tab, float level, float abs_scale, bool silent, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
+                                           float inv_win, const float *__restrict__ guard_tab, float level, float abs_scale, bool silent, int piv_row, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
                                            const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
@@ -746,13 +746,14 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
         const bool act = lane_on && c < ncep && r0 < nfr;
         float *col = img + min(c, ncep - 1);
         // every read of the column block goes out in one batch: the pivot, the lane's own rows, the rows the updates name.
-        // The pivot is the median of three rows a third of the window apart (round 6): with the first row alone, a clip that STARTS with an
-        // outlier of the column -- a burst in otherwise silent audio -- had every d = x - pivot large, and var = Q/n - (S/n)^2 cancelled
-        // (pivot - mean)^2 / var digits away (profiles/r06_guard_fit.txt: a deviation off by 2e-6 relative, the largest logit errors of the family)
-        // A window shorter than the column (no ext_tab: every lane sums its own first window) takes a pivot of its own rows instead -- the row in
-        // the middle of the lane's group: a short window's mean follows the column's drift, and any clip-wide pivot leaves (pivot - mean)^2 / var
-        // of 1e3 .. 1e4 where the window itself is quiet (a random configuration with win_size 15: a deviation off by 5e-4 relative).
-        const float piv = ext_tab ? __builtin_amdgcn_fmed3f(col[0], col[min(16, nfr - 1) * fs], col[min(32, nfr - 1) * fs]) : col[min(r0 + CR / 2, nfr - 1) * fs];
+        // The pivot (round 6): row piv_row of the column -- the clip's first digitally silent frame when it has one, else its first row.  With the
+        // first row always, a clip that STARTS with a burst in otherwise silent audio had every d = x - pivot large, and var = Q/n - (S/n)^2
+        // cancelled (pivot - mean)^2 / var digits away: a deviation off by 2e-6 relative, the largest logit errors of that family
+        // (profiles/r06_guard_fit.txt).  A window shorter than the column (no ext_tab: every lane sums its own first window) takes the row in the
+        // middle of the lane's group instead: a short window's mean follows the column's drift, and any clip-wide pivot leaves (pivot - mean)^2 /
+        // var of 1e3 .. 1e4 where the window itself is quiet (a random configuration with win_size 15: a deviation off by 5e-4 relative).
+        // (The median of three rows a third of the column apart does the same for any clip, for 1 % of the kernel's time: profiles/r06_ab_variants.txt.)
+        const float piv = col[(ext_tab ? piv_row : min(r0 + CR / 2, nfr - 1)) * fs];
         const float4 gcol = ((const float4 *)guard_tab)[cb + cl];   // (absolute, per level, per |window mean|, its alternative); padded to a multiple of CG columns
         // column 0 (the log frame energy, |mean| ~ 10): when its deviation is small against its level, its window means have been summed
         // in the reference's own order (c0_exact) and the window-mean part of its guard does not apply.  The other columns: a clip with
@@ -1426,6 +1427,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         // below the feature tolerance) and the pass is skipped -- the usual case for audio whose loudness changes over the second.
         bool c0_exact = false, silent = false;
         int n_silent = 0;                                               // frames whose rows were replaced by the reference's silent row (wave-uniform)
+        int piv_row = 0;                                                // cmvnw's pivot row (fast_cmvn)
         const bool feats_given = FROM_CEP && feat_in != 0;              // wave-uniform
         if constexpr (!MFE) if (!feats_given) {
             const bool on = lane_m < nfr;
@@ -1434,16 +1436,19 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             // polynomial) sits in column 0
             const unsigned long long smask = __ballot(on && x0 == fast_log(FLT_EPSILON));      // bit r: frame r is silent (lane r looked at row r)
             silent = smask != 0ull;
+            piv_row = silent ? __builtin_ctzll(smask) : 0;
             if constexpr (!FROM_CEP) {
                 // Those frames' DCT outputs are the reference's own (KwsFastPlan::sil_off): the transform of a constant row is a handful of
                 // rounding residues that the reference and the matrix cores do not share, and a column that is otherwise quiet would be decided
                 // by them.  A rare path (no clip of a noise-floored recording has such a frame): kept out of the way of the others.
                 if (silent && FP.sil_off >= 0) {
-                    const float *const srow = shared + FP.sil_off;
-                    const int half_nf = NF / 2;
-                    for (int i = lane_m; i < nfr * 32; i += KWS_WAVE) {
-                        const int r = i >> 5, c = i & 31;
-                        if (((smask >> r) & 1ull) && c >= 1 && c <= half_nf && c < ncep) img[r * fs + c] = srow[c];
+                    // (a scalar walk over the silent frames, one store of NF/2 lanes per frame: one vector register)
+                    const int half_nf = min(NF / 2, ncep - 1);
+                    const float sv = shared[FP.sil_off + min(lane_m + 1, 31)];
+                    float *const dst = img + 1 + lane_m;
+                    for (unsigned long long mm = smask; mm != 0ull; mm &= mm - 1ull) {
+                        const int r = __builtin_ctzll(mm);
+                        if (lane_m < half_nf) dst[r * fs] = sv;
                     }
                     n_silent = __popcll(smask);
                     WAVE_SYNC();
@@ -1518,8 +1523,8 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                 abs_scale = __builtin_amdgcn_sqrtf(live / rows);
                 level *= abs_scale;
             }
-            if (cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
-            else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            if (cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
           }
         }

@@ -529,7 +529,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         k.st_off = 0;
         k.hconv = 0; k.h_ks = 0; k.h_tab_off = 0; k.h_b_off = -1; k.h_b_global = nullptr; k.h_inv_wscale = 1.0f;
         // split operands: the image is converted in place by one pass of at most KWS_FAST_HP channel pairs per lane
-        if (hconv_on && !k.dw && s.in_w * (k.in_cp / 2) <= 16 * KWS_FAST_WAVE && k.in_cp <= 64 && (s.out_w + 15) / 16 <= 4 && k.n_tiles <= 2) {
+        if (hconv_on && kws_fast_block_splits(s)) {
             k.hconv = 1;
             k.m_tiles = (s.out_w + 15) / 16; k.vrows = 0;
             const int ncg = k.in_cp / 8, G = k.taps * ncg, NT = k.n_tiles;

@@ -150,8 +150,11 @@ void forward_f32(const KwsNnPlanF32 &N, const kws_handle::HostF32 &W, const std:
         const KwsConvBlockF32 &k = N.blk[b];
         const std::vector<float> *wp = &W.w[b];
         float unscale = 1.0f;
-        if (blocked && !k.depthwise) {
-            // the fused kernel's contraction: both operands as 22-bit numbers (the dropped lo x lo term is below the accumulator's own rounding)
+        if (blocked && kws_fast_block_splits(k)) {
+            // the fused kernel's contraction of exactly the blocks it runs that way (one predicate with the plan builder): both operands as 22-bit
+            // numbers (the dropped lo x lo term is below the accumulator's own rounding).  The partial sums below are four products deep where the
+            // matrix instruction is thirty-two in three passes: sigma_net is an estimate of the ORDER of the network's own noise (it enters V next to
+            // terms ten times its size), not a model of the instruction
             float s1, s2;
             split22(cur, cs, &s1);
             split22(W.w[b], ws, &s2);

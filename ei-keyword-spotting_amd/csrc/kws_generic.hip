@@ -261,11 +261,7 @@ constexpr int KWS_LCH_DEFAULT = 8;
 // development aid: shader-clock totals per phase of workgroup 0 (kws_dev_generic_prof; tools/gpu_generic_rate.py --prof)
 __device__ long long g_gen_prof[8];
 #ifdef KWS_DEV_SWITCHES
-#ifdef KWS_DEV_SWITCHES
 #define GPH(i) do { const long long now_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_gen_prof[i] += now_ - tlast_; tlast_ = now_; } while (0)
-#else
-#define GPH(i) do { } while (0)          // (a clock read drains the wave's outstanding LDS and scalar requests: development build only)
-#endif
 #else
 #define GPH(i) do { } while (0)          // (a clock read drains the wave's outstanding LDS and scalar requests: development build only)
 #endif

@@ -275,6 +275,14 @@ EI_IMPULSE_ERROR build_fast_plans(kws_handle *h);     // kws_fast_plan.cpp; neve
 #define KWS_GAIN_INPUTS 48
 #define KWS_GAIN_HEADROOM 1.25f        // the calibrated per-column gain is the largest value over the calibration matrices x this (kws_gain.cpp)
 void kws_calibrate_gain(kws_handle *h);               // kws_gain.cpp
+// Does the fused fast kernel run this block's contraction on split 22-bit operands (KwsFastBlock::hconv)?  ONE predicate for the plan builder
+// (kws_fast_plan.cpp) and for the arithmetic kws_gain.cpp models when it measures sigma_net: CONV_2D blocks whose image the
+// in-place split converts in one pass of at most 16 channel pairs per lane and whose outputs fit 4 x 2 tiles.
+static inline bool kws_fast_block_splits(const KwsConvBlockF32 &s)
+{
+    const int in_cp = (s.in_c + 7) / 8 * 8;
+    return !s.depthwise && s.in_w * (in_cp / 2) <= 16 * KWS_FAST_WAVE && in_cp <= 64 && (s.out_w + 15) / 16 <= 4 && (s.out_c + 15) / 16 <= 2;
+}
 
 // kws_api.cpp: stage launchers shared with the stream / SDK entry points (kws_sdk.cpp); internal, not exported
 #define KWS_INTERNAL __attribute__((visibility("hidden")))

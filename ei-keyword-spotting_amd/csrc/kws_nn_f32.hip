@@ -514,8 +514,14 @@ void kws_nn_f32_pick_blocking(KwsConvBlockF32 *k)
     k->rows = nnf_rows_of(*k);
     // the kernel's item splits: items = time blocks x channel blocks (conv) or x out_c (depthwise, the pooling pass: out_w x out_c at most)
     const long n_ob = k->depthwise ? k->out_c : (k->out_c + k->ob - 1) / k->ob;
-    k->inv_item20 = ((long)k->ntb * n_ob + 64) * n_ob < (1L << 20) ? (1u << 20) / (unsigned)n_ob + 1u : 0u;
-    k->inv_outc20 = ((long)std::max(k->ntb * std::max(k->tb, 1), k->out_w) * k->out_c + 64) * k->out_c < (1L << 20) ? (1u << 20) / (unsigned)k->out_c + 1u : 0u;
+    // a reciprocal is used only where x * d < 2^20 (the quotient is then exact) AND x * inv fits nnf_div's 32-bit product (x / d below ~4096:
+    // a single channel block with thousands of time blocks would pass the first test and overflow the second -- ADVICE round 5)
+    auto recip20 = [](long x_max, long d) -> unsigned {
+        const unsigned long inv = (1ul << 20) / (unsigned long)d + 1ul;
+        return (x_max * d < (1L << 20) && (unsigned long)x_max * inv < (1ul << 32)) ? (unsigned)inv : 0u;
+    };
+    k->inv_item20 = recip20((long)k->ntb * n_ob + 64, n_ob);
+    k->inv_outc20 = recip20((long)std::max(k->ntb * std::max(k->tb, 1), k->out_w) * k->out_c + 64, k->out_c);
 }
 
 long long *kws_dev_f32_prof = nullptr;      // development aid: device buffer of KWS_MAX_BLOCKS + 2 phase counters, or NULL
