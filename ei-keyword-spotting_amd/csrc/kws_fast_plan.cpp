@@ -88,9 +88,10 @@ static const float kGuardK = 4.5f, kGuardLin = 1.1f, kGuardScoreTol = 1.0e-4f, k
 //     + 0.25e-6 |mean| covers its 99th percentile (was 4.0e-8 x level + 0.35e-6 |mean|: 3 x the measured total);
 //   * window means of lively columns: 0.4e-6 |mean| (fits per family 0.16e-6 .. 0.30e-6; was 0.5e-6); column 0: 0.2e-6 (measured total
 //     1.4e-7 .. 2.7e-7 |mean| median, 3.3e-7 .. 4.6e-7 at the 99th percentile with a0 = 1.0e-7 on top);
-//   * digitally silent frames carry the reference's own row (KwsFastPlan::sil_off): no spectral error in those rows.
+//   * digitally silent frames carry the reference's own row (KwsFastPlan::sil_off): no spectral error in those rows; column 0 of a clip with such frames,
+//     means not replayed: 0.75e-6 |mean| (0.45e-6 .. 0.75e-6 measured: runs of identical log energies round systematically in the reference's sums).
 // k = 4.5 and the gain's headroom are unchanged.
-static const float kAbs0 = 6.0e-7f, kAlpha0 = 1.0e-7f, kAlphaDct = 1.7e-7f, kAlphaStale = 3.0e-8f, kKappa = 0.4e-6f, kKappa0 = 0.2e-6f, kKappaStale = 0.25e-6f, kKappaSilent = 0.9e-6f, kFloorCep = 3.0e-7f, kRhoDev = 3.0e-7f,
+static const float kAbs0 = 6.0e-7f, kAlpha0 = 1.0e-7f, kAlphaDct = 1.7e-7f, kAlphaStale = 3.0e-8f, kKappa = 0.4e-6f, kKappa0 = 0.2e-6f, kKappaStale = 0.25e-6f, kKappaSilent = 0.9e-6f, kKappaSilent0 = 0.75e-6f, kFloorCep = 3.0e-7f, kRhoDev = 3.0e-7f,
                    kC0Share = 0.05f;
 // per-column rms of |DCT output error| / level x 1.3, columns 1 .. NF/2 (index 0 unused); profiles/r06_guard_fit.txt
 static const float kAlphaDct40[21] = { 0.f, 6.4e-7f, 2.5e-7f, 1.8e-7f, 1.4e-7f, 1.5e-7f, 1.1e-7f, 0.94e-7f, 0.87e-7f, 0.90e-7f, 1.73e-7f, 0.90e-7f, 0.80e-7f, 0.77e-7f, 0.78e-7f,
@@ -232,6 +233,7 @@ static void build_guard(kws_handle *h, KwsFastPlan &F, std::vector<float> &share
         F.c0_rel = scale * std::min(kappa, kKappa0) * per_dev;
         F.c0_inv_rows = 1.0f / (float)nfr;
     }
+    F.c0_sil_fac = (a0 + std::max(kKappaSilent0, std::min(kappa, kKappa0))) / (a0 + std::min(kappa, kKappa0));
     F.pad_off = (int)shared.size();
     for (int v : pmap) { float f; memcpy(&f, &v, sizeof f); shared.push_back(f); }
     // the reference's row of a digitally silent frame (record_silent_row): DCT outputs 1 .. NF/2

@@ -141,7 +141,8 @@ def guard_variance(gm, sdw, mw, lvl, sil, tier):
     rel = np.where((sil > 0)[:, None], coef[3][None, :], coef[2][None, :])    # [clips][columns]
     v = []
     for rel0 in (coef[3][0], coef[2][0]):
-        rel[:, 0] = np.where(sil > 0, coef[3][0], rel0)           # round 6: a clip with silent frames always has column 0's means replayed
+        # (column 0 of a clip with silent frames, means not replayed: the larger coefficient kws_fast_tolerance::c0_silent_factor states)
+        rel[:, 0] = np.where((sil > 0) & (rel0 == coef[2][0]), coef[2][0] * tol["c0_silent_factor"], rel0)
         b = (base + rel[:, None, :] * np.abs(mw)) * rd
         v.append((b * b).reshape(len(sdw), -1).sum(axis=1) + tol["sigma_net"] ** 2)
     return v[0], v[1]

@@ -1,4 +1,6 @@
-"""Development aid: per-phase shader-clock breakdown of kws_fast_kernel (wave 0 of workgroup 0, full-occupancy launch)."""
+"""Development aid: per-phase shader-clock breakdown of kws_fast_kernel (wave 0 of workgroup 0, full-occupancy launch).
+
+    python tools/gpu_fast_phase_profile.py [model.kwsm] [clips = 65536] [input family of tests/kws_families.py; default: the bench's synthetic clips]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +12,13 @@ m = pkg.Model(path)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 pcm = torch.empty((B, 16000), dtype=torch.int16, device="cuda")
 pkg.synth_clips_device(0, 0, B, 16000, pcm.data_ptr())
+if len(sys.argv) > 3:
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kws_families
+    base = torch.from_numpy(np.ascontiguousarray(kws_families.family(sys.argv[3], 2048, seed=5))).to("cuda")
+    pcm = base.repeat((B + 2047) // 2048, 1)[:B].contiguous()
+    print("input family:", sys.argv[3])
 s = torch.empty((B, m.n_labels), dtype=torch.float32, device="cuda")
 prof = torch.zeros(24, dtype=torch.int64, device="cuda")
 L = pkg.lib()
