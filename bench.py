@@ -180,6 +180,7 @@ DSP_B = 8192
 DSP_SHAPES = (("fft 512, 49 frames of 20 ms, 32 filters, 13 cepstra", dict(fft_length=512)),
               ("fft 512, 2 s windows (99 frames)", dict(fft_length=512, raw_samples=32000, blocks=((8, 3, 1), (4, 3, 1)))),
               ("fft 128, 49 frames, cmvnw window 51", dict(fft_length=128, win_size=51)),
+              ("fft 256, frames every 10 ms (98 frames: the tuned spectral kernel over two chunks + the general cmvnw)", dict(frame_stride=0.01, win_size=31, blocks=((8, 3, 1), (4, 3, 1)))),
               ("fft 1024, 50 ms frames, 36 filters, 17 cepstra", dict(fft_length=1024, num_filters=36, ncep=17, frame_length=0.05, frame_stride=0.025, win_size=21,
                                                                    blocks=((8, 3, 1), (4, 3, 1)))))
 

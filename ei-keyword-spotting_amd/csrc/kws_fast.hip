@@ -1525,7 +1525,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                 abs_scale = __builtin_amdgcn_sqrtf(live / rows);
                 level *= abs_scale;
             }
-            if (cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, FP.c0_sil_fac, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            if (KWS_FAST_WPS >= 3 || cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, FP.c0_sil_fac, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, FP.c0_sil_fac, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
           }
@@ -1671,6 +1671,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         for (int i = 0; i < KWS_FAST_NPHASE; ++i) prof_out[i] = ph[i];
 }
 
+#ifndef KWS_FAST_NO_LAUNCHERS      // (tools/fast_one_form.sh: a scratch translation unit that instantiates ONE form of the kernel, for register / spill experiments)
 // ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
@@ -1774,3 +1775,4 @@ int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
         return launch_fast_t<4, 4, true>(P, FP, d_plan, pcm, n_clips, scores, nullptr, nullptr, 1.0f, 0, flag_count, flag_list, n_cu, prof_out, stream);
     return (int)hipErrorInvalidValue;
 }
+#endif      // KWS_FAST_NO_LAUNCHERS

@@ -643,7 +643,8 @@ __global__ __launch_bounds__(KWS_WAVE, OCC) void kws_mfcc8_kernel(KwsDspPlan P, 
         const int half = lane_c >> 5, t = lane_c & 31;
         const int16_t *xbase = pcm + (size_t)clip * n_samples;
         // x[-1] of the window's first sample: its last sample (processing.hpp:68, 104-106) unless the caller says otherwise (continuous mode)
-        const float wrap_prev = wrap ? wrap[clip] : (float)xbase[n_samples - 1] * (1.0f / 32768.0f);
+        // (a chunk of a longer window that starts inside it -- KwsDspPlan::wrap_index < 0 --: the sample before the chunk)
+        const float wrap_prev = P.wrap_index < 0 ? (float)xbase[P.wrap_index] * (1.0f / 32768.0f) : wrap ? wrap[clip] : (float)xbase[n_samples - 1] * (1.0f / 32768.0f);
         // a point's four samples x[2n - 2 .. 2n + 1] of frame f, requested one pass ahead
         auto fetch = [&](int q, fast_i2 (&raw)[2][8]) {
             const int f = min(KWS_M8_CHUNK * q + fg, nfr - 1);

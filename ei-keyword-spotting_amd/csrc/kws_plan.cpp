@@ -85,6 +85,9 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
                        c.win_size <= kws_mfcc_max_win(ncep) && nfr <= kws_mfcc_max_frames_for(N, ncep) &&
                        c.win_size >= ((N == 40 && ncep > 16) ? 17 : 13) && nfr <= 4 * kws_mfcc_cmvn_rows();
     P.generic = tuned ? 0 : 1;
+    P.spectral_tuned = (!tuned && !mfe && c.fft_length == 256 && (N == 32 || N == 40) && frame_len >= c.fft_length && (stride * 2) % 16 == 0 &&
+                        (P.n_samples * 2) % 16 == 0) ? 1 : 0;
+    P.wrap_index = P.n_samples - 1;
     if (mfe && (!tuned || nfr > (N > 16 ? 51 : 52) || c.win_size < (N > 16 ? 17 : 13)))
         return fail(KWS_ERROR_UNSUPPORTED_MODEL, "MFE block: %d frames x %d filters, window %d outside the normalisation kernel's limits (tuned "
                     "configurations only)", nfr, N, c.win_size);
@@ -124,7 +127,7 @@ EI_IMPULSE_ERROR build_dsp_plan(kws_handle *h)
     fstart[N] = (int)fbin.size();
     P.max_nz = max_nz;
     P.filt_nnz = (int)fbin.size();
-    if (max_nz > kws_mfcc_max_nz()) P.generic = 1;            // the tuned kernel keeps a filter's taps in registers
+    if (max_nz > kws_mfcc_max_nz()) { P.generic = 1; P.spectral_tuned = 0; }      // the tuned kernel keeps a filter's taps in registers
     std::vector<int> pmap;
     h_pad_map(nfr, P.pad, pmap);
 

@@ -46,6 +46,13 @@ struct KwsDspPlan {
     // configurations outside the tuned kernel's instantiations run on the general kernels (kws_generic.hip): kf_factor's factor
     // lists (kiss_fft.cpp:303-324: p, m pairs) of the frame transform (fft_len / 2 points) and of the DCT's (n_filters / 2 points)
     int generic;
+    // generic = 1, but the SPECTRAL stage alone fits the tuned kernel's instantiations (fft 256, 32 / 40 filters, aligned frames, short mel filters) -- what
+    // makes the plan general is its frame count or its cmvnw window: int16 windows then take kws_mfcc8_kernel over chunks of at most kws_mfcc_max_frames
+    // frames (frames are independent but for pre-emphasis' predecessor sample, below) and only cmvnw runs on the general kernel (round 6; kws_api.cpp)
+    int spectral_tuned;
+    // kws_mfcc8_kernel, the window's first sample: its predecessor is x[wrap_index] of the window -- n_samples - 1, the reference's wrap
+    // (processing.hpp:68, 104-106) -- unless the launch names another (a chunk that starts inside the window: -1, the sample before it)
+    int wrap_index;
     int fft_levels, dct_levels;
     int fft_fac[24], dct_fac[24];
     // per launch, continuous mode: the rolling feature buffer of a stream is a ring over its first ring_rows rows (the rows behind

@@ -12,10 +12,15 @@ from kws_testlib import L476_CONFIG, ROOT, OracleModel, bits, special_clips, syn
 pytestmark = pytest.mark.gpu
 
 BLOCKS = dict(blocks=((8, 3, 7), (4, 3, 7)), n_labels=3)
+# what kws_mfcc_kernel_name says for a plan the tuned kernels do not serve as a whole.  Round 6: where only the frame count or the cmvnw window
+# makes the plan general (fft 256, 32 / 40 filters), int16 batches take the tuned spectral kernel over chunks of frames and the general cmvnw
+GENERAL_KERNELS = ("kws_spectral_lds_kernel", "kws_spectral_generic_kernel", "kws_mfcc8_kernel (chunked)")
 CASES = {
     "fft512": dict(fft_length=512),                                  # zero-padded frames
     "fft128_win51": dict(fft_length=128, win_size=51),               # truncated frames
-    "stride10ms_win31": dict(frame_stride=0.01, win_size=31),        # overlapping frames: 98 of them
+    "stride10ms_win31": dict(frame_stride=0.01, win_size=31),        # overlapping frames: 98 of them (two chunks of 49 on the tuned spectral kernel)
+    "fft256_2s_40filters": dict(raw_samples=32000, num_filters=40, ncep=20, blocks=((8, 3, 1), (4, 3, 1))),   # 99 frames: three chunks of 33
+    "fft256_win201": dict(win_size=201),                             # 49 frames, a cmvnw window the tuned kernel does not hold: one chunk
     "pre_cof0": dict(pre_cof=0.0),
     "clip4000": dict(raw_samples=4000, blocks=((8, 3, 1), (4, 3, 1))),
     "clip640_one_frame": dict(raw_samples=640, blocks=((8, 3, 1), (4, 3, 1))),      # 1 frame (no pooling: SAME pooling of 1-2 rows
@@ -49,7 +54,7 @@ def test_general_mfcc_kernels_bit_exact(name, pkg, oracle, tmp_path):
     gm = pkg.Model(blob=blob)
     n = om.raw_sample_count
     sp = special_clips()
-    clips = np.concatenate([oracle.synth(5, 0, 70, n), np.stack([sp["impulses"][:n], sp["zeros"][:n], sp["alternating_fullscale"][:n]])])
+    clips = np.concatenate([oracle.synth(5, 0, 70, n), np.stack([np.resize(sp[k], n) for k in ("impulses", "zeros", "alternating_fullscale")])])
     s, f, q = gm.run_classifier_batch(clips, want_features=True)
     so, fo, qo = om.run_batch(clips, want_features=True)
     assert (bits(f) == bits(fo)).all(), name
@@ -67,7 +72,7 @@ def test_general_mfcc_kernels_bit_exact(name, pkg, oracle, tmp_path):
     gm.cmvn_inference_batch_device(mf.data_ptr(), len(clips), s2.data_ptr())
     torch.cuda.synchronize()
     assert (bits(s2.cpu().numpy()) == bits(so)).all(), name
-    if gm.mfcc_kernel in ("kws_spectral_lds_kernel", "kws_spectral_generic_kernel"):
+    if gm.mfcc_kernel in GENERAL_KERNELS:
         with pytest.raises(pkg.KwsError):
             gm.set_mode(pkg.MODE_FAST)                  # the fast kernel is built for the tuned configurations only
     else:
@@ -122,7 +127,7 @@ def test_general_kernels_host_batch_over_two_streams(pkg, oracle, tmp_path):
     path = str(tmp_path / "m.kwsm")
     open(path, "wb").write(blob)
     gm = pkg.Model(blob=blob)
-    assert gm.mfcc_kernel in ("kws_spectral_lds_kernel", "kws_spectral_generic_kernel")
+    assert gm.mfcc_kernel in GENERAL_KERNELS
     om = OracleModel(oracle, path)
     n = 2 * 8192 + 700
     clips = oracle.synth(21, 0, n)
@@ -179,6 +184,7 @@ def test_chunk_length_is_measured_per_handle_and_never_changes_a_bit(name, dev_p
     """kws_spectral_lds_kernel runs with eight or four frames per chunk (csrc/kws_generic.hip); which is faster depends on the shape, so a handle
     measures it on its own first large calls (kws_api.cpp generic_chunk_begin).  Both pinned values and the measured path give the oracle's bits."""
     pkg = dev_pkg            # KWS_DEV_GENERIC_LCH is a development switch: the development build of the library (conftest.py)
+    monkeypatch.setenv("KWS_DEV_GENERIC_NO_TUNED_SPECTRAL", "1")     # (this test is about the cooperative kernel: a shape whose spectral stage the tuned kernel could take stays on it)
     import ctypes
     import torch
     kw = dict(BLOCKS, **CASES[name])
@@ -231,3 +237,45 @@ def test_chunk_length_is_measured_per_handle_and_never_changes_a_bit(name, dev_p
     assert (bits(f) == bits(fo)).all() and L.kws_dev_generic_chunk(gm2.h) == 0
     gm.close()
     gm2.close()
+
+
+
+@pytest.mark.parametrize("name", ["stride10ms_win31", "fft256_2s_40filters", "fft256_win201"])
+def test_tuned_spectral_chunks_equal_the_general_kernel(name, dev_pkg, oracle, tmp_path, monkeypatch):
+    """Round 6: a general plan whose spectral stage fits the tuned kernel runs kws_mfcc8_kernel over chunks of at most 49
+    frames (kws_api.cpp: launch_spectral_tuned_chunks; the predecessor of a later chunk's first sample is the sample before it, not the window's last).
+    Cepstra and features must be the cooperative kernel's bits (development switch KWS_DEV_GENERIC_NO_TUNED_SPECTRAL) and the oracle's, on clips whose
+    chunk boundaries matter (full-scale alternation, impulses) as well."""
+    import torch
+    pkg = dev_pkg
+    kw = dict(BLOCKS, **CASES[name])
+    blob = synth_model_blob(seed=3, **kw)
+    path = str(tmp_path / "m.kwsm")
+    open(path, "wb").write(blob)
+    om = OracleModel(oracle, path)
+    n = om.raw_sample_count
+    sp = special_clips()
+    clips = np.concatenate([oracle.synth(8, 0, 125, n), np.stack([np.resize(sp[k], n) for k in ("impulses", "zeros", "alternating_fullscale")])])
+    d = torch.from_numpy(np.ascontiguousarray(clips)).to("cuda:0")
+
+    def stage(gm):
+        mf = torch.zeros((len(clips), gm.n_features), dtype=torch.float32, device="cuda:0")
+        ft = torch.zeros((len(clips), gm.n_features), dtype=torch.float32, device="cuda:0")
+        gm.mfcc_batch_device(d.data_ptr(), len(clips), mf.data_ptr())
+        gm.extract_mfcc_batch_device(d.data_ptr(), len(clips), ft.data_ptr())
+        torch.cuda.synchronize()
+        return mf.cpu().numpy(), ft.cpu().numpy()
+    gm = pkg.Model(blob=blob)
+    assert gm.mfcc_kernel == "kws_mfcc8_kernel (chunked)"
+    mf1, ft1 = stage(gm)
+    gm.close()
+    monkeypatch.setenv("KWS_DEV_GENERIC_NO_TUNED_SPECTRAL", "1")
+    gm = pkg.Model(blob=blob)
+    assert gm.mfcc_kernel in ("kws_spectral_lds_kernel", "kws_spectral_generic_kernel")
+    mf0, ft0 = stage(gm)
+    gm.close()
+    assert (bits(mf1) == bits(mf0)).all() and (bits(ft1) == bits(ft0)).all(), name
+    want = np.stack([oracle.mfcc_nocmvn(c, om.cfg).reshape(-1) for c in clips[-8:]])
+    assert (bits(mf1[-8:]) == bits(want)).all(), name
+    _, fo, _ = om.run_batch(clips, want_features=True)
+    assert (bits(ft1) == bits(fo)).all(), name
