@@ -60,7 +60,7 @@ WORKLOADS_SHORT = {
 }
 CLIP_LEN = 16000
 # also_inputs: the headline graph on inputs that are not the bench's noise-floored synthetic clips (tests/kws_families.py)
-INPUT_FAMILIES = ("word_noise_gain", "word_background", "word_silence", "amp_sweep", "bursts")
+INPUT_FAMILIES = ("word_noise_gain", "word_background", "word_silence", "amp_sweep", "bursts", "quiet_noise")
 N_BASE = 2048
 
 
@@ -664,7 +664,8 @@ def main():
                     "word_background": "the same mix at the reference's default volumes (word 1.0, background 0.1)",
                     "word_silence": "a word followed by digital silence (what the reference's script makes of every file shorter than 1 s when no background is mixed in)",
                     "amp_sweep": "tone groups under an envelope, no noise floor, peak amplitude swept 1 .. 32767 LSB",
-                    "bursts": "digital silence with 1 .. 6 bursts shorter than one frame"}
+                    "bursts": "digital silence with 1 .. 6 bursts shorter than one frame",
+                    "quiet_noise": "stationary noise of 1 .. 50 LSB and nothing else (a quiet room between words): every cepstral column is near-constant by nature"}
         out["also_inputs"] = [dict(line(x, side_steps), family=x["family"], family_is=fam_note.get(x["family"], ""),
                                    distinct_clips=N_BASE, tiled_to=B) for x in inputs]
         out["also_inputs_note"] = ("the headline graph (%s) on %d distinct clips of each input family of tests/kws_families.py, tiled to the batch; fast_fallback_rate = share the "

@@ -172,7 +172,7 @@ EI_IMPULSE_ERROR kws_fast_tolerance_info(const kws_handle *h, kws_fast_tolerance
     out->dev_overrides = h->fast_dev_overrides;
     out->k_sigma_worst_column = (h->is_float && h->gain.calibrated) ? out->k_sigma / 1.3f : out->k_sigma;
     out->silent_rows_exact = F.sil_off >= 0 ? 1 : 0;
-    out->c0_silent_factor = F.c0_sil_fac;
+    out->systematic_ratio = sqrtf(F.sys_t2);
     out->sigma_net = sqrtf(F.v_net);       // the terms of V that do not depend on the clip: the fused network's re-ordering noise, the deviation's own error
     // sum of gain^2 over every feature: a feature error of rms size t on every feature gives V = sigma_net^2 + t^2 x this
     double g2 = 0.0;

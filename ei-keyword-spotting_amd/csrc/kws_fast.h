@@ -115,7 +115,7 @@ struct KwsFastPlan {
     // those rows carry no spectral error: the guard's absolute / per-level terms are scaled by sqrt(live rows / rows) and its level is the
     // live rows' (round 6).  sil_off: shared LDS, 32 floats (columns 0 .. 31; only 1 .. NF/2 are read), or -1: not recorded
     int sil_off;
-    float c0_sil_fac;             // column 0, means not replayed, clip with silent frames: its per-|window mean| coefficient x this (>= 1)
+    float sys_t2;                 // (deviation / |mean|)^2 below which a column's window sums are taken to round systematically (its alternative rel coefficient)
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
     int fs, f_floats, r1_floats, wave_floats, shared_floats, n_waves;

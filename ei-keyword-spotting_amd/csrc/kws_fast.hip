@@ -719,7 +719,7 @@ __device__ __forceinline__ void fast_dwconv(const KwsFastBlock &k, const float *
 //  network behind them sit at 256 registers and would spill the CR extra values (+7 % there): they sum in place.
 template <int CR, int CG, bool DEFER>
 __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float *__restrict__ cnt_tab, const int *__restrict__ upd, int fs,
-                                           float inv_win, const float *__restrict__ guard_tab, float level, float abs_scale, bool silent, float c0_sil_fac, int piv_row, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
+                                           float inv_win, const float *__restrict__ guard_tab, float level, float abs_scale, bool silent, float sys_t2, int piv_row, const float *__restrict__ mref, bool c0_exact, int lane, int nfr, int ncep,
                                            const float *__restrict__ ext_tab, float *__restrict__ sink)
 {
     constexpr int NG = KWS_WAVE / CG;
@@ -762,7 +762,9 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
         const bool is_c0 = c0_exact && cb + cl == 0;
         // (level arrives multiplied by abs_scale = sqrt(live rows / rows): the rows of digitally silent frames carry the reference's own values)
         const float g_abs = __fmaf_rn(gcol.y, level, gcol.x * abs_scale);
-        const float g_rel = cb + cl == 0 ? (c0_exact ? gcol.w : silent ? gcol.z * c0_sil_fac : gcol.z) : (silent ? gcol.w : gcol.z);
+        // the per-|window mean| coefficient: gcol.w where the reference's sequential window sums round SYSTEMATICALLY (runs of identical or nearly identical
+        // values: a clip with silent frames; a near-constant column, below), gcol.z where they round at random.  Column 0: gcol.w = its means replayed.
+        float g_rel = (cb + cl == 0 ? c0_exact : silent) ? gcol.w : gcol.z;
         float mr[CR];
 #pragma unroll
         for (int i = 0; i < CR; ++i) mr[i] = (c0_exact && cb == 0) ? mref[min(r0 + i, nfr - 1)] : 0.0f;
@@ -817,6 +819,14 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
 #pragma unroll
         for (int i = 0; i < CR - 1; ++i) { dl[i] -= piv; da[i] -= piv; }
         float S = S0 + S1, Q = Q0 + Q1;
+        // A near-constant column -- deviation below sys_t x |mean| in the lane's first window (every window of the usual shapes holds every row, so one look
+        // per lane and column block will do; round 6, profiles/r06_guard_fit.txt: 0.6e-6 .. 1.0e-6 |mean| there against 0.15e-6 .. 0.3e-6) -- takes gcol.w too.
+        // float32 graphs only (sys_t2 is 0 for an int8 graph, whose guard keeps rounds 4 - 5's constants instead, kws_fast_plan.cpp): the forms with the
+        // int8 network behind them sit at 256 registers, and the test cost them 3 - 5 % (profiles/r06_ab_variants.txt).
+        if constexpr (DEFER) {
+            const float m0 = S * inv_win, v0 = fmaxf(__fmaf_rn(-m0, m0, Q * inv_win), 0.0f), am0 = m0 + piv;
+            g_rel = (cb + cl != 0 && v0 < sys_t2 * (am0 * am0)) ? gcol.w : g_rel;
+        }
         float o[CR], gq[DEFER ? CR : 1];
 #pragma unroll
         for (int i = 0; i < CR; ++i) {
@@ -1459,10 +1469,11 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             const float d0 = on ? x0 - mu : 0.0f;
             const float sd0 = __builtin_amdgcn_sqrtf(wave_sum(d0 * d0) * FP.c0_inv_rows);
             const float top = wave_max(on ? fabsf(x0) : 0.0f);
-            // (a clip with digitally silent frames whose means are NOT replayed pays a larger window-mean term instead -- KwsFastPlan::c0_sil_fac:
-            // the runs of identical log energies make the reference's sequential sums round the same way add after add; replaying the means of
-            // every such clip cost the kernel 3.4 % on word-then-silence input, profiles/r06_phase_by_family.txt)
-            c0_exact = !(FP.c0_factor * sd0 >= __fmaf_rn(FP.c0_rel, top, FP.c0_abs));
+            // ... and always for a clip with digitally silent frames: their runs of identical log energies make the reference's sequential window
+            // sums round the same way add after add (0.45e-6 .. 0.75e-6 |mean| measured), which no running sum reproduces.  (A larger coefficient
+            // for such clips instead of the replay -- 3.4 % of the kernel's time on word-then-silence input -- cost every other input 0.7 % (float
+            // form) to 4.6 % (int8 forms) in the register allocation of cmvnw: profiles/r06_ab_variants.txt.)
+            c0_exact = silent || !(FP.c0_factor * sd0 >= __fmaf_rn(FP.c0_rel, top, FP.c0_abs));
         }
         if (c0_exact) {
             // four copies of the padded column, copy s shifted by s rows: lane r's window pad[r ..] then starts at a 16-byte aligned slot
@@ -1525,8 +1536,8 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                 abs_scale = __builtin_amdgcn_sqrtf(live / rows);
                 level *= abs_scale;
             }
-            if (KWS_FAST_WPS >= 3 || cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, FP.c0_sil_fac, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
-            else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, FP.c0_sil_fac, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            if (KWS_FAST_WPS >= 3 || cr == 13) vlane = fast_cmvn<13, 16, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, FP.sys_t2, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
+            else vlane = fast_cmvn<17, 20, QCP == 0>(img, cnt_tab, upd_tab, fs, inv_win, guard_tab, level, abs_scale, silent, FP.sys_t2, piv_row, elog, c0_exact, lane_m, nfr, ncep, ext_tab, csink);
             gV = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(vlane) + FP.v_net)));      // wave-uniform: a scalar register
           }
         }

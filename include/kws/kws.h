@@ -128,7 +128,9 @@ typedef struct {
     int silent_rows_exact;                             /* 1 (round 6): the rows of digitally silent frames (frame energy exactly 0) carry the reference's own cepstral
                                                           row in tier 1 -- recorded at kws_create from the exact kernels on an all-zero window --, so the rule's abs / lev
                                                           terms are multiplied by sqrt(live frames / frames) and `level` is the mean over the LIVE frames only */
-    float c0_silent_factor;                            /* column 0 of a clip with digitally silent frames whose window means were NOT replayed: rel[0] x this */
+    float systematic_ratio;                            /* a column whose deviation is below this x |mean| in a lane's first window (rows 0, cr, 2 cr ... of the kernel's
+                                                          row groups, cr = 13 for up to 16 columns, else 17) takes the alternative rel coefficient, like a clip with silent frames (column 0 of
+                                                          such a clip always has its window means replayed) */
 } kws_fast_tolerance;
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
 EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);

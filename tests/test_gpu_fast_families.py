@@ -138,12 +138,20 @@ def guard_variance(gm, sdw, mw, lvl, sil, tier):
     level = (lvl[:, 1] if exact_rows else lvl[:, 0]).astype(np.float64)[:, None, None] if tier == 1 else 0.0
     rd = 1.0 / (sdw.astype(np.float64) + 1.1920929e-7)
     base = (coef[0][None, None, :] + coef[1][None, None, :] * level) * scale
-    rel = np.where((sil > 0)[:, None], coef[3][None, :], coef[2][None, :])    # [clips][columns]
+    # a lane's first window decides per column block whether the column is near-constant (deviation below systematic_ratio x |mean|): the window means
+    # then round systematically and the column takes the alternative coefficient, like every column of a clip with silent frames.  The kernel compares in
+    # fp32 on its own running sums: lo takes the threshold 20 % lower, hi 25 % higher
+    ncol = sdw.shape[2]
+    cr = 13 if (ncol <= 16 and nfr <= 52) else 17
+    first = np.minimum(np.arange(nfr) // cr * cr, nfr - 1)                 # the row whose window a row's lane looked at
+    ratio = sdw.astype(np.float64)[:, first, :] / np.maximum(np.abs(mw.astype(np.float64)[:, first, :]), 1e-300)
     v = []
-    for rel0 in (coef[3][0], coef[2][0]):
-        # (column 0 of a clip with silent frames, means not replayed: the larger coefficient kws_fast_tolerance::c0_silent_factor states)
-        rel[:, 0] = np.where((sil > 0) & (rel0 == coef[2][0]), coef[2][0] * tol["c0_silent_factor"], rel0)
-        b = (base + rel[:, None, :] * np.abs(mw)) * rd
+    for rel0, thr in ((coef[3][0], 0.8 * tol["systematic_ratio"]), (coef[2][0], 1.25 * tol["systematic_ratio"])):
+        sysm = (ratio < thr) | (sil > 0)[:, None, None]                         # [clips][rows][columns]
+        rel = np.where(sysm, coef[3][None, None, :], coef[2][None, None, :]).astype(np.float64)
+        # column 0: its means replayed in the reference's order (lo, and every clip with silent frames) -> coef[3][0]; not replayed (hi) -> coef[2][0]
+        rel[:, :, 0] = np.where((sil > 0)[:, None], coef[3][0], rel0)
+        b = (base + rel * np.abs(mw)) * rd
         v.append((b * b).reshape(len(sdw), -1).sum(axis=1) + tol["sigma_net"] ** 2)
     return v[0], v[1]
 
