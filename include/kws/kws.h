@@ -105,7 +105,9 @@ int kws_fast_is_fused(const kws_handle *h);
  * int8 graphs have no float logits to protect (the network is bit-exact from its int8 input tensor on): gain[c] is the constant for which
  * the rule reads "k_sigma x the rms of the clip's feature error estimates <= 1e-4", calibrated = 0.
  *   kws_fast_guard   coef [4][n_columns]: abs, lev, rel, and the alternative rel: column 0 -- when its window means were replayed in the reference's
- *                    order (a decision of the kernel); the other columns -- for a clip with digitally silent frames (a frame energy of exactly 0)
+ *                    order (a decision of the kernel; always for a clip with digitally silent frames); the other columns -- where the reference's
+ *                    sequential window sums round systematically: every column of a clip with digitally silent frames (a frame energy of exactly 0),
+ *                    and (float32 graphs) a column whose deviation is below kws_fast_tolerance::systematic_ratio x |mean| in its lane's first window
  *   kws_fast_gain    gain [n_columns] of a float32 graph (logit-difference error per unit of feature error, rms over a column's rows)
  * kws_streams_step_device and kws_cmvn_inference_batch_device start from exact cepstra: their one fast tier is tier 2. */
 typedef struct {
