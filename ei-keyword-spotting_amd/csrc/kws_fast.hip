@@ -15,9 +15,27 @@
 
 #include "kws_device.h"
 #include "kws_fast.h"
+// The second compilation of this file (kws_fast_w3.o, -DKWS_FAST_WPS=3: three waves per SIMD, <= 168 registers, the float32-network forms only) goes into the
+// same library under names of its own; the launchers of the first one hand a plan laid out for three waves (KwsFastPlan::wps) over to them.
+#if KWS_FAST_WPS >= 3
+#define kws_fast_kernel kws_fast_kernel_w3
+#define kws_launch_fast kws_launch_fast_w3
+#define kws_launch_fast_from_cepstra kws_launch_fast_from_cepstra_w3
+#define kws_launch_fast_prof kws_launch_fast_prof_w3
+#endif
 #include "kws_nn_int8_dev.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+// The three-waves-per-SIMD build (KWS_FAST_WPS = 3: 168 registers; an experiment, profiles/r06_occupancy.md): a lane index is made opaque again at the
+// entry of every phase, so that the dozens of lane-derived constants of a LATER phase are not worked out ahead of an earlier one's loops and spilled.
+// Expands to nothing in the product build (two waves per SIMD), whose code it must not perturb.
+#if KWS_FAST_WPS >= 3
+#define KWS_OPAQUE3(v) asm volatile("" : "+v"(v))
+#define KWS_FAST_SINK (shared + FP.sink_off)          // one sink per workgroup (KwsFastPlan::sink_off is relative to the shared block in this build)
+#else
+#define KWS_OPAQUE3(v) do { } while (0)
+#define KWS_FAST_SINK (F + FP.sink_off)               // a sink per wave, behind its image
+#endif
 static_assert(KWS_FAST_ZF == KWS_ZF && KWS_FAST_WAVE == KWS_WAVE, "kws_fast.h mirrors kws_device.h");
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
@@ -94,6 +112,7 @@ template <int MT, int NT>
 __device__ __forceinline__ void fast_conv_finish(const KwsFastBlock &k, v4f (&acc)[MT][NT], const float (&vout)[2], float *__restrict__ stage, int sstride,
                                                  const float *__restrict__ shared, int lane, float *__restrict__ sink, float scale)
 {
+    KWS_OPAQUE3(lane);
     const int lm = lane & 15, lq = lane >> 4;
     const int out_c = k.out_c;
     const int out_w = k.out_w;
@@ -328,6 +347,10 @@ __device__ __forceinline__ float fast_conv_tiles(const KwsFastBlock &k, const fl
 // ---------------------------------------------------------------------------------------------------------
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+// a pointer the plan hands over as void * is a flat address to the compiler: flat loads count on the LDS counter too and return out of order, so every
+// wait near them becomes "everything"; device memory said as such gives global loads (round 6)
+typedef const __attribute__((address_space(1))) char *kws_gptr;
+typedef const __attribute__((address_space(1))) v8h *kws_gv8h;
 #define KWS_FAST_HP 16            // channel pairs a lane converts: images of up to 64 x 16 pairs (the plan checks)
 
 // T trips of the wave, every one of them whole (pairs past the last one: the lane re-reads the last pair and stores the same halves to the same
@@ -400,13 +423,13 @@ __device__ __forceinline__ float fast_conv_small_h(const KwsFastBlock &k, float 
 {
     constexpr int KSM = 8;
     const int lm = lane & 15, lq = lane >> 4, n_ks = k.h_ks;
-    const char *const bg = (const char *)k.h_b_global + lane * 16;
+    const kws_gptr bg = (kws_gptr)k.h_b_global + lane * 16;
     v8h bh[KSM], blo[KSM];
 #pragma unroll
     for (int ks = 0; ks < KSM; ++ks) {
         const int kc = min(ks, n_ks - 1);
-        bh[ks] = *(const v8h *)(bg + (kc * 2) * (KWS_WAVE * 16));
-        blo[ks] = *(const v8h *)(bg + (kc * 2 + 1) * (KWS_WAVE * 16));
+        bh[ks] = *(kws_gv8h)(bg + (kc * 2) * (KWS_WAVE * 16));
+        blo[ks] = *(kws_gv8h)(bg + (kc * 2 + 1) * (KWS_WAVE * 16));
     }
     const float inv_s = fast_split_image(in, k.in_w, k.in_c, k.in_cp, k.in_stride, lane, k.inv_ppr20);
     v4f acc[MT][1];
@@ -463,22 +486,25 @@ __device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float 
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4f{ 0.f, 0.f, 0.f, 0.f };
     const int rowb = k.in_stride * 4, in_w = k.in_w, lo_off = 2 * k.in_cp, n_ks = k.h_ks;
     const int row0 = lm - k.pad_left;                       // image row of this lane's operand for tile 0, tap 0
-    const char *const abase = (const char *)in + row0 * rowb;
     const char *const zb = (const char *)(shared + zero_off);          // 16 bytes of zeros, and again lo_off bytes further
     const int2 *const tab = (const int2 *)(shared + k.h_tab_off) + lq;  // [k-step][lane / 16] { byte offset of the group, tap }
     const char *const bl = (const char *)(shared + (BG ? 0 : k.h_b_off)) + lane * 16;
-    const char *const bg = (const char *)k.h_b_global + lane * 16;
+    const kws_gptr bg = (kws_gptr)k.h_b_global + lane * 16;
     auto fetch = [&](int ks, const int2 &d, v8h (&ah)[MT], v8h (&al)[MT], v8h (&bh)[NT], v8h (&blo)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int off = ((ks * 2) * NT + nt) * (KWS_WAVE * 16);
-            if constexpr (BG) { bh[nt] = *(const v8h *)(bg + off); blo[nt] = *(const v8h *)(bg + off + NT * (KWS_WAVE * 16)); }
+            if constexpr (BG) { bh[nt] = *(kws_gv8h)(bg + off); blo[nt] = *(kws_gv8h)(bg + off + NT * (KWS_WAVE * 16)); }
             else { bh[nt] = *(const v8h *)(bl + off); blo[nt] = *(const v8h *)(bl + off + NT * (KWS_WAVE * 16)); }
         }
+        // (three waves per SIMD: the row tiles' 2 MT row numbers and addresses are formed here from two registers -- hoisted out of the loop as 2 MT
+        // registers they are spilled, and a reload per tile waits inside the loop)
+        int r0v = row0, abv = row0 * rowb;
+        KWS_OPAQUE3(r0v); KWS_OPAQUE3(abv);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bool in_img = (unsigned)(row0 + d.y + 16 * mt) < (unsigned)in_w;
-            const char *p = in_img ? abase + d.x + mt * (16 * rowb) : zb;
+            const bool in_img = (unsigned)(r0v + d.y + 16 * mt) < (unsigned)in_w;
+            const char *p = in_img ? (const char *)in + (abv + d.x + mt * (16 * rowb)) : zb;
             ah[mt] = *(const v8h *)p;
             al[mt] = *(const v8h *)(p + lo_off);
         }
@@ -497,6 +523,71 @@ __device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
     };
+#if KWS_FAST_WPS >= 3
+    if constexpr (BG) {
+        // Three waves per SIMD with the fragments in device memory (the LDS block holds eleven waves and no 36 KB of fragments): an L2 round trip is longer
+        // than a k-step's 3 MT NT matrix instructions, so the fragments rotate through THREE register sets, requested two k-steps ahead, and the image
+        // operands make do with ONE set refilled in two halves -- the lo halves after the products that read them, the hi halves after the rest -- :
+        // 16 (1 + MT) + 16 * 3 NT... = 112 registers with the accumulators for MT = 4, NT = 2, where two whole sets of both took 128 and spilled an accumulator.
+        v8h ah[MT], al[MT], bh[3][NT], blo[3][NT];
+        auto fetch_b = [&](int ks, v8h (&h_)[NT], v8h (&l_)[NT]) {
+            const int kc = ks < n_ks ? ks : n_ks - 1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = ((kc * 2) * NT + nt) * (KWS_WAVE * 16);
+                h_[nt] = *(kws_gv8h)(bg + off); l_[nt] = *(kws_gv8h)(bg + off + NT * (KWS_WAVE * 16));
+            }
+        };
+        auto fetch_a = [&](const int2 &d, v8h (&dst)[MT], int plus) {
+            int r0v = row0, abv = row0 * rowb;
+            KWS_OPAQUE3(r0v); KWS_OPAQUE3(abv);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool in_img = (unsigned)(r0v + d.y + 16 * mt) < (unsigned)in_w;
+                const char *p = in_img ? (const char *)in + (abv + d.x + mt * (16 * rowb)) : zb;
+                dst[mt] = *(const v8h *)(p + plus);
+            }
+        };
+        auto step = [&](int ks, const v8h (&bh_)[NT], const v8h (&bl_)[NT], v8h (&nh_)[NT], v8h (&nl_)[NT]) {
+            fetch_b(ks + 2, nh_, nl_);
+            const int2 dn = tab[4 * min(ks + 1, n_ks)];                  // (row n_ks reads zeros)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh_[nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(dn, al, lo_off);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl_[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh_[nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(dn, ah, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fetch_b(0, bh[0], blo[0]);
+        fetch_b(1, bh[1], blo[1]);
+        { const int2 d = tab[0]; fetch_a(d, al, lo_off); fetch_a(d, ah, 0); }
+        __builtin_amdgcn_s_setprio(1);
+        // (whole trips of three: a k-step past the last one multiplies the zero block by the last fragments)
+        for (int ks = 0; ks < n_ks; ks += 3) {
+            step(ks, bh[0], blo[0], bh[2], blo[2]);
+            step(ks + 1, bh[1], blo[1], bh[0], blo[0]);
+            step(ks + 2, bh[2], blo[2], bh[1], blo[1]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        const float scale = inv_s * k.h_inv_wscale;
+        const float vout[2] = { 0.0f, 0.0f };
+        fast_conv_finish<MT, NT>(k, acc, vout, stage, sstride, shared, lane, sink, scale);
+        return scale;
+    }
+#endif
     // two operand sets, the loop unrolled by two: a set's operands are requested before the other set's matrix instructions are issued
     // (round 6: three sets with requests two steps ahead -- 48 more live registers -- measured 1.9 .. 3.9 % SLOWER same-box, profiles/r06_ab_variants.txt)
     v8h ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
@@ -731,17 +822,22 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
     float vacc = 0.0f;
     // column-independent table entries: the update table of this lane's rows, the first window's extra rows
     int u[CR - 1];                                    // leaving row offset | entering row offset << 16 (floats)
-#pragma unroll
-    for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0 + i, nfr - 1)];
     int xo[KWS_FAST_CMVN_EXT];
     float we[KWS_FAST_CMVN_EXT], m0 = 0.0f;
-    if (ext_tab) {
-        const float *ext = ext_tab + cgrp * (1 + 2 * KWS_FAST_CMVN_EXT);
-        m0 = ext[0];
+    auto tables = [&](int r0_, int cgrp_) {
 #pragma unroll
-        for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) { xo[e] = __float_as_int(ext[1 + 2 * e]); we[e] = ext[2 + 2 * e]; }
-    }
+        for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0_ + i, nfr - 1)];
+        if (ext_tab) {
+            const float *ext = ext_tab + cgrp_ * (1 + 2 * KWS_FAST_CMVN_EXT);
+            m0 = ext[0];
+#pragma unroll
+            for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) { xo[e] = __float_as_int(ext[1 + 2 * e]); we[e] = ext[2 + 2 * e]; }
+        }
+    };
+    if (KWS_FAST_WPS < 3) tables(r0, cgrp);
     for (int cb = 0; cb < ncep; cb += CG) {
+        // (three waves per SIMD: the tables are re-read from LDS in every column block -- kept across the blocks, their ~20 registers are spilled and come back one by one)
+        if (KWS_FAST_WPS >= 3) { int cg_ = cgrp; KWS_OPAQUE3(cg_); tables(cg_ * CR, cg_); }
         const int c = cb + cl;
         const bool act = lane_on && c < ncep && r0 < nfr;
         float *col = img + min(c, ncep - 1);
@@ -977,6 +1073,10 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         const int nbA = (fl >> 2) + 4 * (fl & 3);
         const cf a1 = to_cf(P.tw[16]), a2 = to_cf(P.tw[32]), a3 = to_cf(P.tw[48]);
         const cf b1 = to_cf(P.tw[4 * fl]), b2 = to_cf(P.tw[8 * fl]), b3 = to_cf(P.tw[12 * fl]);
+#if KWS_FAST_WPS >= 3
+        // (three waves per SIMD: the last level's twiddles and the split's are read from the workgroup's LDS table in every pass, KwsFastPlan::twl_off)
+        const float *const twl_c = shared + FP.twl_off + 24 * fl, *const twl_s = shared + FP.twl_off + 192 + 16 * fl;
+#else
         cf c1[4], c2[4], c3[4];
     #pragma unroll
         for (int a = 0; a < 4; ++a) { c1[a] = to_cf(P.tw[fl + 8 * a]); c2[a] = to_cf(P.tw[2 * (fl + 8 * a)]); c3[a] = to_cf(P.tw[3 * (fl + 8 * a)]); }
@@ -987,6 +1087,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             const int k = fl + 8 * (q & 3) + 32 * (q >> 2);
             stw[q] = to_cf(P.stw[(k == 0 ? KWS_NC / 2 : k) - 1]);
         }
+#endif
         const int xwr = fg * KWS_FAST_XS + 18 * fl;                     // exchange buffer: position p of a frame at 2 p + 2 (p / 8)
         const int xrd = fg * KWS_FAST_XS + 2 * fl;
         const int partner = (lane_c & ~7) | ((8 - fl) & 7);
@@ -1167,7 +1268,23 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
 #pragma unroll
             for (int b = 0; b < 4; ++b) bfly4(u[0][b], u[1][b], u[2][b], u[3][b], b1, b2, b3);
 #pragma unroll
+#if KWS_FAST_WPS >= 3
+            for (int a = 0; a < 4; ++a) {
+                const float4 c12 = *(const float4 *)(twl_c + 6 * a);
+                const float2 c3v = *(const float2 *)(twl_c + 6 * a + 4);
+                cf t1, t2, t3;
+                t1.r = c12.x; t1.i = c12.y; t2.r = c12.z; t2.i = c12.w; t3.r = c3v.x; t3.i = c3v.y;
+                bfly4(u[a][0], u[a][1], u[a][2], u[a][3], t1, t2, t3);
+            }
+            cf stw[8];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                const float4 v = *(const float4 *)(twl_s + 2 * q);
+                stw[q].r = v.x; stw[q].i = v.y; stw[q + 1].r = v.z; stw[q + 1].i = v.w;
+            }
+#else
             for (int a = 0; a < 4; ++a) bfly4(u[a][0], u[a][1], u[a][2], u[a][3], c1[a], c2[a], c3[a]);
+#endif
             FPH(1);
             // ---- kiss_fftr split (kiss_fftr.cpp:84-119) and the power spectrum, fp32: |X|^2 / fft_length.  Bin pair (k, 128 - k)
             //      needs positions k and 128 - k: the second lives in lane (8 - fl) % 8 at (3 - a, 3 - b) -- in lane 0 itself, one
@@ -1212,7 +1329,12 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                 }
                 if (fl == 0) {                                       // tmp[0]: DC and Nyquist bins (kiss_fftr.cpp:84-96)
                     const float dc = u[0][0].r + u[0][0].i, ny = u[0][0].r - u[0][0].i;
+#if KWS_FAST_WPS >= 3
+                    // (4 pscale would live in a vector register through the pass loop and come back from scratch here; both factors are powers of two: the same bits)
+                    const float pdc = ((dc * dc) * pscale) * 4.0f, pny = ((ny * ny) * pscale) * 4.0f;
+#else
                     const float pdc = (dc * dc) * (4.0f * pscale), pny = (ny * ny) * (4.0f * pscale);
+#endif
                     esum += pdc + pny;
                     prow[0] = pdc;
                 }
@@ -1391,7 +1513,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             // deviation, 1.2e-7): those columns are left as they are.  c0 <- log(frame energy) (feature.hpp:425-429).
             // Stores without a branch per value: rows past the last frame and coefficients that are not this tile's go to a
             // per-lane sink.
-            float *const sink = F + FP.sink_off + lane_l;
+            float *const sink = KWS_FAST_SINK + lane_l;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -1425,7 +1547,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         float vlane = 0.0f;
         int lane_m = lane;
         asm volatile("" : "+v"(lane_m));
-        float *const csink = F + FP.sink_off + lane_m;
+        float *const csink = KWS_FAST_SINK + lane_m;
         // ---- column 0's window means in the reference's own order (processing.hpp:326-389 over numpy::mean_axis0, numpy.hpp:746-784:
         //      a sequential fp32 sum of win_size padded rows, then a division).  The log frame energy sits near -10 for quiet audio, so
         //      that sum rounds at ~6e-5 per step and the mean carries ~1e-6 |mean| of rounding noise of the reference's own making:
@@ -1589,11 +1711,13 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
 
         // ---- the float32 graph: CONV_2D blocks ping-pong between the two images, then FULLY_CONNECTED and SOFTMAX ----------
         float *cur = F, *oth = R1;
-        float *const wsink = F + FP.sink_off + lane;
+        float *const wsink = KWS_FAST_SINK + lane;
         int lane_n = lane;
         asm volatile("" : "+v"(lane_n));
         for (int b = 0; b < n_blocks; ++b) {
             const KwsFastBlock &k = FP.blk[b];
+            int lane_b = lane_n;
+            KWS_OPAQUE3(lane_b);
             const bool last = b + 1 == n_blocks;
             const int o_stride = last ? k.out_c : FP.blk[b + 1].in_stride;
             const int o_cp = last ? k.out_c : FP.blk[b + 1].in_cp;
@@ -1603,7 +1727,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             const int sstride = pooled ? k.stage_stride : o_stride;
             long long t_loop = 0, t_pre = 0, *tl = (PROF && b == 0) ? &t_loop : nullptr, *tp = (PROF && b == 0) ? &t_pre : nullptr;
             if (k.dw) {
-                fast_dwconv(k, cur, oth, shared, lane_n, o_stride, o_cp);
+                fast_dwconv(k, cur, oth, shared, lane_b, o_stride, o_cp);
                 WAVE_SYNC();
                 float *tmp = cur; cur = oth; oth = tmp;
                 if (PROF && b > 0) { const long long now_ = clock64(); ph[12 + b] += now_ - tlast; }
@@ -1615,32 +1739,32 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                 // split operands on v_mfma_f32_16x16x32_f16: row tiles 1 / 2 / 4 (an idle tile costs 16 cycles per instruction there)
                 const int zo = FP.zero_off;
                 const bool bgl = k.h_b_off < 0;
-                if (bgl && k.n_tiles == 1 && k.m_tiles == 1 && k.h_ks <= 8) cscale = fast_conv_small_h<1>(k, cur, stage, sstride, shared, zo, lane_n, wsink);
+                if (bgl && k.n_tiles == 1 && k.m_tiles == 1 && k.h_ks <= 8) cscale = fast_conv_small_h<1>(k, cur, stage, sstride, shared, zo, lane_b, wsink);
                 else
                 switch ((k.m_tiles > 2 ? 4 : k.m_tiles) * 4 + k.n_tiles) {
-                case 4 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<4, 2, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<4, 2, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
-                case 4 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<4, 1, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<4, 1, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
-                case 2 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<2, 2, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<2, 2, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
-                case 2 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<2, 1, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<2, 1, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
-                case 1 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<1, 2, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<1, 2, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
-                default: cscale = bgl ? fast_conv_tiles_h<1, 1, true>(k, cur, stage, sstride, shared, zo, lane_n, wsink) : fast_conv_tiles_h<1, 1, false>(k, cur, stage, sstride, shared, zo, lane_n, wsink); break;
+                case 4 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<4, 2, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<4, 2, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
+                case 4 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<4, 1, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<4, 1, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
+                case 2 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<2, 2, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<2, 2, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
+                case 2 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<2, 1, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<2, 1, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
+                case 1 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<1, 2, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<1, 2, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
+                default: cscale = bgl ? fast_conv_tiles_h<1, 1, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<1, 1, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
                 }
             } else
             switch (k.m_tiles * 4 + k.n_tiles) {
-            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_n, wsink, tl, tp); break;
-            case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
-            case 3 * 4 + 2: fast_conv_tiles<3, 2>(k, cur, stage, sstride, shared, lane_n, wsink, tl, tp); break;
-            case 3 * 4 + 1: fast_conv_tiles<3, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
-            case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shared, lane_n, wsink); break;
-            case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
-            case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shared, lane_n, wsink); break;
-            default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shared, lane_n, wsink); break;
+            case 4 * 4 + 2: fast_conv_tiles<4, 2>(k, cur, stage, sstride, shared, lane_b, wsink, tl, tp); break;
+            case 4 * 4 + 1: fast_conv_tiles<4, 1>(k, cur, stage, sstride, shared, lane_b, wsink); break;
+            case 3 * 4 + 2: fast_conv_tiles<3, 2>(k, cur, stage, sstride, shared, lane_b, wsink, tl, tp); break;
+            case 3 * 4 + 1: fast_conv_tiles<3, 1>(k, cur, stage, sstride, shared, lane_b, wsink); break;
+            case 2 * 4 + 2: fast_conv_tiles<2, 2>(k, cur, stage, sstride, shared, lane_b, wsink); break;
+            case 2 * 4 + 1: fast_conv_tiles<2, 1>(k, cur, stage, sstride, shared, lane_b, wsink); break;
+            case 1 * 4 + 2: fast_conv_tiles<1, 2>(k, cur, stage, sstride, shared, lane_b, wsink); break;
+            default: fast_conv_tiles<1, 1>(k, cur, stage, sstride, shared, lane_b, wsink); break;
             }
             WAVE_SYNC();
             // (block 0's sub-phases: only the fp32-instruction form takes these clocks; the split-operand form's are tools/gpu_fast_subphase.py's)
             if (PROF && b == 0 && t_loop != 0) { ph[9] += t_loop - t_pre; ph[10] += clock64() - t_loop; ph[11] += t_pre - tlast; }
-            if (k.fpool) fast_pool_finish(k, stage, oth, shared, lane_n, o_stride, o_cp, cscale);
-            else fast_pool(k, stage, oth, lane_n, o_stride, o_cp, pooled);
+            if (k.fpool) fast_pool_finish(k, stage, oth, shared, lane_b, o_stride, o_cp, cscale);
+            else fast_pool(k, stage, oth, lane_b, o_stride, o_cp, pooled);
             WAVE_SYNC();
             float *tmp = cur; cur = oth; oth = tmp;
             if (PROF && b > 0) { const long long now_ = clock64(); ph[12 + b] += now_ - tlast; }
@@ -1686,6 +1810,16 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
 // ---------------------------------------------------------------------------------------------------------
 //  launchers (called from kws_api.cpp)
 // ---------------------------------------------------------------------------------------------------------
+#if KWS_FAST_WPS < 3
+// the same launchers of kws_fast.hip's second compilation (three waves per SIMD, float32-network forms; kws_fast.h): reached through the ones above
+int kws_launch_fast_w3(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
+                       int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream, const KwsNnPlan *d_nn, float *tap_logits);
+int kws_launch_fast_from_cepstra_w3(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
+                                    float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
+                                    const int *sel, float *tap_logits, int feat_in);
+int kws_launch_fast_prof_w3(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
+                            int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream);
+#endif
 template <int NZ, int DG, bool PROF, bool FROM_CEP = false, bool NET = true, int QCP = 0, bool MFE = false>
 static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                          float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu,
@@ -1717,6 +1851,14 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
 {
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
+#define KWS_FAST_ARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream
+#define KWS_FAST_NARGS KWS_FAST_ARGS, nullptr, nullptr, nullptr, tap_logits
+#if KWS_FAST_WPS >= 3
+    if (FP.wps != KWS_FAST_WPS || FP.qnet || FP.mfe || !FP.fuse) return (int)hipErrorInvalidValue;        // this build: the float32-network forms
+#define KWS_FAST_PLAIN(...) ((int)hipErrorInvalidValue)
+#else
+#define KWS_FAST_PLAIN(...) (__VA_ARGS__)
+    if (FP.wps >= 3) return kws_launch_fast_w3(P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, stream, d_nn, tap_logits);
     if (FP.qnet) {
         // int8 graph fused: 16-byte activation rows go with the 32-filter front end, 64-byte rows with the 40-filter one (the plan checks)
 #define KWS_FAST_QARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream, nullptr, d_nn
@@ -1728,8 +1870,6 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
                                                                                                           : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false, 64>(KWS_FAST_QARGS);
         return (int)hipErrorInvalidValue;
     }
-#define KWS_FAST_ARGS P, FP, d_plan, pcm, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, nullptr, stream
-#define KWS_FAST_NARGS KWS_FAST_ARGS, nullptr, nullptr, nullptr, tap_logits
     if (FP.mfe) {
         if (scores || q_out || !features) return (int)hipErrorInvalidValue;          // the MFE form has one output: the mel matrix
         if (FP.dct_groups == 4)
@@ -1740,24 +1880,27 @@ int kws_launch_fast(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPla
                                                                                                             : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false, 0, true>(KWS_FAST_ARGS);
         return (int)hipErrorInvalidValue;
     }
+#endif
     if (FP.dct_groups == 4)
         return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 4, false>(KWS_FAST_NARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false>(KWS_FAST_NARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 4, false>(KWS_FAST_NARGS))
-                       : (FP.nz <= 4 ? launch_fast_t<4, 4, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false, false, false>(KWS_FAST_ARGS)
+                       : KWS_FAST_PLAIN(FP.nz <= 4 ? launch_fast_t<4, 4, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 4, false, false, false>(KWS_FAST_ARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 4, false, false, false>(KWS_FAST_ARGS));
     if (FP.dct_groups == 5)
         return FP.fuse ? (FP.nz <= 4 ? launch_fast_t<4, 5, false>(KWS_FAST_NARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false>(KWS_FAST_NARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 5, false>(KWS_FAST_NARGS))
-                       : (FP.nz <= 4 ? launch_fast_t<4, 5, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false, false, false>(KWS_FAST_ARGS)
+                       : KWS_FAST_PLAIN(FP.nz <= 4 ? launch_fast_t<4, 5, false, false, false>(KWS_FAST_ARGS) : FP.nz <= 8 ? launch_fast_t<8, 5, false, false, false>(KWS_FAST_ARGS)
                                                                                               : launch_fast_t<KWS_FAST_NZ_MAX, 5, false, false, false>(KWS_FAST_ARGS));
     return (int)hipErrorInvalidValue;
 }
 
+#if KWS_FAST_WPS < 3
 // bytes of the workgroup's shared LDS block the fused int8 network's tables take (the layout of the kernel's prologue)
 size_t kws_fast_qnet_bytes(int qcp)
 {
     return (size_t)48 * 256 + ((KWS_HEAD_BYTES + 15) & ~15) + (size_t)((qcp == 16 ? 4 : 16) + 4) * KWS_WAVE * 16 + 6 * KWS_WAVE * 4;
 }
+#endif
 
 // cmvnw + (fused float network | features / int8 tensor) from cepstra in HBM, ring-indexed per P.ring_* (continuous mode)
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
@@ -1767,11 +1910,16 @@ int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, con
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
     if (feat_in && !FP.fuse) return (int)hipErrorInvalidValue;          // features in: only the fused network is left to run
+#if KWS_FAST_WPS >= 3
+    if (FP.wps != KWS_FAST_WPS || !FP.fuse) return (int)hipErrorInvalidValue;
+#else
+    if (FP.wps >= 3) return kws_launch_fast_from_cepstra_w3(P, FP, d_plan, cep, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, stream, sel, tap_logits, feat_in);
+#endif
     // mel taps / DCT are not part of this variant: one instantiation serves every model
     return FP.fuse ? launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list,
                                                       n_cu, nullptr, stream, cep, nullptr, sel, tap_logits, feat_in)
-                   : launch_fast_t<4, 4, false, true, false>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count,
-                                                             flag_list, n_cu, nullptr, stream, cep, nullptr, sel);
+                   : KWS_FAST_PLAIN((launch_fast_t<4, 4, false, true, false>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count,
+                                                             flag_list, n_cu, nullptr, stream, cep, nullptr, sel)));
 }
 
 // development aid: phase clocks (<= 4-tap builds only)
@@ -1780,6 +1928,11 @@ int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
 {
     (void)hipGetLastError();
     if (FP.nz > 4) return (int)hipErrorInvalidValue;
+#if KWS_FAST_WPS >= 3
+    if (FP.wps != KWS_FAST_WPS) return (int)hipErrorInvalidValue;
+#else
+    if (FP.wps >= 3) return kws_launch_fast_prof_w3(P, FP, d_plan, pcm, n_clips, scores, flag_count, flag_list, n_cu, prof_out, stream);
+#endif
     if (FP.dct_groups == 5)
         return launch_fast_t<4, 5, true>(P, FP, d_plan, pcm, n_clips, scores, nullptr, nullptr, 1.0f, 0, flag_count, flag_list, n_cu, prof_out, stream);
     if (FP.dct_groups == 4)

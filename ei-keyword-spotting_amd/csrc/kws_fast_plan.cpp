@@ -268,7 +268,8 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     if (c.fft_length != 256) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: fft_length %d (kernel is built for 256)", c.fft_length);
     if (NF != 32 && NF != 40) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d mel filters (the kernel is instantiated for 32 and 40)", NF);
     // cmvnw row/column split: 16 columns x 4 groups of 13 rows, or 20 columns x 3 groups of 17 rows
-    if (ncep <= 16 && nfr <= 52) { F.cr = 13; F.cg = 16; }
+    // (the three-waves-per-SIMD build holds 13 rows per lane whatever the column count: 40 columns take three passes of 16)
+    if ((ncep <= 16 || F.wps >= 3) && nfr <= 52) { F.cr = 13; F.cg = 16; }
     else if (nfr <= 51) { F.cr = 17; F.cg = 20; }
     else return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d frames x %d cepstra outside the cmvnw layouts", nfr, ncep);
     if (nfr < 2) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d frames", nfr);
@@ -394,6 +395,23 @@ static EI_IMPULSE_ERROR build_fast_dsp(kws_handle *h, KwsFastPlan &F, std::vecto
     if ((e = h->upload(tw1, &F.tap_w1))) return e;
     if ((e = h->upload(s2, &F.tap_start2))) return e;
     if ((e = h->upload(tw2, &F.tap_w2))) return e;
+    F.twl_off = -1;
+    if (F.wps >= 3) {
+        std::vector<float2> tw, stw;
+        h_twiddles(c.fft_length / 2, tw);
+        h_super_twiddles(c.fft_length / 2, stw);
+        while (shared.size() & 3) shared.push_back(0.0f);
+        F.twl_off = (int)shared.size();
+        for (int fl = 0; fl < 8; fl++)
+            for (int a = 0; a < 4; a++)
+                for (int m = 1; m <= 3; m++) { const float2 v = tw[(size_t)m * (fl + 8 * a)]; shared.push_back(v.x); shared.push_back(v.y); }
+        for (int fl = 0; fl < 8; fl++)
+            for (int q = 0; q < 8; q++) {
+                const int k = fl + 8 * (q & 3) + 32 * (q >> 2);
+                const float2 v = stw[(size_t)(k == 0 ? c.fft_length / 4 : k) - 1];
+                shared.push_back(v.x); shared.push_back(v.y);
+            }
+    }
     while (shared.size() & 3) shared.push_back(0.0f);
     F.dct_off = (int)shared.size();                  // the workgroup's LDS copy (a clip's 4 DG reads per lane: not worth an L2 round trip)
     shared.insert(shared.end(), frag.begin(), frag.end());
@@ -405,8 +423,13 @@ static void fast_wave_floats(const kws_handle *h, KwsFastPlan &F, int need_f, in
 {
     const int nfr = h->dsp.n_frames;
     // image + log energies (or a later block's image), then one slot per lane: the sink of stores that fall outside an image
-    F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4) + KWS_FAST_WAVE + 48;
-    F.sink_off = F.f_floats - KWS_FAST_WAVE - 48;
+    if (F.wps >= 3) {
+        // three waves per SIMD: ONE sink for the workgroup, in its shared block (finish_fast_plan; nothing ever reads a sink) -- 256 bytes per wave less
+        F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4) + 48;
+    } else {
+        F.f_floats = round_up(std::max(nfr * F.fs + nfr, need_f), 4) + KWS_FAST_WAVE + 48;
+        F.sink_off = F.f_floats - KWS_FAST_WAVE - 48;
+    }
     F.stash_off = F.f_floats - 48;
     F.r1_floats = round_up(std::max(std::max(KWS_FAST_MEL_CHUNK * KWS_FAST_XS, KWS_FAST_MEL_CHUNK * F.pstride), need_r1), 4);
     F.wave_floats = F.f_floats + F.r1_floats;
@@ -432,11 +455,18 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
                 memcpy(slot, &row, sizeof(int));
             }
     while (shared.size() & 3) shared.push_back(0.0f);
+    if (F.wps >= 3) {
+        F.sink_off = (int)shared.size();             // relative to the shared block in that build (kws_fast.hip: KWS_FAST_SINK)
+        shared.insert(shared.end(), KWS_FAST_WAVE, 0.0f);
+    }
     F.shared_floats = (int)shared.size();
     fast_wave_floats(h, F, need_f, need_r1);
     const int avail = kLdsBytes / 4 - F.shared_floats - F.q_floats;
-    F.n_waves = std::min(4 * KWS_FAST_WPS, avail / F.wave_floats);
+    F.n_waves = std::min(4 * F.wps, avail / F.wave_floats);
     if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_WAVES")) F.n_waves = std::max(1, std::min(F.n_waves, atoi(ev)));   // development aid (occupancy experiments)
+    if (KWS_DEV_ENV("KWS_DEV_FAST_REPORT"))                  // development aid: the LDS split of this plan
+        fprintf(stderr, "fast plan: shared %d B + q %d B + %d waves x %d B (F %d + R1 %d) of %d; built for %d waves per SIMD\n", F.shared_floats * 4, F.q_floats * 4, F.n_waves,
+                F.wave_floats * 4, F.f_floats * 4, F.r1_floats * 4, kLdsBytes, F.wps);
     if (F.n_waves < 4 && !KWS_DEV_ENV("KWS_DEV_FAST_WAVES")) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: %d B shared + %d B per wave does not leave four waves per workgroup",
                                    F.shared_floats * 4, F.wave_floats * 4);
     EI_IMPULSE_ERROR e = h->upload(shared, &F.shared_init);
@@ -450,6 +480,7 @@ static EI_IMPULSE_ERROR build_fast_plain(kws_handle *h)
 {
     KwsFastPlan &F = h->fast_plain;
     memset(&F, 0, sizeof(F));
+    F.wps = 2;
     std::vector<float> shared;
     EI_IMPULSE_ERROR e = build_fast_dsp(h, F, shared);
     if (e) return e;
@@ -466,6 +497,7 @@ static EI_IMPULSE_ERROR build_fast_q(kws_handle *h)
 {
     KwsFastPlan &F = h->fast_q;
     memset(&F, 0, sizeof(F));
+    F.wps = 2;
     if (h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the fused int8 network needs an int8 graph");
     if (h->fast_plain.mfe) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the MFE block's normalisation sits between the front end and the network (not fused)");
     if (!kws_nn_uses_mfma(h->nn)) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the int8 graph is outside the two-block matrix-core shape; it keeps its own kernel");
@@ -489,10 +521,11 @@ static EI_IMPULSE_ERROR build_fast_q(kws_handle *h)
 }
 
 // fused form: float32 graphs made of CONV_2D blocks only
-static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
+static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h, int wps)
 {
     KwsFastPlan &F = h->fast_fused;
     memset(&F, 0, sizeof(F));
+    F.wps = wps;
     if (!h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the fused network is float32 (int8 graphs keep their exact kernels)");
     if (h->fast_plain.mfe) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the MFE block's normalisation sits between the front end and the network (not fused)");
     const KwsNnPlanF32 &N = h->nnf;
@@ -631,7 +664,7 @@ static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h)
         k.h_b_global = dev;
         while (shared.size() & 3) shared.push_back(0.0f);
         const size_t fl = hfrag[b].size() / 2;
-        if ((shared.size() + fl + 4) + (size_t)(4 * KWS_FAST_WPS) * F.wave_floats <= (size_t)kLdsBytes / 4 && !KWS_DEV_ENV("KWS_DEV_FAST_B_GLOBAL")) {
+        if ((shared.size() + fl + 4 + (F.wps >= 3 ? KWS_FAST_WAVE : 0)) + (size_t)(4 * F.wps) * F.wave_floats <= (size_t)kLdsBytes / 4 && !KWS_DEV_ENV("KWS_DEV_FAST_B_GLOBAL")) {
             k.h_b_off = (int)shared.size();
             shared.resize(shared.size() + fl);
             memcpy(&shared[(size_t)k.h_b_off], hfrag[b].data(), fl * sizeof(float));
@@ -658,7 +691,14 @@ EI_IMPULSE_ERROR build_fast_plans(kws_handle *h)
     record_silent_row(h);
     h->fast_plain_ok = build_fast_plain(h) == EI_IMPULSE_OK;
     if (!h->fast_plain_ok) h->fast_why = kws_last_error();
-    h->fast_fused_ok = h->fast_plain_ok && build_fast_fused(h) == EI_IMPULSE_OK;
+    // The float32-network forms exist at two and at three waves per SIMD (kws_fast.h).  Three pay when the LDS block holds twelve waves of the plan --
+    // three on every SIMD: 49x13 fp32 -10 % same-box -- and do not with eleven (one SIMD keeps two and the static split of the clips waits for the
+    // others: the 49x40 graph, +1.4 %; profiles/r06_occupancy.md): such a plan is laid out again for two.
+    int want_wps = 3, min_waves3 = 12;
+    if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_WPS")) { want_wps = atoi(ev) >= 3 ? 3 : 2; min_waves3 = 4; }       // development aid: force one of the builds (A/B runs)
+    h->fast_fused_ok = h->fast_plain_ok && build_fast_fused(h, want_wps) == EI_IMPULSE_OK;
+    if (h->fast_plain_ok && want_wps >= 3 && (!h->fast_fused_ok || h->fast_fused.n_waves < min_waves3))
+        h->fast_fused_ok = build_fast_fused(h, 2) == EI_IMPULSE_OK;
     if (h->fast_plain_ok && !h->fast_fused_ok) h->fast_why = kws_last_error();
     h->fast_q_ok = h->fast_plain_ok && !h->is_float && build_fast_q(h) == EI_IMPULSE_OK;
     if (h->fast_plain_ok && !h->is_float && !h->fast_q_ok) h->fast_why = kws_last_error();

@@ -3,7 +3,7 @@
 contraction loop, epilogue -- read from a scratch build of the library that carries the clock reads (KWS_LIB; built from a patched copy of
 csrc/kws_fast.hip by tools/round5/make_subprof_lib.sh, not part of the product).
 
-    KWS_LIB=ab_tmp/libkws_subprof.so python tools/gpu_fast_subphase.py [steps]"""
+    KWS_LIB=ab_tmp/libkws_subprof.so python tools/gpu_fast_subphase.py [steps] [waves per workgroup = 8]"""
 import ctypes
 import os
 import sys
@@ -33,7 +33,8 @@ def main():
         m.run_classifier_batch_device(pcm.data_ptr(), B, s.data_ptr())
     torch.cuda.synchronize()
     L.kws_dev_fast_sub(buf)
-    clips = steps * 32                                             # wave 0 of workgroup 0 sees 65 536 / 2 048 clips per step
+    waves = int(sys.argv[2]) if len(sys.argv) > 2 else 8           # waves per workgroup of the build (11 for the three-waves-per-SIMD build of the 49x40 graph)
+    clips = steps * B / (256 * waves)                              # wave 0 of workgroup 0 sees 65 536 / (256 x waves) clips per step
     names = ("split of the image into halves", "contraction loop", "epilogue")
     for b in (0, 1):
         tot = sum(buf[4 * b + i] for i in range(3)) or 1

@@ -32,5 +32,7 @@ s = s[:i] + "    SUBT(1);\n" + fin + "\n    SUBT(2);" + s[i + len(fin):]
 open(p, "w").write(s)
 PY
 mkdir -p "$ROOT/ab_tmp"
-make -s -C "$T/ei-keyword-spotting_amd/csrc" OUT="$ROOT/ab_tmp/libkws_subprof.so"
-ls -la "$ROOT/ab_tmp/libkws_subprof.so"
+# EXTRA="-DKWS_FAST_WPS=3" NAME=subprof3: the same for another build of the fast kernel (round 6)
+NAME=${NAME:-subprof}
+make -s -C "$T/ei-keyword-spotting_amd/csrc" OUT="$ROOT/ab_tmp/libkws_$NAME.so" ${EXTRA:+DEVFLAG="$EXTRA"}
+ls -la "$ROOT/ab_tmp/libkws_$NAME.so"
