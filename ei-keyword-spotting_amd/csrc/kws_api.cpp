@@ -521,9 +521,9 @@ EI_IMPULSE_ERROR cmvn_nn_fast_device(kws_handle *h, const float *mfcc, size_t B,
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         HIP_TRY(hipMemsetAsync(h->d_flags3, 0, sizeof(int), s));
     }
-    const KwsFastPlan &FP = fused ? h->fast_fused : h->fast_plain;
+    const KwsFastPlan &FP = fused ? h->fast_fused_cep : h->fast_plain;
     int *const fl = (fused && features) ? h->d_flags3 : h->d_flags;      // the feature-emitting launch's list stands (kws_internal.h: d_flags3)
-    rc = kws_launch_fast_from_cepstra(PR, FP, fused ? h->d_fast_fused : h->d_fast_plain, mfcc, (int)B, scores, fused ? nullptr : fx, q,
+    rc = kws_launch_fast_from_cepstra(PR, FP, fused ? h->d_fast_fused_cep : h->d_fast_plain, mfcc, (int)B, scores, fused ? nullptr : fx, q,
                                       h->nn.in_scale, h->nn.in_zp, fl, fl + 1, h->n_cu, s, nullptr, h->tap_logits);
     if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (!fused && scores) {
@@ -725,7 +725,7 @@ static EI_IMPULSE_ERROR rerun_flagged_device(kws_handle *h, const int16_t *pcm, 
     }
     if (fused) {
         int *const fl = want_f ? h->d_flags3 : h->d_flags2;
-        rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, h->s_cep, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
+        rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused_cep, h->d_fast_fused_cep, h->s_cep, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
                                           fl, fl + 1, h->n_cu, s, h->d_flags, h->tap_logits);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     } else if (scores) {
@@ -787,7 +787,7 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
             HIP_TRY(hipMemsetAsync(h->d_flags2, 0, sizeof(int), s));
             if ((e = mfcc_fused_device(h, pcm, 0, B, fx, nullptr, s))) return e;
             if (!scores) return EI_IMPULSE_OK;                               // extract_mfcc_features only
-            rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, fx, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
+            rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused_cep, h->d_fast_fused_cep, fx, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
                                               h->d_flags, h->d_flags + 1, h->n_cu, s, nullptr, h->tap_logits, 1);
             if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
             rc = kws_launch_nn_f32(h->nnf, h->d_nnf, fx, (int)B, scores, h->tap_logits, h->n_cu, s, h->d_flags);
@@ -827,7 +827,7 @@ static EI_IMPULSE_ERROR classify_fast_device(kws_handle *h, const int16_t *pcm, 
         rc = kws_launch_fast(h->dsp, h->fast_plain, h->d_fast_plain, pcm, (int)B, nullptr, fx, nullptr, h->nn.in_scale, h->nn.in_zp, h->d_flags, h->d_flags + 1, h->n_cu, s);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         HIP_TRY(hipMemsetAsync(h->d_flags3, 0, sizeof(int), s));
-        rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused, h->d_fast_fused, fx, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
+        rc = kws_launch_fast_from_cepstra(h->dsp, h->fast_fused_cep, h->d_fast_fused_cep, fx, (int)B, scores, nullptr, nullptr, h->nn.in_scale, h->nn.in_zp,
                                           h->d_flags3, h->d_flags3 + 1, h->n_cu, s, nullptr, h->tap_logits, 1);
         if (rc) return fail(KWS_ERROR_HIP, "fast kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return EI_IMPULSE_OK;

@@ -90,8 +90,6 @@ struct KwsFastPlan {
     int dct_off;                  // shared LDS: [dct_groups][2][dct_nt][64] B fragments: 2 cos(pi n (2k+1) / 2NF) * ortho scale
     float stale_scale;            // sqrtf(1/(2NF)): coefficients above NF/2 keep the log-mel input x 2 x this (fast-dct-fft.cpp:71)
     // ---- cmvnw
-    int wps;                      // waves per SIMD this plan is laid out for: 2, or 3 = the build of kws_fast.hip with <= 168 registers (12 / 11 waves per workgroup,
-                                  // 13-row cmvnw groups whatever the column count, twiddle table and one sink in the shared block, fragments that do not fit read from L2)
     int cr, cg;                   // rows per lane, columns per pass (13 x 16 or 17 x 20)
     int cnt_off, upd_off;         // shared LDS: cnt[64/cg][n_frames rounded up to 8] window multiplicities of each row group's first
                                   // window; upd[n_frames] = offset of the padded row leaving | entering << 16 (floats, image relative)
@@ -119,10 +117,6 @@ struct KwsFastPlan {
     // those rows carry no spectral error: the guard's absolute / per-level terms are scaled by sqrt(live rows / rows) and its level is the
     // live rows' (round 6).  sil_off: shared LDS, 32 floats (columns 0 .. 31; only 1 .. NF/2 are read), or -1: not recorded
     int sil_off;
-    // (wps = 3 only) shared LDS: the spectral pass loop's last-level and split twiddles per lane & 7 --
-    // [8][12] x float2 { tw[k], tw[2 k], tw[3 k] } for k = fl + 8 a, then [8][8] x float2 super twiddles of the lane's eight bin pairs -- read per
-    // pass instead of living in 40 registers (a register reloaded from scratch inside the pass loop waits for the pass's sample prefetch: one counter)
-    int twl_off;
     float sys_t2;                 // (deviation / |mean|)^2 below which a column's window sums are taken to round systematically (its alternative rel coefficient)
     // ---- per-wave LDS: F = image [n_frames][fs] (log-mel -> cepstra -> features = block 0's input) + log energies [n_frames];
     //      R1 = the FFT's exchange buffer (reused for the eight power rows), later the other activation image
@@ -141,4 +135,15 @@ struct KwsFastPlan {
     int fc_in, fc_out, fc_w_off, fc_b_off;
     float fc_min, fc_max, beta;
     int n_labels;
+    // ---- (round 6; at the end: the offsets of everything above stay what the two-waves-per-SIMD forms were tuned with)
+    int wps;                      // waves per SIMD this plan is laid out for: 2, or 3 = the build of kws_fast.hip with <= 168 registers (12 / 11 waves per workgroup,
+                                  // 13-row cmvnw groups whatever the column count, twiddle table and one sink in the shared block, fragments that do not fit read from L2)
+    // (wps = 3 only) shared LDS: the spectral pass loop's last-level and split twiddles per lane & 7 --
+    // [8][12] x float2 { tw[k], tw[2 k], tw[3 k] } for k = fl + 8 a, then [8][8] x float2 super twiddles of the lane's eight bin pairs -- read per
+    // pass instead of living in 40 registers (a register reloaded from scratch inside the pass loop waits for the pass's sample prefetch: one counter)
+    int twl_off;
+    // (wps = 3 only) two counters in device memory that take turns by launch: the kernel deals its clips out by tickets (kws_fast.hip: the clip loop);
+    // launch_epoch is the HOST copy's count of launches (the device copy's is never read)
+    int *tickets;
+    mutable unsigned launch_epoch;
 };

@@ -20,7 +20,6 @@
 #if KWS_FAST_WPS >= 3
 #define kws_fast_kernel kws_fast_kernel_w3
 #define kws_launch_fast kws_launch_fast_w3
-#define kws_launch_fast_from_cepstra kws_launch_fast_from_cepstra_w3
 #define kws_launch_fast_prof kws_launch_fast_prof_w3
 #endif
 #include "kws_nn_int8_dev.h"
@@ -32,7 +31,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #if KWS_FAST_WPS >= 3
 #define KWS_OPAQUE3(v) asm volatile("" : "+v"(v))
 #define KWS_FAST_SINK (shared + FP.sink_off)          // one sink per workgroup (KwsFastPlan::sink_off is relative to the shared block in this build)
+#define KWS_FAST_EPOCH_PARAM , unsigned epoch = 0     // this build deals its clips out by tickets (kws_fast_kernel: the clip loop); the launch's number picks the counter
 #else
+#define KWS_FAST_EPOCH_PARAM
 #define KWS_OPAQUE3(v) do { } while (0)
 #define KWS_FAST_SINK (F + FP.sink_off)               // a sink per wave, behind its image
 #endif
@@ -824,20 +825,33 @@ __device__ __forceinline__ float fast_cmvn(float *__restrict__ img, const float 
     int u[CR - 1];                                    // leaving row offset | entering row offset << 16 (floats)
     int xo[KWS_FAST_CMVN_EXT];
     float we[KWS_FAST_CMVN_EXT], m0 = 0.0f;
-    auto tables = [&](int r0_, int cgrp_) {
+#if KWS_FAST_WPS < 3
 #pragma unroll
-        for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0_ + i, nfr - 1)];
-        if (ext_tab) {
-            const float *ext = ext_tab + cgrp_ * (1 + 2 * KWS_FAST_CMVN_EXT);
-            m0 = ext[0];
+    for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0 + i, nfr - 1)];
+    if (ext_tab) {
+        const float *ext = ext_tab + cgrp * (1 + 2 * KWS_FAST_CMVN_EXT);
+        m0 = ext[0];
 #pragma unroll
-            for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) { xo[e] = __float_as_int(ext[1 + 2 * e]); we[e] = ext[2 + 2 * e]; }
-        }
-    };
-    if (KWS_FAST_WPS < 3) tables(r0, cgrp);
+        for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) { xo[e] = __float_as_int(ext[1 + 2 * e]); we[e] = ext[2 + 2 * e]; }
+    }
+#endif
     for (int cb = 0; cb < ncep; cb += CG) {
+#if KWS_FAST_WPS >= 3
         // (three waves per SIMD: the tables are re-read from LDS in every column block -- kept across the blocks, their ~20 registers are spilled and come back one by one)
-        if (KWS_FAST_WPS >= 3) { int cg_ = cgrp; KWS_OPAQUE3(cg_); tables(cg_ * CR, cg_); }
+        {
+            int cg_ = cgrp;
+            KWS_OPAQUE3(cg_);
+            const int r0_ = cg_ * CR;
+#pragma unroll
+            for (int i = 0; i < CR - 1; ++i) u[i] = upd[min(r0_ + i, nfr - 1)];
+            if (ext_tab) {
+                const float *ext = ext_tab + cg_ * (1 + 2 * KWS_FAST_CMVN_EXT);
+                m0 = ext[0];
+#pragma unroll
+                for (int e = 0; e < KWS_FAST_CMVN_EXT; ++e) { xo[e] = __float_as_int(ext[1 + 2 * e]); we[e] = ext[2 + 2 * e]; }
+            }
+        }
+#endif
         const int c = cb + cl;
         const bool act = lane_on && c < ncep && r0 < nfr;
         float *col = img + min(c, ncep - 1);
@@ -980,7 +994,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,
                                                           long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr,
                                                           const KwsNnPlan *__restrict__ QNp = nullptr, const int *__restrict__ sel = nullptr,
-                                                          float *__restrict__ tap_logits = nullptr, int feat_in = 0)
+                                                          float *__restrict__ tap_logits = nullptr, int feat_in = 0 KWS_FAST_EPOCH_PARAM)
 {
     static_assert(QCP == 0 || !NET, "the int8 network follows the feature-emitting form");
     static_assert(!MFE || (!NET && QCP == 0 && !FROM_CEP && !PROF), "the MFE form is the spectral prefix: mel energies to HBM");
@@ -991,6 +1005,10 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
     const int lane = threadIdx.x & (KWS_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
     // a workgroup none of whose waves has a clip (the usually empty list of the second tier, a short list) leaves before it stages
     // its 50 KB of tables
+#if KWS_FAST_WPS >= 3
+    // (clips by ticket, see the clip loop: every launch -- also one whose list is empty -- zeroes the counter the handle's NEXT launch will draw from)
+    if (blockIdx.x == 0 && threadIdx.x == 0) FP.tickets[(epoch + 1) & 1] = 0;
+#endif
     if (FROM_CEP && (int)blockIdx.x * (int)(blockDim.x >> 6) >= sel_count(sel, n_clips)) return;
     float *shared = lds;
     float *F = lds + FP.shared_floats + FP.q_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
@@ -1055,9 +1073,28 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
     // (only the forms that start from cepstra are launched over a list: the PCM forms see every clip, and their paired tail pass needs
     // no list look-ups)
     const int n_sel = FROM_CEP ? sel_count(sel, n_clips) : n_clips;
+#if KWS_FAST_WPS >= 3
+    // Three waves per SIMD, clips by TICKET: a workgroup of eleven waves leaves one SIMD with two, whose waves run faster -- with the static split below they
+    // finish early and the launch waits for the SIMDs that hold three (vector pipe 80 % occupied where twelve waves reach 89 %, profiles/r06_occupancy.md).
+    // A wave's first clip is its own number; every further one is drawn from a counter in device memory, two clips ahead (the paired tail pass and the
+    // prefetches want the NEXT clip when a clip starts): the draw's round trip ends long before its value is looked at.  Two counters take turns by
+    // launch (epoch & 1); a launch zeroes the one its successor will use (at the kernel's top) -- launches of a handle are serial (its flag lists are too).
+    int *const tk = FP.tickets + (epoch & 1);
+    int tv = 0;                                                       // lane 0: the ticket drawn last
+    auto draw = [&]() { if (lane == 0) tv = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    draw();
+    int ni = clip_stride + __builtin_amdgcn_readfirstlane(tv);
+    draw();
+    for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci = ni, ni = clip_stride + __builtin_amdgcn_readfirstlane(tv), draw()) {
+        const int clip = FROM_CEP ? sel_clip(sel, ci) : ci;
+        const int next_ci = ni;
+        const int next_clip = ni < n_sel ? ni : -1;                                    // the wave's next clip (paired tail pass; PCM forms only)
+#else
     for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci += clip_stride) {
         const int clip = FROM_CEP ? sel_clip(sel, ci) : ci;
+        const int next_ci = ci + clip_stride;
         const int next_clip = ci + clip_stride < n_sel ? ci + clip_stride : -1;        // the wave's next clip (paired tail pass; PCM forms only)
+#endif
         // ---- per-lane constants of the spectral phase (the FFT is kws_mfcc_kernel's: KissFFT's order, bit for bit).  They are
         //      re-derived per clip from a lane index the compiler cannot see through: hoisted out of the clip loop, the FFT's
         //      twiddles and the three dozen LDS addresses of the pair loop stay live through the DCT, cmvnw and convolution phases
@@ -1128,8 +1165,8 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
             trips(0, 4 * KWS_WAVE);
             // ... and the NEXT window of this wave: one touch per 64-byte line (two per lane cover 8 KB), so that its requests find their lines
             // in the cache a window later; the values are only handed to an empty asm statement at the end of this window
-            if (ci + clip_stride < n_sel) {
-                const char *nsrc = (const char *)(cep + (size_t)sel_clip(sel, ci + clip_stride) * n_val);
+            if (next_ci < n_sel) {
+                const char *nsrc = (const char *)(cep + (size_t)sel_clip(sel, next_ci) * n_val);
                 const int nbytes = n_val * 4 - 4;
                 touched_a = *(const int *)(nsrc + (min(128 * lane, nbytes) & ~3));
                 touched_b = *(const int *)(nsrc + (min(128 * lane + 64, nbytes) & ~3));
@@ -1814,9 +1851,6 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
 // the same launchers of kws_fast.hip's second compilation (three waves per SIMD, float32-network forms; kws_fast.h): reached through the ones above
 int kws_launch_fast_w3(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores, float *features,
                        int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream, const KwsNnPlan *d_nn, float *tap_logits);
-int kws_launch_fast_from_cepstra_w3(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
-                                    float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
-                                    const int *sel, float *tap_logits, int feat_in);
 int kws_launch_fast_prof_w3(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,
                             int *flag_count, int *flag_list, int n_cu, long long *prof_out, hipStream_t stream);
 #endif
@@ -1840,8 +1874,14 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     const int per_wg = FP.n_waves;
     int grid = (n_clips + per_wg - 1) / per_wg;
     if (grid > n_cu) grid = n_cu;
+#if KWS_FAST_WPS >= 3
+    if (!FP.tickets) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
+                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel, tap_logits, feat_in, FP.launch_epoch++);
+#else
     hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
                        features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel, tap_logits, feat_in);
+#endif
     return (int)hipGetLastError();
 }
 
@@ -1902,6 +1942,7 @@ size_t kws_fast_qnet_bytes(int qcp)
 }
 #endif
 
+#if KWS_FAST_WPS < 3
 // cmvnw + (fused float network | features / int8 tensor) from cepstra in HBM, ring-indexed per P.ring_* (continuous mode)
 int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const float *cep, int n_clips, float *scores,
                                  float *features, int8_t *q_out, float in_scale, int in_zp, int *flag_count, int *flag_list, int n_cu, hipStream_t stream,
@@ -1910,17 +1951,14 @@ int kws_launch_fast_from_cepstra(const KwsDspPlan &P, const KwsFastPlan &FP, con
     (void)hipGetLastError();
     if (n_clips <= 0) return 0;
     if (feat_in && !FP.fuse) return (int)hipErrorInvalidValue;          // features in: only the fused network is left to run
-#if KWS_FAST_WPS >= 3
-    if (FP.wps != KWS_FAST_WPS || !FP.fuse) return (int)hipErrorInvalidValue;
-#else
-    if (FP.wps >= 3) return kws_launch_fast_from_cepstra_w3(P, FP, d_plan, cep, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list, n_cu, stream, sel, tap_logits, feat_in);
-#endif
+    if (FP.wps != KWS_FAST_WPS) return (int)hipErrorInvalidValue;       // (the forms that start from cepstra exist at two waves per SIMD only: kws_internal.h, fast_fused_cep)
     // mel taps / DCT are not part of this variant: one instantiation serves every model
     return FP.fuse ? launch_fast_t<4, 4, false, true>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count, flag_list,
                                                       n_cu, nullptr, stream, cep, nullptr, sel, tap_logits, feat_in)
                    : KWS_FAST_PLAIN((launch_fast_t<4, 4, false, true, false>(P, FP, d_plan, nullptr, n_clips, scores, features, q_out, in_scale, in_zp, flag_count,
                                                              flag_list, n_cu, nullptr, stream, cep, nullptr, sel)));
 }
+#endif
 
 // development aid: phase clocks (<= 4-tap builds only)
 int kws_launch_fast_prof(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFastPlan *d_plan, const int16_t *pcm, int n_clips, float *scores,

@@ -471,8 +471,15 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
                                    F.shared_floats * 4, F.wave_floats * 4);
     EI_IMPULSE_ERROR e = h->upload(shared, &F.shared_init);
     if (e) return e;
+    F.tickets = nullptr;
+    F.launch_epoch = 0;
+    if (F.wps >= 3) {
+        const int *dev = nullptr;
+        if ((e = h->upload(std::vector<int>(4, 0), &dev))) return e;
+        F.tickets = const_cast<int *>(dev);
+    }
     std::vector<KwsFastPlan> one(1, F);
-    return h->upload(one, &F == &h->fast_fused ? &h->d_fast_fused : &F == &h->fast_q ? &h->d_fast_q : &h->d_fast_plain);
+    return h->upload(one, &F == &h->fast_fused ? &h->d_fast_fused : &F == &h->fast_fused_cep ? &h->d_fast_fused_cep : &F == &h->fast_q ? &h->d_fast_q : &h->d_fast_plain);
 }
 
 // plain form: extract_mfcc_features only; the feature matrix and / or the int8 input tensor go to HBM
@@ -521,9 +528,8 @@ static EI_IMPULSE_ERROR build_fast_q(kws_handle *h)
 }
 
 // fused form: float32 graphs made of CONV_2D blocks only
-static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h, int wps)
+static EI_IMPULSE_ERROR build_fast_fused(kws_handle *h, int wps, KwsFastPlan &F)
 {
-    KwsFastPlan &F = h->fast_fused;
     memset(&F, 0, sizeof(F));
     F.wps = wps;
     if (!h->is_float) return fail(KWS_ERROR_UNSUPPORTED_MODEL, "fast mode: the fused network is float32 (int8 graphs keep their exact kernels)");
@@ -691,14 +697,20 @@ EI_IMPULSE_ERROR build_fast_plans(kws_handle *h)
     record_silent_row(h);
     h->fast_plain_ok = build_fast_plain(h) == EI_IMPULSE_OK;
     if (!h->fast_plain_ok) h->fast_why = kws_last_error();
-    // The float32-network forms exist at two and at three waves per SIMD (kws_fast.h).  Three pay when the LDS block holds twelve waves of the plan --
-    // three on every SIMD: 49x13 fp32 -10 % same-box -- and do not with eleven (one SIMD keeps two and the static split of the clips waits for the
-    // others: the 49x40 graph, +1.4 %; profiles/r06_occupancy.md): such a plan is laid out again for two.
-    int want_wps = 3, min_waves3 = 12;
+    // The float32-network forms exist at two and at three waves per SIMD (kws_fast.h).  Three pay where a batch enters through the PCM form and the LDS block
+    // holds at least eleven waves of the plan (same-box, profiles/r06_occupancy.md: 49x13 fp32 twelve waves -8.7 %, the 49x40 graph eleven waves -6.1 % with
+    // the clips dealt out by ticket); a graph that enters through the exact kernels' features runs only its network there and is 2.4 % slower at eleven
+    // waves with its fragments read from L2 (the 7-block DS-CNN): such a plan, and one that holds fewer waves, is laid out for two.
+    int want_wps = h->fast_entry_tier <= 1 ? 3 : 2, min_waves3 = 11;
     if (const char *ev = KWS_DEV_ENV("KWS_DEV_FAST_WPS")) { want_wps = atoi(ev) >= 3 ? 3 : 2; min_waves3 = 4; }       // development aid: force one of the builds (A/B runs)
-    h->fast_fused_ok = h->fast_plain_ok && build_fast_fused(h, want_wps) == EI_IMPULSE_OK;
+    h->fast_fused_ok = h->fast_plain_ok && build_fast_fused(h, want_wps, h->fast_fused) == EI_IMPULSE_OK;
     if (h->fast_plain_ok && want_wps >= 3 && (!h->fast_fused_ok || h->fast_fused.n_waves < min_waves3))
-        h->fast_fused_ok = build_fast_fused(h, 2) == EI_IMPULSE_OK;
+        h->fast_fused_ok = build_fast_fused(h, 2, h->fast_fused) == EI_IMPULSE_OK;
+    // the launches that start from cepstra or features keep the two-wave layout (kws_internal.h: fast_fused_cep)
+    if (h->fast_fused_ok) {
+        if (h->fast_fused.wps >= 3) h->fast_fused_ok = build_fast_fused(h, 2, h->fast_fused_cep) == EI_IMPULSE_OK;
+        else { h->fast_fused_cep = h->fast_fused; h->d_fast_fused_cep = h->d_fast_fused; }
+    }
     if (h->fast_plain_ok && !h->fast_fused_ok) h->fast_why = kws_last_error();
     h->fast_q_ok = h->fast_plain_ok && !h->is_float && build_fast_q(h) == EI_IMPULSE_OK;
     if (h->fast_plain_ok && !h->is_float && !h->fast_q_ok) h->fast_why = kws_last_error();

@@ -221,6 +221,10 @@ struct kws_handle {
     struct Gain { std::vector<float> col; float sigma_net = 0.0f, total = 0.0f; int calibrated = 0, n_inputs = 0; } gain;
     KwsFastPlan fast_plain{}, fast_fused{}, fast_q{};   // features / int8 tensor to HBM; float32 graph fused; int8 two-block graph fused
     const KwsFastPlan *d_fast_plain = nullptr, *d_fast_fused = nullptr, *d_fast_q = nullptr;     // the same plans in device memory
+    // the fused plan of the launches that start from cepstra or features (continuous mode, the second tier of a batch call, the features-in route): always
+    // laid out for two waves per SIMD -- those forms are 15 - 47 % slower in the three-wave build (profiles/r06_occupancy.md); equal to fast_fused when that is
+    KwsFastPlan fast_fused_cep{};
+    const KwsFastPlan *d_fast_fused_cep = nullptr;
     const KwsNnPlan *d_nn = nullptr;                    // the int8 plan in device memory (the fused form reads it from there)
     bool fast_plain_ok = false, fast_fused_ok = false, fast_q_ok = false;
     std::string fast_why;
