@@ -54,7 +54,8 @@ class FastTolerance(C.Structure):
     _fields_ = [("score_tol", C.c_float), ("k_sigma", C.c_float), ("lin_margin", C.c_float), ("logit_cap", C.c_float), ("g_c1", C.c_float),
                 ("g_c2", C.c_float), ("sigma_net", C.c_float), ("total_gain", C.c_float), ("uniform_feature_tol", C.c_float),
                 ("calibrated", C.c_int), ("n_columns", C.c_int), ("n_frames", C.c_int), ("entry_tier", C.c_int), ("dev_overrides", C.c_int),
-                ("k_sigma_worst_column", C.c_float), ("silent_rows_exact", C.c_int), ("systematic_ratio", C.c_float)]
+                ("k_sigma_worst_column", C.c_float), ("silent_rows_exact", C.c_int), ("systematic_ratio", C.c_float),
+                ("fused_waves_per_simd", C.c_int), ("fused_waves", C.c_int)]
 
 
 class KwsError(RuntimeError):

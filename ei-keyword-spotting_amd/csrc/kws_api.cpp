@@ -173,6 +173,7 @@ EI_IMPULSE_ERROR kws_fast_tolerance_info(const kws_handle *h, kws_fast_tolerance
     out->k_sigma_worst_column = (h->is_float && h->gain.calibrated) ? out->k_sigma / 1.3f : out->k_sigma;
     out->silent_rows_exact = F.sil_off >= 0 ? 1 : 0;
     out->systematic_ratio = sqrtf(F.sys_t2);
+    if (h->fast_fused_ok) { out->fused_waves_per_simd = h->fast_fused.wps; out->fused_waves = h->fast_fused.n_waves; }
     out->sigma_net = sqrtf(F.v_net);       // the terms of V that do not depend on the clip: the fused network's re-ordering noise, the deviation's own error
     // sum of gain^2 over every feature: a feature error of rms size t on every feature gives V = sigma_net^2 + t^2 x this
     double g2 = 0.0;

@@ -133,6 +133,9 @@ typedef struct {
     float systematic_ratio;                            /* a column whose deviation is below this x |mean| in a lane's first window (rows 0, cr, 2 cr ... of the kernel's
                                                           row groups, cr = 13 for up to 16 columns, else 17) takes the alternative rel coefficient, like a clip with silent frames (column 0 of
                                                           such a clip always has its window means replayed) */
+    int fused_waves_per_simd, fused_waves;             /* (round 6) the build of the fast kernel a float32 graph's batch calls enter through: 2 waves per SIMD (8 per
+                                                          workgroup, 256 registers) or 3 (12 / 11 per workgroup, <= 168 registers, clips dealt out by ticket: plans that
+                                                          enter through the PCM form and hold at least eleven waves in the LDS block); 0, 0: no fused float32 form */
 } kws_fast_tolerance;
 EI_IMPULSE_ERROR kws_fast_fallback_count(kws_handle *h, size_t *count);
 EI_IMPULSE_ERROR kws_fast_exact_count(kws_handle *h, size_t *count);

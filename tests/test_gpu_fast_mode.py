@@ -231,6 +231,46 @@ def test_fast_mode_edge_batches_and_mode_switch(pkg, oracle):
     gm.close()
 
 
+@pytest.mark.parametrize("name,wps,waves", [("l476_no_yes_f32.kwsm", 3, 12), ("cfg2_mfcc40_f32.kwsm", 3, 11), ("cfg5_dscnn_mfcc40_f32.kwsm", 2, 8)])
+def test_three_waves_per_simd_forms(name, wps, waves, pkg, dev_pkg, oracle):
+    """Round 6: the float32-network forms exist for two and for three waves per SIMD (csrc/kws_fast.h: KWS_FAST_WPS; the second compilation deals its
+    clips out by tickets drawn from a counter in device memory).  Which one a model runs is the plan's choice (kws_fast_tolerance::fused_waves_per_simd);
+    whichever it is, a batch's scores do not depend on which wave took which clip: repeated calls -- the ticket counters take turns by launch -- and batch
+    sizes around the wave count give the same bits, both builds stay within the fast mode's bar of the oracle, and they agree with each other to the
+    arithmetic both share (the cmvnw row groups differ for 40-column matrices: 13 rows per lane against 17)."""
+    import torch
+    path = os.path.join(MODELS, name)
+    gm = pkg.Model(path, device=0)
+    tol = gm.fast_tolerance()
+    assert (tol["fused_waves_per_simd"], tol["fused_waves"]) == (wps, waves), tol
+    om = OracleModel(oracle, path)
+    n = 4099                                                                    # not a multiple of either workgroup size
+    host = oracle.synth(77, 5, n)
+    pcm = torch.from_numpy(host).to("cuda:0")
+    so = om.run_batch(host)
+    first = None
+    for rep in range(5):                                                        # odd and even launch numbers: both ticket counters
+        s, _, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm, want_f=False)
+        assert np.abs(s - so).max() <= FAST_SCORE_TOL, (name, rep)
+        first = s if first is None else first
+        assert (bits(s) == bits(first)).all(), (name, rep)
+    for m in (1, 7, 11, 12, 13, 255, 256 * waves + 1):                          # fewer clips than waves, one more than a whole round of the grid
+        s, _, _ = run_device(pkg, gm, pkg.MODE_FAST, pcm[:m].contiguous(), want_f=False)
+        assert (bits(s) == bits(first[:m])).all(), (name, m)
+    gm.close()
+    if wps == 3:
+        # the same model forced onto the other build (development library): both within the bar, and close to each other
+        os.environ["KWS_DEV_FAST_WPS"] = "2"
+        try:
+            g2 = dev_pkg.Model(path, device=0)
+        finally:
+            del os.environ["KWS_DEV_FAST_WPS"]
+        assert g2.fast_tolerance()["fused_waves_per_simd"] == 2
+        s2, _, _ = run_device(dev_pkg, g2, dev_pkg.MODE_FAST, pcm, want_f=False)
+        assert np.abs(s2 - so).max() <= FAST_SCORE_TOL and np.abs(s2 - first).max() <= 2e-5, name
+        g2.close()
+
+
 def test_fast_mode_depthwise_separable_graph_is_fused_and_extract_mfcc(pkg, oracle):
     """BASELINE configs[4]'s float graph (49x40 MFCC + 7-block depthwise-separable CNN): since round 3 the fast kernel runs it fused
     -- pointwise 1x1 CONV_2D blocks on the matrix cores, DEPTHWISE_CONV_2D taps on the vector ALU, more than four blocks -- so the
