@@ -142,8 +142,7 @@ struct KwsFastPlan {
     // [8][12] x float2 { tw[k], tw[2 k], tw[3 k] } for k = fl + 8 a, then [8][8] x float2 super twiddles of the lane's eight bin pairs -- read per
     // pass instead of living in 40 registers (a register reloaded from scratch inside the pass loop waits for the pass's sample prefetch: one counter)
     int twl_off;
-    // (wps = 3 only) two counters in device memory that take turns by launch: the kernel deals its clips out by tickets (kws_fast.hip: the clip loop);
-    // launch_epoch is the HOST copy's count of launches (the device copy's is never read)
+    // (wps = 3 only) two words in device memory, zero between launches: the ticket counter the kernel deals its clips out by, and the count of waves that
+    // have left (kws_fast.hip: the clip loop and the kernel's end)
     int *tickets;
-    mutable unsigned launch_epoch;
 };

@@ -31,9 +31,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #if KWS_FAST_WPS >= 3
 #define KWS_OPAQUE3(v) asm volatile("" : "+v"(v))
 #define KWS_FAST_SINK (shared + FP.sink_off)          // one sink per workgroup (KwsFastPlan::sink_off is relative to the shared block in this build)
-#define KWS_FAST_EPOCH_PARAM , unsigned epoch = 0     // this build deals its clips out by tickets (kws_fast_kernel: the clip loop); the launch's number picks the counter
 #else
-#define KWS_FAST_EPOCH_PARAM
 #define KWS_OPAQUE3(v) do { } while (0)
 #define KWS_FAST_SINK (F + FP.sink_off)               // a sink per wave, behind its image
 #endif
@@ -994,7 +992,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                                                           int *__restrict__ flag_count, int *__restrict__ flag_list,
                                                           long long *__restrict__ prof_out = nullptr, const float *__restrict__ cep = nullptr,
                                                           const KwsNnPlan *__restrict__ QNp = nullptr, const int *__restrict__ sel = nullptr,
-                                                          float *__restrict__ tap_logits = nullptr, int feat_in = 0 KWS_FAST_EPOCH_PARAM)
+                                                          float *__restrict__ tap_logits = nullptr, int feat_in = 0)
 {
     static_assert(QCP == 0 || !NET, "the int8 network follows the feature-emitting form");
     static_assert(!MFE || (!NET && QCP == 0 && !FROM_CEP && !PROF), "the MFE form is the spectral prefix: mel energies to HBM");
@@ -1005,10 +1003,6 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
     const int lane = threadIdx.x & (KWS_WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // uniform: per-wave addresses stay in scalar registers
     // a workgroup none of whose waves has a clip (the usually empty list of the second tier, a short list) leaves before it stages
     // its 50 KB of tables
-#if KWS_FAST_WPS >= 3
-    // (clips by ticket, see the clip loop: every launch -- also one whose list is empty -- zeroes the counter the handle's NEXT launch will draw from)
-    if (blockIdx.x == 0 && threadIdx.x == 0) FP.tickets[(epoch + 1) & 1] = 0;
-#endif
     if (FROM_CEP && (int)blockIdx.x * (int)(blockDim.x >> 6) >= sel_count(sel, n_clips)) return;
     float *shared = lds;
     float *F = lds + FP.shared_floats + FP.q_floats + wave * FP.wave_floats;       // log-mel -> cepstra -> features (block 0's input image)
@@ -1077,15 +1071,19 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
     // Three waves per SIMD, clips by TICKET: a workgroup of eleven waves leaves one SIMD with two, whose waves run faster -- with the static split below they
     // finish early and the launch waits for the SIMDs that hold three (vector pipe 80 % occupied where twelve waves reach 89 %, profiles/r06_occupancy.md).
     // A wave's first clip is its own number; every further one is drawn from a counter in device memory, two clips ahead (the paired tail pass and the
-    // prefetches want the NEXT clip when a clip starts): the draw's round trip ends long before its value is looked at.  Two counters take turns by
-    // launch (epoch & 1); a launch zeroes the one its successor will use (at the kernel's top) -- launches of a handle are serial (its flag lists are too).
-    int *const tk = FP.tickets + (epoch & 1);
+    // prefetches want the NEXT clip when a clip starts): the draw's round trip ends long before its value is looked at.  The counter cleans up after
+    // itself -- a wave that leaves counts itself out, and the last one to do so zeroes both words (below the loop) --, so a launch needs nothing from the
+    // host: no argument that changes from launch to launch, no memset.  Launches of a handle are serial (its flag
+    // lists are too).
+    int *const tk = FP.tickets;
     int tv = 0;                                                       // lane 0: the ticket drawn last
-    auto draw = [&]() { if (lane == 0) tv = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    int ni = 0;
+    // (a draw only while the clip it would follow exists: when the wave leaves the loop, every draw it made has been waited for)
+    auto draw = [&]() { if (ni < n_sel && lane == 0) tv = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     draw();
-    int ni = clip_stride + __builtin_amdgcn_readfirstlane(tv);
+    ni = clip_stride + __builtin_amdgcn_readfirstlane(tv);
     draw();
-    for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci = ni, ni = clip_stride + __builtin_amdgcn_readfirstlane(tv), draw()) {
+    for (int ci = blockIdx.x * n_waves + wave; ci < n_sel; ci = ni, ni = ni < n_sel ? clip_stride + __builtin_amdgcn_readfirstlane(tv) : ni, draw()) {
         const int clip = FROM_CEP ? sel_clip(sel, ci) : ci;
         const int next_ci = ni;
         const int next_clip = ni < n_sel ? ni : -1;                                    // the wave's next clip (paired tail pass; PCM forms only)
@@ -1839,6 +1837,19 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
         FPH(8);
         }   // NET
     }
+#if KWS_FAST_WPS >= 3
+    // the ticket counter's clean-up: every draw of this wave has landed (its value was waited for: the clip loop), so the wave counts itself out; the last
+    // wave of the launch finds every other wave's count -- hence every draw -- behind it and zeroes both words for the next launch
+    if (lane == 0) {
+        // (relaxed: the counters are only ever touched by atomics, which meet in one place, and each wave has waited for its own; an acquire / release
+        // pair at agent scope writes back and invalidates the caches under the waves that are still running: +5 % on the whole launch)
+        const int gone = __hip_atomic_fetch_add(FP.tickets + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == (int)(gridDim.x * (blockDim.x >> 6)) - 1) {
+            __hip_atomic_store(FP.tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(FP.tickets + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#endif
     if (PROF && blockIdx.x == 0 && threadIdx.x == 0 && prof_out)
         for (int i = 0; i < KWS_FAST_NPHASE; ++i) prof_out[i] = ph[i];
 }
@@ -1876,12 +1887,9 @@ static int launch_fast_t(const KwsDspPlan &P, const KwsFastPlan &FP, const KwsFa
     if (grid > n_cu) grid = n_cu;
 #if KWS_FAST_WPS >= 3
     if (!FP.tickets) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
-                       features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel, tap_logits, feat_in, FP.launch_epoch++);
-#else
+#endif
     hipLaunchKernelGGL((kws_fast_kernel<NZ, DG, PROF, FROM_CEP, NET, QCP, MFE>), dim3(grid), dim3(KWS_WAVE * FP.n_waves), smem, stream, P, d_plan, pcm, n_clips, scores,
                        features, q_out, in_scale, in_zp, flag_count, flag_list, prof_out, cep, d_nn, sel, tap_logits, feat_in);
-#endif
     return (int)hipGetLastError();
 }
 

@@ -472,7 +472,6 @@ static EI_IMPULSE_ERROR finish_fast_plan(kws_handle *h, KwsFastPlan &F, std::vec
     EI_IMPULSE_ERROR e = h->upload(shared, &F.shared_init);
     if (e) return e;
     F.tickets = nullptr;
-    F.launch_epoch = 0;
     if (F.wps >= 3) {
         const int *dev = nullptr;
         if ((e = h->upload(std::vector<int>(4, 0), &dev))) return e;

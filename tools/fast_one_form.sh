@@ -8,14 +8,9 @@ HERE=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 cat > $T/one.hip <<EOF
 #define KWS_FAST_NO_LAUNCHERS
-#if KWS_FAST_WPS >= 3
-#define KWS_ONE_EPOCH , unsigned
-#else
-#define KWS_ONE_EPOCH
-#endif
 #include "$HERE/ei-keyword-spotting_amd/csrc/kws_fast.hip"
 template __global__ void kws_fast_kernel$FORM(KwsDspPlan, const KwsFastPlan *, const int16_t *, int, float *, float *, int8_t *, float, int, int *, int *, long long *, const float *,
-                                              const KwsNnPlan *, const int *, float *, int KWS_ONE_EPOCH);
+                                              const KwsNnPlan *, const int *, float *, int);
 EOF
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DKWS_BUILDING_LIBRARY -fno-slp-vectorize "$@" -I$HERE/ei-keyword-spotting_amd/csrc -S --cuda-device-only -o $T/one.s $T/one.hip 2>&1 | grep -v "hip-link" || true
 grep -E "^\s*; (NumVgprs|ScratchSize|Occupancy|LDSByteSize|VGPRBlocks|NumSgprs):|vgpr_spill_count|\.vgpr_count" $T/one.s | head -12
