@@ -30,8 +30,11 @@ pa = prof.cpu().numpy()
 p = pa[:12]
 names = ["load+preemph", "fft", "split+power+energy", "mel+log", "dct", "cmvn", "conv block 0", "conv blocks 1+", "fc+softmax", "(block 0: k loop)", "(block 0: epilogue)", "(block 0: preamble)"]
 tot = p[:9].sum()
-nclips = max(1, B // (256 * int(os.environ.get("KWS_DEV_FAST_WAVES", "8"))))
-print(os.path.basename(path), "rc", rc, "clips by wave 0 ~", nclips, "total cycles", tot, "per clip", tot / nclips)
+tolr = m.fast_tolerance()
+waves = int(os.environ.get("KWS_DEV_FAST_WAVES", tolr.get("fused_waves") or 8))
+nclips = max(1, B // (256 * waves))
+# (three waves per SIMD: the clips are dealt out by ticket, wave 0's count is only about B / waves in all -- read the shares, not the clocks per clip)
+print(os.path.basename(path), "rc", rc, "waves per workgroup", waves, "(per SIMD: %s)" % tolr.get("fused_waves_per_simd"), "clips by wave 0 ~", nclips, "total cycles", tot, "per clip ~", tot / nclips)
 for n, v in zip(names, p):
     if n.startswith("(") and (v <= 0 or v > tot):      # block 0's sub-phase slots: only the fp32-instruction form of the convolution writes them
         continue
