@@ -11,6 +11,12 @@
 // phase is written to keep its own memory operations in flight: loads of a phase are issued as one batch before the arithmetic that
 // consumes them, tile counts are template parameters (no predicated code inside the contraction loops), and the convolution loops
 // fetch their operands ahead of the matrix instructions.  DESIGN.md 4.4 has the phase table, the counters and what was tried and rejected.
+//
+// Round 6: this file is compiled TWICE (csrc/Makefile).  The second compilation, -DKWS_FAST_WPS=3 -> kws_fast_w3.o, builds the PCM-entry float32-network
+// forms for three waves per SIMD (<= 168 registers, twelve / eleven waves per workgroup) under the names *_w3; what it does differently sits behind
+// KWS_FAST_WPS >= 3 below -- twiddles of the pass loop from an LDS table, no register reloaded from scratch inside a loop that prefetches, fragments
+// from L2 in three rotating register sets, one sink per workgroup, clips dealt out to the waves by ticket -- and in profiles/r06_occupancy.md.  A plan
+// says which build runs it (KwsFastPlan::wps).
 #include <atomic>
 
 #include "kws_device.h"
@@ -472,7 +478,12 @@ __device__ __forceinline__ float fast_conv_small_h(const KwsFastBlock &k, float 
 }
 
 // BG: the weight fragments are read from device memory (the workgroup's LDS block has no room for them) instead of LDS
-template <int MT, int NT, bool BG>
+// ROT (three-waves-per-SIMD build): fragments in LDS take the rotating-set loop of the BG form too.  The loop with two whole operand sets needs 128 registers
+// for MT NT = 8 and spills an accumulator at 168 -- and because every tile shape is compiled into the one kernel, its pressure costs the kernel 19 more
+// spilled registers around the block loop whichever shape runs (49x40 fp32, fragments from L2: 1.273 -> 1.254 ms same-box without it).  Where the fragments
+// ARE in LDS the two-set loop is the faster one (49x13 fp32: 1.020 against 1.051 ms), so the choice follows the kernel instantiation: the 40-filter
+// front end's plans (13.6 KB per wave: fragments of a 49-row block in L2) take ROT, the 32-filter one's (fragments in LDS) do not.
+template <int MT, int NT, bool BG, bool ROT = false>
 __device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float *__restrict__ in, float *__restrict__ stage, int sstride,
                                                    const float *__restrict__ shared, int zero_off, int lane, float *__restrict__ sink)
 {
@@ -523,7 +534,7 @@ __device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float 
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
     };
 #if KWS_FAST_WPS >= 3
-    if constexpr (BG) {
+    if constexpr (BG || (ROT && MT * NT >= 8)) {
         // Three waves per SIMD with the fragments in device memory (the LDS block holds eleven waves and no 36 KB of fragments): an L2 round trip is longer
         // than a k-step's 3 MT NT matrix instructions, so the fragments rotate through THREE register sets, requested two k-steps ahead, and the image
         // operands make do with ONE set refilled in two halves -- the lo halves after the products that read them, the hi halves after the rest -- :
@@ -534,7 +545,8 @@ __device__ __forceinline__ float fast_conv_tiles_h(const KwsFastBlock &k, float 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int off = ((kc * 2) * NT + nt) * (KWS_WAVE * 16);
-                h_[nt] = *(kws_gv8h)(bg + off); l_[nt] = *(kws_gv8h)(bg + off + NT * (KWS_WAVE * 16));
+                if constexpr (BG) { h_[nt] = *(kws_gv8h)(bg + off); l_[nt] = *(kws_gv8h)(bg + off + NT * (KWS_WAVE * 16)); }
+                else { h_[nt] = *(const v8h *)(bl + off); l_[nt] = *(const v8h *)(bl + off + NT * (KWS_WAVE * 16)); }
             }
         };
         auto fetch_a = [&](const int2 &d, v8h (&dst)[MT], int plus) {
@@ -1777,7 +1789,7 @@ __global__ __launch_bounds__(256 * KWS_FAST_WPS, KWS_FAST_WPS) void kws_fast_ker
                 if (bgl && k.n_tiles == 1 && k.m_tiles == 1 && k.h_ks <= 8) cscale = fast_conv_small_h<1>(k, cur, stage, sstride, shared, zo, lane_b, wsink);
                 else
                 switch ((k.m_tiles > 2 ? 4 : k.m_tiles) * 4 + k.n_tiles) {
-                case 4 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<4, 2, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<4, 2, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
+                case 4 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<4, 2, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<4, 2, false, (DG > 4)>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
                 case 4 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<4, 1, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<4, 1, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
                 case 2 * 4 + 2: cscale = bgl ? fast_conv_tiles_h<2, 2, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<2, 2, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
                 case 2 * 4 + 1: cscale = bgl ? fast_conv_tiles_h<2, 1, true>(k, cur, stage, sstride, shared, zo, lane_b, wsink) : fast_conv_tiles_h<2, 1, false>(k, cur, stage, sstride, shared, zo, lane_b, wsink); break;
