@@ -143,6 +143,7 @@ struct KwsFastPlan {
     // pass instead of living in 40 registers (a register reloaded from scratch inside the pass loop waits for the pass's sample prefetch: one counter)
     int twl_off;
     // (wps = 3 only) two words in device memory, zero between launches: the ticket counter the kernel deals its clips out by, and the count of waves that
-    // have left (kws_fast.hip: the clip loop and the kernel's end)
+    // have left (kws_fast.hip: the clip loop and the kernel's end).  (A launch that does not run to its end -- a device fault -- leaves them dirty: like the rest of
+    // the handle's device state, they are only good for launches that complete.)
     int *tickets;
 };
