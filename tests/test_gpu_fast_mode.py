@@ -336,6 +336,8 @@ def test_fast_mode_fused_depthwise_separable_graphs(key, dev_pkg, oracle, tmp_pa
     gm = pkg.Model(blob=blob)
     gm.set_mode(pkg.MODE_FAST)
     assert gm.fast_is_fused, key
+    if key.startswith("w3_"):
+        assert gm.fast_tolerance()["fused_waves_per_simd"] == 3, (key, gm.fast_tolerance())          # the build these graphs are here for
     B = 700
     host = np.concatenate([oracle.synth(400 + len(key), 5, B - 6), np.stack(list(special_clips().values()))[:6]])
     pcm = torch.from_numpy(np.ascontiguousarray(host)).to("cuda:0")
@@ -490,6 +492,10 @@ FUSED_POOL_GRAPHS = {
     "pool6_valid_40ch": dict(seed=64, num_filters=40, ncep=40, low=300, high=0, blocks=((32, 3, -6), (16, 3, 1)), n_labels=6),   # 49 -> 8
     "pool2_small_windows": dict(seed=65, ncep=13, blocks=((8, 3, 2), (16, 3, 2)), n_labels=4),         # windows < 4 rows: staging path
     "pool8_valid_then_none": dict(seed=66, ncep=20, blocks=((12, 4, -8), (12, 2, 1)), n_labels=4),     # 49 -> 6 (row 48 dropped), then an un-pooled block
+    # round 6, the three-waves-per-SIMD build: first blocks whose fragments come from L2 (40 filters: the LDS block has no room) in k-step counts that are
+    # not multiples of three -- the rotating-set contraction loop walks whole trips of three, the steps past the last one multiply the zero block
+    "w3_l2_fragments_7_ksteps": dict(seed=67, num_filters=40, ncep=40, low=300, high=0, blocks=((30, 5, 7), (10, 5, 7)), n_labels=4),    # 5 taps x 5 groups = 25 -> 7 k-steps
+    "w3_l2_fragments_5_ksteps": dict(seed=68, num_filters=40, ncep=40, low=300, high=0, blocks=((24, 4, 7), (12, 3, 7)), n_labels=5),    # 4 taps x 5 groups = 20 -> 5 k-steps
 }
 
 
