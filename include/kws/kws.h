@@ -131,7 +131,7 @@ typedef struct {
                                                           row in tier 1 -- recorded at kws_create from the exact kernels on an all-zero window --, so the rule's abs / lev
                                                           terms are multiplied by sqrt(live frames / frames) and `level` is the mean over the LIVE frames only */
     float systematic_ratio;                            /* a column whose deviation is below this x |mean| in a lane's first window (rows 0, cr, 2 cr ... of the kernel's
-                                                          row groups, cr = 13 for up to 16 columns, else 17) takes the alternative rel coefficient, like a clip with silent frames (column 0 of
+                                                          row groups, cr = 13 for up to 16 columns and in the three-waves-per-SIMD build, else 17) takes the alternative rel coefficient, like a clip with silent frames (column 0 of
                                                           such a clip always has its window means replayed) */
     int fused_waves_per_simd, fused_waves;             /* (round 6) the build of the fast kernel a float32 graph's batch calls enter through: 2 waves per SIMD (8 per
                                                           workgroup, 256 registers) or 3 (12 / 11 per workgroup, <= 168 registers, clips dealt out by ticket: plans that
